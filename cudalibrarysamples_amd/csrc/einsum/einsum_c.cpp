@@ -1,0 +1,67 @@
+// einsum_c.cpp — C entry points over cutensor_amd::Einsum<> so that Python (ctypes) can drive the
+// same C++ helper the native samples use.  The reference exposes its helper to Python through
+// pybind11 (cuTENSOR/python/cutensor/torch/einsum.cc:75-137); this is the same seam without a
+// framework dependency: plain pointers and sizes only.
+#include <cstring>
+#include <new>
+
+#include "einsum.hpp"
+
+namespace {
+constexpr int kMaxModes = 64;   // torch/einsum.cc:84
+struct Base {
+    virtual ~Base() {}
+    virtual bool init() const = 0;
+    virtual std::vector<int64_t> shape() const = 0;
+    virtual bool plan(cutensorHandle_t h, uint64_t limit) = 0;
+    virtual uint64_t required() const = 0;
+    virtual bool exec(cutensorHandle_t h, const void* A, const void* B, void* C, void* w, hipStream_t s) = 0;
+    virtual cutensorPlan_t raw() const = 0;
+};
+template <typename T>
+struct Impl : Base {
+    cutensor_amd::Einsum<T, int64_t, kMaxModes> e;
+    Impl(const char* eq, const std::vector<int64_t>& a, const std::vector<int64_t>& b) : e(eq, a, b) {}
+    bool init() const override { return e.isInitialized(); }
+    std::vector<int64_t> shape() const override { return e.getOutputShape(); }
+    bool plan(cutensorHandle_t h, uint64_t limit) override { return e.plan(h, limit); }
+    uint64_t required() const override { return e.requiredWorkspace(); }
+    bool exec(cutensorHandle_t h, const void* A, const void* B, void* C, void* w, hipStream_t s) override {
+        return e.execute(h, A, B, C, w, s);
+    }
+    cutensorPlan_t raw() const override { return e.rawPlan(); }
+};
+}  // namespace
+
+extern "C" {
+
+void* ctamdEinsumCreate(const char* equation, const int64_t* shapeA, int nA, const int64_t* shapeB, int nB, int dtype) {
+    if (equation == nullptr || nA < 0 || nB < 0) return nullptr;
+    std::vector<int64_t> a(shapeA, shapeA + nA), b(shapeB, shapeB + nB);
+    switch (dtype) {
+        case HIP_R_32F:  return static_cast<Base*>(new (std::nothrow) Impl<float>(equation, a, b));
+        case HIP_R_64F:  return static_cast<Base*>(new (std::nothrow) Impl<double>(equation, a, b));
+        case HIP_R_16F:  return static_cast<Base*>(new (std::nothrow) Impl<__half>(equation, a, b));
+        case HIP_R_16BF: return static_cast<Base*>(new (std::nothrow) Impl<__hip_bfloat16>(equation, a, b));
+        default: return nullptr;
+    }
+}
+void ctamdEinsumDestroy(void* e) { delete static_cast<Base*>(e); }
+int ctamdEinsumIsInitialized(void* e) { return e && static_cast<Base*>(e)->init() ? 1 : 0; }
+int ctamdEinsumOutputShape(void* e, int64_t* out, int cap) {
+    if (!e) return -1;
+    const std::vector<int64_t> s = static_cast<Base*>(e)->shape();
+    for (size_t i = 0; i < s.size() && (int)i < cap; ++i) out[i] = s[i];
+    return (int)s.size();
+}
+int ctamdEinsumPlan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) {
+    if (!e || !static_cast<Base*>(e)->plan(h, limit)) return 0;
+    if (required) *required = static_cast<Base*>(e)->required();
+    return 1;
+}
+int ctamdEinsumExecute(void* e, cutensorHandle_t h, const void* A, const void* B, void* C, void* work, hipStream_t stream) {
+    return (e && static_cast<Base*>(e)->exec(h, A, B, C, work, stream)) ? 1 : 0;
+}
+cutensorPlan_t ctamdEinsumRawPlan(void* e) { return e ? static_cast<Base*>(e)->raw() : nullptr; }
+
+}  // extern "C"

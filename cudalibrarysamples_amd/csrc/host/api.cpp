@@ -1,0 +1,838 @@
+// api.cpp — the exported cuTENSOR C ABI (include/cutensor.h) on top of the planners and the
+// gfx950 kernels.  Each entry point cites the reference call site it serves.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <sstream>
+
+#include <hip/hip_runtime.h>
+
+#include "internal.hpp"
+
+using namespace ctamd;
+
+// ---- compute descriptor constants (einsum.cu:39,46,53; contraction.cu:40) ----------------------
+static const cutensorComputeDescriptor kCompute[6] = {
+    {0, CUTENSOR_COMPUTE_16F}, {1, CUTENSOR_COMPUTE_16BF}, {2, CUTENSOR_COMPUTE_TF32},
+    {3, CUTENSOR_COMPUTE_3XTF32}, {4, CUTENSOR_COMPUTE_32F}, {5, CUTENSOR_COMPUTE_64F}};
+extern "C" {
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_16F    = &kCompute[0];
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_16BF   = &kCompute[1];
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_TF32   = &kCompute[2];
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_3XTF32 = &kCompute[3];
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_32F    = &kCompute[4];
+const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_64F    = &kCompute[5];
+}
+
+namespace {
+
+bool valid_compute(cutensorComputeDescriptor_t c) { return c >= &kCompute[0] && c <= &kCompute[5]; }
+
+int log_level() {
+    static int lvl = [] {
+        const char* e = std::getenv("CUTENSOR_LOG_LEVEL");   // contraction_jit.cu:142 hints at this knob
+        return e ? std::atoi(e) : 0;
+    }();
+    return lvl;
+}
+#define CT_LOG(...) do { if (log_level() > 0) { std::fprintf(stderr, "[cutensor-amd] " __VA_ARGS__); std::fputc('\n', stderr); } } while (0)
+
+bool supported_dtype(hipDataType t) {
+    return t == HIP_R_32F || t == HIP_R_64F || t == HIP_R_16F || t == HIP_R_16BF;
+}
+
+// scalar type of alpha/beta for a data type + compute descriptor (einsum.cu:40,47,54;
+// torch/einsum.cc:39): fp64 data -> fp64 scalars, everything else -> fp32 scalars.
+hipDataType scalar_type_for(hipDataType data, const cutensorComputeDescriptor* c) {
+    if (data == HIP_R_64F || (c && c->id == 5)) return HIP_R_64F;
+    return HIP_R_32F;
+}
+
+cutensorStatus_t fill_use(TensorUse& u, const cutensorTensorDescriptor_t d, const int32_t* modes,
+                          cutensorOperator_t op) {
+    if (d == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (d->numModes > 0 && modes == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    u.desc = *d;
+    u.modes.assign(modes, modes + d->numModes);
+    u.op = op;
+    u.present = true;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+double num_elements(const cutensorTensorDescriptor& d) {
+    double n = 1.0;
+    for (int64_t e : d.extent) n *= (double)e;
+    return n;
+}
+
+std::string problem_key(const cutensorOperationDescriptor& op) {
+    std::ostringstream ss;
+    ss << (int)op.kind << ':' << (int)op.A.desc.dtype << ':' << (op.compute ? op.compute->id : -1);
+    auto put = [&](const TensorUse& u) {
+        ss << '|';
+        if (!u.present) return;
+        for (size_t i = 0; i < u.modes.size(); ++i)
+            ss << u.modes[i] << ',' << u.desc.extent[i] << ',' << u.desc.stride[i] << ';';
+        ss << 'a' << u.desc.alignment;
+    };
+    put(op.A); put(op.B); put(op.C); put(op.D);
+    return ss.str();
+}
+
+double scalar_as_double(const void* s, hipDataType t) {
+    if (s == nullptr) return 0.0;
+    return t == HIP_R_64F ? *static_cast<const double*>(s) : (double)*static_cast<const float*>(s);
+}
+
+bool misaligned(const void* p, uint32_t a) { return a > 1 && (reinterpret_cast<uintptr_t>(p) % a) != 0; }
+
+// Optional per-kernel timing of the dominant (GETT) kernel with HIP events recorded on the caller's
+// stream, for bench.py's roofline line.  Off by default; see ctamdProfileBegin/End below.
+struct KernelProfile {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::mutex mtx;
+} g_prof;
+
+}  // namespace
+
+extern "C" {
+
+// ---- handle (contraction.cu:123-124) -----------------------------------------------------------
+cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
+    if (handle == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorHandle* h = new (std::nothrow) cutensorHandle();
+    if (h == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        h->device = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            h->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            h->clockKHz = prop.clockRate > 0 ? prop.clockRate : 2400000;
+            if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+                CT_LOG("warning: device is %s, kernels are built for gfx950", prop.gcnArchName);
+        }
+    } else {
+        (void)hipGetLastError();   // no device: descriptor / planning calls still work
+    }
+    *handle = h;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) {
+    delete handle;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// einsum.cu:445
+cutensorStatus_t cutensorHandleResizePlanCache(cutensorHandle_t handle, const uint32_t numEntries) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    std::lock_guard<std::mutex> g(handle->mtx);
+    handle->planCacheCapacity = numEntries;
+    while (handle->planCache.size() > numEntries) handle->planCache.erase(handle->planCache.begin());
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction_plan_cache.cu:324-337 — one line per cached problem: key \t kernel \t splitK
+cutensorStatus_t cutensorHandleWritePlanCacheToFile(const cutensorHandle_t handle, const char filename[]) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    std::lock_guard<std::mutex> g(handle->mtx);
+    FILE* f = std::fopen(filename, "w");
+    if (f == nullptr) return CUTENSOR_STATUS_IO_ERROR;
+    std::fprintf(f, "cutensor-amd-plancache 1\n");
+    for (const auto& kv : handle->planCache)
+        std::fprintf(f, "%s\t%d\t%u\n", kv.second.key.c_str(), kv.second.kernel, kv.second.splitK);
+    std::fclose(f);
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction_plan_cache.cu:132-148
+cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, const char filename[],
+                                                     uint32_t* numCachelinesRead) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (numCachelinesRead) *numCachelinesRead = 0;
+    FILE* f = std::fopen(filename, "r");
+    if (f == nullptr) return CUTENSOR_STATUS_IO_ERROR;
+    char header[64];
+    int version = 0;
+    if (std::fscanf(f, "%63s %d\n", header, &version) != 2 || std::strcmp(header, "cutensor-amd-plancache") != 0) {
+        std::fclose(f);
+        return CUTENSOR_STATUS_IO_ERROR;
+    }
+    std::lock_guard<std::mutex> g(handle->mtx);
+    std::vector<char> line(1 << 16);
+    uint32_t n = 0;
+    while (std::fgets(line.data(), (int)line.size(), f)) {
+        char* t1 = std::strchr(line.data(), '\t');
+        if (!t1) continue;
+        *t1 = 0;
+        PlanCacheEntry e;
+        e.key = line.data();
+        unsigned sk = 1;
+        if (std::sscanf(t1 + 1, "%d\t%u", &e.kernel, &sk) != 2) continue;
+        e.splitK = sk;
+        if (handle->planCache.size() >= handle->planCacheCapacity && !handle->planCache.count(e.key)) {
+            std::fclose(f);
+            if (numCachelinesRead) *numCachelinesRead = n;
+            return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;   // cache too small for the file
+        }
+        handle->planCache[e.key] = e;
+        ++n;
+    }
+    std::fclose(f);
+    if (numCachelinesRead) *numCachelinesRead = n;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// ---- tensor descriptor (contraction.cu:131-137) ------------------------------------------------
+cutensorStatus_t cutensorCreateTensorDescriptor(const cutensorHandle_t handle, cutensorTensorDescriptor_t* desc,
+                                                const uint32_t numModes, const int64_t extent[],
+                                                const int64_t stride[], cutensorDataType_t dataType,
+                                                uint32_t alignmentRequirement) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || (numModes > 0 && extent == nullptr)) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (numModes > 64) return CUTENSOR_STATUS_NOT_SUPPORTED;
+    if (!supported_dtype(dataType)) return CUTENSOR_STATUS_NOT_SUPPORTED;
+    const size_t es = dtype_size(dataType);
+    if (alignmentRequirement == 0 || alignmentRequirement % es != 0) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorTensorDescriptor* d = new (std::nothrow) cutensorTensorDescriptor();
+    if (d == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    d->numModes = numModes;
+    d->dtype = dataType;
+    d->alignment = alignmentRequirement;
+    d->extent.assign(extent, extent + numModes);
+    d->stride.resize(numModes);
+    int64_t run = 1;
+    for (uint32_t i = 0; i < numModes; ++i) {
+        if (extent[i] <= 0) { delete d; return CUTENSOR_STATUS_INVALID_VALUE; }
+        if (stride != nullptr) {
+            if (stride[i] <= 0) { delete d; return CUTENSOR_STATUS_INVALID_VALUE; }
+            d->stride[i] = stride[i];
+        } else {
+            d->stride[i] = run;   // packed generalized column-major (blocksparse.cu:80-81)
+            run *= extent[i];
+        }
+    }
+    *desc = d;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+cutensorStatus_t cutensorDestroyTensorDescriptor(cutensorTensorDescriptor_t desc) {
+    delete desc;   // NULL tolerated (python/einsum.h:302,396)
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// ---- operation descriptors ----------------------------------------------------------------------
+static cutensorStatus_t new_op(cutensorOperationDescriptor_t* out, cutensorOperationDescriptor& tmp) {
+    cutensorOperationDescriptor* o = new (std::nothrow) cutensorOperationDescriptor(tmp);
+    if (o == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    *out = o;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction.cu:162-168
+cutensorStatus_t cutensorCreateContraction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                           const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                           const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                           const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                           const cutensorTensorDescriptor_t descD, const int32_t modeD[],
+                                           const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::Contraction;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.B, descB, modeB, opB)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.C, descC, modeC, opC)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descD, modeD, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    ContractionView v;
+    std::string why;
+    st = build_contraction_view(op, v, &why);
+    if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateContraction: %s", why.c_str()); return st; }
+    // contraction.cu:61 / :274-276
+    op.flops = 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK;
+    const double es = (double)dtype_size(op.A.desc.dtype);
+    op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.B.desc) + num_elements(op.D.desc));
+    return new_op(desc, op);
+}
+
+// reduction.cu:141-146
+cutensorStatus_t cutensorCreateReduction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                         const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                         const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                         const cutensorTensorDescriptor_t descD, const int32_t modeD[],
+                                         cutensorOperator_t opReduce, const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::Reduction;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.C, descC, modeC, opC)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descD, modeD, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.opReduce = opReduce;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    ReducePlan rp;
+    std::string why;
+    st = plan_reduction(op, 0, handle->numCUs, rp, &why);   // validates the problem
+    if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateReduction: %s", why.c_str()); return st; }
+    const double es = (double)dtype_size(op.A.desc.dtype);
+    op.flops = num_elements(op.A.desc);
+    op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.D.desc));   // reduction.cu:229-231
+    return new_op(desc, op);
+}
+
+// elementwise_permute.cu:142-149
+cutensorStatus_t cutensorCreatePermutation(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                           const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                           const cutensorTensorDescriptor_t descB, const int32_t modeB[],
+                                           const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::Permutation;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descB, modeB, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    EwPlan ep;
+    std::string why;
+    st = plan_elementwise(op, ep, &why);
+    if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreatePermutation: %s", why.c_str()); return st; }
+    op.movedBytes = 2.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);   // elementwise_permute.cu:208
+    return new_op(desc, op);
+}
+
+// elementwise_binary.cu:149-153 — only opAC = ADD is implemented
+cutensorStatus_t cutensorCreateElementwiseBinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                 const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                 const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                 const cutensorTensorDescriptor_t descD, const int32_t modeD[],
+                                                 cutensorOperator_t opAC, const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (opAC != CUTENSOR_OP_ADD) return CUTENSOR_STATUS_NOT_SUPPORTED;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::ElementwiseBinary;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.C, descC, modeC, opC)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descD, modeD, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.opReduce = opAC;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    EwPlan ep;
+    std::string why;
+    st = plan_elementwise(op, ep, &why);
+    if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateElementwiseBinary: %s", why.c_str()); return st; }
+    op.movedBytes = 3.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);
+    return new_op(desc, op);
+}
+
+cutensorStatus_t cutensorDestroyOperationDescriptor(cutensorOperationDescriptor_t desc) {
+    delete desc;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction.cu:176-180, contraction_jit.cu:379-383
+cutensorStatus_t cutensorOperationDescriptorGetAttribute(const cutensorHandle_t handle, cutensorOperationDescriptor_t desc,
+                                                         cutensorOperationDescriptorAttribute_t attr, void* buf,
+                                                         size_t sizeInBytes) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    switch (attr) {
+        case CUTENSOR_OPERATION_DESCRIPTOR_TAG:
+            if (sizeInBytes != sizeof(int32_t)) return CUTENSOR_STATUS_INVALID_VALUE;
+            *static_cast<int32_t*>(buf) = desc->tag;
+            return CUTENSOR_STATUS_SUCCESS;
+        case CUTENSOR_OPERATION_DESCRIPTOR_SCALAR_TYPE:
+            if (sizeInBytes != sizeof(cutensorDataType_t)) return CUTENSOR_STATUS_INVALID_VALUE;
+            *static_cast<cutensorDataType_t*>(buf) = desc->scalarType;
+            return CUTENSOR_STATUS_SUCCESS;
+        case CUTENSOR_OPERATION_DESCRIPTOR_FLOPS:
+            if (sizeInBytes != sizeof(float)) return CUTENSOR_STATUS_INVALID_VALUE;
+            *static_cast<float*>(buf) = (float)desc->flops;
+            return CUTENSOR_STATUS_SUCCESS;
+        case CUTENSOR_OPERATION_DESCRIPTOR_MOVED_BYTES:
+            if (sizeInBytes != sizeof(float)) return CUTENSOR_STATUS_INVALID_VALUE;
+            *static_cast<float*>(buf) = (float)desc->movedBytes;
+            return CUTENSOR_STATUS_SUCCESS;
+        default:
+            return CUTENSOR_STATUS_NOT_SUPPORTED;
+    }
+}
+
+cutensorStatus_t cutensorOperationDescriptorSetAttribute(const cutensorHandle_t handle, cutensorOperationDescriptor_t desc,
+                                                         cutensorOperationDescriptorAttribute_t attr, const void* buf,
+                                                         size_t sizeInBytes) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (attr == CUTENSOR_OPERATION_DESCRIPTOR_TAG && sizeInBytes == sizeof(int32_t)) {
+        desc->tag = *static_cast<const int32_t*>(buf);
+        return CUTENSOR_STATUS_SUCCESS;
+    }
+    return CUTENSOR_STATUS_NOT_SUPPORTED;
+}
+
+// ---- plan preference (contraction.cu:194-198) ----------------------------------------------------
+cutensorStatus_t cutensorCreatePlanPreference(const cutensorHandle_t handle, cutensorPlanPreference_t* pref,
+                                              cutensorAlgo_t algo, cutensorJitMode_t jitMode) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (pref == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorPlanPreference* p = new (std::nothrow) cutensorPlanPreference();
+    if (p == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    p->algo = algo;
+    p->jit = jitMode;   // accepted and ignored: every kernel is ahead-of-time compiled for gfx950
+    *pref = p;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+cutensorStatus_t cutensorDestroyPlanPreference(cutensorPlanPreference_t pref) {
+    delete pref;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction_plan_cache.cu:215-237
+cutensorStatus_t cutensorPlanPreferenceSetAttribute(const cutensorHandle_t handle, cutensorPlanPreference_t pref,
+                                                    cutensorPlanPreferenceAttribute_t attr, const void* buf,
+                                                    size_t sizeInBytes) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (pref == nullptr || buf == nullptr || sizeInBytes != 4) return CUTENSOR_STATUS_INVALID_VALUE;
+    const int32_t v = *static_cast<const int32_t*>(buf);
+    switch (attr) {
+        case CUTENSOR_PLAN_PREFERENCE_AUTOTUNE_MODE: pref->autotune = (cutensorAutotuneMode_t)v; break;
+        case CUTENSOR_PLAN_PREFERENCE_CACHE_MODE: pref->cacheMode = (cutensorCacheMode_t)v; break;
+        case CUTENSOR_PLAN_PREFERENCE_INCREMENTAL_COUNT: pref->incrementalCount = v; break;
+        case CUTENSOR_PLAN_PREFERENCE_ALGO: pref->algo = (cutensorAlgo_t)v; break;
+        case CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK: pref->kernelRank = v; break;
+        case CUTENSOR_PLAN_PREFERENCE_JIT: pref->jit = (cutensorJitMode_t)v; break;
+        default: return CUTENSOR_STATUS_INVALID_VALUE;
+    }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction.cu:207-211
+cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc,
+                                               const cutensorPlanPreference_t planPref,
+                                               const cutensorWorksizePreference_t workspacePref,
+                                               uint64_t* workspaceSizeEstimate) {
+    (void)planPref;
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || workspaceSizeEstimate == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    *workspaceSizeEstimate = 0;
+    if (workspacePref == CUTENSOR_WORKSPACE_MIN) return CUTENSOR_STATUS_SUCCESS;
+    const uint64_t cap = (workspacePref == CUTENSOR_WORKSPACE_MAX) ? (4ull << 30) : (1ull << 30);
+    if (desc->kind == OpKind::Contraction) {
+        ContractionView v;
+        cutensorStatus_t st = build_contraction_view(*desc, v, nullptr);
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        if (v.dtype != HIP_R_32F) return CUTENSOR_STATUS_SUCCESS;
+        // the largest workspace any of the best few candidates would like to have
+        std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs);
+        uint64_t want = 0;
+        for (size_t i = 0; i < ch.size() && i < 4; ++i) want = std::max(want, ch[i].workspace);
+        *workspaceSizeEstimate = want;
+    } else if (desc->kind == OpKind::Reduction) {
+        ReducePlan rp;
+        cutensorStatus_t st = plan_reduction(*desc, cap, handle->numCUs, rp, nullptr);
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        *workspaceSizeEstimate = rp.workspace;
+    }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// ---- measured selection for CUTENSOR_ALGO_DEFAULT_PATIENT -------------------------------------
+// Times the best-ranked candidates on scratch tensors of the problem's own shape; plan creation is
+// outside every timed region of the samples (contraction.cu:218-222 vs :253-270).
+static int autotune_contraction(cutensorHandle_t handle, const cutensorOperationDescriptor& op,
+                                const ContractionView& v, const std::vector<ContractionChoice>& ch) {
+    const size_t es = 4;
+    auto span = [&](const cutensorTensorDescriptor& d) {
+        int64_t n = 1;
+        for (uint32_t i = 0; i < d.numModes; ++i) n += (d.extent[i] - 1) * d.stride[i];
+        return (size_t)n * es;
+    };
+    uint64_t wsMax = 0;
+    const size_t nTry = std::min<size_t>(ch.size(), 12);
+    for (size_t i = 0; i < nTry; ++i) wsMax = std::max(wsMax, ch[i].workspace);
+    void *A = nullptr, *B = nullptr, *D = nullptr, *W = nullptr;
+    int best = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&A, span(op.A.desc)) != hipSuccess || hipMalloc(&B, span(op.B.desc)) != hipSuccess ||
+        hipMalloc(&D, span(op.D.desc)) != hipSuccess || (wsMax && hipMalloc(&W, wsMax) != hipSuccess) ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        goto done;
+    }
+    (void)hipMemset(A, 0x3c, span(op.A.desc));   // 0x3c3c3c3c = 0.0115f: finite, non-trivial data
+    (void)hipMemset(B, 0x3c, span(op.B.desc));
+    {
+        int count = 0;
+        const GettKernelInfo* tab = gett_f32_kernels(&count);
+        float bestMs = 1e30f;
+        for (size_t i = 0; i < nTry; ++i) {
+            GettParams gp;
+            SplitKReduceParams rp;
+            fill_gett_params(v, ch[i], gp, rp);
+            gp.A = v.swapped ? B : A;
+            gp.B = v.swapped ? A : B;
+            gp.C = D; gp.D = D; gp.alpha = 1.f; gp.beta = 0.f;
+            gp.partial = ch[i].splitK > 1 ? static_cast<float*>(W) : nullptr;
+            rp.partial = static_cast<float*>(W); rp.C = D; rp.D = D; rp.alpha = 1.f; rp.beta = 0.f;
+            float ms = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                (void)hipEventRecord(e0, nullptr);
+                if (tab[ch[i].kernel].launch(gp, nullptr) != hipSuccess) break;
+                if (ch[i].splitK > 1 && launch_splitk_reduce(rp, nullptr) != hipSuccess) break;
+                (void)hipEventRecord(e1, nullptr);
+                if (hipEventSynchronize(e1) != hipSuccess) break;
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, e0, e1);
+                if (rep > 0) ms = std::min(ms, t);
+            }
+            CT_LOG("autotune: cand %zu kernel %d (%dx%dx%d) splitK %u -> %.3f us (model %.1f us)", i, ch[i].kernel,
+                   tab[ch[i].kernel].bm, tab[ch[i].kernel].bn, tab[ch[i].kernel].bk, ch[i].splitK, ms * 1e3, ch[i].estimateUs);
+            if (ms < bestMs) { bestMs = ms; best = (int)i; }
+        }
+    }
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (A) (void)hipFree(A);
+    if (B) (void)hipFree(B);
+    if (D) (void)hipFree(D);
+    if (W) (void)hipFree(W);
+    (void)handle;
+    return best;
+}
+
+// contraction.cu:218-222, elementwise_permute.cu:183-187 (limit 0), einsum.cu:324-329 (limit 1 GiB)
+cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_t* plan,
+                                    const cutensorOperationDescriptor_t desc, const cutensorPlanPreference_t pref,
+                                    uint64_t workspaceSizeLimit) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || desc == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorPlanPreference defaults;
+    const cutensorPlanPreference& pr = pref ? *pref : defaults;
+    cutensorPlan* pl = new (std::nothrow) cutensorPlan();
+    if (pl == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    pl->kind = desc->kind;
+    pl->dtype = desc->A.desc.dtype;
+    pl->scalarType = desc->scalarType;
+    pl->alignA = desc->A.desc.alignment;
+    pl->alignB = desc->B.present ? desc->B.desc.alignment : 0;
+    pl->alignC = desc->C.present ? desc->C.desc.alignment : 0;
+    pl->alignD = desc->D.desc.alignment;
+    pl->accumulate64 = desc->compute && desc->compute->id == 5;
+    std::string why;
+    cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+
+    if (desc->kind == OpKind::Contraction) {
+        st = build_contraction_view(*desc, pl->view, &why);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        const bool mfmaPath = pl->view.dtype == HIP_R_32F && !pl->accumulate64;
+        ContractionChoice pick;   // kernel = -1: simple kernel
+        if (mfmaPath) {
+            std::vector<ContractionChoice> ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+            if (!ch.empty()) {
+                size_t idx = 0;
+                const std::string key = problem_key(*desc);
+                bool fromCache = false;
+                if (handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE) {
+                    std::lock_guard<std::mutex> g(handle->mtx);
+                    auto it = handle->planCache.find(key);
+                    if (it != handle->planCache.end()) {
+                        for (size_t i = 0; i < ch.size(); ++i)
+                            if (ch[i].kernel == it->second.kernel && ch[i].splitK == it->second.splitK) { idx = i; fromCache = true; break; }
+                    }
+                }
+                if (!fromCache) {
+                    if ((int)pr.algo >= 0) idx = std::min<size_t>((size_t)pr.algo, ch.size() - 1);
+                    else if (pr.kernelRank > 0) idx = std::min<size_t>((size_t)pr.kernelRank, ch.size() - 1);
+                    else if (pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
+                    if (const char* f = std::getenv("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
+                        int fk = -1; unsigned fs = 1;
+                        if (std::sscanf(f, "%d:%u", &fk, &fs) >= 1)
+                            for (size_t i = 0; i < ch.size(); ++i)
+                                if (ch[i].kernel == fk && ch[i].splitK == fs) { idx = i; break; }
+                    }
+                    if (handle->planCacheCapacity > 0 && pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) {
+                        std::lock_guard<std::mutex> g(handle->mtx);
+                        if (handle->planCache.size() < handle->planCacheCapacity)
+                            handle->planCache[key] = PlanCacheEntry{key, ch[idx].kernel, ch[idx].splitK};
+                    }
+                }
+                pick = ch[idx];
+            }
+        }
+        pl->choice = pick;
+        fill_gett_params(pl->view, pick, pl->gett, pl->skr);
+        pl->requiredWorkspace = pick.workspace;
+        if (log_level() > 0) {
+            int count = 0;
+            const GettKernelInfo* tab = gett_f32_kernels(&count);
+            if (pick.kernel >= 0)
+                CT_LOG("plan: contraction L=%llu M=%llu N=%llu K=%llu layA=%d layB=%d swapped=%d -> kernel %d (%dx%dx%d) splitK=%u ws=%llu est=%.1fus",
+                       (unsigned long long)pl->view.totL, (unsigned long long)pl->view.totM, (unsigned long long)pl->view.totN,
+                       (unsigned long long)pl->view.totK, pl->view.layA, pl->view.layB, (int)pl->view.swapped, pick.kernel,
+                       tab[pick.kernel].bm, tab[pick.kernel].bn, tab[pick.kernel].bk, pick.splitK,
+                       (unsigned long long)pick.workspace, pick.estimateUs);
+            else
+                CT_LOG("plan: contraction -> simple kernel (dtype %d)", (int)pl->view.dtype);
+        }
+    } else if (desc->kind == OpKind::Reduction) {
+        st = plan_reduction(*desc, workspaceSizeLimit, handle->numCUs, pl->red, &why);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        pl->requiredWorkspace = pl->red.workspace;
+        CT_LOG("plan: reduction variant=%d kept=%u red=%u splitR=%u perm=%d", pl->red.variant, pl->red.p.kept.total,
+               pl->red.p.red.total, pl->red.p.splitR, (int)pl->red.isPermutation);
+    } else {
+        st = plan_elementwise(*desc, pl->ew, &why);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        pl->requiredWorkspace = 0;
+        CT_LOG("plan: elementwise variant=%d E0=%u E1=%u rest=%u blocks=%u", pl->ew.variant, pl->ew.p.E0, pl->ew.p.E1,
+               pl->ew.p.rest.total, pl->ew.p.nBlocks);
+    }
+    *plan = pl;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+cutensorStatus_t cutensorDestroyPlan(cutensorPlan_t plan) {
+    delete plan;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction.cu:231-235
+cutensorStatus_t cutensorPlanGetAttribute(const cutensorHandle_t handle, const cutensorPlan_t plan,
+                                          cutensorPlanAttribute_t attr, void* buf, size_t sizeInBytes) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (attr == CUTENSOR_PLAN_REQUIRED_WORKSPACE && sizeInBytes == sizeof(uint64_t)) {
+        *static_cast<uint64_t*>(buf) = plan->requiredWorkspace;
+        return CUTENSOR_STATUS_SUCCESS;
+    }
+    return CUTENSOR_STATUS_INVALID_VALUE;
+}
+
+// ---- execution -----------------------------------------------------------------------------------
+// contraction.cu:261-265, einsum.cu:334-338
+cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                  const void* A, const void* B, const void* beta, const void* C, void* D,
+                                  void* workspace, uint64_t workspaceSize, cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::Contraction) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    const double a = scalar_as_double(alpha, plan->scalarType), b = scalar_as_double(beta, plan->scalarType);
+    if (b != 0.0 && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(B, plan->alignB) || misaligned(D, plan->alignD) ||
+        (b != 0.0 && misaligned(C, plan->alignC)))
+        return CUTENSOR_STATUS_INVALID_VALUE;
+    if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
+        return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+
+    GettParams p = plan->gett;
+    p.A = plan->view.swapped ? B : A;
+    p.B = plan->view.swapped ? A : B;
+    p.C = (b != 0.0) ? C : D;
+    p.D = D;
+    p.alpha = (float)a; p.beta = (float)b;
+    p.alpha64 = a; p.beta64 = b;
+    hipError_t err;
+    if (plan->choice.kernel < 0) {
+        p.partial = nullptr;
+        err = launch_gett_simple(p, (int)plan->dtype, plan->accumulate64, stream);
+    } else {
+        int count = 0;
+        const GettKernelInfo* tab = gett_f32_kernels(&count);
+        p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, stream);
+        err = tab[plan->choice.kernel].launch(p, stream);
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, stream);
+            std::lock_guard<std::mutex> g(g_prof.mtx);
+            g_prof.events.emplace_back(e0, e1);
+        }
+        if (err == hipSuccess && plan->choice.splitK > 1) {
+            SplitKReduceParams r = plan->skr;
+            r.partial = static_cast<float*>(workspace);
+            r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
+            err = launch_splitk_reduce(r, stream);
+        }
+    }
+    if (err != hipSuccess) { CT_LOG("cutensorContract: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+static hipError_t run_elementwise(const EwPlan& ew, hipDataType dtype, double a, const void* A, double g,
+                                  const void* C, void* D, hipStream_t stream) {
+    Ew2DParams p = ew.p;
+    p.A = A;
+    p.C = (ew.usesC && g != 0.0) ? C : nullptr;
+    p.D = D;
+    p.alpha = (float)a; p.gamma = (float)g; p.alpha64 = a; p.gamma64 = g;
+    return launch_elementwise(p, ew.variant, (int)dtype, stream);
+}
+
+// reduction.cu:219-222, einsum.cu:369-372
+cutensorStatus_t cutensorReduce(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                const void* A, const void* beta, const void* C, void* D, void* workspace,
+                                uint64_t workspaceSize, cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::Reduction) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || beta == nullptr || A == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    const double a = scalar_as_double(alpha, plan->scalarType), b = scalar_as_double(beta, plan->scalarType);
+    if (b != 0.0 && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(D, plan->alignD) || (b != 0.0 && misaligned(C, plan->alignC)))
+        return CUTENSOR_STATUS_INVALID_VALUE;
+    hipError_t err;
+    if (plan->red.isPermutation) {
+        err = run_elementwise(plan->red.perm, plan->dtype, a, A, b, C, D, stream);
+    } else {
+        if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
+            return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+        ReduceParams p = plan->red.p;
+        p.A = A; p.C = (b != 0.0) ? C : D; p.D = D;
+        p.alpha = (float)a; p.beta = (float)b; p.alpha64 = a; p.beta64 = b;
+        p.partial = (p.splitR > 1) ? workspace : nullptr;
+        const bool acc64 = plan->accumulate64 || plan->dtype == HIP_R_64F;
+        err = launch_reduce(p, plan->red.variant, (int)plan->dtype, acc64, stream);
+        if (err == hipSuccess && p.splitR > 1) err = launch_reduce_finalize(p, (int)plan->dtype, acc64, stream);
+    }
+    if (err != hipSuccess) { CT_LOG("cutensorReduce: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// elementwise_permute.cu:198-200
+cutensorStatus_t cutensorPermute(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                 const void* A, void* B, const cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::Permutation) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || A == nullptr || B == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(B, plan->alignD)) return CUTENSOR_STATUS_INVALID_VALUE;
+    const double a = scalar_as_double(alpha, plan->scalarType);
+    hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, B, stream);
+    if (err != hipSuccess) { CT_LOG("cutensorPermute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// elementwise_binary.cu:202-205
+cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
+                                                  const void* alpha, const void* A, const void* gamma,
+                                                  const void* C, void* D, cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::ElementwiseBinary) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || gamma == nullptr || A == nullptr || C == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(C, plan->alignC) || misaligned(D, plan->alignD)) return CUTENSOR_STATUS_INVALID_VALUE;
+    const double a = scalar_as_double(alpha, plan->scalarType), g = scalar_as_double(gamma, plan->scalarType);
+    hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, g, C, D, stream);
+    if (err != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// utils.cuh:38
+const char* cutensorGetErrorString(const cutensorStatus_t error) {
+    switch (error) {
+        case CUTENSOR_STATUS_SUCCESS: return "CUTENSOR_STATUS_SUCCESS";
+        case CUTENSOR_STATUS_NOT_INITIALIZED: return "CUTENSOR_STATUS_NOT_INITIALIZED";
+        case CUTENSOR_STATUS_ALLOC_FAILED: return "CUTENSOR_STATUS_ALLOC_FAILED";
+        case CUTENSOR_STATUS_INVALID_VALUE: return "CUTENSOR_STATUS_INVALID_VALUE";
+        case CUTENSOR_STATUS_ARCH_MISMATCH: return "CUTENSOR_STATUS_ARCH_MISMATCH";
+        case CUTENSOR_STATUS_MAPPING_ERROR: return "CUTENSOR_STATUS_MAPPING_ERROR";
+        case CUTENSOR_STATUS_EXECUTION_FAILED: return "CUTENSOR_STATUS_EXECUTION_FAILED";
+        case CUTENSOR_STATUS_INTERNAL_ERROR: return "CUTENSOR_STATUS_INTERNAL_ERROR";
+        case CUTENSOR_STATUS_NOT_SUPPORTED: return "CUTENSOR_STATUS_NOT_SUPPORTED";
+        case CUTENSOR_STATUS_LICENSE_ERROR: return "CUTENSOR_STATUS_LICENSE_ERROR";
+        case CUTENSOR_STATUS_CUBLAS_ERROR: return "CUTENSOR_STATUS_CUBLAS_ERROR";
+        case CUTENSOR_STATUS_CUDA_ERROR: return "CUTENSOR_STATUS_CUDA_ERROR";
+        case CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE: return "CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE";
+        case CUTENSOR_STATUS_INSUFFICIENT_DRIVER: return "CUTENSOR_STATUS_INSUFFICIENT_DRIVER";
+        case CUTENSOR_STATUS_IO_ERROR: return "CUTENSOR_STATUS_IO_ERROR";
+        default: return "<unknown>";
+    }
+}
+
+size_t cutensorGetVersion(void) { return CUTENSOR_VERSION; }
+
+// ---- diagnostics (not part of the cuTENSOR ABI; used by the tests and the bench) ----------------
+// Writes a one-line JSON description of the plan's kernel choice into buf.
+int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
+    if (plan == nullptr || buf == nullptr || len == 0) return -1;
+    int n = 0;
+    if (plan->kind == OpKind::Contraction) {
+        int count = 0;
+        const GettKernelInfo* tab = gett_f32_kernels(&count);
+        const int k = plan->choice.kernel;
+        n = std::snprintf(buf, len,
+                          "{\"op\":\"contraction\",\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
+                          "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
+                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f}",
+                          (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
+                          (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
+                          plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
+                          k >= 0 ? tab[k].bk : 16, k >= 0 ? tab[k].wm : 1, k >= 0 ? tab[k].wn : 1, k >= 0 ? tab[k].wk : 1,
+                          plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
+                          (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs);
+    } else if (plan->kind == OpKind::Reduction && !plan->red.isPermutation) {
+        n = std::snprintf(buf, len, "{\"op\":\"reduction\",\"variant\":%d,\"kept\":%u,\"red\":%u,\"splitR\":%u,\"workspace\":%llu}",
+                          plan->red.variant, plan->red.p.kept.total, plan->red.p.red.total, plan->red.p.splitR,
+                          (unsigned long long)plan->requiredWorkspace);
+    } else {
+        const EwPlan& e = (plan->kind == OpKind::Reduction) ? plan->red.perm : plan->ew;
+        n = std::snprintf(buf, len, "{\"op\":\"elementwise\",\"variant\":%d,\"E0\":%u,\"E1\":%u,\"rest\":%u,\"blocks\":%u}",
+                          e.variant, e.p.E0, e.p.E1, e.p.rest.total, e.p.nBlocks);
+    }
+    return n;
+}
+
+// Per-kernel timing of the GETT kernel inside cutensorContract: Begin() arms it, End() synchronises the
+// recorded event pairs and returns the number of launches and their mean / min duration in ms.
+void ctamdProfileBegin(void) {
+    std::lock_guard<std::mutex> g(g_prof.mtx);
+    g_prof.events.clear();
+    g_prof.enabled = true;
+}
+int ctamdProfileEnd(float* meanMs, float* minMs) {
+    std::lock_guard<std::mutex> g(g_prof.mtx);
+    g_prof.enabled = false;
+    double sum = 0.0;
+    float mn = 1e30f;
+    int n = 0;
+    for (auto& ev : g_prof.events) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) {
+            sum += t;
+            mn = std::min(mn, t);
+            ++n;
+        }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    g_prof.events.clear();
+    if (meanMs) *meanMs = n ? (float)(sum / n) : 0.f;
+    if (minMs) *minMs = n ? mn : 0.f;
+    return n;
+}
+
+// Number of ranked candidates for a contraction descriptor under a workspace limit (so that a
+// caller can sweep CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK / algo >= 0 exhaustively).
+int ctamdCountCandidates(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc, uint64_t wsLimit) {
+    if (handle == nullptr || desc == nullptr || desc->kind != OpKind::Contraction) return -1;
+    ContractionView v;
+    if (build_contraction_view(*desc, v, nullptr) != CUTENSOR_STATUS_SUCCESS) return -1;
+    if (v.dtype != HIP_R_32F) return 0;
+    return (int)rank_contraction_choices(v, wsLimit, handle->numCUs).size();
+}
+
+}  // extern "C"

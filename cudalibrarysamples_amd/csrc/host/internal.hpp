@@ -1,0 +1,146 @@
+// internal.hpp — objects behind the opaque cuTENSOR handles and the planner interfaces.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <cutensor.h>
+
+#include "../kernels/launch.h"
+#include "../kernels/params.h"
+
+// The ABI names these structs only as opaque pointer targets (cutensor/types.h).
+struct cutensorComputeDescriptor {
+    int      id;          // index into the exported constants
+    uint32_t legacyBits;  // cutensorComputeType_t value (Mg entry points)
+};
+
+struct cutensorTensorDescriptor {
+    uint32_t             numModes = 0;
+    std::vector<int64_t> extent;
+    std::vector<int64_t> stride;
+    hipDataType          dtype = HIP_R_32F;
+    uint32_t             alignment = 0;
+    int64_t numElementsSpanned() const;  // 1 + sum (extent-1)*stride
+};
+
+enum class OpKind : int { Contraction = 0, Reduction = 1, Permutation = 2, ElementwiseBinary = 3 };
+
+struct TensorUse {
+    cutensorTensorDescriptor desc;
+    std::vector<int32_t>     modes;
+    cutensorOperator_t       op = CUTENSOR_OP_IDENTITY;
+    bool                     present = false;
+};
+
+struct cutensorOperationDescriptor {
+    OpKind      kind;
+    TensorUse   A, B, C, D;
+    cutensorOperator_t opReduce = CUTENSOR_OP_ADD;   // reduction operator / binary combiner
+    const cutensorComputeDescriptor* compute = nullptr;
+    hipDataType scalarType = HIP_R_32F;
+    int32_t     tag = 0;
+    double      flops = 0.0;
+    double      movedBytes = 0.0;
+};
+
+struct cutensorPlanPreference {
+    cutensorAlgo_t         algo = CUTENSOR_ALGO_DEFAULT;
+    cutensorJitMode_t      jit = CUTENSOR_JIT_MODE_NONE;
+    cutensorAutotuneMode_t autotune = CUTENSOR_AUTOTUNE_MODE_NONE;
+    cutensorCacheMode_t    cacheMode = CUTENSOR_CACHE_MODE_PEDANTIC;
+    int32_t                incrementalCount = 4;
+    int32_t                kernelRank = 0;
+};
+
+namespace ctamd {
+
+// ---- contraction planning --------------------------------------------------------------------
+struct CanonMode {
+    int32_t label;
+    int64_t extent;
+    int64_t sA = 0, sB = 0, sC = 0, sD = 0;   // element strides (kernel-A / kernel-B / C / D)
+};
+
+struct ContractionView {
+    std::vector<CanonMode> L, M, N, K;   // fused, fastest first
+    bool     swapped = false;            // kernel-A is the user's B
+    int      layA = LAY_S, layB = LAY_S; // best layout each operand admits
+    hipDataType dtype = HIP_R_32F;
+    uint64_t totL = 1, totM = 1, totN = 1, totK = 1;
+};
+
+// One executable choice for a contraction.
+struct ContractionChoice {
+    int      kernel = -1;      // index into gett_f32_kernels(); -1 = simple kernel
+    uint32_t splitK = 1;
+    uint32_t kPerSlice = 0;
+    uint64_t workspace = 0;
+    double   estimateUs = 0.0;
+};
+
+cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, ContractionView& v,
+                                        std::string* why);
+// Ranked candidate list (best first) under a workspace limit.
+std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
+                                                        int numCUs);
+void fill_gett_params(const ContractionView& v, const ContractionChoice& c, GettParams& p,
+                      SplitKReduceParams& r);
+
+// ---- element-wise / reduction planning -------------------------------------------------------
+struct EwPlan {
+    int        variant = EW_GENERIC;
+    Ew2DParams p{};              // pointers / scalars are filled at launch
+    bool       usesC = false;
+};
+struct ReducePlan {
+    int          variant = RED_GENERIC;
+    ReduceParams p{};
+    uint64_t     workspace = 0;
+    bool         isPermutation = false;   // no reduced modes: executed by the element-wise family
+    EwPlan       perm;
+};
+
+cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why);
+cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t wsLimit, int numCUs,
+                                ReducePlan& plan, std::string* why);
+
+FastDiv make_fastdiv(uint32_t d);
+size_t  dtype_size(hipDataType t);
+
+}  // namespace ctamd
+
+struct cutensorPlan {
+    OpKind      kind;
+    hipDataType dtype = HIP_R_32F;
+    hipDataType scalarType = HIP_R_32F;
+    uint64_t    requiredWorkspace = 0;
+    uint32_t    alignA = 0, alignB = 0, alignC = 0, alignD = 0;  // pointer alignment the plan relies on
+    // contraction
+    ctamd::ContractionView     view;
+    ctamd::ContractionChoice   choice;
+    ctamd::GettParams          gett{};
+    ctamd::SplitKReduceParams  skr{};
+    bool                       accumulate64 = false;
+    // element-wise / reduction
+    ctamd::EwPlan     ew;
+    ctamd::ReducePlan red;
+};
+
+struct PlanCacheEntry {
+    std::string key;
+    int         kernel;
+    uint32_t    splitK;
+};
+
+struct cutensorHandle {
+    int device = 0;
+    int numCUs = 256;
+    int clockKHz = 2400000;
+    std::mutex mtx;
+    uint32_t planCacheCapacity = 0;
+    std::map<std::string, PlanCacheEntry> planCache;   // problem signature -> tuned choice
+    int logLevel = 0;
+};

@@ -1,0 +1,357 @@
+// plan_contraction.cpp — host planner for cutensorCreateContraction / cutensorCreatePlan.
+//
+// Turns "D_{modesD} = alpha * A_{modesA} * B_{modesB} + beta * C_{modesC}" (reference call site:
+// cuTENSOR/contraction.cu:162-168, mode/extent conventions :46-59, packed column-major strides
+// blocksparse.cu:80-81) into the GEMM view consumed by the gfx950 GETT kernels:
+//
+//   1. classify every mode label: L (in A, B and C), M (A and C), N (B and C), K (A and B);
+//   2. drop extent-1 modes;
+//   3. orient the problem so that the group holding D's stride-1 mode becomes kernel-N (the MFMA
+//      output puts 16 consecutive lanes along n, so D stores are coalesced) — this may swap the
+//      roles of A and B;
+//   4. order the modes of each group by the stride of the tensor whose loads they drive, and fuse
+//      neighbours that are jointly contiguous in every tensor that carries them ("mode fusion");
+//   5. decide, per operand, whether 16-byte lanes can run along a free mode (LAY_F), along the
+//      contracted mode (LAY_K), or not at all (LAY_S);
+//   6. rank (tile shape, split-K) candidates with a small roofline cost model.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "internal.hpp"
+
+namespace ctamd {
+
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{};
+    f.d = d;
+    if (d < 2) {  // never used for division (extent-1 modes are dropped); keep it harmless
+        f.magic = 0;
+        f.shift = 0;
+        return f;
+    }
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;                     // s = ceil(log2 d) >= 1
+    const uint64_t m = ((1ull << (31 + s)) / d) + 1;  // < 2^32, exact for n < 2^31
+    f.magic = (uint32_t)m;
+    f.shift = s - 1;                                  // q = mulhi(n, magic) >> (s-1)
+    return f;
+}
+
+size_t dtype_size(hipDataType t) {
+    switch (t) {
+        case HIP_R_16F: case HIP_R_16BF: return 2;
+        case HIP_R_32F: return 4;
+        case HIP_R_64F: return 8;
+        case HIP_C_32F: return 8;
+        case HIP_C_64F: return 16;
+        default: return 0;
+    }
+}
+
+static int find_mode(const std::vector<int32_t>& modes, int32_t label) {
+    for (size_t i = 0; i < modes.size(); ++i)
+        if (modes[i] == label) return (int)i;
+    return -1;
+}
+
+static bool has_duplicates(const std::vector<int32_t>& modes) {
+    for (size_t i = 0; i < modes.size(); ++i)
+        for (size_t j = i + 1; j < modes.size(); ++j)
+            if (modes[i] == modes[j]) return true;
+    return false;
+}
+
+// Fuse neighbours i, i+1 when every stride slot satisfies s[i+1] == s[i] * extent[i].
+static void fuse_group(std::vector<CanonMode>& g, bool useA, bool useB, bool useCD) {
+    std::vector<CanonMode> out;
+    for (const CanonMode& m : g) {
+        if (!out.empty()) {
+            CanonMode& p = out.back();
+            bool ok = true;
+            if (useA) ok = ok && (m.sA == p.sA * p.extent);
+            if (useB) ok = ok && (m.sB == p.sB * p.extent);
+            if (useCD) ok = ok && (m.sC == p.sC * p.extent) && (m.sD == p.sD * p.extent);
+            if (ok && p.extent * m.extent < (1ll << 31)) {
+                p.extent *= m.extent;
+                continue;
+            }
+        }
+        out.push_back(m);
+    }
+    g.swap(out);
+}
+
+static uint64_t group_total(const std::vector<CanonMode>& g) {
+    uint64_t t = 1;
+    for (const CanonMode& m : g) t *= (uint64_t)m.extent;
+    return t;
+}
+
+cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, ContractionView& v,
+                                        std::string* why) {
+    auto fail = [&](cutensorStatus_t st, const char* msg) {
+        if (why) *why = msg;
+        return st;
+    };
+    const TensorUse &A = op.A, &B = op.B, &C = op.C, &D = op.D;
+    if (has_duplicates(A.modes) || has_duplicates(B.modes) || has_duplicates(C.modes))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
+    if (C.modes != D.modes) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "modes of C and D differ");
+    if (C.desc.extent != D.desc.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extents of C and D differ");
+    if (A.desc.dtype != B.desc.dtype || A.desc.dtype != C.desc.dtype || C.desc.dtype != D.desc.dtype)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mixed data types");
+    if (A.op != CUTENSOR_OP_IDENTITY && A.op != CUTENSOR_OP_CONJ) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "opA");
+    if (B.op != CUTENSOR_OP_IDENTITY && B.op != CUTENSOR_OP_CONJ) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "opB");
+    if (C.op != CUTENSOR_OP_IDENTITY && C.op != CUTENSOR_OP_CONJ) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "opC");
+
+    v = ContractionView{};
+    v.dtype = A.desc.dtype;
+
+    // gather distinct labels in a stable order: A's, then B's, then C's
+    std::vector<int32_t> labels;
+    auto add = [&](const std::vector<int32_t>& ms) {
+        for (int32_t l : ms)
+            if (std::find(labels.begin(), labels.end(), l) == labels.end()) labels.push_back(l);
+    };
+    add(A.modes); add(B.modes); add(C.modes);
+
+    std::vector<CanonMode> gL, gFreeA, gFreeB, gK;   // free-of-A = in A and C, free-of-B = in B and C
+    for (int32_t l : labels) {
+        const int ia = find_mode(A.modes, l), ib = find_mode(B.modes, l), ic = find_mode(C.modes, l);
+        CanonMode m;
+        m.label = l;
+        int64_t e = -1;
+        auto take = [&](const TensorUse& T, int idx, int64_t& stride) -> bool {
+            if (idx < 0) return true;
+            if (e >= 0 && T.desc.extent[idx] != e) return false;
+            e = T.desc.extent[idx];
+            stride = T.desc.stride[idx];
+            return true;
+        };
+        int64_t sa = 0, sb = 0, sc = 0, sd = 0;
+        if (!take(A, ia, sa) || !take(B, ib, sb) || !take(C, ic, sc))
+            return fail(CUTENSOR_STATUS_INVALID_VALUE, "a mode has different extents in different tensors");
+        if (ic >= 0) sd = D.desc.stride[ic];
+        m.extent = e; m.sA = sa; m.sB = sb; m.sC = sc; m.sD = sd;
+        if (e == 1) continue;   // extent-1 modes carry no index
+        if (e <= 0) return fail(CUTENSOR_STATUS_INVALID_VALUE, "non-positive extent");
+        if (ia >= 0 && ib >= 0 && ic >= 0) gL.push_back(m);
+        else if (ia >= 0 && ic >= 0) gFreeA.push_back(m);
+        else if (ib >= 0 && ic >= 0) gFreeB.push_back(m);
+        else if (ia >= 0 && ib >= 0) gK.push_back(m);
+        else return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mode appears in only one tensor");
+    }
+
+    // orientation: the free group that carries D's smallest stride becomes kernel-N
+    int64_t bestA = INT64_MAX, bestB = INT64_MAX;
+    for (const CanonMode& m : gFreeA) bestA = std::min(bestA, m.sD);
+    for (const CanonMode& m : gFreeB) bestB = std::min(bestB, m.sD);
+    v.swapped = (bestA < bestB);   // D's fastest free mode lives in A  => A plays kernel-B
+    if (v.swapped) {
+        for (auto* g : {&gL, &gFreeA, &gFreeB, &gK})
+            for (CanonMode& m : *g) std::swap(m.sA, m.sB);
+        v.M = gFreeB;   // kernel-A = user's B, its free modes
+        v.N = gFreeA;
+    } else {
+        v.M = gFreeA;
+        v.N = gFreeB;
+    }
+    v.K = gK;
+    v.L = gL;
+
+    auto bySA = [](const CanonMode& x, const CanonMode& y) { return x.sA < y.sA; };
+    auto bySB = [](const CanonMode& x, const CanonMode& y) { return x.sB < y.sB; };
+    auto bySD = [](const CanonMode& x, const CanonMode& y) { return x.sD < y.sD; };
+    std::stable_sort(v.M.begin(), v.M.end(), bySA);
+    std::stable_sort(v.N.begin(), v.N.end(), bySD);
+    std::stable_sort(v.L.begin(), v.L.end(), bySD);
+    // K: follow whichever operand is K-contiguous (A first), else A's order.
+    bool kContigA = false, kContigB = false;
+    for (const CanonMode& m : v.K) { kContigA |= (m.sA == 1); kContigB |= (m.sB == 1); }
+    const char* korder = std::getenv("CUTENSOR_AMD_KORDER");   // experiment knob: "A" or "B"
+    bool followB = (!kContigA && kContigB);
+    if (korder && korder[0] == 'B') followB = true;
+    if (korder && korder[0] == 'A') followB = false;
+    if (followB) std::stable_sort(v.K.begin(), v.K.end(), bySB);
+    else         std::stable_sort(v.K.begin(), v.K.end(), bySA);
+
+    fuse_group(v.M, true, false, true);
+    fuse_group(v.N, false, true, true);
+    fuse_group(v.K, true, true, false);
+    fuse_group(v.L, true, true, true);
+
+    v.totL = group_total(v.L); v.totM = group_total(v.M);
+    v.totN = group_total(v.N); v.totK = group_total(v.K);
+    const uint64_t lim = (1ull << 31) - 1;
+    if (v.totL > lim || v.totM > lim || v.totN > lim || v.totK > lim)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "a fused mode group exceeds 2^31-1 elements");
+    if ((int)v.L.size() > kMaxGroupModes || (int)v.M.size() > kMaxGroupModes ||
+        (int)v.N.size() > kMaxGroupModes || (int)v.K.size() > kMaxGroupModes)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 8 unfusable modes in one group");
+
+    // ---- operand layouts (fp32 path: 4-element = 16-byte lanes) ------------------------------
+    auto all_mult4_except = [](const std::vector<const std::vector<CanonMode>*>& groups, bool slotA,
+                               const CanonMode* except) {
+        for (auto* g : groups)
+            for (const CanonMode& m : *g) {
+                if (&m == except) continue;
+                const int64_t s = slotA ? m.sA : m.sB;
+                if (s % 4 != 0) return false;
+            }
+        return true;
+    };
+    const uint32_t alignA = v.swapped ? op.B.desc.alignment : op.A.desc.alignment;
+    const uint32_t alignB = v.swapped ? op.A.desc.alignment : op.B.desc.alignment;
+    auto pick = [&](bool slotA, const std::vector<CanonMode>& freeG, uint32_t align) {
+        if (align % 16 != 0) return (int)LAY_S;
+        std::vector<const std::vector<CanonMode>*> groups = {&freeG, &v.K, &v.L};
+        if (!v.K.empty()) {
+            const CanonMode& k0 = v.K.front();
+            const int64_t s = slotA ? k0.sA : k0.sB;
+            if (s == 1 && k0.extent % 4 == 0 && all_mult4_except(groups, slotA, &k0)) return (int)LAY_K;
+        }
+        if (!freeG.empty()) {
+            const CanonMode& f0 = freeG.front();
+            const int64_t s = slotA ? f0.sA : f0.sB;
+            if (s == 1 && f0.extent % 4 == 0 && all_mult4_except(groups, slotA, &f0)) return (int)LAY_F;
+        }
+        return (int)LAY_S;
+    };
+    v.layA = pick(true, v.M, alignA);
+    v.layB = pick(false, v.N, alignB);
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cost model.  Constants are gfx950 figures from the microarchitecture guide; the model only has
+// to order candidates, not predict wall time.
+// ---------------------------------------------------------------------------------------------
+static double tile_efficiency(const GettKernelInfo& k) {
+    // fraction of MFMA issue a resident workgroup of this shape sustains (measured on MI355X,
+    // see profiles/): small tiles read more LDS bytes per flop and expose more barrier time.
+    const int area = k.bm * k.bn;
+    if (area >= 128 * 128) return 0.85;
+    if (area >= 96 * 96) return 0.80;
+    if (area >= 64 * 64) return 0.65;
+    if (area >= 48 * 48) return 0.70;
+    return 0.45;
+}
+
+std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
+                                                        int numCUs) {
+    std::vector<ContractionChoice> out;
+    int count = 0;
+    const GettKernelInfo* tab = gett_f32_kernels(&count);
+    const double clk = 2.4e9, flopPerClkCU = 256.0;
+    const double hbm = 6.0e12, l2bw = 20.0e12;
+    const double M = (double)v.totM, N = (double)v.totN, K = (double)v.totK, L = (double)v.totL;
+
+    for (int i = 0; i < count; ++i) {
+        const GettKernelInfo& k = tab[i];
+        // a kernel is usable if each operand admits its layout (LAY_S kernels take anything)
+        const bool okA = (k.layA == v.layA) || (k.layA == LAY_S);
+        const bool okB = (k.layB == v.layB) || (k.layB == LAY_S);
+        if (!okA || !okB) continue;
+        if ((k.layA == LAY_S) != (k.layB == LAY_S)) continue;   // table only holds S/S pairs
+        if (k.layA == LAY_S && v.layA != LAY_S && v.layB != LAY_S) continue;  // vector kernels exist
+
+        const uint64_t tilesM = (v.totM + k.bm - 1) / k.bm, tilesN = (v.totN + k.bn - 1) / k.bn;
+        const uint64_t tiles = tilesM * tilesN * v.totL;
+        const uint64_t kTiles = (v.totK + k.bk - 1) / k.bk;
+        // split-K candidates: 1, and powers of two up to what keeps >= 4 K-tiles per slice
+        std::vector<uint32_t> splits = {1};
+        for (uint32_t s = 2; s <= 1024; s *= 2) {
+            if (kTiles / s < 4) break;
+            if (tiles * s > (uint64_t)numCUs * 16) break;
+            splits.push_back(s);
+        }
+        for (uint32_t s : splits) {
+            ContractionChoice c;
+            c.kernel = i;
+            const uint64_t tilesPerSlice = (kTiles + s - 1) / s;
+            c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
+            c.splitK = (uint32_t)((v.totK + c.kPerSlice - 1) / c.kPerSlice);
+            if (c.splitK < 1) c.splitK = 1;
+            if (c.splitK != s && s != 1) continue;   // rounding collapsed this candidate
+            c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
+            if (c.workspace > wsLimit) continue;
+
+            const double blocks = (double)tiles * c.splitK;
+            const double wgPerCU = 2.0;
+            const double slots = numCUs * wgPerCU;
+            const double rounds = std::ceil(blocks / slots);
+            const double flopsBlock = 2.0 * k.bm * k.bn * (double)c.kPerSlice;
+            // a CU shares its MFMA pipes between resident workgroups
+            const double tBlock = flopsBlock / (flopPerClkCU * clk * tile_efficiency(k) / wgPerCU);
+            const double occupancyFill = std::min(1.0, blocks / slots);
+            double tCompute = rounds * tBlock * (occupancyFill < 1.0 && blocks < numCUs ? 0.5 : 1.0);
+            if (blocks <= numCUs) tCompute = flopsBlock / (flopPerClkCU * clk * tile_efficiency(k));
+            // traffic: every tile row re-reads its A panel, every tile column its B panel
+            const double bytesA = 4.0 * L * (double)tilesM * k.bm * K * (double)tilesN;
+            const double bytesB = 4.0 * L * (double)tilesN * k.bn * K * (double)tilesM;
+            const double bytesUnique = 4.0 * L * (M * K + N * K + M * N);
+            const double bytesPartial = (c.splitK > 1) ? 2.0 * (double)c.workspace : 0.0;
+            const double tMem = std::max((bytesA + bytesB) / l2bw, (bytesUnique + bytesPartial) / hbm);
+            const double tFix = (c.splitK > 1) ? 3.0e-6 : 0.0;
+            c.estimateUs = (std::max(tCompute, tMem) + tFix + 2.0e-6) * 1e6;
+            out.push_back(c);
+        }
+    }
+    std::stable_sort(out.begin(), out.end(),
+                     [](const ContractionChoice& a, const ContractionChoice& b) { return a.estimateUs < b.estimateUs; });
+    return out;
+}
+
+static void fill_group(ModeGroup& g, const std::vector<CanonMode>& modes) {
+    std::memset(&g, 0, sizeof(g));
+    g.n = (int32_t)modes.size();
+    uint64_t tot = 1;
+    for (size_t i = 0; i < modes.size(); ++i) {
+        g.div[i] = make_fastdiv((uint32_t)modes[i].extent);
+        tot *= (uint64_t)modes[i].extent;
+    }
+    g.total = (uint32_t)tot;
+}
+
+void fill_gett_params(const ContractionView& v, const ContractionChoice& c, GettParams& p,
+                      SplitKReduceParams& r) {
+    std::memset(&p, 0, sizeof(p));
+    std::memset(&r, 0, sizeof(r));
+    fill_group(p.gM, v.M);
+    fill_group(p.gN, v.N);
+    fill_group(p.gK, v.K);
+    fill_group(p.gL, v.L);
+    for (size_t i = 0; i < v.M.size(); ++i) {
+        p.gM.stride[0][i] = v.M[i].sA; p.gM.stride[1][i] = v.M[i].sD; p.cStrideM[i] = v.M[i].sC;
+    }
+    for (size_t i = 0; i < v.N.size(); ++i) {
+        p.gN.stride[0][i] = v.N[i].sB; p.gN.stride[1][i] = v.N[i].sD; p.cStrideN[i] = v.N[i].sC;
+    }
+    for (size_t i = 0; i < v.K.size(); ++i) {
+        p.gK.stride[0][i] = v.K[i].sA; p.gK.stride[1][i] = v.K[i].sB;
+    }
+    for (size_t i = 0; i < v.L.size(); ++i) {
+        p.gL.stride[0][i] = v.L[i].sA; p.gL.stride[1][i] = v.L[i].sB; p.gL.stride[2][i] = v.L[i].sD;
+        p.cStrideL[i] = v.L[i].sC;
+    }
+    int count = 0;
+    const GettKernelInfo* tab = gett_f32_kernels(&count);
+    int bm = 16, bn = 16, bk = 16;
+    if (c.kernel >= 0 && c.kernel < count) { bm = tab[c.kernel].bm; bn = tab[c.kernel].bn; bk = tab[c.kernel].bk; }
+    (void)bk;
+    p.tilesM = (uint32_t)((v.totM + bm - 1) / bm);
+    p.tilesN = (uint32_t)((v.totN + bn - 1) / bn);
+    p.splitK = c.splitK;
+    p.kPerSlice = c.kPerSlice ? c.kPerSlice : (uint32_t)v.totK;
+    p.nBlocks = (uint32_t)((uint64_t)p.tilesM * p.tilesN * p.splitK * v.totL);
+
+    r.gM = p.gM; r.gN = p.gN; r.gL = p.gL;
+    std::memcpy(r.cStrideM, p.cStrideM, sizeof(r.cStrideM));
+    std::memcpy(r.cStrideN, p.cStrideN, sizeof(r.cStrideN));
+    std::memcpy(r.cStrideL, p.cStrideL, sizeof(r.cStrideL));
+    r.splitK = c.splitK;
+}
+
+}  // namespace ctamd

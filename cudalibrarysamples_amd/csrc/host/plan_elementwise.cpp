@@ -1,0 +1,272 @@
+// plan_elementwise.cpp — host planners for cutensorCreatePermutation / ElementwiseBinary /
+// cutensorCreateReduction (reference call sites: cuTENSOR/elementwise_permute.cu:142-149,
+// cuTENSOR/elementwise_binary.cu:149-153, cuTENSOR/reduction.cu:141-146, cuTENSOR/einsum.cu:346-351).
+//
+// Both planners canonicalise the strided N-mode problem (drop extent-1 modes, sort by stride, fuse
+// jointly contiguous neighbours) and then choose the kernel variant whose vector-width and alignment
+// preconditions hold (see kernels/elementwise.hip and kernels/reduce.hip).
+#include <algorithm>
+#include <cstring>
+
+#include "internal.hpp"
+
+namespace ctamd {
+
+namespace {
+
+struct EwMode {
+    int64_t extent;
+    int64_t sA = 0, sD = 0, sC = 0;
+};
+
+int find_label(const std::vector<int32_t>& modes, int32_t l) {
+    for (size_t i = 0; i < modes.size(); ++i)
+        if (modes[i] == l) return (int)i;
+    return -1;
+}
+
+bool dup_labels(const std::vector<int32_t>& modes) {
+    for (size_t i = 0; i < modes.size(); ++i)
+        for (size_t j = i + 1; j < modes.size(); ++j)
+            if (modes[i] == modes[j]) return true;
+    return false;
+}
+
+void fuse(std::vector<EwMode>& g, bool useC) {
+    std::vector<EwMode> out;
+    for (const EwMode& m : g) {
+        if (!out.empty()) {
+            EwMode& p = out.back();
+            bool ok = (m.sA == p.sA * p.extent) && (m.sD == p.sD * p.extent);
+            if (useC) ok = ok && (m.sC == p.sC * p.extent);
+            if (ok && p.extent * m.extent < (1ll << 31)) {
+                p.extent *= m.extent;
+                continue;
+            }
+        }
+        out.push_back(m);
+    }
+    g.swap(out);
+}
+
+bool fill_rest(ModeGroup& g, const std::vector<EwMode>& modes) {
+    std::memset(&g, 0, sizeof(g));
+    if ((int)modes.size() > kMaxGroupModes) return false;
+    g.n = (int32_t)modes.size();
+    uint64_t tot = 1;
+    for (size_t i = 0; i < modes.size(); ++i) {
+        g.div[i] = make_fastdiv((uint32_t)modes[i].extent);
+        g.stride[0][i] = modes[i].sA;
+        g.stride[1][i] = modes[i].sD;
+        g.stride[2][i] = modes[i].sC;
+        tot *= (uint64_t)modes[i].extent;
+        if (tot >= (1ull << 31)) return false;
+    }
+    g.total = (uint32_t)tot;
+    return true;
+}
+
+}  // namespace
+
+cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why) {
+    auto fail = [&](cutensorStatus_t st, const char* msg) {
+        if (why) *why = msg;
+        return st;
+    };
+    const TensorUse &A = op.A, &C = op.C, &D = op.D;
+    const bool usesC = C.present;
+    if (dup_labels(A.modes) || dup_labels(D.modes) || (usesC && dup_labels(C.modes)))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
+    if (A.desc.dtype != D.desc.dtype || (usesC && C.desc.dtype != D.desc.dtype))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mixed data types");
+    if (A.op != CUTENSOR_OP_IDENTITY || (usesC && C.op != CUTENSOR_OP_IDENTITY))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    for (int32_t l : A.modes)
+        if (find_label(D.modes, l) < 0 && A.desc.extent[find_label(A.modes, l)] != 1)
+            return fail(CUTENSOR_STATUS_INVALID_VALUE, "mode of A missing from the output");
+    if (usesC)
+        for (int32_t l : C.modes)
+            if (find_label(D.modes, l) < 0 && C.desc.extent[find_label(C.modes, l)] != 1)
+                return fail(CUTENSOR_STATUS_INVALID_VALUE, "mode of C missing from the output");
+
+    std::vector<EwMode> modes;
+    for (size_t i = 0; i < D.modes.size(); ++i) {
+        EwMode m;
+        m.extent = D.desc.extent[i];
+        m.sD = D.desc.stride[i];
+        const int ia = find_label(A.modes, D.modes[i]);
+        if (ia >= 0) {
+            if (A.desc.extent[ia] != m.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extent mismatch between A and output");
+            m.sA = A.desc.stride[ia];
+        }   // absent => stride 0 (broadcast)
+        if (usesC) {
+            const int ic = find_label(C.modes, D.modes[i]);
+            if (ic >= 0) {
+                if (C.desc.extent[ic] != m.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extent mismatch between C and output");
+                m.sC = C.desc.stride[ic];
+            }
+        }
+        if (m.extent <= 0) return fail(CUTENSOR_STATUS_INVALID_VALUE, "non-positive extent");
+        if (m.extent == 1) continue;
+        modes.push_back(m);
+    }
+    std::stable_sort(modes.begin(), modes.end(), [](const EwMode& x, const EwMode& y) { return x.sD < y.sD; });
+    fuse(modes, usesC);
+
+    plan = EwPlan{};
+    plan.usesC = usesC;
+    Ew2DParams& p = plan.p;
+    std::memset(&p, 0, sizeof(p));
+    p.E0 = p.E1 = 1;
+    std::vector<EwMode> rest;
+    int i1 = -1;
+    if (!modes.empty()) {
+        const EwMode& m0 = modes[0];
+        if (m0.extent >= (1ll << 31)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mode extent >= 2^31");
+        p.E0 = (uint32_t)m0.extent; p.sA0 = m0.sA; p.sD0 = m0.sD; p.sC0 = m0.sC;
+        if (modes.size() > 1) {
+            i1 = 1;
+            if (m0.sA != 1) {   // partner dim = A's fastest remaining mode
+                for (size_t i = 1; i < modes.size(); ++i)
+                    if (modes[i].sA != 0 && (modes[i1].sA == 0 || modes[i].sA < modes[i1].sA)) i1 = (int)i;
+            }
+            const EwMode& m1 = modes[i1];
+            p.E1 = (uint32_t)m1.extent; p.sA1 = m1.sA; p.sD1 = m1.sD; p.sC1 = m1.sC;
+        }
+        for (size_t i = 1; i < modes.size(); ++i)
+            if ((int)i != i1) rest.push_back(modes[i]);
+    }
+    if (!fill_rest(p.rest, rest)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "too many unfusable modes");
+
+    // ---- variant --------------------------------------------------------------------------
+    const bool f32 = D.desc.dtype == HIP_R_32F;
+    const bool aligned = (A.desc.alignment % 16 == 0) && (D.desc.alignment % 16 == 0) &&
+                         (!usesC || C.desc.alignment % 16 == 0);
+    auto mult4 = [](int64_t s) { return s % 4 == 0; };
+    bool restOK = true;
+    for (const EwMode& m : rest) restOK = restOK && mult4(m.sA) && mult4(m.sD) && (!usesC || mult4(m.sC));
+    // C is read with 16-byte lanes only when it is contiguous along dim0; otherwise element-wise
+    const bool cOK = !usesC || p.sC0 != 1 || (mult4(p.sC1));
+    plan.variant = EW_GENERIC;
+    int t0 = 64, t1 = 4;
+    if (f32 && aligned && restOK && cOK && p.sD0 == 1 && p.E0 % 4 == 0) {
+        if (i1 >= 0 && p.sA1 == 1 && p.sA0 != 1 && p.E1 % 4 == 0 && mult4(p.sA0) && mult4(p.sD1)) {
+            plan.variant = EW_TRANSPOSE; t0 = 64; t1 = 64;
+        } else if (p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
+            plan.variant = EW_ROWCOPY; t0 = 256; t1 = 8;
+        }
+    }
+    p.tiles0 = (p.E0 + t0 - 1) / t0;
+    p.tiles1 = (p.E1 + t1 - 1) / t1;
+    p.divTiles0 = make_fastdiv(p.tiles0);
+    p.divTiles1 = make_fastdiv(p.tiles1);
+    const uint64_t nb = (uint64_t)p.tiles0 * p.tiles1 * p.rest.total;
+    if (nb >= (1ull << 31)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "tensor too large for the tile index space");
+    p.nBlocks = (uint32_t)nb;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t wsLimit, int numCUs,
+                                ReducePlan& plan, std::string* why) {
+    auto fail = [&](cutensorStatus_t st, const char* msg) {
+        if (why) *why = msg;
+        return st;
+    };
+    const TensorUse &A = op.A, &C = op.C, &D = op.D;
+    if (dup_labels(A.modes) || dup_labels(D.modes)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
+    if (C.modes != D.modes) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "modes of C and D differ");
+    if (C.desc.extent != D.desc.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extents of C and D differ");
+    if (A.desc.dtype != D.desc.dtype || C.desc.dtype != D.desc.dtype) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mixed data types");
+    if (A.op != CUTENSOR_OP_IDENTITY || C.op != CUTENSOR_OP_IDENTITY) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    const int rop = (int)op.opReduce;
+    if (rop != CUTENSOR_OP_ADD && rop != CUTENSOR_OP_MUL && rop != CUTENSOR_OP_MAX && rop != CUTENSOR_OP_MIN)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "reduction operator");
+    for (size_t i = 0; i < D.modes.size(); ++i) {
+        const int ia = find_label(A.modes, D.modes[i]);
+        if (ia < 0 && D.desc.extent[i] != 1) return fail(CUTENSOR_STATUS_INVALID_VALUE, "output mode missing from A");
+        if (ia >= 0 && A.desc.extent[ia] != D.desc.extent[i]) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extent mismatch");
+    }
+
+    std::vector<EwMode> kept, red;
+    for (size_t i = 0; i < A.modes.size(); ++i) {
+        EwMode m;
+        m.extent = A.desc.extent[i];
+        m.sA = A.desc.stride[i];
+        if (m.extent <= 0) return fail(CUTENSOR_STATUS_INVALID_VALUE, "non-positive extent");
+        if (m.extent == 1) continue;
+        const int id = find_label(D.modes, A.modes[i]);
+        if (id >= 0) {
+            m.sD = D.desc.stride[id];
+            m.sC = C.desc.stride[id];
+            kept.push_back(m);
+        } else {
+            red.push_back(m);
+        }
+    }
+    plan = ReducePlan{};
+    if (red.empty()) {
+        // pure permutation (einsum.cu:449-450 routes "nij->ijn" here): D = alpha*perm(A) + beta*C
+        cutensorOperationDescriptor e = op;
+        e.kind = OpKind::ElementwiseBinary;
+        e.C.present = true;
+        plan.isPermutation = true;
+        return plan_elementwise(e, plan.perm, why);
+    }
+    auto bySA = [](const EwMode& x, const EwMode& y) { return x.sA < y.sA; };
+    std::stable_sort(kept.begin(), kept.end(), bySA);
+    std::stable_sort(red.begin(), red.end(), bySA);
+    fuse(kept, true);
+    {   // reduced modes: only A matters
+        std::vector<EwMode> out;
+        for (const EwMode& m : red) {
+            if (!out.empty() && m.sA == out.back().sA * out.back().extent &&
+                out.back().extent * m.extent < (1ll << 31)) {
+                out.back().extent *= m.extent;
+                continue;
+            }
+            out.push_back(m);
+        }
+        red.swap(out);
+    }
+    ReduceParams& p = plan.p;
+    std::memset(&p, 0, sizeof(p));
+    if (!fill_rest(p.kept, kept) || !fill_rest(p.red, red))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mode group too large");
+    p.op = rop;
+
+    const bool f32 = A.desc.dtype == HIP_R_32F;
+    const bool acc64 = (op.compute != nullptr && op.compute->id == 5 /*64F*/) || A.desc.dtype == HIP_R_64F;
+    const bool aligned = A.desc.alignment % 16 == 0;
+    auto others_mult4 = [&](const EwMode* except) {
+        for (const EwMode& m : kept) if (&m != except && m.sA % 4 != 0) return false;
+        for (const EwMode& m : red)  if (&m != except && m.sA % 4 != 0) return false;
+        return true;
+    };
+    plan.variant = RED_GENERIC;
+    if (f32 && !acc64 && aligned) {
+        if (!kept.empty() && kept[0].sA == 1 && kept[0].extent % 4 == 0 && others_mult4(&kept[0])) plan.variant = RED_COL;
+        else if (red[0].sA == 1 && red[0].extent % 4 == 0 && others_mult4(&red[0])) plan.variant = RED_ROW;
+    }
+
+    // ---- how far to split the reduced range ------------------------------------------------
+    const uint64_t keptTot = p.kept.total, redTot = p.red.total;
+    uint64_t items, wantItems, minRedPerSplit, gran;
+    if (plan.variant == RED_COL)      { items = keptTot / 4; wantItems = (uint64_t)numCUs * 1024; minRedPerSplit = 32;   gran = 4; }
+    else if (plan.variant == RED_ROW) { items = keptTot;     wantItems = (uint64_t)numCUs * 32;   minRedPerSplit = 8192; gran = 1024; }
+    else                              { items = keptTot;     wantItems = (uint64_t)numCUs * 512;  minRedPerSplit = 64;   gran = 4; }
+    uint64_t split = 1;
+    if (items < wantItems) split = (wantItems + items - 1) / std::max<uint64_t>(items, 1);
+    split = std::min<uint64_t>(split, std::max<uint64_t>(redTot / minRedPerSplit, 1));
+    split = std::min<uint64_t>(split, 4096);
+    const uint64_t accBytes = (acc64 ? 8 : 4);
+    while (split > 1 && split * keptTot * accBytes > wsLimit) split /= 2;
+    uint64_t per = (redTot + split - 1) / split;
+    per = ((per + gran - 1) / gran) * gran;
+    split = (redTot + per - 1) / per;
+    p.splitR = (uint32_t)std::max<uint64_t>(split, 1);
+    p.redPerSplit = (uint32_t)per;
+    plan.workspace = (p.splitR > 1) ? (uint64_t)p.splitR * keptTot * accBytes : 0;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+}  // namespace ctamd

@@ -1,0 +1,230 @@
+// elementwise.hip — HBM-bound strided copy / permutation kernels for gfx950.
+//
+// Replaces the closed kernels behind cutensorPermute (reference call site:
+// cuTENSOR/elementwise_permute.cu:198-200, "C_{c,w,h,n} = alpha * A_{w,h,c,n}" :51-63),
+// cutensorElementwiseBinaryExecute (cuTENSOR/elementwise_binary.cu:202-205) and the permutation-only
+// use of cutensorReduce by the einsum helper (cuTENSOR/einsum.cu:449-450).
+//
+// Every tensor is walked through strides; nothing is reshaped.  The planner hands over two tile
+// modes plus a linearised remainder (Ew2DParams).  Roofline: HBM; algorithmic bytes per element =
+// 2 * sizeof(T) (+ sizeof(T) when a gamma*C term is read) — elementwise_permute.cu:208.
+//
+//   EW_TRANSPOSE  D's stride-1 mode (dim0) differs from A's stride-1 mode (dim1).  A 64 x 64 tile
+//                 is read with 16-byte lanes along dim1 (256-B contiguous segments per row),
+//                 transposed 4x4 in registers, parked in LDS as [dim1][dim0] and written with
+//                 16-byte lanes along dim0.  Both HBM sides see >= 256-B segments.
+//   EW_ROWCOPY    A and D share the stride-1 mode: 16-byte lanes along it, 8 dim1-rows per
+//                 workgroup, no LDS.
+//   EW_GENERIC    anything else (odd extents, unaligned bases, 2- and 8-byte types): one element
+//                 per lane, lanes along dim0.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "launch.h"
+#include "params.h"
+
+namespace ctamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t ew_fast_div(uint32_t n, const FastDiv& d) {
+    return (d.d < 2) ? n : (__umulhi(n, d.magic) >> d.shift);
+}
+
+// offsets of a rest index in A (slot 0), D (slot 1) and C (slot 2)
+__device__ __forceinline__ void rest_offsets(const ModeGroup& g, uint32_t idx, int64_t& oA, int64_t& oD,
+                                             int64_t& oC) {
+    oA = oD = oC = 0;
+    const int n = g.n;
+    for (int i = 0; i < n; ++i) {
+        uint32_t q = 0;
+        if (i + 1 < n) q = ew_fast_div(idx, g.div[i]);
+        const uint32_t digit = idx - q * g.div[i].d;
+        oA += (int64_t)digit * g.stride[0][i];
+        oD += (int64_t)digit * g.stride[1][i];
+        oC += (int64_t)digit * g.stride[2][i];
+        idx = q;
+    }
+}
+
+struct TileId { uint32_t t0, t1, rest; };
+__device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
+    TileId t;
+    uint32_t q = ew_fast_div(b, p.divTiles0);
+    t.t0 = b - q * p.tiles0;
+    const uint32_t q2 = ew_fast_div(q, p.divTiles1);
+    t.t1 = q - q2 * p.tiles1;
+    t.rest = q2;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EW_TRANSPOSE (fp32): requires sD0 == 1, sA1 == 1, E0 % 4 == 0, E1 % 4 == 0, every other stride
+// a multiple of 4 elements and 16-byte aligned bases.
+// ---------------------------------------------------------------------------------------------
+constexpr int TT = 64;          // tile edge
+constexpr int TT_LD = TT + 4;   // LDS row stride (floats), keeps rows 16-byte aligned
+
+__global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams p) {
+    __shared__ __attribute__((aligned(16))) float tile[TT * TT_LD];   // [dim1][dim0]
+    const float* A = static_cast<const float*>(p.A);
+    const float* C = static_cast<const float*>(p.C);
+    float*       D = static_cast<float*>(p.D);
+    const int tid = threadIdx.x;
+
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t i0 = t.t0 * TT, i1 = t.t1 * TT;   // tile origin (dim0, dim1)
+
+        // ---- read: lane -> (dim1 float4 c1 = tid%16, dim0 block r0 = tid/16), 4 dim0 rows each
+        {
+            const uint32_t c1 = i1 + 4 * (tid & 15);
+            const uint32_t r0 = i0 + 4 * (tid >> 4);
+            f32x4 in[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c1 < p.E1 && (r0 + r) < p.E0)
+                    in[r] = __builtin_nontemporal_load(
+                        reinterpret_cast<const f32x4*>(A + oA + (int64_t)(r0 + r) * p.sA0 + c1));
+            }
+            // 4x4 register transpose: out[j] = (in[0][j], in[1][j], in[2][j], in[3][j])
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
+                *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * TT_LD + 4 * (tid >> 4)]) = o;
+            }
+        }
+        __syncthreads();
+        // ---- write: lane -> (dim0 float4 c0 = tid%16, dim1 row = tid/16 + 16*pass)
+        {
+            const uint32_t c0 = i0 + 4 * (tid & 15);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int      lr = (tid >> 4) + 16 * pass;
+                const uint32_t r1 = i1 + lr;
+                if (c0 < p.E0 && r1 < p.E1) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * TT_LD + 4 * (tid & 15)]);
+                    v *= p.alpha;
+                    if (C != nullptr) {
+                        const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
+                        if (p.sC0 == 1) {
+                            v += p.gamma * *reinterpret_cast<const f32x4*>(cp);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += p.gamma * cp[(int64_t)e * p.sC0];
+                        }
+                    }
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// EW_ROWCOPY (fp32): sD0 == 1 and sA0 == 1, E0 % 4 == 0, other strides multiples of 4, aligned.
+// Tile = 256 dim0 elements (64 lanes x float4) x 8 dim1 rows (4 waves x 2 rows).
+// ---------------------------------------------------------------------------------------------
+constexpr int RC_T0 = 256, RC_T1 = 8;
+
+__global__ void __launch_bounds__(256) ew_rowcopy_f32_kernel(const Ew2DParams p) {
+    const float* A = static_cast<const float*>(p.A);
+    const float* C = static_cast<const float*>(p.C);
+    float*       D = static_cast<float*>(p.D);
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * RC_T0 + 4 * (tid & 63);
+        if (c0 >= p.E0) continue;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t r1 = t.t1 * RC_T1 + (tid >> 6) * 2 + r;
+            if (r1 >= p.E1) continue;
+            f32x4 v = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4*>(A + oA + (int64_t)r1 * p.sA1 + c0));
+            v *= p.alpha;
+            if (C != nullptr) {
+                const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
+                if (p.sC0 == 1) {
+                    v += p.gamma * *reinterpret_cast<const f32x4*>(cp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += p.gamma * cp[(int64_t)e * p.sC0];
+                }
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// EW_GENERIC: any strides / dtype.  Tile = 64 dim0 elements x 4 dim1 rows, one element per lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int GN_T0 = 64, GN_T1 = 4;
+
+template <typename T> struct EwScalar { typedef float type; };
+template <> struct EwScalar<double> { typedef double type; };
+
+template <typename T> __device__ __forceinline__ typename EwScalar<T>::type ew_load(const T* p) { return (typename EwScalar<T>::type)(*p); }
+template <> __device__ __forceinline__ float ew_load<__half>(const __half* p) { return __half2float(*p); }
+template <> __device__ __forceinline__ float ew_load<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void ew_store(T* p, typename EwScalar<T>::type v) { *p = (T)v; }
+template <> __device__ __forceinline__ void ew_store<__half>(__half* p, float v) { *p = __float2half(v); }
+template <> __device__ __forceinline__ void ew_store<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
+    typedef typename EwScalar<T>::type S;
+    const T* A = static_cast<const T*>(p.A);
+    const T* C = static_cast<const T*>(p.C);
+    T*       D = static_cast<T*>(p.D);
+    const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
+    const S gamma = sizeof(S) == 8 ? (S)p.gamma64 : (S)p.gamma;
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * GN_T0 + (tid & 63);
+        const uint32_t r1 = t.t1 * GN_T1 + (tid >> 6);
+        if (c0 >= p.E0 || r1 >= p.E1) continue;
+        S v = alpha * ew_load<T>(A + oA + (int64_t)c0 * p.sA0 + (int64_t)r1 * p.sA1);
+        if (C != nullptr) v += gamma * ew_load<T>(C + oC + (int64_t)c0 * p.sC0 + (int64_t)r1 * p.sC1);
+        ew_store<T>(D + oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1, v);
+    }
+}
+
+hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream) {
+    if (p.nBlocks == 0) return hipSuccess;
+    // a grid-stride loop over tiles; cap the grid so that very large tensors do not pay for
+    // millions of workgroup launches (256 CUs x 8 resident 256-thread workgroups x 4 rounds)
+    unsigned grid = p.nBlocks;
+    const unsigned cap = 256u * 8u * 16u;
+    if (grid > cap) grid = cap;
+    if (variant == EW_TRANSPOSE && dtype == HIP_R_32F) {
+        hipLaunchKernelGGL(ew_transpose_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_ROWCOPY && dtype == HIP_R_32F) {
+        hipLaunchKernelGGL(ew_rowcopy_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_GENERIC) {
+        switch (dtype) {
+            case HIP_R_32F:  hipLaunchKernelGGL(ew_generic_kernel<float>, dim3(grid), dim3(256), 0, stream, p); break;
+            case HIP_R_64F:  hipLaunchKernelGGL(ew_generic_kernel<double>, dim3(grid), dim3(256), 0, stream, p); break;
+            case HIP_R_16F:  hipLaunchKernelGGL(ew_generic_kernel<__half>, dim3(grid), dim3(256), 0, stream, p); break;
+            case HIP_R_16BF: hipLaunchKernelGGL(ew_generic_kernel<__hip_bfloat16>, dim3(grid), dim3(256), 0, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ctamd

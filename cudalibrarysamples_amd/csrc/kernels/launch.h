@@ -1,0 +1,48 @@
+// launch.h — host-visible launch interface of the gfx950 kernels (implemented in the .hip files).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "params.h"
+
+namespace ctamd {
+
+enum OperandLayout : int {
+    LAY_F = 0,  // fastest free mode has stride 1: 16-byte lanes along rows
+    LAY_K = 1,  // fastest contracted mode has stride 1: 16-byte lanes along k
+    LAY_S = 2   // arbitrary strides: 4-byte gathers
+};
+
+struct GettKernelInfo {
+    int bm, bn, bk;      // workgroup tile
+    int wm, wn, wk;      // wave grid inside the workgroup
+    int layA, layB;      // OperandLayout of kernel-A / kernel-B
+    int threads;
+    hipError_t (*launch)(const GettParams&, hipStream_t);
+};
+
+// fp32 data, fp32 MFMA (v_mfma_f32_16x16x4_f32)
+const GettKernelInfo* gett_f32_kernels(int* count);
+hipError_t launch_splitk_reduce(const SplitKReduceParams& p, hipStream_t stream);
+
+// simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
+hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,
+                              hipStream_t stream);
+
+// element-wise family (elementwise.hip)
+enum EwVariant : int {
+    EW_TRANSPOSE = 0,  // sD0 == 1 and sA1 == 1: 64x64 LDS tile, 16-byte lanes on both sides
+    EW_ROWCOPY   = 1,  // sD0 == 1 and sA0 == 1: 16-byte lanes along dim0, no LDS
+    EW_GENERIC   = 2   // any strides, any dtype: one element per lane
+};
+hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream);
+
+// reduction family (reduce.hip)
+enum ReduceVariant : int {
+    RED_COL     = 0,   // A's stride-1 mode is kept: lanes along it (float4), loop over reduced modes
+    RED_ROW     = 1,   // A's stride-1 mode is reduced: one workgroup per kept element
+    RED_GENERIC = 2    // any strides, any dtype
+};
+hipError_t launch_reduce(const ReduceParams& p, int variant, int dtype, bool acc64, hipStream_t stream);
+hipError_t launch_reduce_finalize(const ReduceParams& p, int dtype, bool acc64, hipStream_t stream);
+
+}  // namespace ctamd

@@ -1,0 +1,104 @@
+// params.h — plain-old-data kernel arguments shared by the host planner and the gfx950 kernels.
+//
+// A tensor contraction is executed as a GETT: the modes of A, B and C are classified into four
+// groups — L (batch: in A, B and C), M (free: A and C), N (free: B and C), K (contracted: A and B) —
+// and each group is linearised as a mixed-radix number, fastest mode first.  A group index is turned
+// into an element offset inside each tensor by peeling its digits with a multiply-high division and
+// multiplying by the per-tensor stride.  No tensor is ever physically transposed or copied.
+#pragma once
+#include <stdint.h>
+
+namespace ctamd {
+
+constexpr int kMaxGroupModes = 8;   // modes per group after fusion (more => simple fallback kernel)
+
+// Exact unsigned division n / d for n < 2^31, d in [2, 2^31): q = mulhi(n, magic) >> shift.
+struct FastDiv {
+    uint32_t d;
+    uint32_t magic;
+    uint32_t shift;
+};
+
+// One mode group.  stride[t][i]: element stride of mode i in tensor slot t.
+//   M group: slot 0 = A, slot 1 = C/D          N group: slot 0 = B, slot 1 = C/D
+//   K group: slot 0 = A, slot 1 = B            L group: slot 0 = A, slot 1 = B, slot 2 = C/D
+struct ModeGroup {
+    int32_t  n;                          // number of modes (0 => group extent 1)
+    uint32_t total;                      // product of extents (< 2^31)
+    FastDiv  div[kMaxGroupModes];
+    int64_t  stride[3][kMaxGroupModes];
+};
+
+struct GettParams {
+    const void* A;
+    const void* B;
+    const void* C;        // source for beta (may alias D)
+    void*       D;
+    float*      partial;  // split-K workspace: [slice][L][M][N] fp32, or nullptr
+    ModeGroup   gM, gN, gK, gL;
+    float       alpha, beta;
+    double      alpha64, beta64;  // same scalars at full width (fp64 data)
+    uint32_t    tilesM, tilesN;   // number of output tiles
+    uint32_t    splitK;           // number of K slices (>= 1)
+    uint32_t    kPerSlice;        // K elements per slice, multiple of the kernel's BK
+    uint32_t    nBlocks;          // total workgroups = tilesM*tilesN*splitK*L
+    // C and D may have different strides only through separate descriptors; the engine requires
+    // identical mode order/extents (as the ABI does) and carries D strides in slot 1 / 2 above and
+    // C strides here.
+    int64_t     cStrideM[kMaxGroupModes];
+    int64_t     cStrideN[kMaxGroupModes];
+    int64_t     cStrideL[kMaxGroupModes];
+};
+
+// Second stage of split-K: D = alpha * sum_s partial[s] + beta * C
+struct SplitKReduceParams {
+    const float* partial;
+    const void*  C;
+    void*        D;
+    ModeGroup    gM, gN, gL;     // slot 1 (M,N) / slot 2 (L) hold D strides
+    int64_t      cStrideM[kMaxGroupModes];
+    int64_t      cStrideN[kMaxGroupModes];
+    int64_t      cStrideL[kMaxGroupModes];
+    float        alpha, beta;
+    uint32_t     splitK;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise family (cutensorPermute / cutensorElementwiseBinaryExecute and the permutation-only
+// form of cutensorReduce):  D = alpha * perm(A) [+ gamma * perm(C)].
+// The planner picks two "tile" modes — dim0 = D's fastest mode, dim1 = A's fastest mode (or D's
+// second mode when A and D share the fastest one) — and linearises all remaining modes into
+// `rest`.  A workgroup owns one T0 x T1 tile of one rest index.
+// ---------------------------------------------------------------------------------------------
+struct Ew2DParams {
+    const void* A;
+    const void* C;                 // may be nullptr (gamma == 0)
+    void*       D;
+    uint32_t    E0, E1;            // extents of the two tile modes (E1 = 1 when there is none)
+    int64_t     sA0, sA1, sD0, sD1, sC0, sC1;
+    uint32_t    tiles0, tiles1;
+    FastDiv     divTiles0, divTiles1;
+    ModeGroup   rest;              // slot 0 = A, slot 1 = D, slot 2 = C strides
+    uint32_t    nBlocks;
+    float       alpha, gamma;
+    double      alpha64, gamma64;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Reduction (cutensorReduce):  D[kept] = alpha * reduce_{red} A[kept, red] + beta * C[kept].
+// ---------------------------------------------------------------------------------------------
+struct ReduceParams {
+    const void* A;
+    const void* C;
+    void*       D;
+    void*       partial;           // [splitR][keptTotal] accumulators (float or double), or nullptr
+    ModeGroup   kept;              // slot 0 = A, slot 1 = D, slot 2 = C strides
+    ModeGroup   red;               // slot 0 = A strides
+    uint32_t    splitR;            // reduction range split over this many workgroups
+    uint32_t    redPerSplit;       // reduced elements per split (multiple of 4)
+    int32_t     op;                // cutensorOperator_t: ADD / MUL / MIN / MAX
+    float       alpha, beta;
+    double      alpha64, beta64;
+};
+
+}  // namespace ctamd

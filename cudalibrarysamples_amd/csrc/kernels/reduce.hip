@@ -1,0 +1,252 @@
+// reduce.hip — HBM-bound tensor reduction kernels for gfx950.
+//
+// Replaces the closed kernels behind cutensorReduce (reference call sites:
+// cuTENSOR/reduction.cu:219-222 "C_{m,v} = alpha * sum_{h,k} A_{m,h,k,v} + beta * C_{m,v}" :49-61,
+// and cuTENSOR/einsum.cu:369-372).
+//
+// The planner splits A's modes into kept modes (they appear in D) and reduced modes, each a
+// mixed-radix group (params.h).  Roofline: HBM; algorithmic bytes = |A| + |D| (+ |C| iff beta != 0),
+// reduction.cu:229-231.
+//
+//   RED_COL      A's stride-1 mode is kept.  One lane owns 4 consecutive kept elements (float4),
+//                walks its share of the reduced index space and keeps 4 running values.  Wave
+//                loads are 1 KiB contiguous.
+//   RED_ROW      A's stride-1 mode is reduced.  One wave owns one kept element, its lanes stride
+//                over the reduced space with float4 loads and combine through DPP shuffles.
+//   RED_GENERIC  any strides / dtype: one lane per kept element, scalar gathers.
+//
+// When the kept space alone cannot fill 256 CUs the reduced range is split across workgroups
+// (splitR) into a [splitR][kept] partial buffer in the caller's workspace and folded by
+// reduce_finalize_kernel, which also applies alpha / beta.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "launch.h"
+#include "params.h"
+
+namespace ctamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { OP_ADD = 3, OP_MUL = 5, OP_MAX = 6, OP_MIN = 7 };   // cutensorOperator_t values
+
+template <typename S> __device__ __forceinline__ S red_identity(int op) {
+    switch (op) {
+        case OP_MUL: return (S)1;
+        case OP_MAX: return -(S)INFINITY;
+        case OP_MIN: return (S)INFINITY;
+        default: return (S)0;
+    }
+}
+template <typename S> __device__ __forceinline__ S red_apply(int op, S a, S b) {
+    switch (op) {
+        case OP_MUL: return a * b;
+        case OP_MAX: return a > b ? a : b;
+        case OP_MIN: return a < b ? a : b;
+        default: return a + b;
+    }
+}
+
+__device__ __forceinline__ uint32_t rd_fast_div(uint32_t n, const FastDiv& d) {
+    return __umulhi(n, d.magic) >> d.shift;
+}
+template <int SLOT>
+__device__ __forceinline__ int64_t rd_offset(const ModeGroup& g, uint32_t idx) {
+    int64_t off = 0;
+    const int n = g.n;
+    for (int i = 0; i < n; ++i) {
+        uint32_t q = 0;
+        if (i + 1 < n) q = rd_fast_div(idx, g.div[i]);
+        off += (int64_t)(idx - q * g.div[i].d) * g.stride[SLOT][i];
+        idx = q;
+    }
+    return off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RED_COL, fp32.  grid.x covers kept float4 units, grid.y = splitR.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_col_f32_kernel(const ReduceParams p) {
+    const uint32_t unit = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t kv = unit * 4u;
+    if (kv >= p.kept.total) return;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const float* A = static_cast<const float*>(p.A) + rd_offset<0>(p.kept, kv);
+    f32x4 acc;
+    for (int e = 0; e < 4; ++e) acc[e] = red_identity<float>(op);
+    uint32_t r = rBegin;
+    for (; r + 4 <= rEnd; r += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + rd_offset<0>(p.red, r + u)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = red_apply<float>(op, acc[e], v[u][e]);
+    }
+    for (; r < rEnd; ++r) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(A + rd_offset<0>(p.red, r));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = red_apply<float>(op, acc[e], v[e]);
+    }
+    if (p.partial != nullptr) {
+        float* P = static_cast<float*>(p.partial) + (size_t)split * p.kept.total + kv;
+        *reinterpret_cast<f32x4*>(P) = acc;
+        return;
+    }
+    float*       D = static_cast<float*>(p.D);
+    const float* C = static_cast<const float*>(p.C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // kept mode 0 is contiguous in A; in D / C it may have any stride
+        const int64_t oD = rd_offset<1>(p.kept, kv + e);
+        float val = p.alpha * acc[e];
+        if (p.beta != 0.f) val += p.beta * C[rd_offset<2>(p.kept, kv + e)];
+        D[oD] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RED_ROW, fp32.  One wave per (kept element, split); grid.x covers kept/4 (4 waves per block),
+// grid.y = splitR.  redPerSplit is a multiple of 4 and red mode 0 is contiguous with extent % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_row_f32_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= p.kept.total) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const float* A = static_cast<const float*>(p.A) + rd_offset<0>(p.kept, k);
+    float acc = red_identity<float>(op);
+    uint32_t r = rBegin + 4u * lane;
+    for (; r + 3u * 256u < rEnd; r += 4u * 256u) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(A + rd_offset<0>(p.red, r + 256u * u)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = red_apply<float>(op, acc, v[u][e]);
+    }
+    for (; r < rEnd; r += 256u) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(A + rd_offset<0>(p.red, r));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = red_apply<float>(op, acc, v[e]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = red_apply<float>(op, acc, __shfl_down(acc, off, 64));
+    if (lane != 0) return;
+    if (p.partial != nullptr) {
+        static_cast<float*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
+        return;
+    }
+    float val = p.alpha * acc;
+    if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[rd_offset<2>(p.kept, k)];
+    static_cast<float*>(p.D)[rd_offset<1>(p.kept, k)] = val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RED_GENERIC: any dtype / strides.  One lane per (kept element, split).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ double rg_load(const T* p) { return (double)(*p); }
+template <> __device__ __forceinline__ double rg_load<__half>(const __half* p) { return (double)__half2float(*p); }
+template <> __device__ __forceinline__ double rg_load<__hip_bfloat16>(const __hip_bfloat16* p) { return (double)__bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void rg_store(T* p, double v) { *p = (T)v; }
+template <> __device__ __forceinline__ void rg_store<__half>(__half* p, double v) { *p = __float2half((float)v); }
+template <> __device__ __forceinline__ void rg_store<__hip_bfloat16>(__hip_bfloat16* p, double v) { *p = __float2bfloat16((float)v); }
+
+template <typename T, typename S>
+__global__ void __launch_bounds__(256) reduce_generic_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= p.kept.total) return;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const T* A = static_cast<const T*>(p.A) + rd_offset<0>(p.kept, k);
+    S acc = red_identity<S>(op);
+    for (uint32_t r = rBegin; r < rEnd; ++r) acc = red_apply<S>(op, acc, (S)rg_load<T>(A + rd_offset<0>(p.red, r)));
+    if (p.partial != nullptr) {
+        static_cast<S*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
+        return;
+    }
+    const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
+    const S beta  = sizeof(S) == 8 ? (S)p.beta64 : (S)p.beta;
+    S val = alpha * acc;
+    if (beta != (S)0) val += beta * (S)rg_load<T>(static_cast<const T*>(p.C) + rd_offset<2>(p.kept, k));
+    rg_store<T>(static_cast<T*>(p.D) + rd_offset<1>(p.kept, k), (double)val);
+}
+
+// D[k] = alpha * combine_s partial[s][k] + beta * C[k]
+template <typename T, typename S>
+__global__ void __launch_bounds__(256) reduce_finalize_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= p.kept.total) return;
+    const int op = p.op;
+    const S* P = static_cast<const S*>(p.partial) + k;
+    S acc = red_identity<S>(op);
+    for (uint32_t s = 0; s < p.splitR; ++s) acc = red_apply<S>(op, acc, P[(size_t)s * p.kept.total]);
+    const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
+    const S beta  = sizeof(S) == 8 ? (S)p.beta64 : (S)p.beta;
+    S val = alpha * acc;
+    if (beta != (S)0) val += beta * (S)rg_load<T>(static_cast<const T*>(p.C) + rd_offset<2>(p.kept, k));
+    rg_store<T>(static_cast<T*>(p.D) + rd_offset<1>(p.kept, k), (double)val);
+}
+
+template <typename T, typename S>
+static void launch_generic_t(const ReduceParams& p, hipStream_t stream) {
+    const dim3 grid((p.kept.total + 255u) / 256u, p.splitR);
+    hipLaunchKernelGGL((reduce_generic_kernel<T, S>), grid, dim3(256), 0, stream, p);
+}
+template <typename T, typename S>
+static void launch_finalize_t(const ReduceParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((reduce_finalize_kernel<T, S>), dim3((p.kept.total + 255u) / 256u), dim3(256), 0, stream, p);
+}
+
+hipError_t launch_reduce(const ReduceParams& p, int variant, int dtype, bool acc64, hipStream_t stream) {
+    if (p.kept.total == 0) return hipSuccess;
+    if (variant == RED_COL && dtype == HIP_R_32F) {
+        const dim3 grid(((p.kept.total / 4u) + 255u) / 256u, p.splitR);
+        hipLaunchKernelGGL(reduce_col_f32_kernel, grid, dim3(256), 0, stream, p);
+    } else if (variant == RED_ROW && dtype == HIP_R_32F) {
+        const dim3 grid((p.kept.total + 3u) / 4u, p.splitR);
+        hipLaunchKernelGGL(reduce_row_f32_kernel, grid, dim3(256), 0, stream, p);
+    } else if (variant == RED_GENERIC) {
+        switch (dtype) {
+            case HIP_R_32F:  if (acc64) launch_generic_t<float, double>(p, stream); else launch_generic_t<float, float>(p, stream); break;
+            case HIP_R_64F:  launch_generic_t<double, double>(p, stream); break;
+            case HIP_R_16F:  launch_generic_t<__half, float>(p, stream); break;
+            case HIP_R_16BF: launch_generic_t<__hip_bfloat16, float>(p, stream); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_finalize(const ReduceParams& p, int dtype, bool acc64, hipStream_t stream) {
+    if (p.kept.total == 0) return hipSuccess;
+    switch (dtype) {
+        case HIP_R_32F:  if (acc64) launch_finalize_t<float, double>(p, stream); else launch_finalize_t<float, float>(p, stream); break;
+        case HIP_R_64F:  launch_finalize_t<double, double>(p, stream); break;
+        case HIP_R_16F:  launch_finalize_t<__half, float>(p, stream); break;
+        case HIP_R_16BF: launch_finalize_t<__hip_bfloat16, float>(p, stream); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace ctamd

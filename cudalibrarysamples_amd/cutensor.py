@@ -1,0 +1,127 @@
+"""ctypes mirror of include/cutensor.h — same names, same argument meaning, same status codes.
+
+Reference interface being mirrored: the cuTENSOR 2.x call sequence of cuTENSOR/contraction.cu:122-265,
+cuTENSOR/reduction.cu:141-222 and cuTENSOR/elementwise_permute.cu:142-200.  Functions return the raw
+cutensorStatus_t; `check()` turns a non-success status into CuTensorError (the samples' handle_error,
+cuTENSOR/utils.cuh:35-39).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcutensor.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libcutensor.so (gfx950 HIP engine) is not built: %s missing. Build it with "
+        "`make -C cudalibrarysamples_amd/csrc` or `__graft_entry__.build()`; there is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+# ---- enums (include/cutensor/types.h) ----------------------------------------------------------
+R_32F, R_64F, R_16F, R_16BF = 0, 1, 2, 14
+STATUS_SUCCESS, STATUS_NOT_INITIALIZED, STATUS_INVALID_VALUE = 0, 1, 7
+STATUS_NOT_SUPPORTED, STATUS_INSUFFICIENT_WORKSPACE, STATUS_IO_ERROR = 15, 19, 21
+OP_IDENTITY, OP_ADD, OP_MUL, OP_MAX, OP_MIN = 1, 3, 5, 6, 7
+ALGO_DEFAULT, ALGO_DEFAULT_PATIENT = -1, -6
+WORKSPACE_MIN, WORKSPACE_DEFAULT, WORKSPACE_MAX = 1, 2, 3
+JIT_MODE_NONE = 0
+OPERATION_DESCRIPTOR_TAG, OPERATION_DESCRIPTOR_SCALAR_TYPE, OPERATION_DESCRIPTOR_FLOPS, OPERATION_DESCRIPTOR_MOVED_BYTES = 0, 1, 2, 3
+PLAN_REQUIRED_WORKSPACE = 0
+PLAN_PREFERENCE_ALGO, PLAN_PREFERENCE_KERNEL_RANK = 3, 4
+
+_vp = ctypes.c_void_p
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+EXPORTS = {
+    # name: (argtypes)
+    "cutensorCreate": (ctypes.POINTER(_vp),),
+    "cutensorDestroy": (_vp,),
+    "cutensorHandleResizePlanCache": (_vp, ctypes.c_uint32),
+    "cutensorHandleWritePlanCacheToFile": (_vp, ctypes.c_char_p),
+    "cutensorHandleReadPlanCacheFromFile": (_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)),
+    "cutensorCreateTensorDescriptor": (_vp, ctypes.POINTER(_vp), ctypes.c_uint32, _i64p, _i64p, ctypes.c_int, ctypes.c_uint32),
+    "cutensorDestroyTensorDescriptor": (_vp,),
+    "cutensorCreateContraction": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                  _vp, _i32p, ctypes.c_int, _vp, _i32p, _vp),
+    "cutensorCreateReduction": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                _vp, _i32p, ctypes.c_int, _vp),
+    "cutensorCreatePermutation": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, _vp),
+    "cutensorCreateElementwiseBinary": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                        _vp, _i32p, ctypes.c_int, _vp),
+    "cutensorDestroyOperationDescriptor": (_vp,),
+    "cutensorOperationDescriptorGetAttribute": (_vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t),
+    "cutensorOperationDescriptorSetAttribute": (_vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t),
+    "cutensorCreatePlanPreference": (_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int),
+    "cutensorDestroyPlanPreference": (_vp,),
+    "cutensorPlanPreferenceSetAttribute": (_vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t),
+    "cutensorEstimateWorkspaceSize": (_vp, _vp, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)),
+    "cutensorCreatePlan": (_vp, ctypes.POINTER(_vp), _vp, _vp, ctypes.c_uint64),
+    "cutensorDestroyPlan": (_vp,),
+    "cutensorPlanGetAttribute": (_vp, _vp, ctypes.c_int, _vp, ctypes.c_size_t),
+    "cutensorContract": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp),
+    "cutensorReduce": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp),
+    "cutensorPermute": (_vp, _vp, _vp, _vp, _vp, _vp),
+    "cutensorElementwiseBinaryExecute": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp),
+}
+DATA_SYMBOLS = ["CUTENSOR_COMPUTE_DESC_16F", "CUTENSOR_COMPUTE_DESC_16BF", "CUTENSOR_COMPUTE_DESC_TF32",
+                "CUTENSOR_COMPUTE_DESC_3XTF32", "CUTENSOR_COMPUTE_DESC_32F", "CUTENSOR_COMPUTE_DESC_64F"]
+
+for _name, _args in EXPORTS.items():
+    _f = getattr(lib, _name)
+    _f.argtypes = list(_args)
+    _f.restype = ctypes.c_int
+    globals()[_name] = _f
+lib.cutensorGetErrorString.argtypes = [ctypes.c_int]
+lib.cutensorGetErrorString.restype = ctypes.c_char_p
+lib.cutensorGetVersion.restype = ctypes.c_size_t
+lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
+lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
+lib.ctamdProfileBegin.restype = None
+lib.ctamdProfileEnd.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+lib.ctamdEinsumCreate.argtypes = [ctypes.c_char_p, _i64p, ctypes.c_int, _i64p, ctypes.c_int, ctypes.c_int]
+lib.ctamdEinsumCreate.restype = _vp
+lib.ctamdEinsumDestroy.argtypes = [_vp]
+lib.ctamdEinsumDestroy.restype = None
+lib.ctamdEinsumIsInitialized.argtypes = [_vp]
+lib.ctamdEinsumOutputShape.argtypes = [_vp, _i64p, ctypes.c_int]
+lib.ctamdEinsumPlan.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+lib.ctamdEinsumExecute.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.ctamdEinsumRawPlan.argtypes = [_vp]
+lib.ctamdEinsumRawPlan.restype = _vp
+
+
+def compute_desc(name):
+    """Value of the exported data symbol CUTENSOR_COMPUTE_DESC_<name> (an opaque pointer)."""
+    return _vp.in_dll(lib, "CUTENSOR_COMPUTE_DESC_" + name)
+
+
+class CuTensorError(RuntimeError):
+    def __init__(self, status):
+        self.status = status
+        RuntimeError.__init__(self, lib.cutensorGetErrorString(status).decode())
+
+
+def check(status):
+    if status != STATUS_SUCCESS:
+        raise CuTensorError(status)
+
+
+def getErrorString(status):
+    return lib.cutensorGetErrorString(status).decode()
+
+
+def describe_plan(plan):
+    buf = ctypes.create_string_buffer(1024)
+    lib.ctamdDescribePlan(plan, buf, 1024)
+    import json
+    return json.loads(buf.value.decode())
+
+
+def i64(values):
+    return (ctypes.c_int64 * max(len(values), 1))(*values)
+
+
+def i32(values):
+    return (ctypes.c_int32 * max(len(values), 1))(*[ord(v) if isinstance(v, str) else int(v) for v in values])

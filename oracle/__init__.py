@@ -1,0 +1,157 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy front end of oracle/oracle.c (strided N-mode contraction / reduction / permutation with
+fp64 accumulation, plus the einsum.cu equation front end).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this package; the product package never does.
+
+Tensors are numpy arrays whose axes are labelled by a mode string/list; extents and element strides
+are taken from the array itself, so any memory layout (C, F, sliced) is described exactly the way a
+cuTENSOR tensor descriptor would describe it.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", _SO, src])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _modes(m):
+    return [ord(c) if isinstance(c, str) else int(c) for c in m]
+
+
+def _desc(arr, modes):
+    modes = _modes(modes)
+    if arr.ndim != len(modes):
+        raise ValueError("mode list %r does not match array rank %d" % (modes, arr.ndim))
+    n = arr.ndim
+    ext = (ctypes.c_int64 * max(n, 1))(*arr.shape)
+    strides = [s // arr.itemsize for s in arr.strides]
+    if any(s < 0 for s in strides):
+        raise ValueError("negative strides are not supported")
+    st = (ctypes.c_int64 * max(n, 1))(*strides)
+    md = (ctypes.c_int32 * max(n, 1))(*modes)
+    return n, md, ext, st
+
+
+def _ptr(arr):
+    return ctypes.c_void_p(arr.ctypes.data)
+
+
+def contract(A, modesA, B, modesB, D, modesD, alpha=1.0, beta=0.0, C=None, acc64=True):
+    """D[modesD] = alpha * sum A[modesA]*B[modesB] + beta*C[modesD]; D is written in place."""
+    if C is None:
+        C = D
+    if A.dtype != B.dtype or A.dtype != D.dtype or C.dtype != D.dtype:
+        raise ValueError("dtype mismatch")
+    if A.dtype == np.float32:
+        fn = lib().oracle_contract_f32 if acc64 else lib().oracle_contract_f32_naive
+    elif A.dtype == np.float64:
+        fn = lib().oracle_contract_f64
+    else:
+        raise ValueError("oracle supports float32/float64")
+    nA, mA, eA, sA = _desc(A, modesA)
+    nB, mB, eB, sB = _desc(B, modesB)
+    nC, mC, eC, sC = _desc(C, modesD)
+    _, _, eD, sD = _desc(D, modesD)
+    if tuple(C.shape) != tuple(D.shape):
+        raise ValueError("C and D shapes differ")
+    fn.restype = ctypes.c_int
+    rc = fn(nA, mA, eA, sA, _ptr(A), nB, mB, eB, sB, _ptr(B), nC, mC, eC, sC, _ptr(C), sD, _ptr(D),
+            ctypes.c_double(alpha), ctypes.c_double(beta))
+    if rc != 0:
+        raise RuntimeError("oracle_contract failed: %d" % rc)
+    return D
+
+
+OP_ADD, OP_MUL, OP_MAX, OP_MIN = 3, 5, 6, 7
+
+
+def reduce(A, modesA, D, modesD, alpha=1.0, beta=0.0, C=None, op=OP_ADD):
+    if C is None:
+        C = D
+    fn = {np.dtype(np.float32): lib().oracle_reduce_f32, np.dtype(np.float64): lib().oracle_reduce_f64}[A.dtype]
+    nA, mA, eA, sA = _desc(A, modesA)
+    nC, mC, eC, sC = _desc(C, modesD)
+    _, _, _, sD = _desc(D, modesD)
+    fn.restype = ctypes.c_int
+    rc = fn(nA, mA, eA, sA, _ptr(A), nC, mC, eC, sC, _ptr(C), sD, _ptr(D), ctypes.c_double(alpha),
+            ctypes.c_double(beta), int(op))
+    if rc != 0:
+        raise RuntimeError("oracle_reduce failed: %d" % rc)
+    return D
+
+
+def permute(A, modesA, B, modesB, alpha=1.0, C=None, gamma=0.0):
+    fn = {np.dtype(np.float32): lib().oracle_permute_f32, np.dtype(np.float64): lib().oracle_permute_f64}[A.dtype]
+    nA, mA, eA, sA = _desc(A, modesA)
+    nB, mB, eB, sB = _desc(B, modesB)
+    if C is not None:
+        _, _, _, sC = _desc(C, modesB)
+        cp = _ptr(C)
+    else:
+        sC, cp = None, None
+    fn.restype = ctypes.c_int
+    rc = fn(nA, mA, eA, sA, _ptr(A), nB, mB, eB, sB, _ptr(B), ctypes.c_double(alpha), cp, sC,
+            ctypes.c_double(gamma))
+    if rc != 0:
+        raise RuntimeError("oracle_permute failed: %d" % rc)
+    return B
+
+
+def einsum_parse(equation, shapeA, shapeB=(), max_modes=40):
+    """Restatement of Einsum::Einsum (einsum.cu:63-223).  Returns None when "not supported", else a
+    dict with the REVERSED (cuTENSOR column-major order) mode/extent lists and the row-major output shape."""
+    nA, nB = len(shapeA), len(shapeB)
+    sa = (ctypes.c_int64 * max(nA, 1))(*shapeA)
+    sb = (ctypes.c_int64 * max(nB, 1))(*shapeB)
+    mA = (ctypes.c_int32 * 66)(); eA = (ctypes.c_int64 * 66)()
+    mB = (ctypes.c_int32 * 66)(); eB = (ctypes.c_int64 * 66)()
+    mC = (ctypes.c_int32 * 66)(); eC = (ctypes.c_int64 * 66)()
+    nC = ctypes.c_int(0)
+    fn = lib().oracle_einsum_parse
+    fn.restype = ctypes.c_int
+    ok = fn(equation.encode(), nA, sa, nB, sb, int(max_modes), mA, eA, mB, eB, ctypes.byref(nC), mC, eC)
+    if not ok:
+        return None
+    n = nC.value
+    return {
+        "modesA": [chr(mA[i]) for i in range(nA)], "extentA": [eA[i] for i in range(nA)],
+        "modesB": [chr(mB[i]) for i in range(nB)], "extentB": [eB[i] for i in range(nB)],
+        "modesC": [chr(mC[i]) for i in range(n)], "extentC": [eC[i] for i in range(n)],
+        "output_shape": [eC[n - 1 - i] for i in range(n)],
+    }
+
+
+def einsum(equation, a, b=None):
+    """Framework-level einsum through the oracle (row-major numpy arrays in, row-major out)."""
+    p = einsum_parse(equation, a.shape, b.shape if b is not None else ())
+    if p is None:
+        raise ValueError("not supported: %s" % equation)
+    out = np.zeros(p["output_shape"], dtype=a.dtype)
+    # numpy axis i of a row-major array carries mode modes[::-1][i]
+    ma, mc = p["modesA"][::-1], p["modesC"][::-1]
+    if b is not None:
+        contract(a, ma, b, p["modesB"][::-1], out, mc)
+    else:
+        reduce(a, ma, out, mc)
+    return out

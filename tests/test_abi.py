@@ -1,0 +1,150 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/*.h declares, and the host logic
+(descriptors, planning, workspace invariants, error behaviour) follows the reference call sites.
+No compute entry point is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ct(built):
+    import cudalibrarysamples_amd.cutensor as ct
+    return ct
+
+
+@pytest.fixture(scope="module")
+def ops(built):
+    from cudalibrarysamples_amd import ops
+    return ops
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cutensor(?:Mg)?[A-Z]\w*)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(ct):
+    names = _declared_functions("cutensor.h")
+    assert "cutensorContract" in names and "cutensorCreatePlan" in names
+    for n in names:
+        assert hasattr(ct.lib, n), "libcutensor.so does not export %s" % n
+    for d in ct.DATA_SYMBOLS:
+        assert ctypes.c_void_p.in_dll(ct.lib, d).value, d
+
+
+def test_mg_symbols_exported(built):
+    mg = ctypes.CDLL(os.path.join(ROOT, "cudalibrarysamples_amd", "lib", "libcutensorMg.so"))
+    for n in _declared_functions("cutensorMg.h"):
+        assert hasattr(mg, n), "libcutensorMg.so does not export %s" % n
+
+
+def test_lifecycle_and_null_tolerance(ct):
+    h = ctypes.c_void_p()
+    assert ct.cutensorCreate(ctypes.byref(h)) == ct.STATUS_SUCCESS
+    # Destroy*(NULL) must be tolerated (python/einsum.h:302,396)
+    assert ct.cutensorDestroyTensorDescriptor(None) == ct.STATUS_SUCCESS
+    assert ct.cutensorDestroyPlan(None) == ct.STATUS_SUCCESS
+    assert ct.cutensorDestroyOperationDescriptor(None) == ct.STATUS_SUCCESS
+    assert ct.cutensorHandleResizePlanCache(h, 1024) == ct.STATUS_SUCCESS     # einsum.cu:445
+    assert ct.getErrorString(15) == "CUTENSOR_STATUS_NOT_SUPPORTED"
+    assert ct.cutensorCreate(None) == ct.STATUS_INVALID_VALUE
+    assert ct.cutensorDestroy(h) == ct.STATUS_SUCCESS
+
+
+def test_contraction_sample_sequence(ct, ops):
+    """contraction.cu:122-239 up to (not including) the execution."""
+    h = ops.Handle()
+    p = ops.contraction_plan(h, [96, 64, 64, 96], "mhkn", [96, 64, 64, 64], "ukvh", [96, 96, 96, 64], "munv")
+    assert p.scalar_type == ct.R_32F                      # contraction.cu:176-182
+    assert p.required_workspace <= p.workspace_estimate   # contraction.cu:239
+    d = p.describe()
+    # M = m*n = 9216, N = u*v = 6144, K = 4096; D is m-contiguous so the engine
+    # swaps operands to put (m, n) on the coalesced side
+    assert sorted([d["M"], d["N"]]) == [6144, 9216] and d["K"] == 4096 and d["N"] == 9216
+    flops = ctypes.c_float(0)
+    assert ct.cutensorOperationDescriptorGetAttribute(h.h, p.op, ct.OPERATION_DESCRIPTOR_FLOPS, ctypes.byref(flops), 4) == 0
+    assert abs(flops.value - 463856467968.0) / 463856467968.0 < 1e-6    # contraction.cu:61
+    p.destroy()
+
+
+def test_headline_einsum_plan_uses_split_k(ct, ops):
+    h = ops.Handle()
+    p = ops.contraction_plan(h, [64, 64, 64, 96], "dcba", [96, 64, 64, 64], "ebcd", [96, 96], "ea",
+                             workspace_limit=1 << 30)
+    d = p.describe()
+    assert (d["M"], d["N"], d["K"]) == (96, 96, 262144)
+    assert d["layA"] == 1 and d["layB"] == 0       # A K-contiguous, B free-contiguous
+    assert d["splitK"] > 1 and d["blocks"] >= 256  # a single 96x96 tile must be split over the chip
+    assert p.required_workspace == d["splitK"] * 96 * 96 * 4
+    # with no workspace the same problem still plans (no split)
+    p0 = ops.contraction_plan(h, [64, 64, 64, 96], "dcba", [96, 64, 64, 64], "ebcd", [96, 96], "ea", workspace_limit=0)
+    assert p0.required_workspace == 0 and p0.describe()["splitK"] == 1
+
+
+def test_mode_fusion_and_batch(ct, ops):
+    h = ops.Handle()
+    # 'lik,lkj->lij' row-major == cuTENSOR modes reversed; l is a batch mode
+    p = ops.contraction_plan(h, [50, 50, 50], "kil", [50, 50, 50], "jkl", [50, 50, 50], "jil")
+    d = p.describe()
+    assert (d["L"], d["M"], d["N"], d["K"]) == (50, 50, 50, 50)
+    # fully fusable GEMM: A[m1,m2,k] B[k,n] -> C[m1,m2,n] fuses (m1,m2)
+    p = ops.contraction_plan(h, [8, 4, 16], "abk", [16, 12], "kn", [8, 4, 12], "abn")
+    d = p.describe()
+    assert sorted([d["M"], d["N"]]) == [12, 32] and d["K"] == 16
+
+
+def test_error_behaviour(ct, ops):
+    h = ops.Handle()
+    with pytest.raises(ct.CuTensorError) as e:      # extent mismatch between A and B for mode k
+        ops.contraction_plan(h, [4, 5], "mk", [6, 7], "kn", [4, 7], "mn")
+    assert e.value.status == ct.STATUS_INVALID_VALUE
+    with pytest.raises(ct.CuTensorError) as e:      # a mode that appears in one tensor only
+        ops.contraction_plan(h, [4, 5, 3], "mkz", [5, 7], "kn", [4, 7], "mn")
+    assert e.value.status == ct.STATUS_NOT_SUPPORTED
+    d = ctypes.c_void_p()
+    assert ct.cutensorCreateTensorDescriptor(h.h, ctypes.byref(d), 2, ct.i64([4, -1]), None, ct.R_32F, 128) == ct.STATUS_INVALID_VALUE
+    assert ct.cutensorCreateTensorDescriptor(None, ctypes.byref(d), 2, ct.i64([4, 4]), None, ct.R_32F, 128) == ct.STATUS_NOT_INITIALIZED
+
+
+def test_permutation_and_reduction_plans(ct, ops):
+    h = ops.Handle()
+    p = ops.permutation_plan(h, [32, 128, 128, 128], "whcn", [128, 32, 128, 128], "cwhn")   # elementwise_permute.cu:51-63
+    d = p.describe()
+    assert d["variant"] == 0 and d["E0"] == 128 and d["E1"] == 4096 and p.required_workspace == 0
+    r = ops.reduction_plan(h, [196, 256, 64, 64], "mhkv", [196, 64], "mv")                   # reduction.cu:49-61
+    d = r.describe()
+    assert d["kept"] == 196 * 64 and d["red"] == 256 * 64 and r.required_workspace <= r.workspace_estimate
+    # einsum.cu:449-450: a reduction descriptor without reduced modes is a permutation
+    q = ops.reduction_plan(h, [5, 4, 2], "jin", [2, 5, 4], "nji")
+    assert q.describe()["op"] == "elementwise"
+
+
+def test_plan_cache_file_roundtrip(ct, ops, tmp_path):
+    h = ops.Handle(plan_cache=8)
+    f = str(tmp_path / "cache.txt").encode()
+    assert ct.cutensorHandleWritePlanCacheToFile(h.h, f) == ct.STATUS_SUCCESS
+    n = ctypes.c_uint32(7)
+    assert ct.cutensorHandleReadPlanCacheFromFile(h.h, f, ctypes.byref(n)) == ct.STATUS_SUCCESS and n.value == 0
+    assert ct.cutensorHandleReadPlanCacheFromFile(h.h, b"/nonexistent/x", ctypes.byref(n)) == ct.STATUS_IO_ERROR   # contraction_plan_cache.cu:136
+
+
+def test_einsum_helper_parsing(ct):
+    """C++ Einsum<> mirror vs the oracle's restatement of einsum.cu:63-223 (host logic only)."""
+    import oracle
+    cases = [("ijn,jmk->inkm", (2, 4, 5), (4, 8, 7)), ("ijn,jmk", (2, 4, 5), (4, 8, 7)), ("nij", (2, 4, 5), ()),
+             ("nij->ijn", (2, 4, 5), ()), ("nij->ji", (2, 4, 5), ()), ("abcd,dcbe->ae", (96, 64, 64, 64), (64, 64, 64, 96)),
+             ("ab...,bc->ac", (2, 3, 4), (3, 4)), ("ab,bc->ac", (2, 3, 4), (3, 4)), (" a b , b c -> a c ", (2, 3), (3, 4))]
+    for eq, sa, sb in cases:
+        e = ct.lib.ctamdEinsumCreate(eq.encode(), ct.i64(list(sa)), len(sa), ct.i64(list(sb)), len(sb), ct.R_32F)
+        ref = oracle.einsum_parse(eq, sa, sb, max_modes=64)
+        assert bool(ct.lib.ctamdEinsumIsInitialized(e)) == (ref is not None), eq
+        if ref is not None:
+            out = (ctypes.c_int64 * 64)()
+            n = ct.lib.ctamdEinsumOutputShape(e, out, 64)
+            assert [out[i] for i in range(n)] == ref["output_shape"], eq
+        ct.lib.ctamdEinsumDestroy(e)

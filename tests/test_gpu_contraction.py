@@ -1,0 +1,165 @@
+"""GPU parity: cutensorContract through the C ABI vs the CPU oracle (fp64 accumulation) on the same
+seeded tensors.  fp32 tolerance: rtol 1e-4 of the result magnitude; the reference's own
+bound is rtol 5e-3 / atol 6e-3 (einsum_test.py:35-42)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from util import assert_close, from_device, make_tensor, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+    assert torch.cuda.is_available()
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    return ct, ops, ops.Handle(), torch
+
+
+def run_contraction(env, extents, mA, mB, mC, alpha=1.0, beta=0.0, seed=0, algo=None, rank=0, ws_limit=1 << 28,
+                    rtol=1e-4, expect=None):
+    ct, ops, h, torch = env
+    eA, eB, eC = [extents[c] for c in mA], [extents[c] for c in mB], [extents[c] for c in mC]
+    A, B, C = make_tensor(eA, seed + 1), make_tensor(eB, seed + 2), make_tensor(eC, seed + 3)
+    kw = dict(workspace_limit=ws_limit, kernel_rank=rank)
+    if algo is not None:
+        kw["algo"] = algo
+    p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, **kw)
+    d = p.describe()
+    if expect:
+        for k, v in expect.items():
+            assert d[k] == v, (k, d)
+    dA, dB, dC = to_device(A), to_device(B), to_device(C)
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(alpha, dA.data_ptr(), dB.data_ptr(), beta, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(),
+               p.required_workspace, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = from_device(dC, C)
+    ref = np.zeros_like(C)
+    oracle.contract(A, mA, B, mB, ref, mC, alpha=alpha, beta=beta, C=C)
+    scale = float(np.max(np.abs(ref))) if ref.size else 1.0
+    assert_close(got, ref, rtol=rtol, atol=rtol * scale, what="%s,%s->%s %s" % (mA, mB, mC, d))
+    p.destroy()
+    return d
+
+
+def test_contraction_sample_modes_shrunk(env):
+    # contraction.cu:46-59 (C_{m,u,n,v} = alpha A_{m,h,k,n} B_{u,k,v,h} + beta C), alpha 1.1 (:184)
+    ext = dict(m=24, n=12, u=16, v=8, h=8, k=12)
+    run_contraction(env, ext, "mhkn", "ukvh", "munv", alpha=1.1, beta=0.0)
+    run_contraction(env, ext, "mhkn", "ukvh", "munv", alpha=1.1, beta=0.7, seed=10)
+
+
+@pytest.mark.parametrize("case", [
+    # (extents, modesA, modesB, modesC): every operand-layout combination of the GETT kernels
+    (dict(m=64, n=48, k=40), "mk", "kn", "mn"),      # A free-contig (after swap), B K-contig
+    (dict(m=64, n=48, k=40), "km", "kn", "mn"),      # both K-contiguous
+    (dict(m=64, n=48, k=40), "mk", "nk", "mn"),      # both free-contiguous
+    (dict(m=64, n=48, k=40), "km", "nk", "nm"),      # output n-contiguous
+    (dict(m=33, n=17, k=29), "mk", "kn", "mn"),      # odd extents -> scalar-gather kernels
+    (dict(m=100, n=36, k=52), "km", "nk", "mn"),     # M, N not multiples of the tile
+    (dict(a=8, b=12, c=16, d=20, e=24), "dcba", "ebcd", "ea"),   # headline equation, shrunk
+    (dict(l=6, i=20, j=24, k=28), "kil", "jkl", "jil"),          # batch mode (lik,lkj->lij reversed)
+    (dict(l=5, i=12, j=16, k=8, m=4), "mkil", "mjkl", "jil"),    # likm,lkjm->lij reversed
+    (dict(i=40, j=56), "i", "j", "ij"),                          # outer product (no contracted mode)
+    (dict(i=48, k=64), "ik", "k", "i"),                          # matrix-vector
+    (dict(k=4096), "k", "k", ""),                                # dot product -> scalar
+    (dict(a=4, b=1, c=16, d=8), "abd", "dbc", "ac"),             # extent-1 mode
+])
+def test_contraction_layouts(env, case):
+    ext, mA, mB, mC = case
+    run_contraction(env, ext, mA, mB, mC, alpha=1.0, beta=0.0)
+    run_contraction(env, ext, mA, mB, mC, alpha=-0.5, beta=2.0, seed=7)
+
+
+def test_every_candidate_kernel_and_split(env):
+    """Sweep all ranked (kernel, split-K) candidates of two problems: every instantiated GETT kernel
+    and the split-K reduction are exercised and must agree with the oracle."""
+    ct, ops, h, torch = env
+    problems = [
+        (dict(a=96, b=8, c=8, d=16, e=96), "dcba", "ebcd", "ea"),    # LAY_K x LAY_F, deep K
+        (dict(m=160, n=144, k=256), "mk", "nk", "mn"),               # LAY_F x LAY_F
+        (dict(m=160, n=144, k=256), "km", "kn", "mn"),               # LAY_K x LAY_K
+        (dict(m=144, n=160, k=256), "mk", "kn", "mn"),               # LAY_F x LAY_K (after swap)
+        (dict(m=70, n=50, k=300), "mk", "kn", "mn"),                 # LAY_S x LAY_S
+    ]
+    seen = set()
+    for ext, mA, mB, mC in problems:
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        p0 = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 28)
+        n = ct.lib.ctamdCountCandidates(h.h, p0.op, 1 << 28)
+        p0.destroy()
+        assert n > 0
+        for r in range(n):
+            d = run_contraction(env, ext, mA, mB, mC, alpha=1.25, beta=0.5, algo=r, seed=r)
+            seen.add((d["kernel"], d["splitK"] > 1))
+    kernels = {k for k, _ in seen}
+    assert len(kernels) >= 20, kernels          # 22 instantiations in gett_f32.hip
+    assert any(s for _, s in seen)
+
+
+def test_strided_descriptors_and_separate_output(env):
+    """Non-packed strides (sub-tensor views) and D != C."""
+    ct, ops, h, torch = env
+    big = make_tensor([40, 24, 36], 3)
+    A = big[4:36, :, 2:34:2]               # extents 32,24,16 strides 1,40,1920
+    B = make_tensor([24, 16, 20], 4)
+    C = make_tensor([32, 20], 5)
+    strideA = [s // 4 for s in A.strides]
+    p = ops.contraction_plan(h, list(A.shape), "ijk", list(B.shape), "jkl", list(C.shape), "il", strideA=strideA,
+                             alignment=16)
+    dbig, dB, dC = to_device(big), to_device(B), to_device(C)
+    dD = torch.zeros_like(dC)
+    offset = (A.ctypes.data - big.ctypes.data)
+    p.contract(2.0, dbig.data_ptr() + offset, dB.data_ptr(), -1.0, dC.data_ptr(), dD.data_ptr(), 0, 0, 0)
+    torch.cuda.synchronize()
+    ref = np.zeros_like(C)
+    oracle.contract(np.asfortranarray(A), "ijk", B, "jkl", ref, "il", alpha=2.0, beta=-1.0, C=C)
+    assert_close(from_device(dD, C), ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), what="strided")
+    assert np.array_equal(from_device(dC, C), C)          # C untouched when D != C
+
+
+def test_headline_einsum_full_size(env):
+    """BASELINE config 2 at full size: 'abcd,dcbe->ae', 96/64/64/64/96, U(0,1) fp32, vs the fp64
+    oracle on every output element (201 MB of inputs, 4.8 GFLOP)."""
+    ct, ops, h, torch = env
+    from cudalibrarysamples_amd import torch_einsum
+    rng = np.random.default_rng(2024)
+    a = rng.random((96, 64, 64, 64), dtype=np.float32)
+    b = rng.random((64, 64, 64, 96), dtype=np.float32)
+    got = torch_einsum.einsum("abcd,dcbe->ae", torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    ref = a.reshape(96, -1).astype(np.float64) @ np.ascontiguousarray(b.transpose(2, 1, 0, 3)).reshape(-1, 96).astype(np.float64)
+    # spot-check the oracle itself on one row against this fp64 TTGT (the oracle at full size takes ~10 s)
+    row = np.zeros((1, 96), dtype=np.float32)
+    row_ref = oracle.einsum("abcd,dcbe->ae", a[5:6], b)
+    np.testing.assert_allclose(row_ref[0], ref[5], rtol=1e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4)
+    del row
+
+
+def test_contraction_sample_full_size_sampled(env):
+    """BASELINE config 1 shape on the GPU: contraction.cu defaults (464 GFLOP), alpha 1.1 beta 0;
+    4096 sampled outputs against fp64 dot products."""
+    ct, ops, h, torch = env
+    ext = dict(m=96, n=96, u=96, v=64, h=64, k=64)
+    mA, mB, mC = "mhkn", "ukvh", "munv"
+    eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+    A, B = make_tensor(eA, 1234), make_tensor(eB, 1235)
+    p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC)
+    dA, dB = to_device(A), to_device(B)
+    dC = torch.zeros(int(np.prod(eC)), dtype=torch.float32, device="cuda")
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(1.1, dA.data_ptr(), dB.data_ptr(), 0.0, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), p.required_workspace, 0)
+    torch.cuda.synchronize()
+    got = np.reshape(dC.cpu().numpy(), eC, order="F")
+    rng = np.random.default_rng(99)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    for _ in range(4096):
+        m, u, n, v = (int(rng.integers(0, ext[c])) for c in "munv")
+        ref = 1.1 * np.einsum("hk,kh->", A64[m, :, :, n], B64[u, :, v, :])
+        assert abs(got[m, u, n, v] - ref) <= 1e-4 * abs(ref), (m, u, n, v, got[m, u, n, v], ref)

@@ -1,0 +1,122 @@
+"""GPU parity: cutensorPermute / cutensorReduce / ElementwiseBinary through the C ABI vs the oracle.
+Permutations are bit-exact for alpha = 1 (pure data movement); reductions rtol 1e-5."""
+import numpy as np
+import pytest
+
+import oracle
+from util import assert_close, from_device, make_tensor, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+    assert torch.cuda.is_available()
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    return ct, ops, ops.Handle(), torch
+
+
+@pytest.mark.parametrize("case", [
+    (dict(w=32, h=16, c=64, n=8), "whcn", "cwhn", 0),       # elementwise_permute.cu:51-63 shrunk -> TRANSPOSE
+    (dict(a=128, b=20, c=68), "abc", "cab", 0),            # config 3 permute A[a,b,c] -> C[c,a,b]
+    (dict(a=72, b=36, c=132), "abc", "cba", 0),            # full reversal, partial 64-tiles
+    (dict(a=256, b=12, c=10), "abc", "acb", 1),            # shared fastest mode -> ROWCOPY
+    (dict(a=4096), "a", "a", 1),                           # 1-D copy
+    (dict(a=33, b=17, c=5), "abc", "cab", 2),              # odd extents -> GENERIC
+    (dict(a=7), "a", "a", 2),
+    (dict(a=1, b=64, c=64), "abc", "cba", 0),              # extent-1 mode dropped
+])
+def test_permutation(env, case):
+    ct, ops, h, torch = env
+    ext, mA, mB, variant = case
+    eA, eB = [ext[c] for c in mA], [ext[c] for c in mB]
+    A = make_tensor(eA, 11)
+    p = ops.permutation_plan(h, eA, mA, eB, mB)
+    assert p.describe()["variant"] == variant, p.describe()
+    dA = to_device(A)
+    dB = torch.zeros(int(np.prod(eB)), dtype=torch.float32, device="cuda")
+    for alpha in (1.0, 1.5):
+        p.permute(alpha, dA.data_ptr(), dB.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ref = np.zeros(eB, dtype=np.float32, order="F")
+        oracle.permute(A, mA, ref, mB, alpha=alpha)
+        got = np.reshape(dB.cpu().numpy(), eB, order="F")
+        if alpha == 1.0:
+            assert np.array_equal(got, ref), (mA, mB)
+        else:
+            assert_close(got, ref, rtol=1e-6, what="permute")
+
+
+@pytest.mark.parametrize("case", [
+    (dict(m=196, h=16, k=8, v=12), "mhkv", "mv", 0),        # reduction.cu:49-61 shrunk -> RED_COL (+split)
+    (dict(a=64, b=40, c=24), "abc", "ac", 0),               # config 3 reduce C[a,c] = sum_b
+    (dict(a=64, b=40, c=24), "abc", "c", 1),                # C[c] = sum_{a,b} -> RED_ROW
+    (dict(a=4096, b=6), "ab", "b", 1),
+    (dict(a=33, b=7, c=5), "abc", "ac", 2),                 # odd -> GENERIC
+    (dict(a=64, b=48), "ab", "", 1),                        # full reduction to a scalar
+    (dict(n=5, i=4, j=6), "jin", "ij", 2),                  # einsum.cu:451 "nij->ji" reversed
+])
+def test_reduction(env, case):
+    ct, ops, h, torch = env
+    ext, mA, mC, variant = case
+    eA, eC = [ext[c] for c in mA], [ext[c] for c in mC]
+    A, C = make_tensor(eA, 21), make_tensor(eC, 22)
+    p = ops.reduction_plan(h, eA, mA, eC, mC)
+    assert p.describe()["variant"] == variant, p.describe()
+    assert p.required_workspace <= p.workspace_estimate
+    dA, dC = to_device(A), to_device(C)
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    for alpha, beta in ((1.1, 0.0), (0.5, 2.0)):
+        dD = dC.clone()
+        p.reduce(alpha, dA.data_ptr(), beta, dD.data_ptr(), dD.data_ptr(), ws.data_ptr(), p.required_workspace, 0)
+        torch.cuda.synchronize()
+        ref = np.zeros_like(C)
+        oracle.reduce(A, mA, ref, mC, alpha=alpha, beta=beta, C=C)
+        assert_close(from_device(dD, C), ref, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()), what="reduce %s->%s" % (mA, mC))
+
+
+def test_reduction_operators(env):
+    ct, ops, h, torch = env
+    eA, eC = [32, 24, 8], [32, 8]
+    A = make_tensor(eA, 31, lo=0.5, hi=1.5)
+    dA = to_device(A)
+    for op in (ct.OP_MAX, ct.OP_MIN):
+        p = ops.reduction_plan(h, eA, "abc", eC, "ac", op_reduce=op)
+        dD = torch.zeros(int(np.prod(eC)), dtype=torch.float32, device="cuda")
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        p.reduce(1.0, dA.data_ptr(), 0.0, dD.data_ptr(), dD.data_ptr(), ws.data_ptr(), p.required_workspace, 0)
+        torch.cuda.synchronize()
+        ref = np.zeros(eC, dtype=np.float32, order="F")
+        oracle.reduce(A, "abc", ref, "ac", op=op)
+        assert np.array_equal(np.reshape(dD.cpu().numpy(), eC, order="F"), ref)
+
+
+def test_reduce_as_permutation_with_beta(env):
+    """einsum.cu:449-450 routes permutations through cutensorReduce; beta*C must be honoured."""
+    ct, ops, h, torch = env
+    eA, eC = [8, 64, 20], [20, 8, 64]
+    A, C = make_tensor(eA, 41), make_tensor(eC, 42)
+    p = ops.reduction_plan(h, eA, "abc", eC, "cab")
+    dA, dC = to_device(A), to_device(C)
+    p.reduce(2.0, dA.data_ptr(), 0.5, dC.data_ptr(), dC.data_ptr(), 0, 0, 0)
+    torch.cuda.synchronize()
+    ref = np.zeros_like(C)
+    oracle.permute(A, "abc", ref, "cab", alpha=2.0, C=C, gamma=0.5)
+    assert_close(from_device(dC, C), ref, rtol=1e-6, what="reduce-as-permute")
+
+
+def test_large_2d_transpose_roundtrip(env):
+    """Size-independent property at a large size: transposing twice is the identity (bit-exact), and
+    a checksum of the transposed tensor equals the checksum of the input."""
+    ct, ops, h, torch = env
+    n = 4096
+    a = torch.rand(n * n, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    p = ops.permutation_plan(h, [n, n], "ab", [n, n], "ba")
+    p.permute(1.0, a.data_ptr(), b.data_ptr(), 0)
+    p.permute(1.0, b.data_ptr(), c.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
+    assert torch.equal(b.view(n, n), a.view(n, n).t().contiguous().view(n, n))

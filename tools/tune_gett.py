@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Sweep every ranked (kernel, split-K) candidate of a contraction on the GPU and print one JSON line
+per candidate (time per call from torch/HIP events on the launch stream).  Used to calibrate the
+planner's cost model; results are copied into profiles/."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+PROBLEMS = {
+    "einsum": (dict(a=96, b=64, c=64, d=64, e=96), "dcba", "ebcd", "ea"),
+    "contraction": (dict(m=96, n=96, u=96, v=64, h=64, k=64), "mhkn", "ukvh", "munv"),
+    "gemm4096": (dict(i=4096, j=4096, k=4096), "ik", "kj", "ij"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--problem", default="einsum")
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--max", type=int, default=64)
+    args = ap.parse_args()
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    ext, mA, mB, mC = PROBLEMS[args.problem]
+    eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+    flop = 2.0 * np.prod([float(v) for v in ext.values()])
+    h = ops.Handle()
+    A = torch.rand(int(np.prod(eA)), device="cuda")
+    B = torch.rand(int(np.prod(eB)), device="cuda")
+    C = torch.zeros(int(np.prod(eC)), device="cuda")
+    p0 = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 30)
+    n = ct.lib.ctamdCountCandidates(h.h, p0.op, 1 << 30)
+    print(json.dumps({"problem": args.problem, "candidates": n, "default": p0.describe()}), flush=True)
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    for r in range(min(n, args.max)):
+        p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 30, algo=r)
+        for _ in range(3):
+            p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream().cuda_stream
+        e0.record()
+        for _ in range(args.reps):
+            p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.reps
+        d = p.describe()
+        print(json.dumps({"rank": r, "us": us, "tflops": flop / us / 1e6, "kernel": d["kernel"],
+                          "tile": [d["bm"], d["bn"], d["bk"]], "waves": [d["wm"], d["wn"], d["wk"]],
+                          "splitK": d["splitK"], "blocks": d["blocks"], "model_us": d["model_us"]}), flush=True)
+        p.destroy()
+
+
+if __name__ == "__main__":
+    main()
