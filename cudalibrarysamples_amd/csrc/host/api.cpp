@@ -825,6 +825,13 @@ int ctamdProfileEnd(float* meanMs, float* minMs) {
     return n;
 }
 
+// Number of instantiated fp32 GETT kernels (test coverage bookkeeping).
+int ctamdKernelCount(void) {
+    int count = 0;
+    (void)gett_f32_kernels(&count);
+    return count;
+}
+
 // Number of ranked candidates for a contraction descriptor under a workspace limit (so that a
 // caller can sweep CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK / algo >= 0 exhaustively).
 int ctamdCountCandidates(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc, uint64_t wsLimit) {

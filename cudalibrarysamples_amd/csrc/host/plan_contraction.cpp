@@ -189,7 +189,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "a fused mode group exceeds 2^31-1 elements");
     if ((int)v.L.size() > kMaxGroupModes || (int)v.M.size() > kMaxGroupModes ||
         (int)v.N.size() > kMaxGroupModes || (int)v.K.size() > kMaxGroupModes)
-        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 8 unfusable modes in one group");
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 4 unfusable modes in one group");
 
     // ---- operand layouts (fp32 path: 4-element = 16-byte lanes) ------------------------------
     auto all_mult4_except = [](const std::vector<const std::vector<CanonMode>*>& groups, bool slotA,
@@ -256,6 +256,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         if (!okA || !okB) continue;
         if ((k.layA == LAY_S) != (k.layB == LAY_S)) continue;   // table only holds S/S pairs
         if (k.layA == LAY_S && v.layA != LAY_S && v.layB != LAY_S) continue;  // vector kernels exist
+        if (k.kfast && (v.K.empty() || (v.K.front().extent % k.bk) != 0)) continue;   // tile would straddle a K-mode period
 
         const uint64_t tilesM = (v.totM + k.bm - 1) / k.bm, tilesN = (v.totN + k.bn - 1) / k.bn;
         const uint64_t tiles = tilesM * tilesN * v.totL;
@@ -308,6 +309,7 @@ static void fill_group(ModeGroup& g, const std::vector<CanonMode>& modes) {
     std::memset(&g, 0, sizeof(g));
     g.n = (int32_t)modes.size();
     uint64_t tot = 1;
+    for (int i = 0; i < kMaxGroupModes; ++i) g.div[i] = FastDiv{1u, 0u, 0u};   // padding: digit = remaining index (0)
     for (size_t i = 0; i < modes.size(); ++i) {
         g.div[i] = make_fastdiv((uint32_t)modes[i].extent);
         tot *= (uint64_t)modes[i].extent;

@@ -54,6 +54,7 @@ bool fill_rest(ModeGroup& g, const std::vector<EwMode>& modes) {
     if ((int)modes.size() > kMaxGroupModes) return false;
     g.n = (int32_t)modes.size();
     uint64_t tot = 1;
+    for (int i = 0; i < kMaxGroupModes; ++i) g.div[i] = FastDiv{1u, 0u, 0u};   // padding modes
     for (size_t i = 0; i < modes.size(); ++i) {
         g.div[i] = make_fastdiv((uint32_t)modes[i].extent);
         g.stride[0][i] = modes[i].sA;

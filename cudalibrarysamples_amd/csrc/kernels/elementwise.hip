@@ -37,10 +37,9 @@ __device__ __forceinline__ uint32_t ew_fast_div(uint32_t n, const FastDiv& d) {
 __device__ __forceinline__ void rest_offsets(const ModeGroup& g, uint32_t idx, int64_t& oA, int64_t& oD,
                                              int64_t& oC) {
     oA = oD = oC = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = ew_fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {   // padding modes: {d = 1, magic = 0, stride = 0}
+        const uint32_t q = __umulhi(idx, g.div[i].magic) >> g.div[i].shift;
         const uint32_t digit = idx - q * g.div[i].d;
         oA += (int64_t)digit * g.stride[0][i];
         oD += (int64_t)digit * g.stride[1][i];

@@ -45,14 +45,16 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& d) {
     return __umulhi(n, d.magic) >> d.shift;
 }
 
-// Element offset of group index idx in tensor slot SLOT.
+// Element offset of group index idx in tensor slot SLOT.  Fixed trip count, no control flow: the
+// planner pads unused modes with {d = 1, magic = 0, stride = 0}, for which the digit is the (by then
+// zero) remaining index.  With constant indices the group descriptor is read from the kernel
+// arguments once and lives in SGPRs; a wave-uniform idx is decoded entirely on the scalar unit.
 template <int SLOT>
 __device__ __forceinline__ int64_t group_offset(const ModeGroup& g, uint32_t idx) {
     int64_t off = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = fast_div(idx, g.div[i]);
         const uint32_t digit = idx - q * g.div[i].d;
         off += (int64_t)digit * g.stride[SLOT][i];
         idx = q;
@@ -66,10 +68,9 @@ __device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t*
                                               uint32_t idx, int64_t& offD, int64_t& offC) {
     offD = 0;
     offC = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = fast_div(idx, g.div[i]);
         const uint32_t digit = idx - q * g.div[i].d;
         offD += (int64_t)digit * g.stride[SLOT][i];
         offC += (int64_t)digit * cstride[i];
@@ -101,8 +102,9 @@ struct OperandTile {
     static constexpr int NROWOFF = (LAY == LAY_S) ? 4 * NU : NU;
     static_assert(UNITS % THREADS == 0, "tile must divide evenly over the workgroup");
 
-    int64_t  rowOff[NROWOFF];   // element offset of this unit's row(s); -1 = out of range
-    f32x4    v[NU];             // staged data
+    // Element offset of this lane's row(s).  Rows beyond the tensor edge are clamped to a valid row:
+    // they only feed accumulators of output rows/columns that the epilogue never stores.
+    int64_t  rowOff[NROWOFF];
 
     template <int SLOT_R>
     __device__ __forceinline__ void init_rows(const ModeGroup& g, uint32_t row0, int tid) {
@@ -111,54 +113,92 @@ struct OperandTile {
             const int u = tid + i * THREADS;
             if constexpr (LAY == LAY_K) {
                 const uint32_t r = row0 + u / KV;
-                rowOff[i] = (r < g.total) ? group_offset<SLOT_R>(g, r) : -1;
+                rowOff[i] = group_offset<SLOT_R>(g, r < g.total ? r : g.total - 1);
             } else if constexpr (LAY == LAY_F) {
-                const uint32_t r = row0 + 4 * (u % RV);
-                rowOff[i] = (r < g.total) ? group_offset<SLOT_R>(g, r) : -1;
+                const uint32_t r = row0 + 4 * (u % RV);   // extent % 4 == 0: a float4 is all in or all out
+                rowOff[i] = group_offset<SLOT_R>(g, r < g.total ? r : g.total - 4);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t r = row0 + 4 * (u % RV) + e;
-                    rowOff[4 * i + e] = (r < g.total) ? group_offset<SLOT_R>(g, r) : -1;
+                    rowOff[4 * i + e] = group_offset<SLOT_R>(g, r < g.total ? r : g.total - 1);
                 }
             }
         }
     }
 
-    // Issue the global loads of the K-tile starting at k0 (elements k0 .. k0+BK-1, clipped to kEnd).
+    // Fast-K addressing: when the extent of the fastest K mode is a multiple of BK, a K-tile never
+    // crosses a period of that mode, so element (row, k0 + kl) sits at
+    //     X + [rowOff + kl * stride0]  +  offset_of(k0)
+    // where the bracket is a per-lane constant (folded into rowOff by fold_k) and offset_of(k0) is
+    // wave-uniform (scalar unit).  The per-tile cost is one 64-bit add per load.
     template <int SLOT_K>
-    __device__ __forceinline__ void load(const float* __restrict__ X, const ModeGroup& gK,
-                                         uint32_t k0, uint32_t kEnd, int tid) {
+    __device__ __forceinline__ void fold_k(const ModeGroup& gK, int tid) {
+        const int64_t stride0 = gK.stride[SLOT_K][0];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + i * THREADS;
-            const uint32_t k = (LAY == LAY_K) ? k0 + 4 * (u % KV) : k0 + u / RV;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (k < kEnd) {
-                const int64_t offK = group_offset<SLOT_K>(gK, k);
-                if constexpr (LAY == LAY_S) {
+            const int64_t kl = (LAY == LAY_K) ? 4 * (u % KV) : u / RV;
+            if constexpr (LAY == LAY_S) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int64_t ro = rowOff[4 * i + e];
-                        if (ro >= 0) val[e] = X[ro + offK];
-                    }
-                } else {
-                    const int64_t ro = rowOff[i];
-                    if (ro >= 0) val = *reinterpret_cast<const f32x4*>(X + ro + offK);
-                }
+                for (int e = 0; e < 4; ++e) rowOff[4 * i + e] += kl * stride0;
+            } else {
+                rowOff[i] += kl * stride0;
             }
-            v[i] = val;
         }
     }
 
-    __device__ __forceinline__ void store_lds(float* lds, int tid) const {
+    // Issue the global loads of the K-tile starting at k0 into v[].  Branch-free and consumer-free:
+    // on the generic path k positions beyond kEnd load a clamped, valid address and are zeroed later,
+    // in store_lds; on the fast-K path every tile is full and nothing ever reads a load result before
+    // its LDS store, so the compiler's vmcnt waits leave the younger ring slots in flight.
+    // Returns the k-validity bits of this lane's units (bit i: unit i lies inside [k0, kEnd)).
+    template <int SLOT_K, bool KFAST>
+    __device__ __forceinline__ uint32_t load(f32x4 (&v)[NU], const float* __restrict__ X, const ModeGroup& gK,
+                                             uint32_t k0, uint32_t kEnd, int tid) const {
+        constexpr uint32_t KSTEP = (LAY == LAY_K) ? 4u : 1u;   // elements one unit covers along k
+        int64_t off0 = 0;
+        if constexpr (KFAST) off0 = group_offset<SLOT_K>(gK, k0);   // wave-uniform
+        uint32_t kMask = 0;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int u = tid + i * THREADS;
+            int64_t offK = off0;
+            if constexpr (KFAST) {
+                kMask |= 1u << i;
+            } else {
+                const uint32_t kl = (LAY == LAY_K) ? 4 * (u % KV) : u / RV;
+                const bool okK = (k0 + kl) < kEnd;
+                const uint32_t kc = okK ? (k0 + kl) : (kEnd - KSTEP);   // clamp into the slice
+                offK = group_offset<SLOT_K>(gK, kc);
+                kMask |= (okK ? 1u : 0u) << i;
+            }
+            if constexpr (LAY == LAY_S) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = X[rowOff[4 * i + e] + offK];
+            } else {
+                v[i] = *reinterpret_cast<const f32x4*>(X + rowOff[i] + offK);
+            }
+        }
+        return kMask;
+    }
+
+    // LDS store of one staged tile; on the generic path k positions beyond the slice become zeros.
+    template <bool KFAST>
+    __device__ static __forceinline__ void store_lds(const f32x4 (&v)[NU], uint32_t kMask, float* lds, int tid) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int u = tid + i * THREADS;
             int idx;
             if constexpr (LAY == LAY_K) idx = (u / KV) * LDS_STRIDE + 4 * (u % KV);
             else                        idx = (u / RV) * LDS_STRIDE + 4 * (u % RV);
-            *reinterpret_cast<f32x4*>(lds + idx) = v[i];
+            f32x4 val = v[i];
+            if constexpr (!KFAST) {
+                const bool okK = (kMask >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = okK ? v[i][e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(lds + idx) = val;
         }
     }
 
@@ -177,10 +217,12 @@ struct OperandTile {
     }
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_, int PF_, bool KFAST_>
 struct GettCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
     static constexpr int LA = LA_, LB = LB_, MINW = MINW_;
+    static constexpr int PF = PF_;   // K-tiles in flight in registers (prefetch distance)
+    static constexpr bool KFAST = KFAST_;   // fast-K addressing (extent of the fastest K mode % BK == 0)
     static constexpr int THREADS = 64 * WM * WN * WK;
     static constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave sub-tile must be 16-granular");
@@ -217,15 +259,18 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 
     const float* A = static_cast<const float*>(p.A);
     const float* B = static_cast<const float*>(p.B);
-    if (p.gL.n > 0) {
-        A += group_offset<0>(p.gL, l);
-        B += group_offset<1>(p.gL, l);
-    }
+    A += group_offset<0>(p.gL, l);
+    B += group_offset<1>(p.gL, l);
 
     TileA ta;
     TileB tb;
     ta.template init_rows<0>(p.gM, m0, tid);
     tb.template init_rows<0>(p.gN, n0, tid);
+    constexpr bool KFAST = Cfg::KFAST;
+    if constexpr (KFAST) {
+        ta.template fold_k<0>(p.gK, tid);
+        tb.template fold_k<1>(p.gK, tid);
+    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -233,31 +278,38 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nTiles = (kEnd > kBegin) ? (int)((kEnd - kBegin + BK - 1) / BK) : 0;
+    const int  nTiles = (kEnd > kBegin) ? (int)((kEnd - kBegin + BK - 1) / BK) : 0;
+    constexpr int PF = Cfg::PF;
 
-    if (nTiles > 0) {
-        ta.template load<0>(A, p.gK, kBegin, kEnd, tid);
-        tb.template load<1>(B, p.gK, kBegin, kEnd, tid);
-        ta.store_lds(lds, tid);
-        tb.store_lds(lds + TileA::LDS_FLOATS, tid);
-        if (nTiles > 1) {
-            ta.template load<0>(A, p.gK, kBegin + BK, kEnd, tid);
-            tb.template load<1>(B, p.gK, kBegin + BK, kEnd, tid);
+    // Register ring: PF K-tiles are in flight from HBM/L2 at any time (24-48 KB per tile), which is
+    // what covers the ~2 us loaded-HBM latency at 25 GB/s per CU.  All ring indices are compile-time
+    // constants (the t-loop is unrolled by PF), so the compiler's counted vmcnt waits only for the
+    // oldest tile at each LDS store.
+    f32x4 va[PF][TileA::NU], vb[PF][TileB::NU];
+    uint32_t ma[PF], mb[PF];   // k-validity bits of each ring slot (all ones on the fast-K path)
+
+    // one K-tile: LDS store of ring slot s, optional refill of the slot, barrier, MFMA block
+    auto tile_step = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int t,
+                         bool refill) {
+        float* buf = lds + (t & 1) * STAGE_FLOATS;
+        // buf was last read by compute(t-2); every wave has passed barrier(t-1) after that
+        TileA::template store_lds<KFAST>(ra, mka, buf, tid);
+        TileB::template store_lds<KFAST>(rb, mkb, buf + TileA::LDS_FLOATS, tid);
+        if (refill) {
+            mka = ta.template load<0, KFAST>(ra, A, p.gK, kBegin + (uint32_t)(t + PF) * BK, kEnd, tid);
+            mkb = tb.template load<1, KFAST>(rb, B, p.gK, kBegin + (uint32_t)(t + PF) * BK, kEnd, tid);
         }
         __syncthreads();
-    }
-
-    for (int t = 0; t < nTiles; ++t) {
-        const float* la = lds + (t & 1) * STAGE_FLOATS;
-        const float* lb = la + TileA::LDS_FLOATS;
+        const float* la = buf;
+        const float* lb = buf + TileA::LDS_FLOATS;
 #pragma unroll
         for (int ss = 0; ss < BK / (16 * WK); ++ss) {
-            const int s = wk + ss * WK;
+            const int ks = wk + ss * WK;
             f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = TileA::fragment(la, wm * (BM / WM) + 16 * i, s, lane);
+            for (int i = 0; i < TM; ++i) fa[i] = TileA::fragment(la, wm * (BM / WM) + 16 * i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = TileB::fragment(lb, wn * (BN / WN) + 16 * j, s, lane);
+            for (int j = 0; j < TN; ++j) fb[j] = TileB::fragment(lb, wn * (BN / WN) + 16 * j, ks, lane);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -266,22 +318,43 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nTiles) {
-            float* nxt = lds + ((t + 1) & 1) * STAGE_FLOATS;
-            ta.store_lds(nxt, tid);
-            tb.store_lds(nxt + TileA::LDS_FLOATS, tid);
-            if (t + 2 < nTiles) {
-                ta.template load<0>(A, p.gK, kBegin + (uint32_t)(t + 2) * BK, kEnd, tid);
-                tb.template load<1>(B, p.gK, kBegin + (uint32_t)(t + 2) * BK, kEnd, tid);
+    };
+
+    if (nTiles >= PF) {
+        // prologue: fill the whole ring, unconditionally — the steady loop must be entered with a
+        // deterministic set of loads in flight, or the compiler's wait counts collapse to vmcnt(0)
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            ma[s] = ta.template load<0, KFAST>(va[s], A, p.gK, kBegin + (uint32_t)s * BK, kEnd, tid);
+            mb[s] = tb.template load<1, KFAST>(vb[s], B, p.gK, kBegin + (uint32_t)s * BK, kEnd, tid);
+        }
+        // steady state: every step refills its slot unconditionally (no control flow around the loads)
+        const int nSteady = ((nTiles - PF) / PF) * PF;
+        for (int t0 = 0; t0 < nSteady; t0 += PF) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) tile_step(va[s], vb[s], ma[s], mb[s], t0 + s, true);
+        }
+        // drain: the last PF .. 2*PF-1 tiles
+        for (int t0 = nSteady; t0 < nTiles; t0 += PF) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                const int t = t0 + s;
+                if (t < nTiles) tile_step(va[s], vb[s], ma[s], mb[s], t, t + PF < nTiles);
             }
         }
-        __syncthreads();
+    } else {
+        // fewer K-tiles than ring slots: plain load -> store -> multiply
+        for (int t = 0; t < nTiles; ++t) {
+            ma[0] = ta.template load<0, KFAST>(va[0], A, p.gK, kBegin + (uint32_t)t * BK, kEnd, tid);
+            mb[0] = tb.template load<1, KFAST>(vb[0], B, p.gK, kBegin + (uint32_t)t * BK, kEnd, tid);
+            tile_step(va[0], vb[0], ma[0], mb[0], t, false);
+        }
     }
 
     // ---- fold the K-split waves of this workgroup ----------------------------------------
     if constexpr (WK > 1) {
         constexpr int PER_WAVE = TM * TN * 4 * 64;
-        // the last loop barrier guarantees every wave is done reading the stage buffers
+        __syncthreads();   // every wave is done reading the stage buffers
         if (wk > 0) {
             float* red = lds + ((wk - 1) * (WM * WN) + (wn * WM + wm)) * PER_WAVE;
 #pragma unroll
@@ -309,7 +382,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
     // MFMA C/D map: acc[i][j][r] is row 4*(lane>>4)+r, column lane&15 of fragment (i, j).
     const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
     if (p.partial != nullptr) {
-        float* P = p.partial + ((size_t)slice * (p.gL.n > 0 ? p.gL.total : 1u) + l) * (size_t)Mtot * Ntot;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mtot * Ntot;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -327,7 +400,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 
     const float* C = static_cast<const float*>(p.C);
     float*       D = static_cast<float*>(p.D);
-    if (p.gL.n > 0) {
+    {
         int64_t oD, oC;
         group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
         D += oD;
@@ -368,27 +441,42 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 // partial reads and the D writes are coalesced).  HBM-bound: splitK*4 bytes read per output.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const SplitKReduceParams p) {
+    // 256 lanes = 32 consecutive outputs x 8 slice groups: each lane sums every 8th slice of its
+    // output (128-B coalesced rows of the partial buffer), the 8 groups meet in LDS.
+    __shared__ float red[8][33];
     const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
-    const uint32_t Ltot = p.gL.n > 0 ? p.gL.total : 1u;
+    const uint32_t Ltot = p.gL.total;
     const size_t   plane = (size_t)Mtot * Ntot;
     const size_t   total = plane * Ltot;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t l = (uint32_t)(e / plane);
-        const size_t   rem = e - (size_t)l * plane;
-        const uint32_t m = (uint32_t)(rem / Ntot);
-        const uint32_t n = (uint32_t)(rem - (size_t)m * Ntot);
-        float sum = 0.f;
+    const int      o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t   e = (size_t)blockIdx.x * 32 + o;
+    float sum = 0.f;
+    if (e < total) {
         const float* src = p.partial + e;
-        for (uint32_t s = 0; s < p.splitK; ++s) sum += src[(size_t)s * total];
-        int64_t oDl = 0, oCl = 0, oDm, oCm, oDn, oCn;
-        if (p.gL.n > 0) group_offset2<2>(p.gL, p.cStrideL, l, oDl, oCl);
-        group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
-        group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
-        float val = p.alpha * sum;
-        if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[oCl + oCm + oCn];
-        static_cast<float*>(p.D)[oDl + oDm + oDn] = val;
+        uint32_t s = g;
+        for (; s + 24 < p.splitK; s += 32) {
+            const float x0 = src[(size_t)s * total], x1 = src[(size_t)(s + 8) * total];
+            const float x2 = src[(size_t)(s + 16) * total], x3 = src[(size_t)(s + 24) * total];
+            sum += (x0 + x1) + (x2 + x3);
+        }
+        for (; s < p.splitK; s += 8) sum += src[(size_t)s * total];
     }
+    red[g][o] = sum;
+    __syncthreads();
+    if (g != 0 || e >= total) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) sum += red[k][o];
+    const uint32_t l = (uint32_t)(e / plane);
+    const size_t   rem = e - (size_t)l * plane;
+    const uint32_t m = (uint32_t)(rem / Ntot);
+    const uint32_t n = (uint32_t)(rem - (size_t)m * Ntot);
+    int64_t oDl = 0, oCl = 0, oDm, oCm, oDn, oCn;
+    group_offset2<2>(p.gL, p.cStrideL, l, oDl, oCl);
+    group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
+    group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
+    float val = p.alpha * sum;
+    if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[oCl + oCm + oCn];
+    static_cast<float*>(p.D)[oDl + oDm + oDn] = val;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -400,24 +488,34 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-#define CTAMD_SHAPE_LIST(X, LA, LB)              \
-    X(128, 128, 32, 2, 2, 1, LA, LB, 2)          \
-    X(96, 96, 32, 2, 2, 1, LA, LB, 2)            \
-    X(64, 64, 32, 2, 2, 1, LA, LB, 2)            \
-    X(48, 48, 64, 1, 1, 4, LA, LB, 2)            \
-    X(32, 32, 64, 1, 1, 4, LA, LB, 2)
+// X(bm, bn, bk, wm, wn, wk, layA, layB, min waves/SIMD, prefetch depth, fast-K)
+#define CTAMD_SHAPE_LIST(X, LA, LB)                    \
+    X(128, 128, 32, 2, 2, 1, LA, LB, 2, 2, true)       \
+    X(96, 96, 32, 2, 2, 1, LA, LB, 2, 3, true)         \
+    X(64, 64, 32, 2, 2, 1, LA, LB, 2, 3, true)         \
+    X(48, 48, 64, 1, 1, 4, LA, LB, 2, 3, true)         \
+    X(32, 32, 64, 1, 1, 4, LA, LB, 2, 3, true)         \
+    X(64, 64, 32, 2, 2, 1, LA, LB, 2, 2, false)        \
+    X(32, 32, 64, 1, 1, 4, LA, LB, 2, 2, false)
 
 #define CTAMD_ALL_KERNELS(X)         \
     CTAMD_SHAPE_LIST(X, LAY_F, LAY_F) \
     CTAMD_SHAPE_LIST(X, LAY_F, LAY_K) \
     CTAMD_SHAPE_LIST(X, LAY_K, LAY_F) \
     CTAMD_SHAPE_LIST(X, LAY_K, LAY_K) \
-    X(64, 64, 32, 2, 2, 1, LAY_S, LAY_S, 2) \
-    X(32, 32, 64, 1, 1, 4, LAY_S, LAY_S, 2)
+    X(64, 64, 32, 2, 2, 1, LAY_S, LAY_S, 2, 2, false) \
+    X(32, 32, 64, 1, 1, 4, LAY_S, LAY_S, 2, 2, false) \
+    /* experimental variants of the headline shapes (prefetch depth) */ \
+    X(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 2, true) \
+    X(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 4, true) \
+    X(48, 48, 64, 1, 1, 4, LAY_K, LAY_F, 2, 2, true) \
+    X(48, 48, 64, 1, 1, 4, LAY_K, LAY_F, 2, 4, true) \
+    X(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 1, true) \
+    X(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 3, true)
 
-#define CTAMD_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw) \
-    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk,   \
-     &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw>>},
+#define CTAMD_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast) \
+    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, kfast ? 1 : 0, \
+     &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast>>},
 
 static const GettKernelInfo g_gett_f32_table[] = {CTAMD_ALL_KERNELS(CTAMD_ENTRY)};
 
@@ -427,10 +525,9 @@ const GettKernelInfo* gett_f32_kernels(int* count) {
 }
 
 hipError_t launch_splitk_reduce(const SplitKReduceParams& p, hipStream_t stream) {
-    const uint32_t Ltot = p.gL.n > 0 ? p.gL.total : 1u;
+    const uint32_t Ltot = p.gL.total;
     const size_t total = (size_t)p.gM.total * p.gN.total * Ltot;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    const size_t blocks = (total + 31) / 32;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
     return hipGetLastError();

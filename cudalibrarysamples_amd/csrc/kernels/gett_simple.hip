@@ -21,10 +21,9 @@ __device__ __forceinline__ uint32_t gs_fast_div(uint32_t n, const FastDiv& d) {
 template <int SLOT>
 __device__ __forceinline__ int64_t gs_offset(const ModeGroup& g, uint32_t idx) {
     int64_t off = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = gs_fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = gs_fast_div(idx, g.div[i]);
         off += (int64_t)(idx - q * g.div[i].d) * g.stride[SLOT][i];
         idx = q;
     }
@@ -32,10 +31,9 @@ __device__ __forceinline__ int64_t gs_offset(const ModeGroup& g, uint32_t idx) {
 }
 __device__ __forceinline__ int64_t gs_offset_c(const ModeGroup& g, const int64_t* cs, uint32_t idx) {
     int64_t off = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = gs_fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = gs_fast_div(idx, g.div[i]);
         off += (int64_t)(idx - q * g.div[i].d) * cs[i];
         idx = q;
     }
@@ -62,12 +60,10 @@ __global__ void __launch_bounds__(256) gett_simple_kernel(const GettParams p) {
     const T* B = static_cast<const T*>(p.B);
     const T* C = static_cast<const T*>(p.C);
     T*       D = static_cast<T*>(p.D);
-    if (p.gL.n > 0) {
-        A += gs_offset<0>(p.gL, l);
-        B += gs_offset<1>(p.gL, l);
-        D += gs_offset<2>(p.gL, l);
-        C += gs_offset_c(p.gL, p.cStrideL, l);
-    }
+    A += gs_offset<0>(p.gL, l);
+    B += gs_offset<1>(p.gL, l);
+    D += gs_offset<2>(p.gL, l);
+    C += gs_offset_c(p.gL, p.cStrideL, l);
     const uint32_t m = mt * 16 + ty, n = nt * 16 + tx;
     const bool okM = m < p.gM.total, okN = n < p.gN.total;
     const int64_t offAm = okM ? gs_offset<0>(p.gM, m) : 0;

@@ -17,6 +17,8 @@ struct GettKernelInfo {
     int wm, wn, wk;      // wave grid inside the workgroup
     int layA, layB;      // OperandLayout of kernel-A / kernel-B
     int threads;
+    int pf;              // K-tiles in flight in registers
+    int kfast;           // 1: requires extent(fastest K mode) % bk == 0
     hipError_t (*launch)(const GettParams&, hipStream_t);
 };
 

@@ -10,7 +10,7 @@
 
 namespace ctamd {
 
-constexpr int kMaxGroupModes = 8;   // modes per group after fusion (more => simple fallback kernel)
+constexpr int kMaxGroupModes = 4;   // modes per group after fusion (more => NOT_SUPPORTED)
 
 // Exact unsigned division n / d for n < 2^31, d in [2, 2^31): q = mulhi(n, magic) >> shift.
 struct FastDiv {
@@ -23,7 +23,7 @@ struct FastDiv {
 //   M group: slot 0 = A, slot 1 = C/D          N group: slot 0 = B, slot 1 = C/D
 //   K group: slot 0 = A, slot 1 = B            L group: slot 0 = A, slot 1 = B, slot 2 = C/D
 struct ModeGroup {
-    int32_t  n;                          // number of modes (0 => group extent 1)
+    int32_t  n;                          // number of real modes; entries n.. are padding {d=1, magic=0, stride=0}
     uint32_t total;                      // product of extents (< 2^31)
     FastDiv  div[kMaxGroupModes];
     int64_t  stride[3][kMaxGroupModes];

@@ -54,11 +54,11 @@ __device__ __forceinline__ uint32_t rd_fast_div(uint32_t n, const FastDiv& d) {
 }
 template <int SLOT>
 __device__ __forceinline__ int64_t rd_offset(const ModeGroup& g, uint32_t idx) {
+    // fixed trip count, branch-free: padding modes are {d = 1, magic = 0, stride = 0}
     int64_t off = 0;
-    const int n = g.n;
-    for (int i = 0; i < n; ++i) {
-        uint32_t q = 0;
-        if (i + 1 < n) q = rd_fast_div(idx, g.div[i]);
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = rd_fast_div(idx, g.div[i]);
         off += (int64_t)(idx - q * g.div[i].d) * g.stride[SLOT][i];
         idx = q;
     }

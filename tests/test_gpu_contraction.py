@@ -77,14 +77,19 @@ def test_contraction_layouts(env, case):
 
 
 def test_every_candidate_kernel_and_split(env):
-    """Sweep all ranked (kernel, split-K) candidates of two problems: every instantiated GETT kernel
-    and the split-K reduction are exercised and must agree with the oracle."""
+    """Sweep all ranked (kernel, split-K) candidates of a set of problems chosen so that every
+    instantiated GETT kernel (all layout pairs, fast-K and generic-K addressing, every tile shape and
+    prefetch depth) and the split-K fold are exercised; each must agree with the oracle."""
     ct, ops, h, torch = env
     problems = [
-        (dict(a=96, b=8, c=8, d=16, e=96), "dcba", "ebcd", "ea"),    # LAY_K x LAY_F, deep K
-        (dict(m=160, n=144, k=256), "mk", "nk", "mn"),               # LAY_F x LAY_F
-        (dict(m=160, n=144, k=256), "km", "kn", "mn"),               # LAY_K x LAY_K
-        (dict(m=144, n=160, k=256), "mk", "kn", "mn"),               # LAY_F x LAY_K (after swap)
+        (dict(a=96, b=4, c=4, d=64, e=96), "dcba", "ebcd", "ea"),    # LAY_K x LAY_F, fast-K, 3 K modes
+        (dict(m=160, n=144, k=256), "mk", "nk", "mn"),               # LAY_F x LAY_F, fast-K
+        (dict(m=160, n=144, k=256), "km", "kn", "mn"),               # LAY_K x LAY_K, fast-K
+        (dict(m=144, n=160, k=256), "mk", "kn", "nm"),               # LAY_F x LAY_K, fast-K
+        (dict(a=40, b=6, c=20, e=56), "cba", "ebc", "ea"),           # LAY_K x LAY_F, generic K (20 % 32 != 0)
+        (dict(m=72, n=40, k=12, j=9), "mkj", "nkj", "mn"),           # LAY_F x LAY_F, generic K
+        (dict(m=72, n=40, k=12, j=9), "kjm", "kjn", "mn"),           # LAY_K x LAY_K, generic K
+        (dict(m=40, n=72, k=12, j=9), "mkj", "kjn", "nm"),           # LAY_F x LAY_K, generic K
         (dict(m=70, n=50, k=300), "mk", "kn", "mn"),                 # LAY_S x LAY_S
     ]
     seen = set()
@@ -98,7 +103,8 @@ def test_every_candidate_kernel_and_split(env):
             d = run_contraction(env, ext, mA, mB, mC, alpha=1.25, beta=0.5, algo=r, seed=r)
             seen.add((d["kernel"], d["splitK"] > 1))
     kernels = {k for k, _ in seen}
-    assert len(kernels) >= 20, kernels          # 22 instantiations in gett_f32.hip
+    missing = set(range(ct.lib.ctamdKernelCount())) - kernels
+    assert not missing, "GETT kernels never exercised: %s" % sorted(missing)
     assert any(s for _, s in seen)
 
 
