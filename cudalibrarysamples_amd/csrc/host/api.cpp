@@ -776,12 +776,13 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
         const int k = plan->choice.kernel;
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
-                          "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
+                          "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
                           "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f}",
                           (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
                           k >= 0 ? tab[k].bk : 16, k >= 0 ? tab[k].wm : 1, k >= 0 ? tab[k].wn : 1, k >= 0 ? tab[k].wk : 1,
+                          k >= 0 ? tab[k].pf : 0, k >= 0 ? tab[k].ablation : 0,
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs);
     } else if (plan->kind == OpKind::Reduction && !plan->red.isPermutation) {
@@ -827,9 +828,10 @@ int ctamdProfileEnd(float* meanMs, float* minMs) {
 
 // Number of instantiated fp32 GETT kernels (test coverage bookkeeping).
 int ctamdKernelCount(void) {
-    int count = 0;
-    (void)gett_f32_kernels(&count);
-    return count;
+    int count = 0, n = 0;
+    const GettKernelInfo* tab = gett_f32_kernels(&count);
+    for (int i = 0; i < count; ++i) n += tab[i].ablation ? 0 : 1;   // ablation variants sit at the end of the table
+    return n;
 }
 
 // Number of ranked candidates for a contraction descriptor under a workspace limit (so that a

@@ -248,8 +248,10 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
     const double hbm = 6.0e12, l2bw = 20.0e12;
     const double M = (double)v.totM, N = (double)v.totN, K = (double)v.totK, L = (double)v.totL;
 
+    const bool withAblations = std::getenv("CUTENSOR_AMD_ABLATION") != nullptr;
     for (int i = 0; i < count; ++i) {
         const GettKernelInfo& k = tab[i];
+        if (k.ablation && !withAblations) continue;
         // a kernel is usable if each operand admits its layout (LAY_S kernels take anything)
         const bool okA = (k.layA == v.layA) || (k.layA == LAY_S);
         const bool okB = (k.layB == v.layB) || (k.layB == LAY_S);

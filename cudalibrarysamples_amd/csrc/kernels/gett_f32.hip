@@ -217,11 +217,12 @@ struct OperandTile {
     }
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_, int PF_, bool KFAST_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_, int PF_, bool KFAST_, int ABL_ = 0>
 struct GettCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
     static constexpr int LA = LA_, LB = LB_, MINW = MINW_;
     static constexpr int PF = PF_;   // K-tiles in flight in registers (prefetch distance)
+    static constexpr int ABL = ABL_;        // measurement-only ablations: 1 = no refills (LDS+MFMA), 2 = no MFMA (memory path)
     static constexpr bool KFAST = KFAST_;   // fast-K addressing (extent of the fastest K mode % BK == 0)
     static constexpr int THREADS = 64 * WM * WN * WK;
     static constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         // buf was last read by compute(t-2); every wave has passed barrier(t-1) after that
         TileA::template store_lds<KFAST>(ra, mka, buf, tid);
         TileB::template store_lds<KFAST>(rb, mkb, buf + TileA::LDS_FLOATS, tid);
-        if (refill) {
+        if (refill && Cfg::ABL != 1) {
             mka = ta.template load<0, KFAST>(ra, A, p.gK, kBegin + (uint32_t)(t + PF) * BK, kEnd, tid);
             mkb = tb.template load<1, KFAST>(rb, B, p.gK, kBegin + (uint32_t)(t + PF) * BK, kEnd, tid);
         }
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         const float* la = buf;
         const float* lb = buf + TileA::LDS_FLOATS;
 #pragma unroll
-        for (int ss = 0; ss < BK / (16 * WK); ++ss) {
+        for (int ss = 0; ss < (Cfg::ABL == 2 ? 0 : BK / (16 * WK)); ++ss) {
             const int ks = wk + ss * WK;
             f32x4 fa[TM], fb[TN];
 #pragma unroll
@@ -514,10 +515,19 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
     X(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 3, true)
 
 #define CTAMD_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast) \
-    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, kfast ? 1 : 0, \
+    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, kfast ? 1 : 0, 0, \
      &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast>>},
+// measurement-only ablations of the headline kernel (never ranked unless CUTENSOR_AMD_ABLATION is set)
+#define CTAMD_ABL_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, abl) \
+    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, 1, abl, \
+     &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, true, abl>>},
 
-static const GettKernelInfo g_gett_f32_table[] = {CTAMD_ALL_KERNELS(CTAMD_ENTRY)};
+static const GettKernelInfo g_gett_f32_table[] = {
+    CTAMD_ALL_KERNELS(CTAMD_ENTRY)
+    CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 1)
+    CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 2)
+    CTAMD_ABL_ENTRY(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2, 1)
+    CTAMD_ABL_ENTRY(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2, 2)};
 
 const GettKernelInfo* gett_f32_kernels(int* count) {
     *count = (int)(sizeof(g_gett_f32_table) / sizeof(g_gett_f32_table[0]));

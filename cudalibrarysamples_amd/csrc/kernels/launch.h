@@ -19,6 +19,7 @@ struct GettKernelInfo {
     int threads;
     int pf;              // K-tiles in flight in registers
     int kfast;           // 1: requires extent(fastest K mode) % bk == 0
+    int ablation;        // != 0: measurement-only variant (wrong results), never ranked by default
     hipError_t (*launch)(const GettParams&, hipStream_t);
 };
 

@@ -1,0 +1,119 @@
+"""GPU parity of the cuTENSORMg path on the devices that are visible (the GPU box has one): the call
+sequence of cuTENSORMg/contraction_multi_gpu.cu:151-383 with its 2x2 block-cyclic descriptors, shrunk
+extents, every grid cell on device 0 — both with a one-device handle and with a handle that lists
+device 0 several times ("virtual" devices), which exercises sharding, gather views, per-piece local
+contractions and the scatter back into the owners' cell buffers."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg(built):
+    import torch
+    assert torch.cuda.is_available()
+    from cudalibrarysamples_amd import cutensormg
+    return cutensormg, torch
+
+
+def distribute(M, block, dc):
+    """Global matrix (numpy, any layout) -> list of per-cell packed buffers.
+    Cell (c0, c1) (first mode fastest) holds blocks (b0, b1) with b_i % dc_i == c_i, stored
+    [w0, w1, lb0, lb1] first index fastest (contraction_multi_gpu.cu:256: packed block storage)."""
+    e0, e1 = M.shape
+    nb0, nb1 = e0 // block[0], e1 // block[1]
+    cells = []
+    for c1 in range(dc[1]):
+        for c0 in range(dc[0]):
+            pass
+    out = {}
+    for c1 in range(dc[1]):
+        for c0 in range(dc[0]):
+            lb0, lb1 = nb0 // dc[0], nb1 // dc[1]
+            buf = np.zeros((block[0], block[1], lb0, lb1), dtype=M.dtype, order="F")
+            for l1 in range(lb1):
+                for l0 in range(lb0):
+                    b0, b1 = l0 * dc[0] + c0, l1 * dc[1] + c1
+                    buf[:, :, l0, l1] = M[b0 * block[0]:(b0 + 1) * block[0], b1 * block[1]:(b1 + 1) * block[1]]
+            out[c0 + dc[0] * c1] = buf
+    return [out[i] for i in range(dc[0] * dc[1])]
+
+
+def collect(cells, shape, block, dc, dtype):
+    M = np.zeros(shape, dtype=dtype)
+    nb0, nb1 = shape[0] // block[0], shape[1] // block[1]
+    for c1 in range(dc[1]):
+        for c0 in range(dc[0]):
+            buf = cells[c0 + dc[0] * c1]
+            for l1 in range(nb1 // dc[1]):
+                for l0 in range(nb0 // dc[0]):
+                    b0, b1 = l0 * dc[0] + c0, l1 * dc[1] + c1
+                    M[b0 * block[0]:(b0 + 1) * block[0], b1 * block[1]:(b1 + 1) * block[1]] = buf[:, :, l0, l1]
+    return M
+
+
+@pytest.mark.parametrize("handle_devices,extent,block,beta", [
+    ([0], 256, 128, 0.0),              # the sample on a 1-GPU node (contraction_multi_gpu.cu:129-139)
+    ([0, 0, 0, 0], 256, 128, 0.0),     # four logical devices -> i sharded four ways inside two blocks
+    ([0, 0], 256, 64, 0.5),            # block-cyclic with two local blocks per cell, beta != 0
+    ([0, 0, 0], 192, 32, 0.0),         # shard boundaries that are not block boundaries
+])
+def test_mg_contraction(mg, handle_devices, extent, block, beta):
+    cm, torch = mg
+    rng = np.random.default_rng(7)
+    E, BS, DC = extent, block, 2
+    A = rng.random((E, E), dtype=np.float32)      # A[i,k]
+    B = rng.random((E, E), dtype=np.float32)      # B[k,j]
+    C = rng.random((E, E), dtype=np.float32)      # C[i,j]
+    h = ctypes.c_void_p()
+    cm.check(cm.cutensorMgCreate(ctypes.byref(h), len(handle_devices), cm.i32(handle_devices)))
+    cell_devices = [handle_devices[i % len(handle_devices)] for i in range(DC * DC)]   # fillUp(), :178-187
+
+    def desc():
+        d = ctypes.c_void_p()
+        cm.check(cm.cutensorMgCreateTensorDescriptor(h, ctypes.byref(d), 2, cm.i64([E, E]), None, cm.i64([BS, BS]), None,
+                                                     cm.i32([DC, DC]), DC * DC, cm.i32(cell_devices), 0))
+        return d
+
+    dA, dB, dC = desc(), desc(), desc()
+    cd = ctypes.c_void_p()
+    cm.check(cm.cutensorMgCreateContractionDescriptor(h, ctypes.byref(cd), dA, cm.i32("ik"), dB, cm.i32("kj"), dC, cm.i32("ij"),
+                                                      dC, cm.i32("ij"), cm.COMPUTE_32F))
+    find = ctypes.c_void_p()
+    cm.check(cm.cutensorMgCreateContractionFind(h, ctypes.byref(find), cm.ALGO_DEFAULT))
+    n = len(handle_devices)
+    ws_sizes = (ctypes.c_int64 * n)()
+    host_size = ctypes.c_int64(0)
+    cm.check(cm.cutensorMgContractionGetWorkspace(h, cd, find, 2, ws_sizes, ctypes.byref(host_size)))
+    plan = ctypes.c_void_p()
+    cm.check(cm.cutensorMgCreateContractionPlan(h, ctypes.byref(plan), cd, find, ws_sizes, host_size.value))
+
+    cellsA = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in distribute(A, (BS, BS), (DC, DC))]
+    cellsB = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in distribute(B, (BS, BS), (DC, DC))]
+    cellsC = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in distribute(C, (BS, BS), (DC, DC))]
+    ws = [torch.empty(int(ws_sizes[i]), dtype=torch.uint8, device="cuda") for i in range(n)]
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    torch.cuda.synchronize()
+    alpha, b = ctypes.c_float(1.0), ctypes.c_float(beta)
+    pa = cm.ptr_array([t.data_ptr() for t in cellsA])
+    pb = cm.ptr_array([t.data_ptr() for t in cellsB])
+    pc = cm.ptr_array([t.data_ptr() for t in cellsC])
+    pw = cm.ptr_array([t.data_ptr() for t in ws])
+    ps = cm.ptr_array([s.cuda_stream for s in streams])
+    cm.check(cm.cutensorMgContraction(h, plan, ctypes.byref(alpha), pa, pb, ctypes.byref(b), pc, pc, pw, None, ps))
+    torch.cuda.synchronize()
+
+    lb = E // (BS * DC)
+    got_cells = [np.reshape(t.cpu().numpy(), (BS, BS, lb, lb), order="F") for t in cellsC]
+    got = collect(got_cells, (E, E), (BS, BS), (DC, DC), np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64) + beta * C
+    np.testing.assert_allclose(got, ref, rtol=1e-4)
+
+    for f, o in ((cm.cutensorMgDestroyContractionPlan, plan), (cm.cutensorMgDestroyContractionFind, find),
+                 (cm.cutensorMgDestroyContractionDescriptor, cd), (cm.cutensorMgDestroyTensorDescriptor, dA),
+                 (cm.cutensorMgDestroyTensorDescriptor, dB), (cm.cutensorMgDestroyTensorDescriptor, dC),
+                 (cm.cutensorMgDestroy, h)):
+        cm.check(f(o))

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--problem", default="einsum")
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--max", type=int, default=64)
+    ap.add_argument("--splits", type=str, default="", help="comma list of split-K values to keep (empty = all)")
+    ap.add_argument("--tiles", type=str, default="", help="comma list of bm values to keep (empty = all)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -37,8 +39,18 @@ def main():
     n = ct.lib.ctamdCountCandidates(h.h, p0.op, 1 << 30)
     print(json.dumps({"problem": args.problem, "candidates": n, "default": p0.describe()}), flush=True)
     ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    for r in range(min(n, args.max)):
+    keep_s = {int(x) for x in args.splits.split(",") if x}
+    keep_t = {int(x) for x in args.tiles.split(",") if x}
+    done = 0
+    for r in range(n):
+        if done >= args.max:
+            break
         p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 30, algo=r)
+        d0 = p.describe()
+        if (keep_s and d0["splitK"] not in keep_s) or (keep_t and d0["bm"] not in keep_t):
+            p.destroy()
+            continue
+        done += 1
         for _ in range(3):
             p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
         torch.cuda.synchronize()
@@ -53,7 +65,7 @@ def main():
         d = p.describe()
         print(json.dumps({"rank": r, "us": us, "tflops": flop / us / 1e6, "kernel": d["kernel"],
                           "tile": [d["bm"], d["bn"], d["bk"]], "waves": [d["wm"], d["wn"], d["wk"]],
-                          "splitK": d["splitK"], "blocks": d["blocks"], "model_us": d["model_us"]}), flush=True)
+                          "pf": d["pf"], "abl": d["abl"], "splitK": d["splitK"], "blocks": d["blocks"], "model_us": d["model_us"]}), flush=True)
         p.destroy()
 
 
