@@ -217,11 +217,12 @@ struct OperandTile {
     }
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_, int PF_, bool KFAST_, int ABL_ = 0>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int WK_, int LA_, int LB_, int MINW_, int PF_, bool KFAST_, int ABL_ = 0, int NBUF_ = 2>
 struct GettCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, WK = WK_;
     static constexpr int LA = LA_, LB = LB_, MINW = MINW_;
     static constexpr int PF = PF_;   // K-tiles in flight in registers (prefetch distance)
+    static constexpr int NBUF = NBUF_;      // LDS stage buffers: 2 = store/barrier/multiply per tile, 3 = streamed fragments
     static constexpr int ABL = ABL_;        // measurement-only ablations: 1 = no refills (LDS+MFMA), 2 = no MFMA (memory path)
     static constexpr bool KFAST = KFAST_;   // fast-K addressing (extent of the fastest K mode % BK == 0)
     static constexpr int THREADS = 64 * WM * WN * WK;
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
     using TileB = OperandTile<Cfg::LB, BN, BK, THREADS>;
     constexpr int STAGE_FLOATS = TileA::LDS_FLOATS + TileB::LDS_FLOATS;
     constexpr int RED_FLOATS   = (WK > 1) ? (WK - 1) * BM * BN : 0;
-    constexpr int LDS_FLOATS   = (2 * STAGE_FLOATS > RED_FLOATS) ? 2 * STAGE_FLOATS : RED_FLOATS;
+    constexpr int LDS_FLOATS   = (Cfg::NBUF * STAGE_FLOATS > RED_FLOATS) ? Cfg::NBUF * STAGE_FLOATS : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid  = threadIdx.x;
@@ -289,6 +290,112 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
     f32x4 va[PF][TileA::NU], vb[PF][TileB::NU];
     uint32_t ma[PF], mb[PF];   // k-validity bits of each ring slot (all ones on the fast-K path)
 
+    if constexpr (Cfg::NBUF == 3) {
+        // ---------------------------------------------------------------------------------------
+        // Streamed pipeline (3 LDS stage buffers).  Tile T is parked in LDS two iterations before
+        // it is multiplied, so when iteration t runs, tiles t and t+1 are both resident and visible:
+        // the MFMA operand fragments form one continuous, double-buffered stream (the fragments of
+        // the next 16-step — possibly the first step of the next tile — are fetched while the
+        // current step's MFMAs issue) and the per-tile barrier only guards buffer reuse, it is no
+        // longer between an LDS store and the reads that need it.
+        //   iteration t:  LDS <- ring slot of tile t+2 ; ring slot <- HBM tile t+2+PF ;
+        //                 16-steps of tile t (prefetching fragments) ; barrier
+        // ---------------------------------------------------------------------------------------
+        static_assert(Cfg::NBUF != 3 || PF >= 2, "streamed pipeline needs two tiles staged ahead");
+        constexpr int NSTEP = BK / (16 * WK);
+        auto stage = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int T, bool refill) {
+            float* buf = lds + (T % 3) * STAGE_FLOATS;
+            TileA::template store_lds<KFAST>(ra, mka, buf, tid);
+            TileB::template store_lds<KFAST>(rb, mkb, buf + TileA::LDS_FLOATS, tid);
+            if (refill && Cfg::ABL != 1) {
+                mka = ta.template load<0, KFAST>(ra, A, p.gK, kBegin + (uint32_t)(T + PF) * BK, kEnd, tid);
+                mkb = tb.template load<1, KFAST>(rb, B, p.gK, kBegin + (uint32_t)(T + PF) * BK, kEnd, tid);
+            }
+        };
+        auto load_frags = [&](f32x4 (&xa)[TM], f32x4 (&xb)[TN], int T, int step) {
+            const float* la = lds + (T % 3) * STAGE_FLOATS;
+            const float* lb = la + TileA::LDS_FLOATS;
+            const int ks = wk + step * WK;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = TileA::fragment(la, wm * (BM / WM) + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) xb[j] = TileB::fragment(lb, wn * (BN / WN) + 16 * j, ks, lane);
+        };
+        f32x4 fa[TM], fb[TN], na[TM], nb[TN];
+        auto iteration = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int t,
+                             bool stage2, bool refill2, bool hasNext) {
+            if (stage2) stage(ra, rb, mka, mkb, t + 2, refill2);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) load_frags(na, nb, t, s + 1);
+                else if (hasNext)  load_frags(na, nb, t + 1, 0);
+                if constexpr (Cfg::ABL != 2) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = na[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = nb[j];
+            }
+            __syncthreads();
+        };
+
+        if (nTiles >= PF + 2) {
+            // prologue (unconditional, so the steady loop is entered with a deterministic load queue)
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                ma[s] = ta.template load<0, KFAST>(va[s], A, p.gK, kBegin + (uint32_t)s * BK, kEnd, tid);
+                mb[s] = tb.template load<1, KFAST>(vb[s], B, p.gK, kBegin + (uint32_t)s * BK, kEnd, tid);
+            }
+            stage(va[0], vb[0], ma[0], mb[0], 0, true);
+            stage(va[1 % PF], vb[1 % PF], ma[1 % PF], mb[1 % PF], 1, true);
+            __syncthreads();
+            load_frags(fa, fb, 0, 0);
+            const int nSteady = ((nTiles - 2 - PF) / PF) * PF;   // iterations whose refill (tile t+2+PF) exists
+            for (int t0 = 0; t0 < nSteady; t0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s)
+                    iteration(va[(s + 2) % PF], vb[(s + 2) % PF], ma[(s + 2) % PF], mb[(s + 2) % PF], t0 + s, true, true, true);
+            }
+            for (int t0 = nSteady; t0 < nTiles; t0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) {
+                    const int t = t0 + s;
+                    if (t < nTiles)
+                        iteration(va[(s + 2) % PF], vb[(s + 2) % PF], ma[(s + 2) % PF], mb[(s + 2) % PF], t,
+                                  t + 2 < nTiles, t + 2 + PF < nTiles, t + 1 < nTiles);
+                }
+            }
+        } else {
+            // short K: plain load -> LDS -> multiply, one tile at a time
+            for (int t = 0; t < nTiles; ++t) {
+                ma[0] = ta.template load<0, KFAST>(va[0], A, p.gK, kBegin + (uint32_t)t * BK, kEnd, tid);
+                mb[0] = tb.template load<1, KFAST>(vb[0], B, p.gK, kBegin + (uint32_t)t * BK, kEnd, tid);
+                float* buf = lds + (t % 3) * STAGE_FLOATS;
+                TileA::template store_lds<KFAST>(va[0], ma[0], buf, tid);
+                TileB::template store_lds<KFAST>(vb[0], mb[0], buf + TileA::LDS_FLOATS, tid);
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    load_frags(fa, fb, t, s);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
     // one K-tile: LDS store of ring slot s, optional refill of the slot, barrier, MFMA block
     auto tile_step = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int t,
                          bool refill) {
@@ -350,6 +457,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
             mb[0] = tb.template load<1, KFAST>(vb[0], B, p.gK, kBegin + (uint32_t)t * BK, kEnd, tid);
             tile_step(va[0], vb[0], ma[0], mb[0], t, false);
         }
+    }
+
     }
 
     // ---- fold the K-split waves of this workgroup ----------------------------------------
@@ -514,9 +623,23 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
     X(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 1, true) \
     X(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 3, true)
 
+// streamed (3-buffer) pipeline variants: X3(bm, bn, bk, wm, wn, wk, layA, layB, minw, pf)
+#define CTAMD_STREAMED_KERNELS(X3)                   \
+    X3(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 2)      \
+    X3(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3)      \
+    X3(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 1, 4)      \
+    X3(48, 48, 64, 1, 1, 4, LAY_K, LAY_F, 2, 2)      \
+    X3(48, 48, 64, 1, 1, 4, LAY_K, LAY_F, 2, 3)      \
+    X3(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 1, 2)    \
+    X3(96, 96, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2)      \
+    X3(128, 128, 16, 2, 2, 1, LAY_F, LAY_F, 2, 3)
+
 #define CTAMD_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast) \
     {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, kfast ? 1 : 0, 0, \
      &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, kfast>>},
+#define CTAMD_ENTRY3(bm, bn, bk, wm, wn, wk, la, lb, minw, pf) \
+    {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, 1, 0, \
+     &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, true, 0, 3>>},
 // measurement-only ablations of the headline kernel (never ranked unless CUTENSOR_AMD_ABLATION is set)
 #define CTAMD_ABL_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, abl) \
     {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, 1, abl, \
@@ -524,6 +647,7 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
 
 static const GettKernelInfo g_gett_f32_table[] = {
     CTAMD_ALL_KERNELS(CTAMD_ENTRY)
+    CTAMD_STREAMED_KERNELS(CTAMD_ENTRY3)
     CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 1)
     CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 2)
     CTAMD_ABL_ENTRY(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2, 1)

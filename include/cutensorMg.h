@@ -15,7 +15,7 @@
 
 #include <stdint.h>
 
-#include <cutensor/types.h>
+#include <cutensor.h>   /* the Mg sample only includes this header and calls cutensorGetErrorString (contraction_multi_gpu.cu:43) */
 
 #ifdef __cplusplus
 extern "C" {

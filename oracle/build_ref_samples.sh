@@ -1,0 +1,29 @@
+#!/bin/bash
+# Builds the reference's OWN sample drivers, from the sources where they lie under /root/reference,
+# against OUR libcutensor.so / libcutensorMg.so.  Nothing is copied into the repository: outputs go to
+# oracle/_ref/ (git-ignored, but shipped to the GPU box with the snapshot).  The sources are compiled
+# unmodified with `hipcc -x hip`; tests/sample_compat/ supplies <cuda_runtime.h>/<cuda_fp16.h> for the
+# runtime names the samples call themselves.  The reference's build system (Makefile/CMake, needs nvcc
+# and the closed libcutensor) is not used.
+set -u
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+REF=/root/reference
+OUT="$ROOT/oracle/_ref"
+[ -d "$REF/cuTENSOR" ] || { echo "reference tree not present: skipping"; exit 0; }
+mkdir -p "$OUT"
+FLAGS="-x hip --offload-arch=gfx950 -std=c++17 -O2 -w -I$ROOT/tests/sample_compat -I$ROOT/include"
+LINK="-L$ROOT/cudalibrarysamples_amd/lib -Wl,-rpath,\$ORIGIN/../../cudalibrarysamples_amd/lib"
+rc=0
+for s in contraction einsum reduction elementwise_permute; do
+    if hipcc $FLAGS "$REF/cuTENSOR/$s.cu" -o "$OUT/$s" $LINK -lcutensor 2> "$OUT/$s.log"; then
+        echo "built oracle/_ref/$s"
+    else
+        echo "FAILED oracle/_ref/$s (see oracle/_ref/$s.log)"; rc=1
+    fi
+done
+if hipcc $FLAGS "$REF/cuTENSORMg/contraction_multi_gpu.cu" -o "$OUT/contraction_multi_gpu" $LINK -lcutensorMg -lcutensor 2> "$OUT/contraction_multi_gpu.log"; then
+    echo "built oracle/_ref/contraction_multi_gpu"
+else
+    echo "FAILED oracle/_ref/contraction_multi_gpu (see oracle/_ref/contraction_multi_gpu.log)"; rc=1
+fi
+exit $rc

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) result: per-kernel duration stats and, if present, the mean
+PMC counter values per dispatch for the engine's kernels.  Usage: rocprof_summary.py <db> [<db> ...]"""
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name[:110]
+
+
+def main():
+    for db in sys.argv[1:]:
+        c = sqlite3.connect(db)
+        print("# %s" % db)
+        rows = list(c.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration) from kernels "
+                              "group by name order by sum(duration) desc"))
+        tot = sum(r[5] for r in rows) or 1
+        print("%-112s %6s %10s %10s %10s %6s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+        for name, n, avg, mn, mx, sm in rows[:8]:
+            print("%-112s %6d %10.2f %10.2f %10.2f %6.1f" % (short(name), n, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * sm / tot))
+        try:
+            pm = list(c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                "where kernel_name like '%ctamd%' group by kernel_name, counter_name"))
+        except sqlite3.Error:
+            pm = []
+        for kname, cname, val, n in pm:
+            print("PMC %-70s %-28s mean_per_dispatch %.6g (n=%d)" % (short(kname)[:70], cname, val, n))
+
+
+if __name__ == "__main__":
+    main()
