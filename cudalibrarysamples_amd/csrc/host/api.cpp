@@ -90,6 +90,8 @@ bool misaligned(const void* p, uint32_t a) { return a > 1 && (reinterpret_cast<u
 
 // Optional per-kernel timing of the dominant (GETT) kernel with HIP events recorded on the caller's
 // stream, for bench.py's roofline line.  Off by default; see ctamdProfileBegin/End below.
+unsigned long long* g_timingBuffer = nullptr;   // diagnostics: see ctamdSetTimingBuffer
+
 struct KernelProfile {
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -647,6 +649,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     p.D = D;
     p.alpha = (float)a; p.beta = (float)b;
     p.alpha64 = a; p.beta64 = b;
+    p.timing = g_timingBuffer;
     hipError_t err;
     if (plan->choice.kernel < 0) {
         p.partial = nullptr;
@@ -796,6 +799,10 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     }
     return n;
 }
+
+// Diagnostics: device buffer of 8 x uint64 per workgroup that the GETT kernel fills with phase
+// timestamps (shader clock and wall clock); nullptr switches it off.
+void ctamdSetTimingBuffer(void* deviceBuffer) { g_timingBuffer = static_cast<unsigned long long*>(deviceBuffer); }
 
 // Per-kernel timing of the GETT kernel inside cutensorContract: Begin() arms it, End() synchronises the
 // recorded event pairs and returns the number of launches and their mean / min duration in ms.

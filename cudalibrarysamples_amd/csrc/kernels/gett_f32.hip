@@ -245,6 +245,14 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
+    // optional phase timestamps (diagnostics only): [0] entry, [1] ring filled / first tiles staged,
+    // [2] steady loop done, [3] drain done, [4] exit (shader clock); [5]/[6] entry/exit wall clock
+    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 8 : nullptr;
+    auto stamp = [&](int slot) {
+        if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5) ? wall_clock64() : __builtin_readcyclecounter();
+    };
+    stamp(0);
+    stamp(5);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = (wave / WM) % WN, wk = wave / (WM * WN);
 
@@ -358,11 +366,13 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
             __syncthreads();
             load_frags(fa, fb, 0, 0);
             const int nSteady = ((nTiles - 2 - PF) / PF) * PF;   // iterations whose refill (tile t+2+PF) exists
+            stamp(1);
             for (int t0 = 0; t0 < nSteady; t0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s)
                     iteration(va[(s + 2) % PF], vb[(s + 2) % PF], ma[(s + 2) % PF], mb[(s + 2) % PF], t0 + s, true, true, true);
             }
+            stamp(2);
             for (int t0 = nSteady; t0 < nTiles; t0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
@@ -438,10 +448,12 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         }
         // steady state: every step refills its slot unconditionally (no control flow around the loads)
         const int nSteady = ((nTiles - PF) / PF) * PF;
+        stamp(1);
         for (int t0 = 0; t0 < nSteady; t0 += PF) {
 #pragma unroll
             for (int s = 0; s < PF; ++s) tile_step(va[s], vb[s], ma[s], mb[s], t0 + s, true);
         }
+        stamp(2);
         // drain: the last PF .. 2*PF-1 tiles
         for (int t0 = nSteady; t0 < nTiles; t0 += PF) {
 #pragma unroll
@@ -461,6 +473,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 
     }
 
+    stamp(3);
     // ---- fold the K-split waves of this workgroup ----------------------------------------
     if constexpr (WK > 1) {
         constexpr int PER_WAVE = TM * TN * 4 * 64;
@@ -505,6 +518,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
                     if (n < Ntot) P[(size_t)m * Ntot + n] = acc[i][j][r];
                 }
             }
+        stamp(4);
+        stamp(6);
         return;
     }
 
@@ -546,14 +561,240 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ping-pong variant for split-K dominated problems (one output tile, very deep K — the headline
+// einsum 'abcd,dcbe->ae').  One 8-wave workgroup per CU, organised as two 4-wave teams that own
+// alternate K-tiles of the slice.  A workgroup-wide barrier separates phases; in every phase one
+// team multiplies its current tile out of its LDS buffer while the other team parks its next tile
+// (register ring -> LDS) and refills the ring from HBM:
+//
+//      phase      0     1     2     3     4   ...
+//      team 0     S0    C0    S1    C1    S2          S = stage tile, C = multiply tile
+//      team 1     -     S0'   C0'   S1'   C1'
+//
+// Each SIMD hosts one wave of each team, so its MFMA pipe always has exactly one wave feeding it
+// while the LDS-store / address / load-issue work of the other wave rides along for free.  Compared
+// with two independent 4-wave workgroups per CU this keeps a single prologue and a single partial
+// tile per CU (half the split-K traffic) and removes the finish-time skew between co-resident
+// workgroups.  Both teams fold their accumulators through LDS at the end.
+// ---------------------------------------------------------------------------------------------
+template <class Cfg>
+__global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(const GettParams p) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN, TT = Cfg::THREADS;   // TT = threads per team
+    constexpr int PF = Cfg::PF;
+    constexpr bool KFAST = Cfg::KFAST;
+    static_assert(Cfg::WK == 1, "teams replace the in-tile K split");
+    using TileA = OperandTile<Cfg::LA, BM, BK, TT>;
+    using TileB = OperandTile<Cfg::LB, BN, BK, TT>;
+    constexpr int STAGE_FLOATS = TileA::LDS_FLOATS + TileB::LDS_FLOATS;
+    constexpr int PER_WAVE = TM * TN * 4 * 64;
+    constexpr int RED_FLOATS = WM * WN * PER_WAVE;
+    constexpr int LDS_FLOATS = (2 * STAGE_FLOATS > RED_FLOATS) ? 2 * STAGE_FLOATS : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid  = threadIdx.x;
+    const int team = __builtin_amdgcn_readfirstlane(tid / TT);
+    const int ttid = tid - team * TT;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(ttid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 8 : nullptr;
+    auto stamp = [&](int slot) {
+        if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5) ? wall_clock64() : __builtin_readcyclecounter();
+    };
+    stamp(0);
+    stamp(5);
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t mt = id % p.tilesM; id /= p.tilesM;
+    const uint32_t nt = id % p.tilesN; id /= p.tilesN;
+    const uint32_t slice = id % p.splitK;
+    const uint32_t l = id / p.splitK;
+    const uint32_t m0 = mt * BM, n0 = nt * BN;
+    const uint32_t kBegin = slice * p.kPerSlice;
+    uint32_t kEnd = kBegin + p.kPerSlice;
+    if (kEnd > p.gK.total) kEnd = p.gK.total;
+
+    const float* A = static_cast<const float*>(p.A) + group_offset<0>(p.gL, l);
+    const float* B = static_cast<const float*>(p.B) + group_offset<1>(p.gL, l);
+
+    TileA ta;
+    TileB tb;
+    ta.template init_rows<0>(p.gM, m0, ttid);
+    tb.template init_rows<0>(p.gN, n0, ttid);
+    if constexpr (KFAST) {
+        ta.template fold_k<0>(p.gK, ttid);
+        tb.template fold_k<1>(p.gK, ttid);
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nTiles = (kEnd > kBegin) ? (int)((kEnd - kBegin + BK - 1) / BK) : 0;
+    const int nMine = (nTiles - team + 1) / 2;      // this team owns tiles team, team + 2, ...
+    const int nPhases = 2 * ((nTiles + 1) / 2) + 1;   // barriers every wave must execute
+    float* buf = lds + team * STAGE_FLOATS;
+    auto tile_k = [&](int i) { return kBegin + (uint32_t)(2 * i + team) * BK; };
+
+    f32x4 va[PF][TileA::NU], vb[PF][TileB::NU];
+    uint32_t ma[PF], mb[PF];
+    int barriers = 0;
+
+    auto stage = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int i, bool refill) {
+        TileA::template store_lds<KFAST>(ra, mka, buf, ttid);
+        TileB::template store_lds<KFAST>(rb, mkb, buf + TileA::LDS_FLOATS, ttid);
+        if (refill) {
+            mka = ta.template load<0, KFAST>(ra, A, p.gK, tile_k(i + PF), kEnd, ttid);
+            mkb = tb.template load<1, KFAST>(rb, B, p.gK, tile_k(i + PF), kEnd, ttid);
+        }
+    };
+    auto multiply = [&]() {
+        const float* la = buf;
+        const float* lb = buf + TileA::LDS_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = TileA::fragment(la, wm * (BM / WM) + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = TileB::fragment(lb, wn * (BN / WN) + 16 * j, ks, lane);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        }
+    };
+    // one owned tile: stage | barrier | multiply | barrier
+    auto step = [&](f32x4 (&ra)[TileA::NU], f32x4 (&rb)[TileB::NU], uint32_t& mka, uint32_t& mkb, int i, bool refill) {
+        stage(ra, rb, mka, mkb, i, refill);
+        __syncthreads();
+        multiply();
+        __syncthreads();
+        barriers += 2;
+    };
+
+    if (team == 1) {   // team 1 runs one phase behind team 0
+        __syncthreads();
+        barriers += 1;
+    }
+    if (nMine >= PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            ma[s] = ta.template load<0, KFAST>(va[s], A, p.gK, tile_k(s), kEnd, ttid);
+            mb[s] = tb.template load<1, KFAST>(vb[s], B, p.gK, tile_k(s), kEnd, ttid);
+        }
+        const int nSteady = ((nMine - PF) / PF) * PF;
+        stamp(1);
+        for (int i0 = 0; i0 < nSteady; i0 += PF) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) step(va[s], vb[s], ma[s], mb[s], i0 + s, true);
+        }
+        stamp(2);
+        for (int i0 = nSteady; i0 < nMine; i0 += PF) {
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                const int i = i0 + s;
+                if (i < nMine) step(va[s], vb[s], ma[s], mb[s], i, i + PF < nMine);
+            }
+        }
+    } else {
+        for (int i = 0; i < nMine; ++i) {
+            ma[0] = ta.template load<0, KFAST>(va[0], A, p.gK, tile_k(i), kEnd, ttid);
+            mb[0] = tb.template load<1, KFAST>(vb[0], B, p.gK, tile_k(i), kEnd, ttid);
+            step(va[0], vb[0], ma[0], mb[0], i, false);
+        }
+    }
+    for (; barriers < nPhases; ++barriers) __syncthreads();   // both teams meet the same barrier count
+    stamp(3);
+
+    // ---- fold team 1 into team 0 (all stage buffers are idle after the last barrier) --------------
+    if (team == 1) {
+        float* red = lds + (wn * WM + wm) * PER_WAVE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((i * TN + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (team == 1) return;
+    {
+        const float* red = lds + (wn * WM + wm) * PER_WAVE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * TN + j) * 4 + r) * 64 + lane];
+    }
+
+    // ---- epilogue (same as gett_f32_kernel) -----------------------------------------------------------
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    if (p.partial != nullptr) {
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mtot * Ntot;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = m0 + wm * (BM / WM) + 16 * i + 4 * (lane >> 4) + r;
+                if (m >= Mtot) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const uint32_t n = n0 + wn * (BN / WN) + 16 * j + (lane & 15);
+                    if (n < Ntot) P[(size_t)m * Ntot + n] = acc[i][j][r];
+                }
+            }
+        stamp(4);
+        stamp(6);
+        return;
+    }
+    const float* C = static_cast<const float*>(p.C);
+    float*       D = static_cast<float*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    const float alpha = p.alpha, beta = p.beta;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t n = n0 + wn * (BN / WN) + 16 * j + (lane & 15);
+        if (n >= Ntot) continue;
+        int64_t offDn, offCn;
+        group_offset2<1>(p.gN, p.cStrideN, n, offDn, offCn);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = m0 + wm * (BM / WM) + 16 * i + 4 * (lane >> 4) + r;
+                if (m >= Mtot) continue;
+                int64_t offDm, offCm;
+                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+                float val = alpha * acc[i][j][r];
+                if (beta != 0.f) val += beta * C[offCm + offCn];
+                D[offDm + offDn] = val;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-K second stage: D[l,m,n] = alpha * sum_s partial[s][l][m][n] + beta * C[l,m,n].
 // One thread per output element, n fastest (kernel-N carries C's stride-1 mode, so both the
 // partial reads and the D writes are coalesced).  HBM-bound: splitK*4 bytes read per output.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const SplitKReduceParams p) {
-    // 256 lanes = 32 consecutive outputs x 8 slice groups: each lane sums every 8th slice of its
-    // output (128-B coalesced rows of the partial buffer), the 8 groups meet in LDS.
-    __shared__ float red[8][33];
+__global__ void __launch_bounds__(512) splitk_reduce_kernel(const SplitKReduceParams p) {
+    // 512 lanes = 32 consecutive outputs x 16 slice groups: each lane sums every 16th slice of its
+    // output (128-B coalesced rows of the partial buffer), the 16 groups meet in LDS.
+    __shared__ float red[16][33];
     const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
     const uint32_t Ltot = p.gL.total;
     const size_t   plane = (size_t)Mtot * Ntot;
@@ -564,18 +805,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const SplitKReducePa
     if (e < total) {
         const float* src = p.partial + e;
         uint32_t s = g;
-        for (; s + 24 < p.splitK; s += 32) {
-            const float x0 = src[(size_t)s * total], x1 = src[(size_t)(s + 8) * total];
-            const float x2 = src[(size_t)(s + 16) * total], x3 = src[(size_t)(s + 24) * total];
+        for (; s + 48 < p.splitK; s += 64) {
+            const float x0 = src[(size_t)s * total], x1 = src[(size_t)(s + 16) * total];
+            const float x2 = src[(size_t)(s + 32) * total], x3 = src[(size_t)(s + 48) * total];
             sum += (x0 + x1) + (x2 + x3);
         }
-        for (; s < p.splitK; s += 8) sum += src[(size_t)s * total];
+        for (; s < p.splitK; s += 16) sum += src[(size_t)s * total];
     }
     red[g][o] = sum;
     __syncthreads();
     if (g != 0 || e >= total) return;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) sum += red[k][o];
+    for (int k = 1; k < 16; ++k) sum += red[k][o];
     const uint32_t l = (uint32_t)(e / plane);
     const size_t   rem = e - (size_t)l * plane;
     const uint32_t m = (uint32_t)(rem / Ntot);
@@ -595,6 +836,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const SplitKReducePa
 template <class Cfg>
 static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(gett_f32_kernel<Cfg>, dim3(p.nBlocks), dim3(Cfg::THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <class Cfg>
+static hipError_t launch_pingpong(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(gett_f32_pingpong_kernel<Cfg>, dim3(p.nBlocks), dim3(2 * Cfg::THREADS), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -640,6 +887,17 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
 #define CTAMD_ENTRY3(bm, bn, bk, wm, wn, wk, la, lb, minw, pf) \
     {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, 1, 0, \
      &launch_cfg<GettCfg<bm, bn, bk, wm, wn, wk, la, lb, minw, pf, true, 0, 3>>},
+// two-team ping-pong kernels: XP(bm, bn, bk, wm, wn, layA, layB, pf, kfast)
+#define CTAMD_PINGPONG_KERNELS(XP)             \
+    XP(96, 96, 32, 2, 2, LAY_K, LAY_F, 2, true)  \
+    XP(96, 96, 32, 2, 2, LAY_K, LAY_F, 3, true)  \
+    XP(96, 96, 32, 2, 2, LAY_F, LAY_F, 2, true)  \
+    XP(96, 96, 32, 2, 2, LAY_F, LAY_K, 2, true)  \
+    XP(96, 96, 32, 2, 2, LAY_K, LAY_K, 2, true)  \
+    XP(64, 64, 32, 2, 2, LAY_K, LAY_F, 2, false)
+#define CTAMD_ENTRYP(bm, bn, bk, wm, wn, la, lb, pf, kfast) \
+    {bm, bn, bk, wm, wn, 1, la, lb, 2 * 64 * wm * wn, pf, kfast ? 1 : 0, 0, \
+     &launch_pingpong<GettCfg<bm, bn, bk, wm, wn, 1, la, lb, 2, pf, kfast>>},
 // measurement-only ablations of the headline kernel (never ranked unless CUTENSOR_AMD_ABLATION is set)
 #define CTAMD_ABL_ENTRY(bm, bn, bk, wm, wn, wk, la, lb, minw, pf, abl) \
     {bm, bn, bk, wm, wn, wk, la, lb, 64 * wm * wn * wk, pf, 1, abl, \
@@ -648,6 +906,7 @@ static hipError_t launch_cfg(const GettParams& p, hipStream_t stream) {
 static const GettKernelInfo g_gett_f32_table[] = {
     CTAMD_ALL_KERNELS(CTAMD_ENTRY)
     CTAMD_STREAMED_KERNELS(CTAMD_ENTRY3)
+    CTAMD_PINGPONG_KERNELS(CTAMD_ENTRYP)
     CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 1)
     CTAMD_ABL_ENTRY(96, 96, 32, 2, 2, 1, LAY_K, LAY_F, 2, 3, 2)
     CTAMD_ABL_ENTRY(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2, 1)
@@ -663,7 +922,7 @@ hipError_t launch_splitk_reduce(const SplitKReduceParams& p, hipStream_t stream)
     const size_t total = (size_t)p.gM.total * p.gN.total * Ltot;
     const size_t blocks = (total + 31) / 32;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ struct GettParams {
     const void* C;        // source for beta (may alias D)
     void*       D;
     float*      partial;  // split-K workspace: [slice][L][M][N] fp32, or nullptr
+    unsigned long long* timing;   // diagnostics: 8 timestamps per workgroup (nullptr = off)
     ModeGroup   gM, gN, gK, gL;
     float       alpha, beta;
     double      alpha64, beta64;  // same scalars at full width (fp64 data)

@@ -78,6 +78,8 @@ lib.cutensorGetErrorString.restype = ctypes.c_char_p
 lib.cutensorGetVersion.restype = ctypes.c_size_t
 lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
+lib.ctamdSetTimingBuffer.argtypes = [_vp]
+lib.ctamdSetTimingBuffer.restype = None
 lib.ctamdProfileBegin.restype = None
 lib.ctamdProfileEnd.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 lib.ctamdEinsumCreate.argtypes = [ctypes.c_char_p, _i64p, ctypes.c_int, _i64p, ctypes.c_int, ctypes.c_int]
