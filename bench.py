@@ -145,8 +145,19 @@ def main():
         clock_ghz = getattr(prop, "clock_rate", 2400000) / 1e6
         peak = cus * 256 * clock_ghz / 1e3      # TFLOP/s from the device's own CU count and max clock
         achieved = FLOP / (mean_ms.value * 1e-3) / 1e12 if n else 0.0
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected by separate
+        # `rocprofv3 --pmc` runs of this same command, tools/gpu_profile.sh; corrected per
+        # MI355X_MICROARCH.md and committed under profiles/).  Counters cannot be read from inside the
+        # timed process, so the committed per-launch figure of the same kernel is reported, else null.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_einsum.json")) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak if peak else None, "traffic": None,
+                "frac": achieved / peak if peak else None, "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic_einsum.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
                 "kernel": "gett_f32_kernel<%dx%dx%d,w%dx%dx%d>" % (desc["bm"], desc["bn"], desc["bk"], desc["wm"], desc["wn"], desc["wk"]),
                 "launches": n, "mean_us": mean_ms.value * 1e3, "min_us": min_ms.value * 1e3,
                 "algorithmic_flop_per_launch": FLOP, "algorithmic_bytes_per_launch": BYTES,
