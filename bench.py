@@ -68,7 +68,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from cudalibrarysamples_amd import cutensor as ct, ops
+    from cudalibrarysamples_amd import cutensor as ct, ops, sharding
 
     # ---- synthetic inputs: U(0,1) fp32, fixed seed per rank, generated on the device ---------------
     g = torch.Generator(device="cuda")
@@ -101,7 +101,7 @@ def main():
             # fold the K-shards: RCCL all-reduce of the 36 KB result, overlapped with the next step
             if len(pending) >= nbuf - 1:
                 pending.pop(0).wait()
-            pending.append(dist.all_reduce(out, async_op=True))
+            pending.append(sharding.fold_partials(out, dist, async_op=True))
 
     def drain():
         while pending:
