@@ -671,7 +671,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             SplitKReduceParams r = plan->skr;
             r.partial = static_cast<float*>(workspace);
             r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
-            err = launch_splitk_reduce(r, stream);
+            err = tab[plan->choice.kernel].fragPartials ? launch_splitk_reduce_frag(r, stream) : launch_splitk_reduce(r, stream);
         }
     }
     if (err != hipSuccess) { CT_LOG("cutensorContract: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
@@ -780,7 +780,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
                           "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
-                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f}",
+                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f",
                           (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
@@ -788,6 +788,12 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           k >= 0 ? tab[k].pf : 0, k >= 0 ? tab[k].ablation : 0,
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs);
+        // contracted digits, fastest first: [extent, strideA, strideB]
+        if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
+        for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)
+            n += std::snprintf(buf + n, len - n, "%s[%lld,%lld,%lld]", i ? "," : "", (long long)plan->view.K[i].extent,
+                               (long long)plan->view.K[i].sA, (long long)plan->view.K[i].sB);
+        if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, "]}");
     } else if (plan->kind == OpKind::Reduction && !plan->red.isPermutation) {
         n = std::snprintf(buf, len, "{\"op\":\"reduction\",\"variant\":%d,\"kept\":%u,\"red\":%u,\"splitR\":%u,\"workspace\":%llu}",
                           plan->red.variant, plan->red.p.kept.total, plan->red.p.red.total, plan->red.p.splitR,
@@ -833,12 +839,17 @@ int ctamdProfileEnd(float* meanMs, float* minMs) {
     return n;
 }
 
-// Number of instantiated fp32 GETT kernels (test coverage bookkeeping).
+// Instantiated fp32 GETT kernels (test coverage bookkeeping): table size, and whether entry i is a
+// measurement-only ablation variant (never planned unless CUTENSOR_AMD_ABLATION is set).
 int ctamdKernelCount(void) {
-    int count = 0, n = 0;
+    int count = 0;
+    (void)gett_f32_kernels(&count);
+    return count;
+}
+int ctamdKernelIsAblation(int i) {
+    int count = 0;
     const GettKernelInfo* tab = gett_f32_kernels(&count);
-    for (int i = 0; i < count; ++i) n += tab[i].ablation ? 0 : 1;   // ablation variants sit at the end of the table
-    return n;
+    return (i >= 0 && i < count && tab[i].ablation) ? 1 : 0;
 }
 
 // Number of ranked candidates for a contraction descriptor under a workspace limit (so that a

@@ -170,11 +170,39 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     // K: follow whichever operand is K-contiguous (A first), else A's order.
     bool kContigA = false, kContigB = false;
     for (const CanonMode& m : v.K) { kContigA |= (m.sA == 1); kContigB |= (m.sB == 1); }
-    const char* korder = std::getenv("CUTENSOR_AMD_KORDER");   // experiment knob: "A" or "B"
+    // CUTENSOR_AMD_KORDER (experiment knob): "A" / "B" = follow that operand's strides; otherwise an
+    // explicit digit list, fastest first, e.g. "d,c:4,b,c" = mode d, the inner 4 of mode c, mode b, the
+    // rest of c (labels as characters).  Any order of the contracted digits is a valid GETT view; the
+    // order decides how a K slice maps to memory in A and B.
+    const char* korder = std::getenv("CUTENSOR_AMD_KORDER");
     bool followB = (!kContigA && kContigB);
-    if (korder && korder[0] == 'B') followB = true;
-    if (korder && korder[0] == 'A') followB = false;
-    if (followB) std::stable_sort(v.K.begin(), v.K.end(), bySB);
+    bool custom = false;
+    if (korder && korder[0] == 'B' && korder[1] == 0) followB = true;
+    else if (korder && korder[0] == 'A' && korder[1] == 0) followB = false;
+    else if (korder && korder[0]) {
+        std::vector<CanonMode> rest = v.K, out;
+        bool ok = true;
+        for (const char* c = korder; *c && ok;) {
+            const int32_t label = (int32_t)(unsigned char)*c++;
+            int64_t inner = 0;
+            if (*c == ':') { ++c; inner = std::strtoll(c, const_cast<char**>(&c), 10); }
+            if (*c == ',') ++c;
+            auto it = std::find_if(rest.begin(), rest.end(), [&](const CanonMode& m) { return m.label == label; });
+            if (it == rest.end()) { ok = false; break; }
+            if (inner > 1 && inner < it->extent && it->extent % inner == 0) {
+                CanonMode lo = *it;
+                lo.extent = inner;
+                out.push_back(lo);
+                it->extent /= inner; it->sA *= inner; it->sB *= inner;
+            } else {
+                out.push_back(*it);
+                rest.erase(it);
+            }
+        }
+        if (ok && rest.empty()) { v.K = out; custom = true; }
+    }
+    if (custom) { /* keep the requested order */ }
+    else if (followB) std::stable_sort(v.K.begin(), v.K.end(), bySB);
     else         std::stable_sort(v.K.begin(), v.K.end(), bySA);
 
     fuse_group(v.M, true, false, true);
@@ -232,6 +260,7 @@ static double tile_efficiency(const GettKernelInfo& k) {
     // fraction of MFMA issue a resident workgroup of this shape sustains (measured on MI355X,
     // see profiles/): small tiles read more LDS bytes per flop and expose more barrier time.
     const int area = k.bm * k.bn;
+    if (k.fragPartials) return area >= 96 * 96 ? 0.92 : 0.75;   // streaming kernels: LDS-DMA ring, prefetched fragments
     if (area >= 128 * 128) return 0.85;
     if (area >= 96 * 96) return 0.80;
     if (area >= 64 * 64) return 0.65;
@@ -273,16 +302,21 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         for (uint32_t s : splits) {
             ContractionChoice c;
             c.kernel = i;
+            // streaming kernels walk their LDS ring in whole turns: equal slices of a multiple of S tiles
+            if (k.fragPartials && (v.totK % k.bk != 0 || kTiles % s != 0 || (kTiles / s) % (uint64_t)k.pf != 0)) continue;
             const uint64_t tilesPerSlice = (kTiles + s - 1) / s;
             c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
             c.splitK = (uint32_t)((v.totK + c.kPerSlice - 1) / c.kPerSlice);
             if (c.splitK < 1) c.splitK = 1;
             if (c.splitK != s && s != 1) continue;   // rounding collapsed this candidate
-            c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
+            if (k.fragPartials)   // accumulator-order partials cover whole (padded) tiles
+                c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * tiles * k.bm * k.bn * 4ull : 0ull;
+            else
+                c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
             if (c.workspace > wsLimit) continue;
 
             const double blocks = (double)tiles * c.splitK;
-            const double wgPerCU = 2.0;
+            const double wgPerCU = k.fragPartials ? 1.0 : 2.0;   // streaming kernels own the CU's LDS
             const double slots = numCUs * wgPerCU;
             const double rounds = std::ceil(blocks / slots);
             const double flopsBlock = 2.0 * k.bm * k.bn * (double)c.kPerSlice;
@@ -356,6 +390,8 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
     std::memcpy(r.cStrideN, p.cStrideN, sizeof(r.cStrideN));
     std::memcpy(r.cStrideL, p.cStrideL, sizeof(r.cStrideL));
     r.splitK = c.splitK;
+    r.tilesM = p.tilesM; r.tilesN = p.tilesN;
+    r.fragTM = (uint32_t)bm / 32u; r.fragTN = (uint32_t)bn / 32u;
 }
 
 }  // namespace ctamd

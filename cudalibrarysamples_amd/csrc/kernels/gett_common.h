@@ -1,0 +1,59 @@
+// gett_common.h — device helpers shared by the gfx950 GETT kernels (mixed-radix group addressing,
+// XCD-aware tile remap).  Device code only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "params.h"
+
+namespace ctamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& d) {
+    return __umulhi(n, d.magic) >> d.shift;
+}
+
+// Element offset of group index idx in tensor slot SLOT.  Fixed trip count, no control flow: the
+// planner pads unused modes with {d = 1, magic = 0, stride = 0}, for which the digit is the (by then
+// zero) remaining index.  With constant indices the group descriptor is read from the kernel
+// arguments once and lives in SGPRs; a wave-uniform idx is decoded entirely on the scalar unit.
+template <int SLOT>
+__device__ __forceinline__ int64_t group_offset(const ModeGroup& g, uint32_t idx) {
+    int64_t off = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = fast_div(idx, g.div[i]);
+        const uint32_t digit = idx - q * g.div[i].d;
+        off += (int64_t)digit * g.stride[SLOT][i];
+        idx = q;
+    }
+    return off;
+}
+
+// Offsets of idx in the D tensor (slot SLOT of the group) and in C (explicit stride array).
+template <int SLOT>
+__device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t* cstride,
+                                              uint32_t idx, int64_t& offD, int64_t& offC) {
+    offD = 0;
+    offC = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = fast_div(idx, g.div[i]);
+        const uint32_t digit = idx - q * g.div[i].d;
+        offD += (int64_t)digit * g.stride[SLOT][i];
+        offC += (int64_t)digit * cstride[i];
+        idx = q;
+    }
+}
+
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nBlocks) {
+    // Workgroup b is dispatched to XCD b % 8 (observed, used for speed only).  Give every XCD a
+    // contiguous range of logical tile ids; bijective for any nBlocks.
+    const uint32_t q = nBlocks >> 3, r = nBlocks & 7u;
+    const uint32_t xcd = b & 7u, i = b >> 3;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+}  // namespace ctamd

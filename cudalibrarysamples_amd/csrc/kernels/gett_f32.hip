@@ -34,58 +34,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "params.h"
 #include "launch.h"
+#include "gett_common.h"
 
 namespace ctamd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& d) {
-    return __umulhi(n, d.magic) >> d.shift;
-}
-
-// Element offset of group index idx in tensor slot SLOT.  Fixed trip count, no control flow: the
-// planner pads unused modes with {d = 1, magic = 0, stride = 0}, for which the digit is the (by then
-// zero) remaining index.  With constant indices the group descriptor is read from the kernel
-// arguments once and lives in SGPRs; a wave-uniform idx is decoded entirely on the scalar unit.
-template <int SLOT>
-__device__ __forceinline__ int64_t group_offset(const ModeGroup& g, uint32_t idx) {
-    int64_t off = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxGroupModes; ++i) {
-        const uint32_t q = fast_div(idx, g.div[i]);
-        const uint32_t digit = idx - q * g.div[i].d;
-        off += (int64_t)digit * g.stride[SLOT][i];
-        idx = q;
-    }
-    return off;
-}
-
-// Offsets of idx in the D tensor (slot SLOT of the group) and in C (explicit stride array).
-template <int SLOT>
-__device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t* cstride,
-                                              uint32_t idx, int64_t& offD, int64_t& offC) {
-    offD = 0;
-    offC = 0;
-#pragma unroll
-    for (int i = 0; i < kMaxGroupModes; ++i) {
-        const uint32_t q = fast_div(idx, g.div[i]);
-        const uint32_t digit = idx - q * g.div[i].d;
-        offD += (int64_t)digit * g.stride[SLOT][i];
-        offC += (int64_t)digit * cstride[i];
-        idx = q;
-    }
-}
-
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nBlocks) {
-    // Workgroup b is dispatched to XCD b % 8 (observed, used for speed only).  Give every XCD a
-    // contiguous range of logical tile ids; bijective for any nBlocks.
-    const uint32_t q = nBlocks >> 3, r = nBlocks & 7u;
-    const uint32_t xcd = b & 7u, i = b >> 3;
-    const uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + i;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Tile loader for one operand.  ROWS = BM or BN, SLOT_R = slot of this tensor in its free group,
@@ -247,7 +202,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
     const int lane = tid & 63;
     // optional phase timestamps (diagnostics only): [0] entry, [1] ring filled / first tiles staged,
     // [2] steady loop done, [3] drain done, [4] exit (shader clock); [5]/[6] entry/exit wall clock
-    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 16 : nullptr;
     auto stamp = [&](int slot) {
         if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5) ? wall_clock64() : __builtin_readcyclecounter();
     };
@@ -599,7 +554,7 @@ __global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(ttid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 16 : nullptr;
     auto stamp = [&](int slot) {
         if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5) ? wall_clock64() : __builtin_readcyclecounter();
     };
@@ -913,8 +868,16 @@ static const GettKernelInfo g_gett_f32_table[] = {
     CTAMD_ABL_ENTRY(128, 128, 32, 2, 2, 1, LAY_F, LAY_F, 2, 2, 2)};
 
 const GettKernelInfo* gett_f32_kernels(int* count) {
-    *count = (int)(sizeof(g_gett_f32_table) / sizeof(g_gett_f32_table[0]));
-    return g_gett_f32_table;
+    // register-staged kernels of this file followed by the streaming kernels (stable indices)
+    static const std::vector<GettKernelInfo> merged = [] {
+        std::vector<GettKernelInfo> v(g_gett_f32_table, g_gett_f32_table + sizeof(g_gett_f32_table) / sizeof(g_gett_f32_table[0]));
+        int n = 0;
+        const GettKernelInfo* st = gett_f32_stream_kernels(&n);
+        v.insert(v.end(), st, st + n);
+        return v;
+    }();
+    *count = (int)merged.size();
+    return merged.data();
 }
 
 hipError_t launch_splitk_reduce(const SplitKReduceParams& p, hipStream_t stream) {

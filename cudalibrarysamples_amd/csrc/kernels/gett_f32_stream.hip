@@ -1,0 +1,539 @@
+// gett_f32_stream.hip — fp32 GETT "streaming" kernels for gfx950 (MI355X, CDNA4).
+//
+// Same contraction semantics and GEMM view as gett_f32.hip (reference call sites:
+// cuTENSOR/contraction.cu:261-265, cuTENSOR/einsum.cu:334-338), different machine mapping, built for
+// the problems whose time is the K loop itself — above all the headline einsum 'abcd,dcbe->ae'
+// (one 96 x 96 output tile, K = 262,144 split over all 256 CUs), where a CU has to sustain
+// ~10 B/clk of HBM reads *and* ~100 % MFMA issue at the same time.
+//
+//   * HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, no
+//     VALU work per byte.  A wave-instruction moves 64 x 16 B into one contiguous 1-KiB piece of LDS;
+//     which 16-byte unit of the tile a lane fetches is free, so the LDS image is shaped by permuting
+//     the *source* units:
+//       - K-contiguous operand (LAY_K): image [row][32 k] (128-B rows, one full HBM line per row);
+//         unit p of row r holds k-unit p ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment
+//         reads (16 rows x 4 k-units per lane group) hit 16 distinct 16-B slots: conflict-free.
+//       - free-contiguous operand (LAY_F): image [32 k][ROWS] (ROWS % 32 == 0); k-rows with bit 2
+//         of k set are rotated by 16 floats, so the two k-slots a half-wave reads with ds_read_b32
+//         fall in opposite bank halves: conflict-free.
+//   * S-deep LDS ring (24 KiB per stage at 96 x 96 x 32): S - 1 K-tiles are in flight per CU, which
+//     covers the ~2 us loaded HBM latency; the only wait in the loop is a *counted* vmcnt.
+//   * one 8-wave workgroup per CU: four multiplying waves (one per SIMD) and four data-moving waves
+//     (one per SIMD) that do nothing but issue LDS-DMA and keep the K-tile odometer — an LDS-DMA
+//     instruction blocks its wave's issue for 60-100+ cycles, which on a multiplying wave would drain
+//     the one-deep MFMA queue.  The MFMA operand fragments are double buffered in registers and
+//     fetched one 16-step ahead, interleaved with the MFMAs of the current step; the per-tile barrier
+//     sits a third into the tile's last 16-step, so the fragment reads of the next tile are covered by
+//     the MFMAs that are still to be issued.  The ring walk is unrolled S times: every LDS address is
+//     a lane-constant base plus an immediate.
+//   * split-K partial tiles are written in the accumulator's own register order (16 B per lane,
+//     1 KiB per wave-instruction) and folded by splitk_reduce_frag_kernel.
+//
+// Roofline: fp32 MFMA (v_mfma_f32_16x16x4_f32, 256 flop/clk/CU); algorithmic flops = 2*L*M*N*K,
+// algorithmic bytes = |A| + |B| + |D|.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "params.h"
+#include "launch.h"
+#include "gett_common.h"
+
+namespace ctamd {
+
+constexpr int kStreamBK = 32;
+
+// 64 lanes x 16 B from per-lane global addresses into one contiguous 1-KiB piece of LDS starting at the
+// wave-uniform address dst (the compiler moves it to M0).  The builtin exists only in the device pass;
+// hipcc's host pass silently drops the stubs of kernel templates that mention it, hence the guard.
+__device__ __forceinline__ void lds_dma_16(const float* src, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+#else
+    (void)src; (void)dst;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// One operand of the streamed tile: where each lane's LDS-DMA pieces come from, and how MFMA operand
+// fragments are read back.  ROWS = BM or BN (multiple of 32); 4 waves share the ROWS/8 pieces.
+// ---------------------------------------------------------------------------------------------
+template <int LAY, int ROWS>
+struct StreamOperand {
+    static_assert(ROWS % 32 == 0, "tile rows must be a multiple of 32");
+    static constexpr int PIECES   = ROWS / 8;        // 1-KiB pieces per tile (either layout)
+    static constexpr int PER_WAVE = PIECES / 4;
+    static constexpr int FLOATS   = ROWS * kStreamBK;
+    static constexpr int UR       = ROWS / 4;        // 16-byte units per k-row (LAY_F)
+
+    int64_t src[PER_WAVE];   // element offset of this lane's unit of piece i (tile k0 = 0)
+
+    // SLOT_R / SLOT_K: slot of this tensor in its free group / in the K group
+    template <int SLOT_K>
+    __device__ __forceinline__ void init(const ModeGroup& gFree, const ModeGroup& gK, uint32_t row0, int wave, int lane) {
+        const int64_t strideK0 = gK.stride[SLOT_K][0];
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int c = wave + 4 * i;
+            if constexpr (LAY == LAY_K) {
+                const int r = 8 * c + (lane >> 3), p = lane & 7;
+                const int u = p ^ ((r >> 1) & 7);
+                uint32_t row = row0 + r;
+                if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
+                src[i] = group_offset<0>(gFree, row) + 4 * u;    // K-contiguous: strideK0 == 1
+            } else {
+                const int g = 64 * c + lane;
+                const int kr = g / UR, p = g % UR;
+                const int u = (p + 4 * ((kr >> 2) & 1)) % UR;
+                uint32_t row = row0 + 4 * u;
+                if (row >= gFree.total) row = gFree.total - 4;   // extent % 4 == 0: a unit is all in or all out
+                src[i] = group_offset<0>(gFree, row) + (int64_t)kr * strideK0;
+            }
+        }
+    }
+
+    // issue this wave's pieces of one tile: X + src + offK (wave-uniform) -> stage + piece
+    __device__ __forceinline__ void issue(const float* __restrict__ X, int64_t offK, float* stage, int wave) const {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i)
+            lds_dma_16(X + src[i] + offK, stage + (wave + 4 * i) * 256);
+    }
+
+    // per-lane constant part of the fragment address (floats) for the 16-row fragment at rbase
+    __device__ static __forceinline__ int frag_base(int rbase, int lane) {
+        const int i = lane & 15, q = lane >> 4;
+        if constexpr (LAY == LAY_K) {
+            const int r = rbase + i;
+            return r * 32 + ((q ^ ((r >> 1) & 7)) << 2);          // 16-step 1 flips bit 2 of the unit: ^ 16 floats
+        } else {
+            const int n = rbase + i;
+            const int p = ((n >> 2) - 4 * (q & 1) + UR) % UR;
+            return (4 * q) * ROWS + p * 4 + (n & 3);              // + (16 s + kk) * ROWS
+        }
+    }
+
+    // operand registers of the four MFMAs of 16-step s: out[kk] feeds MFMA kk (k = 16 s + 4 q + kk)
+    template <int STEP>
+    __device__ static __forceinline__ f32x4 fragment(const float* lds, int base) {
+        if constexpr (LAY == LAY_K) {
+            return *reinterpret_cast<const f32x4*>(lds + (STEP ? (base ^ 16) : base));
+        } else {
+            f32x4 o;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) o[kk] = lds[base + (16 * STEP + kk) * ROWS];
+            return o;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Wave-uniform walk over the K-tiles of a slice, one tile (kStreamBK k's) per advance(): element
+// offsets of the tile in A and B without a division on the common path.  The fastest contracted digit
+// holds n0 tiles per period (fast-K: its extent is a multiple of kStreamBK); stepping inside it and
+// the carry into the second digit are additions of precomputed constants; a carry beyond the second
+// digit (rare) re-derives the offsets from the linear index.
+// ---------------------------------------------------------------------------------------------
+struct KOdometer {
+    uint32_t j0, n0, j1, e1, hi;
+    int64_t  offA, offB, stepA, stepB, wrapA, wrapB;
+
+    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
+        const uint32_t E0 = gK.div[0].d;
+        n0 = E0 / kStreamBK;
+        e1 = gK.div[1].d;
+        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
+        j0 = (k0 - q0 * E0) / kStreamBK;
+        hi = (e1 < 2) ? q0 : fast_div(q0, gK.div[1]);
+        j1 = q0 - hi * e1;
+        offA = group_offset<0>(gK, k0);
+        offB = group_offset<1>(gK, k0);
+        stepA = (int64_t)kStreamBK * gK.stride[0][0];
+        stepB = (int64_t)kStreamBK * gK.stride[1][0];
+        wrapA = gK.stride[0][1] - (int64_t)(n0 - 1) * stepA;
+        wrapB = gK.stride[1][1] - (int64_t)(n0 - 1) * stepB;
+    }
+    __device__ __forceinline__ void advance(const ModeGroup& gK) {
+        const bool c0 = (j0 + 1 == n0);
+        j0 = c0 ? 0u : j0 + 1;
+        offA += c0 ? wrapA : stepA;
+        offB += c0 ? wrapB : stepB;
+        j1 += c0 ? 1u : 0u;
+        if (j1 == e1) {   // carry beyond the second digit
+            j1 = 0;
+            hi += 1;
+            const uint32_t k = hi * e1 * gK.div[0].d;
+            if (k < gK.total) {
+                offA = group_offset<0>(gK, k);
+                offB = group_offset<1>(gK, k);
+            }
+        }
+    }
+};
+
+template <int BM_, int BN_, int LA_, int LB_, int S_, int ABL_ = 0>
+struct StreamCfg {
+    static constexpr int BM = BM_, BN = BN_, LA = LA_, LB = LB_, S = S_;
+    static constexpr int ABL = ABL_;   // measurement-only: 1 = no refills (LDS + MFMA only), 2 = no MFMA (memory path only),
+                                       // 3 = full kernel + wait-time accounting (slots 8-10 of the timing buffer)
+    static constexpr int TM = BM / 32, TN = BN / 32;    // 16 x 16 fragments per wave (2 x 2 waves)
+};
+
+#define CTAMD_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// Workgroup = 8 waves: waves 0-3 multiply (one per SIMD, each owns a quarter of the output tile),
+// waves 4-7 only move data (one per SIMD, each owns a quarter of every tile's LDS-DMA pieces).  An
+// LDS-DMA instruction holds its wave's issue port for 60-100+ cycles; on a wave of its own that time
+// overlaps the multiplying wave's MFMAs instead of draining its one-deep MFMA queue.
+// Both roles execute exactly nTiles workgroup barriers:
+//   barrier #0      : tile 0 has landed
+//   barrier #(t+1)  : tile t+1 has landed (loaders waited for their pieces) and every multiplying wave
+//                     has finished reading tile t (its fragments are in registers) -> slot t % S is free
+template <class Cfg>
+__global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParams p) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = kStreamBK, S = Cfg::S;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    using OpA = StreamOperand<Cfg::LA, BM>;
+    using OpB = StreamOperand<Cfg::LB, BN>;
+    constexpr int STAGE = OpA::FLOATS + OpB::FLOATS;
+    constexpr int LOADS = OpA::PER_WAVE + OpB::PER_WAVE;   // LDS-DMA instructions per loader wave per tile
+    static_assert(S >= 3 && S <= 6 && S * STAGE * 4 <= 160 * 1024, "LDS ring must fit 160 KiB");
+    static_assert(LOADS * (S - 1) <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const bool loader = wave8 >= 4;
+    unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 16 : nullptr;
+    auto stamp = [&](int slot) {
+        if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5 && slot != 7) ? wall_clock64() : __builtin_readcyclecounter();
+    };
+    stamp(0);
+    stamp(5);
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t mt = id % p.tilesM; id /= p.tilesM;
+    const uint32_t nt = id % p.tilesN; id /= p.tilesN;
+    const uint32_t slice = id % p.splitK;
+    const uint32_t l = id / p.splitK;
+    const uint32_t m0 = mt * BM, n0 = nt * BN;
+    const uint32_t kBegin = slice * p.kPerSlice;
+    uint32_t kEnd = kBegin + p.kPerSlice;
+    if (kEnd > p.gK.total) kEnd = p.gK.total;
+    // fast-K: every tile is full; the planner guarantees nTiles % S == 0 and nTiles >= S
+    const int nTiles = (int)((kEnd - kBegin) / BK);
+
+    if (loader) {
+        // =========================== data movers ======================================================
+        const float* A = static_cast<const float*>(p.A) + group_offset<0>(p.gL, l);
+        const float* B = static_cast<const float*>(p.B) + group_offset<1>(p.gL, l);
+        OpA oa;
+        OpB ob;
+        oa.template init<0>(p.gM, p.gK, m0, wave, lane);
+        ob.template init<1>(p.gN, p.gK, n0, wave, lane);
+        KOdometer odo;
+        odo.init(p.gK, kBegin);
+        auto issue = [&](int slot) {
+            float* stage = lds + slot * STAGE;
+            oa.issue(A, odo.offA, stage, wave);
+            ob.issue(B, odo.offB, stage + OpA::FLOATS, wave);
+            odo.advance(p.gK);
+        };
+        if (tlog != nullptr && tid == 256) tlog[7] = __builtin_readcyclecounter();   // setup done, first issue
+        // Progressive start: the multiplying waves are released as soon as tile 0 has landed, while the
+        // rest of the ring is still being requested (an LDS-DMA issue that misses the TLB takes hundreds
+        // of cycles, so S tiles of issue time in front of barrier #0 would be S times the start-up cost).
+        issue(0);
+        issue(1);
+        CTAMD_WAIT_VMCNT(LOADS);
+        __builtin_amdgcn_s_barrier();                      // #0
+#pragma unroll
+        for (int T = 2; T < S; ++T) issue(T);
+        int slot = 0;
+        unsigned long long waitV = 0, waitB = 0;
+        for (int t = 0; t + S < nTiles; ++t) {             // outstanding: tiles t+1 .. t+S-1
+            unsigned long long c0 = 0, c1 = 0, c2 = 0;
+            if constexpr (Cfg::ABL == 3) c0 = __builtin_readcyclecounter();
+            if constexpr (Cfg::ABL == 1) CTAMD_WAIT_VMCNT(0); else CTAMD_WAIT_VMCNT(LOADS * (S - 2));
+            if constexpr (Cfg::ABL == 3) c1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();                  // #(t+1): slot t % S is free
+            if constexpr (Cfg::ABL == 3) { c2 = __builtin_readcyclecounter(); waitV += c1 - c0; waitB += c2 - c1; }
+            if constexpr (Cfg::ABL != 1) issue(slot);
+            slot = (slot + 1 == S) ? 0 : slot + 1;
+        }
+        if constexpr (Cfg::ABL == 3) {
+            if (tlog != nullptr && tid == 256) { tlog[9] = waitV; tlog[10] = waitB; }
+        }
+        // the last S tiles are already on their way: S-1 more barriers with exact waits
+        if constexpr (S > 2) { CTAMD_WAIT_VMCNT(LOADS * (S - 2)); __builtin_amdgcn_s_barrier(); }
+        if constexpr (S > 3) { CTAMD_WAIT_VMCNT(LOADS * (S - 3)); __builtin_amdgcn_s_barrier(); }
+        if constexpr (S > 4) { CTAMD_WAIT_VMCNT(LOADS * (S - 4)); __builtin_amdgcn_s_barrier(); }
+        if constexpr (S > 5) { CTAMD_WAIT_VMCNT(LOADS * (S - 5)); __builtin_amdgcn_s_barrier(); }
+        CTAMD_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                      // #(nTiles-1)
+        return;
+    }
+
+    // =============================== multipliers ======================================================
+    __builtin_amdgcn_s_setprio(2);
+    const int wm = wave & 1, wn = wave >> 1;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int baseA[TM], baseB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) baseA[i] = OpA::frag_base(wm * (BM / 2) + 16 * i, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) baseB[j] = OpB::frag_base(wn * (BN / 2) + 16 * j, lane);
+
+    f32x4 a0[TM], b0[TN], a1[TM], b1[TN];   // fragments of the even / odd 16-step
+    auto load0 = [&](const float* st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = OpA::template fragment<0>(st, baseA[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = OpB::template fragment<0>(st + OpA::FLOATS, baseB[j]);
+    };
+    auto load1 = [&](const float* st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = OpA::template fragment<1>(st, baseA[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = OpB::template fragment<1>(st + OpA::FLOATS, baseB[j]);
+    };
+    // MFMAs [FIRST, LAST) of one 16-step, numbered kk-major so that consecutive MFMAs never share an
+    // accumulator (dependent latency 40 cycles > issue interval 32)
+#define CTAMD_MFMA_RANGE(FA, FB, FIRST, LAST)                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+        const int idx = (kk * TM + i) * TN + j;                                                        \
+        if (Cfg::ABL != 2 && idx >= (FIRST) && idx < (LAST))                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(FA[i][kk], FB[j][kk], acc[i][j], 0, 0, 0); \
+    }
+    constexpr int NMFMA = 4 * TM * TN;          // MFMAs per 16-step
+    constexpr int SPLIT = NMFMA / 3;            // MFMAs of the odd step issued before the barrier
+    // scheduling hint: n x (1 MFMA, 1 LDS read)
+#define CTAMD_INTERLEAVE_DS(n)                                         \
+    _Pragma("unroll") for (int z = 0; z < (n); ++z) {                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             \
+    }
+
+    __builtin_amdgcn_s_barrier();                          // #0: tile 0 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    load0(lds);
+    stamp(1);
+    unsigned long long waitC = 0;   // ABL == 3: cycles this wave spent in the per-tile barrier
+
+    // One K-tile in ring slot U (compile-time, so every LDS address is base + immediate).  The fragments
+    // of the odd 16-step are fetched under the MFMAs of the even step; the barrier sits a third into the
+    // odd step and the first fragments of the next tile are fetched under the remaining two thirds.
+#define CTAMD_TILE_BODY(U, LASTTILE)                                                                       \
+    {                                                                                                      \
+        const float* cur = lds + (U) * STAGE;                                                              \
+        const float* nxt = lds + (((U) + 1) % S) * STAGE;                                                  \
+        load1(cur);                                                                                        \
+        CTAMD_MFMA_RANGE(a0, b0, 0, NMFMA)                                                                 \
+        CTAMD_INTERLEAVE_DS(TM + 4 * TN)                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        CTAMD_MFMA_RANGE(a1, b1, 0, SPLIT)                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if constexpr (!(LASTTILE)) {                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of the tile are back */ \
+            unsigned long long cb0 = 0;                                                                    \
+            if constexpr (Cfg::ABL == 3) cb0 = __builtin_readcyclecounter();                               \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            if constexpr (Cfg::ABL == 3) waitC += __builtin_readcyclecounter() - cb0;                      \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            load0(nxt);                                                                                    \
+            CTAMD_MFMA_RANGE(a1, b1, SPLIT, NMFMA)                                                         \
+            CTAMD_INTERLEAVE_DS(TM + 4 * TN)                                                               \
+        } else {                                                                                           \
+            CTAMD_MFMA_RANGE(a1, b1, SPLIT, NMFMA)                                                         \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+#define CTAMD_BODY_MID(U) CTAMD_TILE_BODY(U, false)
+#define CTAMD_BODY_END(U) CTAMD_TILE_BODY(U, (U) == S - 1)
+    // compile-time unrolling over the ring slots
+#define CTAMD_FOR_SLOTS(M)                                                     \
+    { M(0) M(1) M(2)                                                           \
+      if constexpr (S > 3) { M(3) } if constexpr (S > 4) { M(4) }              \
+      if constexpr (S > 5) { M(5) } }
+    const int groups = nTiles / S;
+    for (int g = 0; g + 1 < groups; ++g) CTAMD_FOR_SLOTS(CTAMD_BODY_MID)
+    stamp(2);
+    CTAMD_FOR_SLOTS(CTAMD_BODY_END)
+    stamp(3);
+    if constexpr (Cfg::ABL == 3) {
+        if (tlog != nullptr && tid == 0) tlog[8] = waitC;
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    if (p.partial != nullptr) {
+        // accumulator-order partials: [slice][l][nt][mt][wave][i][j][lane] x 16 B
+        const size_t tileIdx = (((size_t)slice * p.gL.total + l) * p.tilesN + nt) * p.tilesM + mt;
+        f32x4* P = reinterpret_cast<f32x4*>(p.partial) + (tileIdx * 4 + wave) * (size_t)(TM * TN * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) __builtin_nontemporal_store(acc[i][j], P + (i * TN + j) * 64);
+        stamp(4);
+        stamp(6);
+        return;
+    }
+    const float* C = static_cast<const float*>(p.C);
+    float*       D = static_cast<float*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    int64_t offDn[TN], offCn[TN];
+    bool    okN[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t n = n0 + wn * (BN / 2) + 16 * j + (lane & 15);
+        okN[j] = n < Ntot;
+        offDn[j] = 0;
+        offCn[j] = 0;
+        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    }
+    const float alpha = p.alpha, beta = p.beta;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t m = m0 + wm * (BM / 2) + 16 * i + 4 * (lane >> 4) + r;
+            if (m >= Mtot) continue;
+            int64_t offDm, offCm;
+            group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!okN[j]) continue;
+                float val = alpha * acc[i][j][r];
+                if (beta != 0.f) val += beta * C[offCm + offCn[j]];
+                D[offDm + offDn[j]] = val;
+            }
+        }
+    stamp(4);
+    stamp(6);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K fold for accumulator-order partials: D = alpha * sum_s partial[s] + beta * C.
+// One lane owns one 16-byte accumulator register quad (4 consecutive m at one n) of one output tile;
+// a workgroup covers 16 quads x 16 slice groups (quarter-waves read 256-B contiguous runs), the
+// groups meet in LDS.  HBM/L2-bound: splitK * 4 B read per output element.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_reduce_frag_kernel(const SplitKReduceParams p) {
+    __shared__ f32x4 red[16][17];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const uint32_t quadsPerTile = 4u * p.fragTM * p.fragTN * 64u;
+    const size_t   tilesTotal = (size_t)p.gL.total * p.tilesN * p.tilesM;
+    const size_t   quadsTotal = tilesTotal * quadsPerTile;
+    const size_t   e = (size_t)blockIdx.x * 16 + q;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (e < quadsTotal) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + e;
+        // 16 slices per lane and pass, all loads in flight before the first add (one memory round trip
+        // per pass; a 256-way split is exactly one pass)
+        for (uint32_t s0 = g; s0 < p.splitK; s0 += 256) {
+            f32x4 x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t sl = s0 + 16u * u;
+                x[u] = (sl < p.splitK) ? __builtin_nontemporal_load(src + (size_t)sl * quadsTotal) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) sum += (x[u] + x[u + 1]) + (x[u + 2] + x[u + 3]);
+        }
+    }
+    red[g][q] = sum;
+    __syncthreads();
+    if (g != 0 || e >= quadsTotal) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) sum += red[k][q];
+    // decode e -> (l, nt, mt, wave, i, j, lane)
+    size_t rem = e;
+    const uint32_t lane = (uint32_t)(rem % 64); rem /= 64;
+    const uint32_t j = (uint32_t)(rem % p.fragTN); rem /= p.fragTN;
+    const uint32_t i = (uint32_t)(rem % p.fragTM); rem /= p.fragTM;
+    const uint32_t wave = (uint32_t)(rem % 4); rem /= 4;
+    const uint32_t mt = (uint32_t)(rem % p.tilesM); rem /= p.tilesM;
+    const uint32_t nt = (uint32_t)(rem % p.tilesN); rem /= p.tilesN;
+    const uint32_t l = (uint32_t)rem;
+    const uint32_t bm = 32u * p.fragTM, bn = 32u * p.fragTN;
+    const uint32_t n = nt * bn + (wave >> 1) * (bn / 2) + 16 * j + (lane & 15);
+    if (n >= p.gN.total) return;
+    int64_t oDl = 0, oCl = 0, oDn, oCn;
+    group_offset2<2>(p.gL, p.cStrideL, l, oDl, oCl);
+    group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t m = mt * bm + (wave & 1) * (bm / 2) + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= p.gM.total) continue;
+        int64_t oDm, oCm;
+        group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
+        float val = p.alpha * sum[r];
+        if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[oCl + oCm + oCn];
+        static_cast<float*>(p.D)[oDl + oDm + oDn] = val;
+    }
+}
+
+hipError_t launch_splitk_reduce_frag(const SplitKReduceParams& p, hipStream_t stream) {
+    const size_t quads = (size_t)p.gL.total * p.tilesN * p.tilesM * 4u * p.fragTM * p.fragTN * 64u;
+    const size_t blocks = (quads + 15) / 16;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel table
+// ---------------------------------------------------------------------------------------------
+template <class Cfg>
+static hipError_t launch_stream(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(gett_f32_stream_kernel<Cfg>, dim3(p.nBlocks), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
+// XS(bm, bn, layA, layB, stages)
+#define CTAMD_STREAM_KERNELS(XS)        \
+    XS(96, 96, LAY_K, LAY_F, 4)         \
+    XS(96, 96, LAY_K, LAY_F, 6)         \
+    XS(96, 96, LAY_K, LAY_F, 3)         \
+    XS(96, 96, LAY_F, LAY_F, 4)         \
+    XS(96, 96, LAY_F, LAY_K, 4)         \
+    XS(96, 96, LAY_K, LAY_K, 4)         \
+    XS(128, 128, LAY_F, LAY_F, 4)       \
+    XS(128, 128, LAY_K, LAY_F, 4)       \
+    XS(128, 128, LAY_F, LAY_K, 4)       \
+    XS(128, 128, LAY_K, LAY_K, 4)       \
+    XS(64, 64, LAY_F, LAY_F, 4)         \
+    XS(64, 64, LAY_K, LAY_F, 4)         \
+    XS(64, 64, LAY_F, LAY_K, 4)         \
+    XS(64, 64, LAY_K, LAY_K, 4)
+
+#define CTAMD_STREAM_ENTRY(bm, bn, la, lb, s) \
+    {bm, bn, kStreamBK, 2, 2, 1, la, lb, 512, s, 1, 0, &launch_stream<StreamCfg<bm, bn, la, lb, s>>, 1},
+
+#define CTAMD_STREAM_ABL(bm, bn, la, lb, s, abl) \
+    {bm, bn, kStreamBK, 2, 2, 1, la, lb, 512, s, 1, abl, &launch_stream<StreamCfg<bm, bn, la, lb, s, abl>>, 1},
+
+static const GettKernelInfo g_stream_table[] = {
+    CTAMD_STREAM_KERNELS(CTAMD_STREAM_ENTRY)
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 1)
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 2)
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 3)};
+
+const GettKernelInfo* gett_f32_stream_kernels(int* count) {
+    *count = (int)(sizeof(g_stream_table) / sizeof(g_stream_table[0]));
+    return g_stream_table;
+}
+
+}  // namespace ctamd

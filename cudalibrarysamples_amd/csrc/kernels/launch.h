@@ -21,11 +21,16 @@ struct GettKernelInfo {
     int kfast;           // 1: requires extent(fastest K mode) % bk == 0
     int ablation;        // != 0: measurement-only variant (wrong results), never ranked by default
     hipError_t (*launch)(const GettParams&, hipStream_t);
+    int fragPartials;    // 1: split-K partials are written in accumulator order (padded tiles), folded by
+                         //    launch_splitk_reduce_frag; 0: row-major [M][N], launch_splitk_reduce
 };
 
 // fp32 data, fp32 MFMA (v_mfma_f32_16x16x4_f32)
 const GettKernelInfo* gett_f32_kernels(int* count);
 hipError_t launch_splitk_reduce(const SplitKReduceParams& p, hipStream_t stream);
+hipError_t launch_splitk_reduce_frag(const SplitKReduceParams& p, hipStream_t stream);
+// streaming (LDS-DMA ring) kernels, gett_f32_stream.hip; gett_f32_kernels() returns the merged table
+const GettKernelInfo* gett_f32_stream_kernels(int* count);
 
 // simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,

@@ -35,7 +35,7 @@ struct GettParams {
     const void* C;        // source for beta (may alias D)
     void*       D;
     float*      partial;  // split-K workspace: [slice][L][M][N] fp32, or nullptr
-    unsigned long long* timing;   // diagnostics: 8 timestamps per workgroup (nullptr = off)
+    unsigned long long* timing;   // diagnostics: 16 x uint64 per workgroup (nullptr = off)
     ModeGroup   gM, gN, gK, gL;
     float       alpha, beta;
     double      alpha64, beta64;  // same scalars at full width (fp64 data)
@@ -62,6 +62,9 @@ struct SplitKReduceParams {
     int64_t      cStrideL[kMaxGroupModes];
     float        alpha, beta;
     uint32_t     splitK;
+    // accumulator-order partials (streaming kernels): output tile grid and 16x16 fragments per wave
+    uint32_t     tilesM, tilesN;
+    uint32_t     fragTM, fragTN;
 };
 
 // ---------------------------------------------------------------------------------------------

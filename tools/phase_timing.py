@@ -31,7 +31,7 @@ def main():
     p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, **kw)
     d = p.describe()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    tbuf = torch.zeros(d["blocks"] * 8, dtype=torch.int64, device="cuda")
+    tbuf = torch.zeros(d["blocks"] * 16, dtype=torch.int64, device="cuda")
     for _ in range(5):
         p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
     torch.cuda.synchronize()
@@ -39,7 +39,7 @@ def main():
     p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
     torch.cuda.synchronize()
     ct.lib.ctamdSetTimingBuffer(None)
-    t = tbuf.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    t = tbuf.cpu().numpy().reshape(-1, 16).astype(np.float64)
     cyc = t[:, :5]
     phases = np.diff(cyc, axis=1)          # prologue, steady, drain, epilogue (shader cycles)
     wall0, wall1 = t[:, 5], t[:, 6]        # 100 MHz wall clock
@@ -48,6 +48,9 @@ def main():
         "cycles_mean": dict(zip(["prologue", "steady", "drain", "epilogue"], [float(x) for x in phases.mean(axis=0)])),
         "cycles_max": dict(zip(["prologue", "steady", "drain", "epilogue"], [float(x) for x in phases.max(axis=0)])),
         "total_cycles_mean": float((cyc[:, 4] - cyc[:, 0]).mean()),
+        "wait_cycles_mean": {"multiplier_barrier": float(t[:, 8].mean()), "loader_vmcnt": float(t[:, 9].mean()),
+                             "loader_barrier": float(t[:, 10].mean())} if (t[:, 8] > 0).any() else None,
+        "setup_cycles_mean": float((t[:, 7] - t[:, 0]).mean()) if (t[:, 7] > 0).all() else None,   # entry -> first LDS-DMA issue (streaming kernels)
         "wall_us_first_start_to_last_end": float((wall1.max() - wall0.min()) / 100.0),
         "wall_us_start_skew": float((wall0.max() - wall0.min()) / 100.0),
         "wall_us_end_skew": float((wall1.max() - wall1.min()) / 100.0),

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PROBLEMS = {
     "einsum": (dict(a=96, b=64, c=64, d=64, e=96), "dcba", "ebcd", "ea"),
+    "einsum48": (dict(a=96, b=48, c=64, d=64, e=96), "dcba", "ebcd", "ea"),
     "contraction": (dict(m=96, n=96, u=96, v=64, h=64, k=64), "mhkn", "ukvh", "munv"),
     "gemm4096": (dict(i=4096, j=4096, k=4096), "ik", "kj", "ij"),
 }
@@ -25,6 +26,7 @@ def main():
     ap.add_argument("--max", type=int, default=64)
     ap.add_argument("--splits", type=str, default="", help="comma list of split-K values to keep (empty = all)")
     ap.add_argument("--tiles", type=str, default="", help="comma list of bm values to keep (empty = all)")
+    ap.add_argument("--kernels", type=str, default="", help="comma list of kernel table indices to keep (empty = all)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -41,13 +43,14 @@ def main():
     ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     keep_s = {int(x) for x in args.splits.split(",") if x}
     keep_t = {int(x) for x in args.tiles.split(",") if x}
+    keep_k = {int(x) for x in args.kernels.split(",") if x}
     done = 0
     for r in range(n):
         if done >= args.max:
             break
         p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 30, algo=r)
         d0 = p.describe()
-        if (keep_s and d0["splitK"] not in keep_s) or (keep_t and d0["bm"] not in keep_t):
+        if (keep_s and d0["splitK"] not in keep_s) or (keep_t and d0["bm"] not in keep_t) or (keep_k and d0["kernel"] not in keep_k):
             p.destroy()
             continue
         done += 1
@@ -62,10 +65,18 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / args.reps
+        # GETT kernel alone (HIP events recorded by the library around the kernel launch)
+        import ctypes
+        ct.lib.ctamdProfileBegin()
+        for _ in range(args.reps):
+            p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, stream)
+        torch.cuda.synchronize()
+        mean_ms, min_ms = ctypes.c_float(0), ctypes.c_float(0)
+        ct.lib.ctamdProfileEnd(ctypes.byref(mean_ms), ctypes.byref(min_ms))
         d = p.describe()
-        print(json.dumps({"rank": r, "us": us, "tflops": flop / us / 1e6, "kernel": d["kernel"],
+        print(json.dumps({"rank": r, "us": us, "kernel_us": mean_ms.value * 1e3, "kernel_min_us": min_ms.value * 1e3, "tflops": flop / us / 1e6, "kernel": d["kernel"],
                           "tile": [d["bm"], d["bn"], d["bk"]], "waves": [d["wm"], d["wn"], d["wk"]],
-                          "pf": d["pf"], "abl": d["abl"], "splitK": d["splitK"], "blocks": d["blocks"], "model_us": d["model_us"]}), flush=True)
+                          "pf": d["pf"], "abl": d["abl"], "Kdigits": d.get("Kdigits"), "splitK": d["splitK"], "blocks": d["blocks"], "model_us": d["model_us"]}), flush=True)
         p.destroy()
 
 
