@@ -278,9 +278,19 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
     const double M = (double)v.totM, N = (double)v.totN, K = (double)v.totK, L = (double)v.totL;
 
     const bool withAblations = std::getenv("CUTENSOR_AMD_ABLATION") != nullptr;
+    // byte span of an operand beyond its batch offset: the streaming kernels address it through a buffer
+    // descriptor with 32-bit byte offsets
+    auto span_bytes = [&](bool slotA) {
+        uint64_t n = 1;
+        for (const std::vector<CanonMode>* g : {slotA ? &v.M : &v.N, &v.K})
+            for (const CanonMode& m : *g) n += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(slotA ? m.sA : m.sB);
+        return n * 4ull;
+    };
+    const bool fits32 = span_bytes(true) < (1ull << 32) - (1ull << 20) && span_bytes(false) < (1ull << 32) - (1ull << 20);
     for (int i = 0; i < count; ++i) {
         const GettKernelInfo& k = tab[i];
         if (k.ablation && !withAblations) continue;
+        if (k.fragPartials && !fits32) continue;
         // a kernel is usable if each operand admits its layout (LAY_S kernels take anything)
         const bool okA = (k.layA == v.layA) || (k.layA == LAY_S);
         const bool okB = (k.layB == v.layB) || (k.layB == LAY_S);

@@ -31,6 +31,21 @@ __device__ __forceinline__ int64_t group_offset(const ModeGroup& g, uint32_t idx
     return off;
 }
 
+// Same, modulo 2^32, for the kernels whose operands are addressed with 32-bit offsets.  Fixed trip
+// count on purpose: a trip count read from the descriptor (g.n) makes the descriptor loads dependent —
+// every dependent round of kernel-argument loads costs ~900 cycles at kernel start.
+template <int SLOT>
+__device__ __forceinline__ uint32_t group_offset32(const ModeGroup& g, uint32_t idx) {
+    uint32_t off = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = fast_div(idx, g.div[i]);
+        off += (idx - q * g.div[i].d) * (uint32_t)g.stride[SLOT][i];
+        idx = q;
+    }
+    return off;
+}
+
 // Offsets of idx in the D tensor (slot SLOT of the group) and in C (explicit stride array).
 template <int SLOT>
 __device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t* cstride,

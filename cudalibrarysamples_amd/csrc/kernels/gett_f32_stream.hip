@@ -42,14 +42,41 @@ namespace ctamd {
 
 constexpr int kStreamBK = 32;
 
-// 64 lanes x 16 B from per-lane global addresses into one contiguous 1-KiB piece of LDS starting at the
-// wave-uniform address dst (the compiler moves it to M0).  The builtin exists only in the device pass;
-// hipcc's host pass silently drops the stubs of kernel templates that mention it, hence the guard.
-__device__ __forceinline__ void lds_dma_16(const float* src, float* dst) {
+// 64 lanes x 16 B into one contiguous 1-KiB piece of LDS starting at the wave-uniform address dst (the
+// compiler moves it to M0).  Source = buffer descriptor (SGPRs) + per-lane byte offset (a loop-invariant
+// VGPR) + wave-uniform byte offset of the K-tile (an SGPR): `buffer_load_dwordx4 v, s[0:3], s offen lds`.
+// No vector ALU instruction is needed per piece — on gfx950 the fp32 MFMA issues through the same port
+// as the vector ALU, so a data-moving wave that needs a v_add per address only gets to issue while the
+// multiplying wave of its SIMD is stalled (measured: 290 cycles of barrier wait per K-tile).
+// The builtins exist only in the device pass; hipcc's host pass silently drops the stubs of kernel
+// templates that mention them, hence the guards.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
 #else
-    (void)src; (void)dst;
+typedef int BufRsrc;
+#endif
+__device__ __forceinline__ BufRsrc make_rsrc(const float* base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // raw buffer, stride 0, num_records = 2^32 - 1 bytes (the planner only selects these kernels for
+    // operands whose byte span fits 32 bits), dword 3 = gfx9 raw-buffer format word
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+#else
+    (void)base; return 0;
+#endif
+}
+__device__ __forceinline__ void store_wt_16(f32x4 v, BufRsrc rsrc, uint32_t byteOff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)byteOff, 0, /*aux: sc1*/ 16);
+#else
+    (void)v; (void)rsrc; (void)byteOff;
+#endif
+}
+__device__ __forceinline__ void lds_dma_16(BufRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)laneBytes, (int)tileBytes, 0, 0);
+#else
+    (void)rsrc; (void)laneBytes; (void)tileBytes; (void)dst;
 #endif
 }
 
@@ -65,7 +92,7 @@ struct StreamOperand {
     static constexpr int FLOATS   = ROWS * kStreamBK;
     static constexpr int UR       = ROWS / 4;        // 16-byte units per k-row (LAY_F)
 
-    int64_t src[PER_WAVE];   // element offset of this lane's unit of piece i (tile k0 = 0)
+    uint32_t src[PER_WAVE];  // byte offset of this lane's unit of piece i (tile k0 = 0)
 
     // SLOT_R / SLOT_K: slot of this tensor in its free group / in the K group
     template <int SLOT_K>
@@ -79,23 +106,23 @@ struct StreamOperand {
                 const int u = p ^ ((r >> 1) & 7);
                 uint32_t row = row0 + r;
                 if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
-                src[i] = group_offset<0>(gFree, row) + 4 * u;    // K-contiguous: strideK0 == 1
+                src[i] = (group_offset32<0>(gFree, row) + 4u * (uint32_t)u) * 4u;    // K-contiguous: strideK0 == 1
             } else {
                 const int g = 64 * c + lane;
                 const int kr = g / UR, p = g % UR;
                 const int u = (p + 4 * ((kr >> 2) & 1)) % UR;
                 uint32_t row = row0 + 4 * u;
                 if (row >= gFree.total) row = gFree.total - 4;   // extent % 4 == 0: a unit is all in or all out
-                src[i] = group_offset<0>(gFree, row) + (int64_t)kr * strideK0;
+                src[i] = (group_offset32<0>(gFree, row) + (uint32_t)kr * (uint32_t)strideK0) * 4u;
             }
         }
     }
 
-    // issue this wave's pieces of one tile: X + src + offK (wave-uniform) -> stage + piece
-    __device__ __forceinline__ void issue(const float* __restrict__ X, int64_t offK, float* stage, int wave) const {
+    // issue this wave's pieces of one tile: X + src + offK bytes (wave-uniform) -> stage + piece
+    __device__ __forceinline__ void issue(BufRsrc X, uint32_t offKBytes, float* stage, int wave) const {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i)
-            lds_dma_16(X + src[i] + offK, stage + (wave + 4 * i) * 256);
+            lds_dma_16(X, src[i], offKBytes, stage + (wave + 4 * i) * 256);
     }
 
     // per-lane constant part of the fragment address (floats) for the 16-row fragment at rbase
@@ -133,23 +160,27 @@ struct StreamOperand {
 // digit (rare) re-derives the offsets from the linear index.
 // ---------------------------------------------------------------------------------------------
 struct KOdometer {
+    // everything here is wave-uniform and lives in SGPRs (readfirstlane pins it): the walk costs scalar
+    // instructions only.  Offsets are bytes modulo 2^32 (operand byte spans fit 32 bits).
     uint32_t j0, n0, j1, e1, hi;
-    int64_t  offA, offB, stepA, stepB, wrapA, wrapB;
+    uint32_t offA, offB, stepA, stepB, wrapA, wrapB;
+
+    __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
     __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
         const uint32_t E0 = gK.div[0].d;
-        n0 = E0 / kStreamBK;
-        e1 = gK.div[1].d;
+        n0 = sgpr(E0 / kStreamBK);
+        e1 = sgpr(gK.div[1].d);
         const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
-        j0 = (k0 - q0 * E0) / kStreamBK;
-        hi = (e1 < 2) ? q0 : fast_div(q0, gK.div[1]);
-        j1 = q0 - hi * e1;
-        offA = group_offset<0>(gK, k0);
-        offB = group_offset<1>(gK, k0);
-        stepA = (int64_t)kStreamBK * gK.stride[0][0];
-        stepB = (int64_t)kStreamBK * gK.stride[1][0];
-        wrapA = gK.stride[0][1] - (int64_t)(n0 - 1) * stepA;
-        wrapB = gK.stride[1][1] - (int64_t)(n0 - 1) * stepB;
+        j0 = sgpr((k0 - q0 * E0) / kStreamBK);
+        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
+        j1 = sgpr(q0 - hi * e1);
+        offA = sgpr((uint32_t)group_offset<0>(gK, k0) * 4u);
+        offB = sgpr((uint32_t)group_offset<1>(gK, k0) * 4u);
+        stepA = sgpr((uint32_t)((int64_t)kStreamBK * gK.stride[0][0]) * 4u);
+        stepB = sgpr((uint32_t)((int64_t)kStreamBK * gK.stride[1][0]) * 4u);
+        wrapA = sgpr((uint32_t)gK.stride[0][1] * 4u - (n0 - 1) * stepA);
+        wrapB = sgpr((uint32_t)gK.stride[1][1] * 4u - (n0 - 1) * stepB);
     }
     __device__ __forceinline__ void advance(const ModeGroup& gK) {
         const bool c0 = (j0 + 1 == n0);
@@ -162,8 +193,8 @@ struct KOdometer {
             hi += 1;
             const uint32_t k = hi * e1 * gK.div[0].d;
             if (k < gK.total) {
-                offA = group_offset<0>(gK, k);
-                offB = group_offset<1>(gK, k);
+                offA = sgpr((uint32_t)group_offset<0>(gK, k) * 4u);
+                offB = sgpr((uint32_t)group_offset<1>(gK, k) * 4u);
             }
         }
     }
@@ -173,7 +204,8 @@ template <int BM_, int BN_, int LA_, int LB_, int S_, int ABL_ = 0>
 struct StreamCfg {
     static constexpr int BM = BM_, BN = BN_, LA = LA_, LB = LB_, S = S_;
     static constexpr int ABL = ABL_;   // measurement-only: 1 = no refills (LDS + MFMA only), 2 = no MFMA (memory path only),
-                                       // 3 = full kernel + wait-time accounting (slots 8-10 of the timing buffer)
+                                       // 3 = full kernel + wait-time accounting (slots 8-10 of the timing buffer),
+                                       // 4 = full kernel (correct results), data movers at s_setprio 3
     static constexpr int TM = BM / 32, TN = BN / 32;    // 16 x 16 fragments per wave (2 x 2 waves)
 };
 
@@ -225,8 +257,9 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
 
     if (loader) {
         // =========================== data movers ======================================================
-        const float* A = static_cast<const float*>(p.A) + group_offset<0>(p.gL, l);
-        const float* B = static_cast<const float*>(p.B) + group_offset<1>(p.gL, l);
+        const BufRsrc A = make_rsrc(static_cast<const float*>(p.A) + group_offset<0>(p.gL, l));
+        const BufRsrc B = make_rsrc(static_cast<const float*>(p.B) + group_offset<1>(p.gL, l));
+        if constexpr (Cfg::ABL == 4) __builtin_amdgcn_s_setprio(3);   // experiment: data movers outrank the multipliers
         OpA oa;
         OpB ob;
         oa.template init<0>(p.gM, p.gK, m0, wave, lane);
@@ -376,11 +409,14 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     if (p.partial != nullptr) {
         // accumulator-order partials: [slice][l][nt][mt][wave][i][j][lane] x 16 B
         const size_t tileIdx = (((size_t)slice * p.gL.total + l) * p.tilesN + nt) * p.tilesM + mt;
-        f32x4* P = reinterpret_cast<f32x4*>(p.partial) + (tileIdx * 4 + wave) * (size_t)(TM * TN * 64) + lane;
+        // write-through (sc1) stores: the lines leave the XCD's L2 while other workgroups still multiply,
+        // so the kernel boundary in front of the fold kernel has no dirty partials left to flush
+        f32x4* P = reinterpret_cast<f32x4*>(p.partial) + (tileIdx * 4 + wave) * (size_t)(TM * TN * 64);
+        const BufRsrc rP = make_rsrc(reinterpret_cast<const float*>(P));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) __builtin_nontemporal_store(acc[i][j], P + (i * TN + j) * 64);
+            for (int j = 0; j < TN; ++j) store_wt_16(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + lane) * 16));
         stamp(4);
         stamp(6);
         return;
@@ -426,56 +462,61 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
 
 // ---------------------------------------------------------------------------------------------
 // Split-K fold for accumulator-order partials: D = alpha * sum_s partial[s] + beta * C.
-// One lane owns one 16-byte accumulator register quad (4 consecutive m at one n) of one output tile;
-// a workgroup covers 16 quads x 16 slice groups (quarter-waves read 256-B contiguous runs), the
-// groups meet in LDS.  HBM/L2-bound: splitK * 4 B read per output element.
+// One lane owns one 16-byte accumulator register quad (4 consecutive m at one n) of one output tile.
+// A workgroup covers 8 quads (one 128-byte line per slice) x 32 slice groups; every lane has all its
+// loads (splitK / 32 of them, 8 for a 256-way split) in flight before the first add, the slice groups
+// of a wave meet through lane shuffles and the four waves through LDS.  Latency-bound, not
+// bandwidth-bound (9.4 MB for the headline einsum): many small workgroups, one memory round trip.
+// The sum order is fixed by the layout, so results are reproducible run to run.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) splitk_reduce_frag_kernel(const SplitKReduceParams p) {
-    __shared__ f32x4 red[16][17];
-    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    __shared__ f32x4 red[4][8];
+    const int q = threadIdx.x & 7, g = threadIdx.x >> 3;     // g = 0..31, 8 groups per wave
     const uint32_t quadsPerTile = 4u * p.fragTM * p.fragTN * 64u;
     const size_t   tilesTotal = (size_t)p.gL.total * p.tilesN * p.tilesM;
     const size_t   quadsTotal = tilesTotal * quadsPerTile;
-    const size_t   e = (size_t)blockIdx.x * 16 + q;
+    const size_t   e = (size_t)blockIdx.x * 8 + q;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     if (e < quadsTotal) {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + e;
-        // 16 slices per lane and pass, all loads in flight before the first add (one memory round trip
-        // per pass; a 256-way split is exactly one pass)
         for (uint32_t s0 = g; s0 < p.splitK; s0 += 256) {
-            f32x4 x[16];
+            f32x4 x[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t sl = s0 + 16u * u;
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t sl = s0 + 32u * u;
                 x[u] = (sl < p.splitK) ? __builtin_nontemporal_load(src + (size_t)sl * quadsTotal) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) sum += (x[u] + x[u + 1]) + (x[u + 2] + x[u + 3]);
+            sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
         }
     }
-    red[g][q] = sum;
-    __syncthreads();
-    if (g != 0 || e >= quadsTotal) return;
+    // the 8 slice groups of a wave: lanes that differ in bits 3..5
 #pragma unroll
-    for (int k = 1; k < 16; ++k) sum += red[k][q];
+    for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sum[c] += __shfl_xor(sum[c], m, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 8) red[wave][q] = sum;
+    __syncthreads();
+    if (threadIdx.x >= 8 || e >= quadsTotal) return;
+    sum = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
     // decode e -> (l, nt, mt, wave, i, j, lane)
     size_t rem = e;
     const uint32_t lane = (uint32_t)(rem % 64); rem /= 64;
     const uint32_t j = (uint32_t)(rem % p.fragTN); rem /= p.fragTN;
     const uint32_t i = (uint32_t)(rem % p.fragTM); rem /= p.fragTM;
-    const uint32_t wave = (uint32_t)(rem % 4); rem /= 4;
+    const uint32_t w = (uint32_t)(rem % 4); rem /= 4;
     const uint32_t mt = (uint32_t)(rem % p.tilesM); rem /= p.tilesM;
     const uint32_t nt = (uint32_t)(rem % p.tilesN); rem /= p.tilesN;
     const uint32_t l = (uint32_t)rem;
     const uint32_t bm = 32u * p.fragTM, bn = 32u * p.fragTN;
-    const uint32_t n = nt * bn + (wave >> 1) * (bn / 2) + 16 * j + (lane & 15);
+    const uint32_t n = nt * bn + (w >> 1) * (bn / 2) + 16 * j + (lane & 15);
     if (n >= p.gN.total) return;
     int64_t oDl = 0, oCl = 0, oDn, oCn;
     group_offset2<2>(p.gL, p.cStrideL, l, oDl, oCl);
     group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const uint32_t m = mt * bm + (wave & 1) * (bm / 2) + 16 * i + 4 * (lane >> 4) + r;
+        const uint32_t m = mt * bm + (w & 1) * (bm / 2) + 16 * i + 4 * (lane >> 4) + r;
         if (m >= p.gM.total) continue;
         int64_t oDm, oCm;
         group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
@@ -485,10 +526,82 @@ __global__ void __launch_bounds__(256) splitk_reduce_frag_kernel(const SplitKRed
     }
 }
 
+// The same fold for the common case of one M mode, one N mode and no batch: every argument fits one
+// 96-byte kernel-argument block, fetched in a single round (a dependent round of argument loads costs
+// ~0.45 us at the start of a 3-us kernel), and the output address is two multiplies.
+struct FoldFlatParams {
+    const float* partial;
+    const float* C;
+    float*       D;
+    int64_t      sDm, sDn, sCm, sCn;
+    float        alpha, beta;
+    uint32_t     splitK, quadsTotal, fragTM, fragTN, tilesM, Mtot, Ntot;
+};
+
+__global__ void __launch_bounds__(256) splitk_reduce_frag_flat_kernel(const FoldFlatParams p) {
+    __shared__ f32x4 red[4][8];
+    const int q = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const uint32_t e = blockIdx.x * 8 + q;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (e < p.quadsTotal) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + e;
+        for (uint32_t s0 = g; s0 < p.splitK; s0 += 256) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t sl = s0 + 32u * u;
+                x[u] = (sl < p.splitK) ? __builtin_nontemporal_load(src + (size_t)sl * p.quadsTotal) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        }
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sum[c] += __shfl_xor(sum[c], m, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 8) red[wave][q] = sum;
+    __syncthreads();
+    if (threadIdx.x >= 8 || e >= p.quadsTotal) return;
+    sum = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+    uint32_t rem = e;
+    const uint32_t lane = rem % 64; rem /= 64;
+    const uint32_t j = rem % p.fragTN; rem /= p.fragTN;
+    const uint32_t i = rem % p.fragTM; rem /= p.fragTM;
+    const uint32_t w = rem % 4; rem /= 4;
+    const uint32_t mt = rem % p.tilesM;
+    const uint32_t nt = rem / p.tilesM;
+    const uint32_t bm = 32u * p.fragTM, bn = 32u * p.fragTN;
+    const uint32_t n = nt * bn + (w >> 1) * (bn / 2) + 16 * j + (lane & 15);
+    if (n >= p.Ntot) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t m = mt * bm + (w & 1) * (bm / 2) + 16 * i + 4 * (lane >> 4) + r;
+        if (m >= p.Mtot) continue;
+        float val = p.alpha * sum[r];
+        if (p.beta != 0.f) val += p.beta * p.C[(int64_t)m * p.sCm + (int64_t)n * p.sCn];
+        p.D[(int64_t)m * p.sDm + (int64_t)n * p.sDn] = val;
+    }
+}
+
 hipError_t launch_splitk_reduce_frag(const SplitKReduceParams& p, hipStream_t stream) {
     const size_t quads = (size_t)p.gL.total * p.tilesN * p.tilesM * 4u * p.fragTM * p.fragTN * 64u;
-    const size_t blocks = (quads + 15) / 16;
+    const size_t blocks = (quads + 7) / 8;
     if (blocks == 0) return hipSuccess;
+    if (p.gL.total == 1 && p.gM.n <= 1 && p.gN.n <= 1 && quads < (1ull << 31)) {
+        FoldFlatParams f;
+        f.partial = p.partial;
+        f.C = static_cast<const float*>(p.C);
+        f.D = static_cast<float*>(p.D);
+        f.sDm = p.gM.stride[1][0]; f.sDn = p.gN.stride[1][0];
+        f.sCm = p.cStrideM[0];     f.sCn = p.cStrideN[0];
+        f.alpha = p.alpha; f.beta = p.beta;
+        f.splitK = p.splitK; f.quadsTotal = (uint32_t)quads;
+        f.fragTM = p.fragTM; f.fragTN = p.fragTN; f.tilesM = p.tilesM;
+        f.Mtot = p.gM.total; f.Ntot = p.gN.total;
+        hipLaunchKernelGGL(splitk_reduce_frag_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(splitk_reduce_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -529,7 +642,8 @@ static const GettKernelInfo g_stream_table[] = {
     CTAMD_STREAM_KERNELS(CTAMD_STREAM_ENTRY)
     CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 1)
     CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 2)
-    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 3)};
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 3)
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 4)};
 
 const GettKernelInfo* gett_f32_stream_kernels(int* count) {
     *count = (int)(sizeof(g_stream_table) / sizeof(g_stream_table[0]));

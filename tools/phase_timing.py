@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--algo", type=int, default=-1)
     ap.add_argument("--b", type=int, default=64)
+    ap.add_argument("--dump", type=str, default="", help="save the raw per-workgroup timing records (.npy)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -40,6 +41,8 @@ def main():
     torch.cuda.synchronize()
     ct.lib.ctamdSetTimingBuffer(None)
     t = tbuf.cpu().numpy().reshape(-1, 16).astype(np.float64)
+    if args.dump:
+        np.save(args.dump, tbuf.cpu().numpy().reshape(-1, 16))
     cyc = t[:, :5]
     phases = np.diff(cyc, axis=1)          # prologue, steady, drain, epilogue (shader cycles)
     wall0, wall1 = t[:, 5], t[:, 6]        # 100 MHz wall clock
