@@ -577,13 +577,18 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 pick = ch[idx];
             }
         }
+        if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, pick);
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
         pl->requiredWorkspace = pick.workspace;
         if (log_level() > 0) {
             int count = 0;
             const GettKernelInfo* tab = gett_f32_kernels(&count);
-            if (pick.kernel >= 0)
+            if (pick.family == 1)
+                CT_LOG("plan: contraction (16-bit MFMA) L=%llu M=%llu N=%llu K=%llu layA=%d layB=%d swapped=%d -> h16 kernel %d",
+                       (unsigned long long)pl->view.totL, (unsigned long long)pl->view.totM, (unsigned long long)pl->view.totN,
+                       (unsigned long long)pl->view.totK, pl->view.layA, pl->view.layB, (int)pl->view.swapped, pick.kernel);
+            else if (pick.kernel >= 0)
                 CT_LOG("plan: contraction L=%llu M=%llu N=%llu K=%llu layA=%d layB=%d swapped=%d -> kernel %d (%dx%dx%d) splitK=%u ws=%llu est=%.1fus",
                        (unsigned long long)pl->view.totL, (unsigned long long)pl->view.totM, (unsigned long long)pl->view.totN,
                        (unsigned long long)pl->view.totK, pl->view.layA, pl->view.layB, (int)pl->view.swapped, pick.kernel,
@@ -654,6 +659,19 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     if (plan->choice.kernel < 0) {
         p.partial = nullptr;
         err = launch_gett_simple(p, (int)plan->dtype, plan->accumulate64, stream);
+    } else if (plan->choice.family == 1) {
+        int count = 0;
+        const GettKernelInfo* tab = gett_h16_kernels(&count);
+        p.partial = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, stream);
+        err = tab[plan->choice.kernel].launch(p, stream);
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, stream);
+            std::lock_guard<std::mutex> g(g_prof.mtx);
+            g_prof.events.emplace_back(e0, e1);
+        }
     } else {
         int count = 0;
         const GettKernelInfo* tab = gett_f32_kernels(&count);
@@ -775,13 +793,13 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     int n = 0;
     if (plan->kind == OpKind::Contraction) {
         int count = 0;
-        const GettKernelInfo* tab = gett_f32_kernels(&count);
+        const GettKernelInfo* tab = (plan->choice.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
         const int k = plan->choice.kernel;
         n = std::snprintf(buf, len,
-                          "{\"op\":\"contraction\",\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
+                          "{\"op\":\"contraction\",\"family\":%d,\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
                           "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
                           "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f",
-                          (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
+                          plan->choice.family, (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
                           k >= 0 ? tab[k].bk : 16, k >= 0 ? tab[k].wm : 1, k >= 0 ? tab[k].wn : 1, k >= 0 ? tab[k].wk : 1,

@@ -74,7 +74,8 @@ struct ContractionView {
 
 // One executable choice for a contraction.
 struct ContractionChoice {
-    int      kernel = -1;      // index into gett_f32_kernels(); -1 = simple kernel
+    int      kernel = -1;      // index into the family's kernel table; -1 = simple kernel
+    int      family = 0;       // 0 = gett_f32_kernels() (fp32 data), 1 = gett_h16_kernels() (bf16 / fp16 data)
     uint32_t splitK = 1;
     uint32_t kPerSlice = 0;
     uint64_t workspace = 0;
@@ -86,6 +87,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
 // Ranked candidate list (best first) under a workspace limit.
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
                                                         int numCUs);
+bool pick_h16_choice(const ContractionView& v, ContractionChoice& c);
 void fill_gett_params(const ContractionView& v, const ContractionChoice& c, GettParams& p,
                       SplitKReduceParams& r);
 

@@ -219,14 +219,15 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
         (int)v.N.size() > kMaxGroupModes || (int)v.K.size() > kMaxGroupModes)
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 4 unfusable modes in one group");
 
-    // ---- operand layouts (fp32 path: 4-element = 16-byte lanes) ------------------------------
-    auto all_mult4_except = [](const std::vector<const std::vector<CanonMode>*>& groups, bool slotA,
-                               const CanonMode* except) {
+    // ---- operand layouts: 16-byte lanes = 4 fp32 or 8 bf16/fp16 elements ------------------------
+    const int64_t vec = (dtype_size(v.dtype) == 2) ? 8 : 4;
+    auto all_mult4_except = [vec](const std::vector<const std::vector<CanonMode>*>& groups, bool slotA,
+                                  const CanonMode* except) {
         for (auto* g : groups)
             for (const CanonMode& m : *g) {
                 if (&m == except) continue;
                 const int64_t s = slotA ? m.sA : m.sB;
-                if (s % 4 != 0) return false;
+                if (s % vec != 0) return false;
             }
         return true;
     };
@@ -238,12 +239,12 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
         if (!v.K.empty()) {
             const CanonMode& k0 = v.K.front();
             const int64_t s = slotA ? k0.sA : k0.sB;
-            if (s == 1 && k0.extent % 4 == 0 && all_mult4_except(groups, slotA, &k0)) return (int)LAY_K;
+            if (s == 1 && k0.extent % vec == 0 && all_mult4_except(groups, slotA, &k0)) return (int)LAY_K;
         }
         if (!freeG.empty()) {
             const CanonMode& f0 = freeG.front();
             const int64_t s = slotA ? f0.sA : f0.sB;
-            if (s == 1 && f0.extent % 4 == 0 && all_mult4_except(groups, slotA, &f0)) return (int)LAY_F;
+            if (s == 1 && f0.extent % vec == 0 && all_mult4_except(groups, slotA, &f0)) return (int)LAY_F;
         }
         return (int)LAY_S;
     };
@@ -351,6 +352,34 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
     return out;
 }
 
+// 16-bit data (bf16 / fp16, fp32 accumulation): one kernel shape (256 x 256 x 64, gett_h16.hip), picked
+// when both operands admit 16-byte lanes, the fastest contracted mode holds whole 64-deep K-tiles and
+// both operands can be addressed with 32-bit byte offsets.  Returns false -> the simple kernel runs.
+bool pick_h16_choice(const ContractionView& v, ContractionChoice& c) {
+    if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
+    if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
+    if (v.K.empty() || v.K.front().extent % 64 != 0 || v.totK % 64 != 0) return false;
+    auto span_bytes = [&](bool slotA) {
+        uint64_t n = 1;
+        for (const std::vector<CanonMode>* g : {slotA ? &v.M : &v.N, &v.K})
+            for (const CanonMode& m : *g) n += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(slotA ? m.sA : m.sB);
+        return n * 2ull;
+    };
+    if (span_bytes(true) >= (1ull << 32) - (1ull << 20) || span_bytes(false) >= (1ull << 32) - (1ull << 20)) return false;
+    int count = 0;
+    const GettKernelInfo* tab = gett_h16_kernels(&count);
+    c = ContractionChoice{};
+    c.family = 1;
+    c.kernel = (v.dtype == HIP_R_16BF ? 0 : 4) + (v.layA == LAY_F ? 2 : 0) + (v.layB == LAY_F ? 1 : 0);
+    if (c.kernel >= count) return false;
+    c.splitK = 1;
+    c.kPerSlice = (uint32_t)v.totK;
+    c.workspace = 0;
+    const double tiles = std::ceil((double)v.totM / tab[c.kernel].bm) * std::ceil((double)v.totN / tab[c.kernel].bn) * (double)v.totL;
+    c.estimateUs = std::ceil(tiles / 256.0) * (2.0 * tab[c.kernel].bm * tab[c.kernel].bn * (double)v.totK) / (4096.0 * 2.4e9 * 0.6) * 1e6;
+    return true;
+}
+
 static void fill_group(ModeGroup& g, const std::vector<CanonMode>& modes) {
     std::memset(&g, 0, sizeof(g));
     g.n = (int32_t)modes.size();
@@ -385,7 +414,7 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
         p.cStrideL[i] = v.L[i].sC;
     }
     int count = 0;
-    const GettKernelInfo* tab = gett_f32_kernels(&count);
+    const GettKernelInfo* tab = (c.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
     int bm = 16, bn = 16, bk = 16;
     if (c.kernel >= 0 && c.kernel < count) { bm = tab[c.kernel].bm; bn = tab[c.kernel].bn; bk = tab[c.kernel].bk; }
     (void)bk;

@@ -1,0 +1,412 @@
+// gett_h16.hip — bf16 / fp16 GETT kernels for gfx950 (MI355X, CDNA4): 16-bit data, fp32 accumulation
+// on v_mfma_f32_32x32x16_{bf16,f16}.
+//
+// Reference call sites: cuTENSOR/contraction.cu:261-265 with the types of :33-40 set to 16-bit data
+// (BASELINE configs[3]: C[m,n] = sum_k A[m,k] B[k,n], M = N = K = 8192) and the PyTorch binding's
+// CUDA_R_16BF / CUTENSOR_COMPUTE_DESC_16BF pairing (python/cutensor/torch/einsum.cc:35-40); alpha and
+// beta are fp32 host scalars (einsum.cc:39).
+//
+// Same GEMM view as gett_f32.hip (mode groups M / N / K / L as mixed-radix numbers, nothing is ever
+// transposed in memory); machine mapping:
+//
+//   * one 512-thread workgroup per CU owns a 256 x 256 output tile; K advances in tiles of 64.
+//   * HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, issued from
+//     inline asm so that the compiler's wait-count pass does not drain it in front of every ds_read).
+//     A K-tile is four 16-KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255) and the LDS
+//     holds two K-tiles = eight half-tile slots (128 KiB).  Which 16-byte unit of the half-tile a lane
+//     fetches is free, so the LDS image is shaped by permuting the *source* units:
+//       - K-contiguous operand (LAY_K): image [128 rows][64 k] (128-byte rows); unit p of row r holds
+//         k-unit p ^ ((r >> 1) & 7): the ds_read_b128 fragment reads (32 rows x 2 k-units) are
+//         conflict-free;
+//       - free-contiguous operand (LAY_F): image [64 k][128 rows] (256-byte k-rows); unit p of k-row k
+//         holds row-unit p ^ (4 * (k & 3)); fragments are read with the transposing ds_read_b64_tr_b16
+//         (4 k x 16 rows per 16-lane group), the four k-rows of a half-wave fall into the four 64-byte
+//         quarters of the bank row: conflict-free.
+//   * 8 waves as 2 (M) x 4 (N); a wave owns rows {64 wr + [0,64)} of both A halves and columns
+//     {32 wc + [0,32)} of both B halves: 2 x 2 x 2 accumulator fragments of 32 x 32 (128 registers).
+//     A K-tile is four phases, one accumulator quadrant (64 x 32, eight MFMAs) each, in the order
+//     (a0,b0) (a0,b1) (a1,b1) (a1,b0): a phase reads only the operand half that changes, so A-half 0 and
+//     B-half 0 are dead after phase 0, B-half 1 after phase 1, A-half 1 after phase 2 — each slot is
+//     restaged (two K-tiles ahead) one phase after its last read, one half-tile per phase, and five
+//     half-tiles (80 KiB per CU) are always in flight behind a *counted* vmcnt.
+//   * the two wave rows run half a phase apart (one extra barrier at the start for wr = 1): while the
+//     four waves of one row issue their eight MFMAs, the four waves of the other row (one per SIMD
+//     each) read fragments and issue LDS-DMA — matrix pipe beside memory pipe on every SIMD.
+//
+// Roofline: bf16/fp16 MFMA (4096 flop/clk/CU dense); algorithmic flops = 2*L*M*N*K, algorithmic bytes =
+// |A| + |B| + |D| (16-bit elements).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "params.h"
+#include "launch.h"
+#include "gett_common.h"
+
+namespace ctamd {
+
+constexpr int kHBK   = 64;            // K-tile
+constexpr int kHTile = 256;           // BM = BN
+constexpr int kHalfBytes = 16384;     // one half-tile: 128 rows x 64 k x 2 B
+
+typedef short    s16x4 __attribute__((ext_vector_type(4)));
+typedef short    s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+
+// Raw buffer descriptor (stride 0, num_records 2^32 - 1, gfx9 raw-buffer format word), built from
+// readfirstlane'd words so that the compiler knows it is wave-uniform: an inline-asm "s" operand that is
+// not provably uniform is silently given VGPRs.
+typedef int HRsrc __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ HRsrc h_make_rsrc(const void* base) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    HRsrc r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+    r[2] = -1;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// 64 lanes x 16 B -> the 1-KiB LDS piece at byte address ldsByte (wave-uniform).  Hidden from the
+// compiler's wait-count bookkeeping on purpose: completion is counted by hand (CTAMD_H_VMCNT).
+// s_nop 4: the SGPR operands may come straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).
+__device__ __forceinline__ void h_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, uint32_t ldsByte) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
+#else
+    (void)rsrc; (void)laneBytes; (void)tileBytes; (void)ldsByte;
+#endif
+}
+
+#define CTAMD_H_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define CTAMD_H_LGKM0()  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool BF>
+__device__ __forceinline__ f32x16 h_mfma(s16x8 a, s16x8 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else              return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
+    (void)a; (void)b; return c;
+#endif
+}
+
+__device__ __forceinline__ float h_to_float(uint16_t v, bool bf) {
+    if (bf) return __uint_as_float((uint32_t)v << 16);
+    return (float)__builtin_bit_cast(_Float16, v);
+}
+__device__ __forceinline__ uint16_t h_from_float(float f, bool bf) {
+    if (bf) {   // round to nearest even; NaN stays NaN
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One operand (A rows or B columns) of the streamed K-tile.
+// ---------------------------------------------------------------------------------------------
+template <int LAY>
+struct HOperand {
+    uint32_t src[2][2];   // byte offset of this lane's 16-byte unit: [half-tile][piece i of this wave], tile k0 = 0
+
+    __device__ __forceinline__ void init(const ModeGroup& gFree, uint32_t strideK0, uint32_t row0, int wave, int lane) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = wave + 8 * i;                      // 1-KiB piece of the half-tile
+                if constexpr (LAY == LAY_K) {
+                    const int r = 8 * c + (lane >> 3), p = lane & 7;
+                    const int u = p ^ ((r >> 1) & 7);
+                    uint32_t row = row0 + 128 * h + r;
+                    if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
+                    src[h][i] = (group_offset32<0>(gFree, row) + 8u * (uint32_t)u) * 2u;
+                } else {
+                    const int kk = 4 * c + (lane >> 4), p = lane & 15;
+                    const int u = p ^ (4 * ((lane >> 4) & 3));
+                    uint32_t row = row0 + 128 * h + 8 * u;
+                    if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
+                    src[h][i] = (group_offset32<0>(gFree, row) + (uint32_t)kk * strideK0) * 2u;
+                }
+            }
+    }
+
+    __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t tileBytes, uint32_t slotByte, int wave) const {
+        h_dma16(X, src[h][0], tileBytes, slotByte + (uint32_t)wave * 1024u);
+        h_dma16(X, src[h][1], tileBytes, slotByte + (uint32_t)(wave + 8) * 1024u);
+    }
+};
+
+// Per-lane constant parts of the fragment addresses (bytes inside a half-tile slot).
+//   LAY_K: offK[s], s = 16-k step 0..3, for any 32-row fragment base rb: + rb * 128
+//   LAY_F: offF, depends on (rb >> 5) through the swizzle; + s * 4096 + h * 1024
+__device__ __forceinline__ uint32_t h_offK(int lane, int s) {
+    const int x0 = (lane >> 5) ^ ((lane >> 1) & 7);
+    return (uint32_t)((lane & 31) * 128 + (((x0 ^ (2 * s)) & 7) << 4));
+}
+__device__ __forceinline__ uint32_t h_offF(int lane, int rbq) {
+    const int g = lane >> 4, i = lane & 15;
+    const int kk = 8 * (g >> 1) + (i >> 2);
+    const int u = (((rbq ^ (i >> 2)) & 3) << 2) | (2 * (g & 1) + ((i >> 1) & 1));
+    return (uint32_t)(kk * 256 + (u << 4) + 8 * (i & 1));
+}
+
+template <int LAY>
+__device__ __forceinline__ s16x8 h_read_frag(const char* slot, int rb, int s, const uint32_t (&offK)[4], uint32_t offF) {
+    if constexpr (LAY == LAY_K) {
+        return *reinterpret_cast<const s16x8*>(slot + rb * 128 + offK[s]);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef s16x4 __attribute__((address_space(3))) * lptr;
+        const char* p = slot + s * 4096 + offF;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 1024));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+        (void)slot; (void)rb; (void)s; (void)offK; (void)offF; return s16x8{};
+#endif
+    }
+}
+
+// Wave-uniform walk over the K-tiles of the contraction: byte offsets of tile t in A and B.  Fast-K: the
+// fastest contracted digit's extent is a multiple of kHBK, so a tile never straddles a digit boundary.
+struct HOdometer {
+    uint32_t j0, n0, j1, e1, hi;
+    uint32_t offA, offB, stepA, stepB, wrapA, wrapB;
+    __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ __forceinline__ void init(const ModeGroup& gK) {
+        const uint32_t E0 = gK.div[0].d;
+        n0 = sgpr(E0 / kHBK);
+        e1 = sgpr(gK.div[1].d);
+        j0 = 0; j1 = 0; hi = 0; offA = 0; offB = 0;
+        stepA = sgpr((uint32_t)((int64_t)kHBK * gK.stride[0][0]) * 2u);
+        stepB = sgpr((uint32_t)((int64_t)kHBK * gK.stride[1][0]) * 2u);
+        wrapA = sgpr((uint32_t)gK.stride[0][1] * 2u - (n0 - 1) * stepA);
+        wrapB = sgpr((uint32_t)gK.stride[1][1] * 2u - (n0 - 1) * stepB);
+    }
+    __device__ __forceinline__ void advance(const ModeGroup& gK) {
+        const bool c0 = (j0 + 1 == n0);
+        j0 = c0 ? 0u : j0 + 1;
+        offA += c0 ? wrapA : stepA;
+        offB += c0 ? wrapB : stepB;
+        j1 += c0 ? 1u : 0u;
+        if (j1 == e1) {   // carry beyond the second digit
+            j1 = 0;
+            hi += 1;
+            const uint32_t k = hi * e1 * gK.div[0].d;
+            if (k < gK.total) {
+                offA = sgpr(group_offset32<0>(gK, k) * 2u);
+                offB = sgpr(group_offset32<1>(gK, k) * 2u);
+            }
+        }
+    }
+};
+
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    // slot index: buffer * 4 + {0: A-half 0, 1: A-half 1, 2: B-half 0, 3: B-half 1}
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- tile mapping: XCD-contiguous ids, then groups of 8 tile rows so that the 32 tiles an XCD runs
+    //      at a time form an 8 x 4 block (12 operand panels for 32 tiles) ---------------------------------
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const int nTiles = (int)(p.gK.total / kHBK);
+
+    const HRsrc rA = h_make_rsrc(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l));
+    const HRsrc rB = h_make_rsrc(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l));
+    HOperand<LA> oa;
+    HOperand<LB> ob;
+    oa.init(p.gM, (uint32_t)p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, (uint32_t)p.gK.stride[1][0], n0, wave, lane);
+
+    uint32_t offK[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) offK[s] = h_offK(lane, s);
+    const uint32_t offFa0 = h_offF(lane, 2 * wr), offFa1 = h_offF(lane, 2 * wr + 1), offFb = h_offF(lane, wc);
+
+    HOdometer odo;
+    odo.init(p.gK);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
+
+    // ---- prologue: K-tiles 0 and 1 except A-half 1 of tile 1, in consumption order --------------------
+    uint32_t tA = odo.offA, tB = odo.offB;
+    oa.issue(rA, 0, tA, ldsBase + 0 * kHalfBytes, wave);
+    ob.issue(rB, 0, tB, ldsBase + 2 * kHalfBytes, wave);
+    ob.issue(rB, 1, tB, ldsBase + 3 * kHalfBytes, wave);
+    oa.issue(rA, 1, tA, ldsBase + 1 * kHalfBytes, wave);
+    if (1 < nTiles) odo.advance(p.gK);
+    uint32_t offA1 = odo.offA;                    // A offset of tile t + 1 (t = current tile)
+    oa.issue(rA, 0, odo.offA, ldsBase + 4 * kHalfBytes, wave);
+    ob.issue(rB, 0, odo.offB, ldsBase + 6 * kHalfBytes, wave);
+    ob.issue(rB, 1, odo.offB, ldsBase + 7 * kHalfBytes, wave);
+    int tNext = 2;                                // K-tile the odometer is about to describe
+    if (tNext < nTiles) odo.advance(p.gK);
+    uint32_t offA2 = odo.offA, offB2 = odo.offB;  // offsets of tile t + 2
+    CTAMD_H_VMCNT(10);                            // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
+
+    f32x16 acc[2][2][2];                          // [A half][32-row fragment][B half]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int z = 0; z < 2; ++z)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][z][r] = 0.f;
+    s16x8 a[2][4], b0[4], b1[4];
+
+    // rows of this wave inside an A half-tile: 64 wr + 32 fa; columns inside a B half-tile: 32 wc
+#define CTAMD_H_READ_A(SLOT)                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+        a[0][s] = h_read_frag<LA>(lds + (SLOT) * kHalfBytes, 64 * wr, s, offK, offFa0);            \
+        a[1][s] = h_read_frag<LA>(lds + (SLOT) * kHalfBytes, 64 * wr + 32, s, offK, offFa1);       \
+    }
+#define CTAMD_H_READ_B(SLOT, DST)                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) DST[s] = h_read_frag<LB>(lds + (SLOT) * kHalfBytes, 32 * wc, s, offK, offFb);
+    // Register fences (empty asm statements with "+v" operands): hipcc moves register-only MFMAs across
+    // barriers, waits and sched_barrier alike; making the operands opaque right after the barrier and the
+    // accumulators opaque right after the last MFMA pins the eight MFMAs of a phase inside its segment.
+#define CTAMD_H_FENCE_A() asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), \
+                                            "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+#define CTAMD_H_FENCE_B(BREG) asm volatile("" : "+v"(BREG[0]), "+v"(BREG[1]), "+v"(BREG[2]), "+v"(BREG[3]));
+#define CTAMD_H_FENCE_ACC(AH, BH) asm volatile("" : "+v"(acc[AH][0][BH]), "+v"(acc[AH][1][BH]));
+#define CTAMD_H_MFMA(AH, BH, BREG)                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+        acc[AH][0][BH] = h_mfma<BF>(a[0][s], BREG[s], acc[AH][0][BH]);                             \
+        acc[AH][1][BH] = h_mfma<BF>(a[1][s], BREG[s], acc[AH][1][BH]);                             \
+    }
+
+    // One phase.  P = LDS buffer of the current K-tile (compile time), Q = phase inside the tile.
+    //   load segment : fragment reads of the operand half that changes, one half-tile of LDS-DMA (the slot
+    //                  freed one phase ago), counted wait (five half-tiles stay in flight), own reads done
+    //   barrier      : the other wave row has finished its MFMA segment / issued its half of the DMA
+    //   MFMA segment : 8 x 32x32x16 on one accumulator quadrant
+    //   barrier
+#define CTAMD_H_PHASE(P, Q)                                                                        \
+    {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if constexpr ((Q) == 0) { CTAMD_H_READ_A((P) * 4 + 0) CTAMD_H_READ_B((P) * 4 + 2, b0) }   \
+        if constexpr ((Q) == 1) { CTAMD_H_READ_B((P) * 4 + 3, b1) }                                \
+        if constexpr ((Q) == 2) { CTAMD_H_READ_A((P) * 4 + 1) }                                    \
+        if constexpr ((Q) == 0) oa.issue(rA, 1, offA1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 1) oa.issue(rA, 0, offA2, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
+        if constexpr ((Q) == 2) ob.issue(rB, 0, offB2, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);        \
+        if constexpr ((Q) == 3) {                                                                  \
+            ob.issue(rB, 1, offB2, ldsBase + ((P) * 4 + 3) * kHalfBytes, wave);                    \
+            offA1 = offA2;                                                                         \
+            ++tNext;                                                                               \
+            if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
+            offA2 = odo.offA; offB2 = odo.offB;                                                    \
+        }                                                                                          \
+        CTAMD_H_VMCNT(10);                                                                         \
+        CTAMD_H_LGKM0();                                                                           \
+        __builtin_amdgcn_s_barrier();                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        CTAMD_H_FENCE_A()                                                                          \
+        if constexpr ((Q) == 0 || (Q) == 3) { CTAMD_H_FENCE_B(b0) } else { CTAMD_H_FENCE_B(b1) }   \
+        __builtin_amdgcn_s_setprio(1);                                                             \
+        if constexpr ((Q) == 0) { CTAMD_H_MFMA(0, 0, b0) CTAMD_H_FENCE_ACC(0, 0) }                 \
+        if constexpr ((Q) == 1) { CTAMD_H_MFMA(0, 1, b1) CTAMD_H_FENCE_ACC(0, 1) }                 \
+        if constexpr ((Q) == 2) { CTAMD_H_MFMA(1, 1, b1) CTAMD_H_FENCE_ACC(1, 1) }                 \
+        if constexpr ((Q) == 3) { CTAMD_H_MFMA(1, 0, b0) CTAMD_H_FENCE_ACC(1, 0) }                 \
+        __builtin_amdgcn_s_setprio(0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        __builtin_amdgcn_s_barrier();                                                              \
+    }
+#define CTAMD_H_TILE(P) CTAMD_H_PHASE(P, 0) CTAMD_H_PHASE(P, 1) CTAMD_H_PHASE(P, 2) CTAMD_H_PHASE(P, 3)
+
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_H_TILE(0) CTAMD_H_TILE(1) }
+    if (t < nTiles) { CTAMD_H_TILE(0) }
+    if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
+    CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive the workgroup
+
+    // ---- epilogue: D = alpha * acc + beta * C, 16-bit stores (32 lanes x 2 B contiguous along n) -------
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    const float alpha = p.alpha, beta = p.beta;
+    int64_t offDn[2], offCn[2];
+    bool    okN[2];
+#pragma unroll
+    for (int bh = 0; bh < 2; ++bh) {
+        const uint32_t n = n0 + 128 * bh + 32 * wc + (lane & 31);
+        okN[bh] = n < Ntot;
+        offDn[bh] = 0; offCn[bh] = 0;
+        if (okN[bh]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[bh], offCn[bh]);
+    }
+    auto store_frag = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < Mtot) {
+                int64_t offDm, offCm;
+                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+                if (okN[0]) {
+                    float val = alpha * c0[r];
+                    if (beta != 0.f) val += beta * h_to_float(C[offCm + offCn[0]], BF);
+                    D[offDm + offDn[0]] = h_from_float(val, BF);
+                }
+                if (okN[1]) {
+                    float val = alpha * c1[r];
+                    if (beta != 0.f) val += beta * h_to_float(C[offCm + offCn[1]], BF);
+                    D[offDm + offDn[1]] = h_from_float(val, BF);
+                }
+            }
+        }
+    };
+    store_frag(acc[0][0][0], acc[0][0][1], m0 + 64 * wr);
+    store_frag(acc[0][1][0], acc[0][1][1], m0 + 64 * wr + 32);
+    store_frag(acc[1][0][0], acc[1][0][1], m0 + 128 + 64 * wr);
+    store_frag(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
+// bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F)
+#define CTAMD_H16_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 0, &launch_h16<bf, la, lb>, 0},
+static const GettKernelInfo g_h16_table[] = {
+    CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16_ENTRY(false, LAY_K, LAY_K) CTAMD_H16_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16_ENTRY(false, LAY_F, LAY_K) CTAMD_H16_ENTRY(false, LAY_F, LAY_F)};
+
+const GettKernelInfo* gett_h16_kernels(int* count) {
+    *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
+    return g_h16_table;
+}
+
+}  // namespace ctamd

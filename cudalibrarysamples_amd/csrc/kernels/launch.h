@@ -32,6 +32,9 @@ hipError_t launch_splitk_reduce_frag(const SplitKReduceParams& p, hipStream_t st
 // streaming (LDS-DMA ring) kernels, gett_f32_stream.hip; gett_f32_kernels() returns the merged table
 const GettKernelInfo* gett_f32_stream_kernels(int* count);
 
+// bf16 / fp16 data, fp32 accumulation (v_mfma_f32_32x32x16_{bf16,f16}), gett_h16.hip
+const GettKernelInfo* gett_h16_kernels(int* count);
+
 // simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,
                               hipStream_t stream);

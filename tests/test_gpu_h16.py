@@ -1,0 +1,121 @@
+"""GPU parity of the 16-bit (bf16 / fp16 data, fp32 accumulate) MFMA contraction path — SURVEY §8 row a6,
+BASELINE configs[3]: contraction.cu:33-40 retyped to CUDA_R_16BF + CUTENSOR_COMPUTE_DESC_16BF as in
+python/cutensor/torch/einsum.cc:35-40 — through the C ABI (cutensorContract) against the oracle on
+inputs already rounded to the 16-bit type.
+
+Tolerance: the result is the fp32-accumulated sum rounded once to the 16-bit output type, so
+|got - ref| <= 2^-8 |ref| (bf16) / 2^-11 |ref| (fp16) plus fp32 accumulation noise; the tests use
+rtol 8e-3 (bf16) / 2e-3 (fp16) as stated in DESIGN.md, with a small atol for sums that cancel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import torch
+    assert torch.cuda.is_available()
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    return torch, ct, ops, ops.Handle()
+
+
+def _packed_strides(ext):
+    s, acc = [], 1
+    for e in ext:
+        s.append(acc)
+        acc *= e
+    return s
+
+
+def _run(env, ext, mA, mB, mC, dtype_name="bfloat16", alpha=1.0, beta=0.0, seed=0, expect_mfma=True):
+    """D = alpha * A * B + beta * C in packed column-major layout; returns (got, ref) as float64 arrays of
+    shape extC (Fortran order)."""
+    torch, ct, ops, h = env
+    tdt = getattr(torch, dtype_name)
+    cdt = ct.R_16BF if dtype_name == "bfloat16" else ct.R_16F
+    eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    # column-major packed tensor with modes m0 (fastest) .. == a torch tensor of the reversed shape
+    A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+    B = (torch.rand(eB[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+    C = (torch.rand(eC[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+    D = C.clone()
+    plan = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=cdt, workspace_limit=1 << 28)
+    d = plan.describe()
+    if expect_mfma:
+        assert d["family"] == 1 and d["kernel"] >= 0, d
+    plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr())
+    torch.cuda.synchronize()
+    # oracle on the rounded inputs: fp64 einsum over the reversed (row-major) views
+    rA, rB, rC = mA[::-1], mB[::-1], mC[::-1]
+    ref = torch.einsum("%s,%s->%s" % (rA, rB, rC), A.double().cpu(), B.double().cpu())
+    ref = alpha * ref + beta * C.double().cpu()
+    return D.double().cpu().numpy(), ref.numpy(), d
+
+
+LAYOUTS = {
+    # name: (modes of A, modes of B)   C is always [m, n] with m fastest
+    "sample_mk_kn": ("mk", "kn"),     # contraction.cu GEMM-like config: A free-contiguous, B K-contiguous
+    "km_kn": ("km", "kn"),            # both K-contiguous
+    "mk_nk": ("mk", "nk"),            # both free-contiguous
+    "km_nk": ("km", "nk"),
+}
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+@pytest.mark.parametrize("dims", [(512, 512, 256), (520, 264, 192), (256, 256, 64), (8, 1032, 128)])
+def test_gemm_like_bf16(env, layout, dims):
+    m, n, k = dims
+    mA, mB = LAYOUTS[layout]
+    got, ref, d = _run(env, dict(m=m, n=n, k=k), mA, mB, "mn", seed=hash((layout, dims)) % 1000)
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+
+
+def test_alpha_beta_and_fp16(env):
+    got, ref, _ = _run(env, dict(m=384, n=264, k=128), "mk", "kn", "mn", alpha=1.5, beta=-0.75, seed=3)
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
+    got, ref, _ = _run(env, dict(m=264, n=384, k=192), "km", "nk", "mn", dtype_name="float16", alpha=0.5, beta=0.25, seed=4)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-2)
+
+
+def test_multi_mode_contraction_bf16(env):
+    """Tensor (not matrix) shapes: C[m,u,n,v] = A[m,h,k,n] B[u,k,v,h] (contraction.cu:43) in bf16 with a
+    64-deep fastest contracted mode, and the headline einsum's mode structure 'abcd,dcbe->ae'."""
+    got, ref, d = _run(env, dict(m=24, n=16, u=16, v=24, h=6, k=64), "mhkn", "ukvh", "munv", seed=7)
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
+    got, ref, d = _run(env, dict(a=96, b=4, c=6, d=64, e=96), "dcba", "ebcd", "ea", seed=8)
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=5e-2)
+
+
+def test_unaligned_shapes_fall_back(env):
+    """Extents that do not admit 16-byte lanes / 64-deep K-tiles still give correct results (simple kernel)."""
+    got, ref, d = _run(env, dict(m=37, n=29, k=50), "mk", "kn", "mn", seed=9, expect_mfma=False)
+    assert d["kernel"] < 0 or d["family"] == 0
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+
+
+def test_full_size_8192_sampled(env):
+    """BASELINE configs[3] at full size: 8192^3 bf16; 4096 sampled outputs against fp64 dot products of the
+    rounded inputs, plus linearity in alpha (size-independent property)."""
+    torch, ct, ops, h = env
+    n = 8192
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    A = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)   # A[m,k], m fastest: A[k][m] row-major
+    B = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)   # B[k,n], k fastest: B[n][k] row-major
+    D1 = torch.empty((n, n), device="cuda", dtype=torch.bfloat16)                     # C[m,n], m fastest: C[n][m]
+    D2 = torch.empty_like(D1)
+    plan = ops.contraction_plan(h, [n, n], "mk", [n, n], "kn", [n, n], "mn", dtype=ct.R_16BF)
+    assert plan.describe()["family"] == 1
+    plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D1.data_ptr(), D1.data_ptr())
+    plan.contract(2.0, A.data_ptr(), B.data_ptr(), 0.0, D2.data_ptr(), D2.data_ptr())
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(12)
+    ms, ns = rng.integers(0, n, 4096), rng.integers(0, n, 4096)
+    mi, ni = torch.from_numpy(ms).cuda(), torch.from_numpy(ns).cuda()
+    ref = (A[:, mi].double() * B[ni, :].double().t()).sum(dim=0).cpu().numpy()       # sum_k A[k][m] * B[n][k]
+    got = D1[ni, mi].double().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.15)     # |sum of 8192 U(-1,1)^2 terms| ~ 30; atol covers cancellation
+    np.testing.assert_array_equal((D1.float() * 2).cpu().numpy(), D2.float().cpu().numpy())   # exact: scaling by 2 commutes with rounding
