@@ -125,6 +125,7 @@ cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
 }
 
 cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) {
+    if (handle != nullptr && handle->syncPool != nullptr) (void)hipFree(handle->syncPool);
     delete handle;
     return CUTENSOR_STATUS_SUCCESS;
 }
@@ -580,6 +581,27 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, pick);
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
+        // In-launch fold of the split-K partials: only when every workgroup of the launch owns a CU of its own
+        // (they wait for each other) and the output is a plain matrix; otherwise the fold is a second kernel.
+        if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK > 1) {
+            int cnt = 0;
+            const GettKernelInfo* tabf = gett_f32_kernels(&cnt);
+            const char* env = std::getenv("CUTENSOR_AMD_FUSED_FOLD");
+            const bool allowed = env && env[0] == '1';   // opt-in: measured slower than the two-kernel fold
+            if (allowed && tabf[pick.kernel].fragPartials && !tabf[pick.kernel].ablation && pl->gett.nBlocks <= (uint32_t)handle->numCUs &&
+                pl->view.totL == 1 && pl->view.M.size() <= 1 && pl->view.N.size() <= 1) {
+                std::lock_guard<std::mutex> g(handle->mtx);
+                if (handle->syncPool == nullptr) {
+                    void* ptr = nullptr;
+                    const size_t bytes = (size_t)cutensorHandle::kSyncSlots * 64;
+                    if (hipMalloc(&ptr, bytes) == hipSuccess && hipMemset(ptr, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+                        handle->syncPool = static_cast<uint32_t*>(ptr);
+                    else
+                        (void)hipGetLastError();
+                }
+                pl->fusedFold = handle->syncPool != nullptr;
+            }
+        }
         pl->requiredWorkspace = pick.workspace;
         if (log_level() > 0) {
             int count = 0;
@@ -676,6 +698,14 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         int count = 0;
         const GettKernelInfo* tab = gett_f32_kernels(&count);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
+        if (plan->fusedFold) {
+            uint32_t slot;
+            {
+                std::lock_guard<std::mutex> g(handle->mtx);
+                slot = handle->syncNext++ % cutensorHandle::kSyncSlots;
+            }
+            p.sync = handle->syncPool + (size_t)slot * 16;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
@@ -685,7 +715,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             std::lock_guard<std::mutex> g(g_prof.mtx);
             g_prof.events.emplace_back(e0, e1);
         }
-        if (err == hipSuccess && plan->choice.splitK > 1) {
+        if (err == hipSuccess && plan->choice.splitK > 1 && !plan->fusedFold) {
             SplitKReduceParams r = plan->skr;
             r.partial = static_cast<float*>(workspace);
             r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
@@ -798,14 +828,14 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"family\":%d,\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
                           "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
-                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f",
+                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f,\"fusedFold\":%d",
                           plan->choice.family, (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
                           k >= 0 ? tab[k].bk : 16, k >= 0 ? tab[k].wm : 1, k >= 0 ? tab[k].wn : 1, k >= 0 ? tab[k].wk : 1,
                           k >= 0 ? tab[k].pf : 0, k >= 0 ? tab[k].ablation : 0,
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
-                          (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs);
+                          (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold);
         // contracted digits, fastest first: [extent, strideA, strideB]
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
         for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)

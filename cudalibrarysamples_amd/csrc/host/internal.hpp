@@ -126,6 +126,7 @@ struct cutensorPlan {
     ctamd::GettParams          gett{};
     ctamd::SplitKReduceParams  skr{};
     bool                       accumulate64 = false;
+    bool                       fusedFold = false;     // split-K partials are folded inside the GETT launch
     // element-wise / reduction
     ctamd::EwPlan     ew;
     ctamd::ReducePlan red;
@@ -145,4 +146,9 @@ struct cutensorHandle {
     uint32_t planCacheCapacity = 0;
     std::map<std::string, PlanCacheEntry> planCache;   // problem signature -> tuned choice
     int logLevel = 0;
+    // {arrivals, departures} counter pairs for in-launch split-K folds, 64 B apart, zeroed once; a launch
+    // draws the next slot round-robin and its last workgroup re-arms it (gett_f32_stream.hip)
+    uint32_t* syncPool = nullptr;
+    uint32_t  syncNext = 0;
+    static constexpr uint32_t kSyncSlots = 256;
 };

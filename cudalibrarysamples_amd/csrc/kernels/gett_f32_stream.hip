@@ -418,6 +418,82 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
 #pragma unroll
             for (int j = 0; j < TN; ++j) store_wt_16(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + lane) * 16));
         stamp(4);
+        if (p.sync == nullptr) {   // the fold runs as its own kernel
+            stamp(6);
+            return;
+        }
+        // ---- in-launch fold (planner: one workgroup per CU, all co-resident; flat M / N / no batch) ------
+        // Publish: the partial stores above are write-through; every storing wave drains them, the four
+        // multiplying waves meet (the data movers have ended), one lane bumps the arrival counter with an
+        // agent-scope atomic.  Consume: that lane polls the counter relaxed, ONE agent-scope acquire drops
+        // this CU's stale L1 lines, the workgroup meets again and then reads its share of every slice with
+        // plain loads (cdna_hip_programming.md Guideline 16, recipe R1).  The wait is bounded: a grid that is
+        // not co-resident yields wrong numbers, never a hang.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        uint32_t* cnt = p.sync;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.nBlocks && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // the last workgroup through re-arms the counters for the next launch that draws this slot
+            if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.nBlocks - 1) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        stamp(11);
+        // share: 128-byte lines (8 accumulator quads) of the tile image, line i -> workgroup i mod nBlocks
+        const uint32_t quadsTotal = p.tilesM * p.tilesN * 4u * TM * TN * 64u;
+        const uint32_t lines = quadsTotal / 8u;
+        const int q = tid & 7, g = tid >> 3;                // 8 quads x 32 slice groups (256 multiplying threads)
+        f32x4* red = reinterpret_cast<f32x4*>(lds);         // the ring is idle now
+        for (uint32_t line = blockIdx.x; line < lines; line += p.nBlocks) {
+            const uint32_t e = line * 8u + q;
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.partial) + e;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (uint32_t s0 = g; s0 < p.splitK; s0 += 256) {
+                f32x4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t sl = s0 + 32u * u;
+                    x[u] = (sl < p.splitK) ? __builtin_nontemporal_load(src + (size_t)sl * quadsTotal) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            }
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sum[c] += __shfl_xor(sum[c], m, 64);
+            if (lane < 8) red[wave * 8 + q] = sum;
+            __builtin_amdgcn_s_barrier();
+            if (tid < 8) {
+                sum = (red[q] + red[8 + q]) + (red[16 + q] + red[24 + q]);
+                uint32_t rem = e;
+                const uint32_t ln = rem % 64; rem /= 64;
+                const uint32_t fj = rem % TN; rem /= TN;
+                const uint32_t fi = rem % TM; rem /= TM;
+                const uint32_t w = rem % 4; rem /= 4;
+                const uint32_t tmt = rem % p.tilesM;
+                const uint32_t tnt = rem / p.tilesM;
+                const uint32_t n = tnt * BN + (w >> 1) * (BN / 2) + 16 * fj + (ln & 15);
+                if (n < Ntot) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t m = tmt * BM + (w & 1) * (BM / 2) + 16 * fi + 4 * (ln >> 4) + r;
+                        if (m >= Mtot) continue;
+                        float val = p.alpha * sum[r];
+                        if (p.beta != 0.f)
+                            val += p.beta * static_cast<const float*>(p.C)[(int64_t)m * p.cStrideM[0] + (int64_t)n * p.cStrideN[0]];
+                        static_cast<float*>(p.D)[(int64_t)m * p.gM.stride[1][0] + (int64_t)n * p.gN.stride[1][0]] = val;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
         stamp(6);
         return;
     }

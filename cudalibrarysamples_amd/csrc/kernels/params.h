@@ -36,6 +36,7 @@ struct GettParams {
     void*       D;
     float*      partial;  // split-K workspace: [slice][L][M][N] fp32, or nullptr
     unsigned long long* timing;   // diagnostics: 16 x uint64 per workgroup (nullptr = off)
+    uint32_t*   sync;     // {arrivals, departures} of an in-launch split-K fold (streaming kernels), or nullptr
     ModeGroup   gM, gN, gK, gL;
     float       alpha, beta;
     double      alpha64, beta64;  // same scalars at full width (fp64 data)
