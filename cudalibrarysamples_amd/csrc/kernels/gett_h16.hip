@@ -27,8 +27,8 @@
 //     A K-tile is four phases, one accumulator quadrant (64 x 32, eight MFMAs) each, in the order
 //     (a0,b0) (a0,b1) (a1,b1) (a1,b0): a phase reads only the operand half that changes, so A-half 0 and
 //     B-half 0 are dead after phase 0, B-half 1 after phase 1, A-half 1 after phase 2 — each slot is
-//     restaged (two K-tiles ahead) one phase after its last read, one half-tile per phase, and five
-//     half-tiles (80 KiB per CU) are always in flight behind a *counted* vmcnt.
+//     restaged (one to two K-tiles ahead) two or three phases after its last read, one half-tile per
+//     phase, and four half-tiles (64 KiB per CU) are always in flight behind a *counted* vmcnt.
 //   * the two wave rows run half a phase apart (one extra barrier at the start for wr = 1): while the
 //     four waves of one row issue their eight MFMAs, the four waves of the other row (one per SIMD
 //     each) read fragments and issue LDS-DMA — matrix pipe beside memory pipe on every SIMD.
@@ -72,10 +72,15 @@ __device__ __forceinline__ HRsrc h_make_rsrc(const void* base) {
 // 64 lanes x 16 B -> the 1-KiB LDS piece at byte address ldsByte (wave-uniform).  Hidden from the
 // compiler's wait-count bookkeeping on purpose: completion is counted by hand (CTAMD_H_VMCNT).
 // s_nop 4: the SGPR operands may come straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).
+template <bool PAD = true>
 __device__ __forceinline__ void h_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, uint32_t ldsByte) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
+    if constexpr (PAD)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
+    else   // main loop: every SGPR operand was produced by the scalar ALU, or long ago
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
 #else
     (void)rsrc; (void)laneBytes; (void)tileBytes; (void)ldsByte;
 #endif
@@ -137,9 +142,10 @@ struct HOperand {
             }
     }
 
+    template <bool PAD = true>
     __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t tileBytes, uint32_t slotByte, int wave) const {
-        h_dma16(X, src[h][0], tileBytes, slotByte + (uint32_t)wave * 1024u);
-        h_dma16(X, src[h][1], tileBytes, slotByte + (uint32_t)(wave + 8) * 1024u);
+        h_dma16<PAD>(X, src[h][0], tileBytes, slotByte + (uint32_t)wave * 1024u);
+        h_dma16<PAD>(X, src[h][1], tileBytes, slotByte + (uint32_t)(wave + 8) * 1024u);
     }
 };
 
@@ -248,21 +254,26 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     odo.init(p.gK);
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
 
-    // ---- prologue: K-tiles 0 and 1 except A-half 1 of tile 1, in consumption order --------------------
-    uint32_t tA = odo.offA, tB = odo.offB;
-    oa.issue(rA, 0, tA, ldsBase + 0 * kHalfBytes, wave);
-    ob.issue(rB, 0, tB, ldsBase + 2 * kHalfBytes, wave);
-    ob.issue(rB, 1, tB, ldsBase + 3 * kHalfBytes, wave);
-    oa.issue(rA, 1, tA, ldsBase + 1 * kHalfBytes, wave);
+    // ---- prologue: K-tile 0 and the first halves of K-tile 1, in consumption order ---------------------
+    // Staging schedule (global phase P = 4 t + q; one half-tile per phase, restaged two or more phases
+    // after the slot's last read, so a slot is never rewritten while the other wave row may still have
+    // reads of it in flight):
+    //   q = 0: B-half 1 of tile t + 1     q = 1: A-half 1 of tile t + 1
+    //   q = 2: A-half 0 of tile t + 2     q = 3: B-half 0 of tile t + 2
+    // A half-tile is first read at least five phases after it was issued and the wait in front of each
+    // phase's first barrier leaves four half-tiles (8 LDS-DMA instructions of this wave) in flight.
+    oa.issue(rA, 0, odo.offA, ldsBase + 0 * kHalfBytes, wave);
+    ob.issue(rB, 0, odo.offB, ldsBase + 2 * kHalfBytes, wave);
+    ob.issue(rB, 1, odo.offB, ldsBase + 3 * kHalfBytes, wave);
+    oa.issue(rA, 1, odo.offA, ldsBase + 1 * kHalfBytes, wave);
     if (1 < nTiles) odo.advance(p.gK);
-    uint32_t offA1 = odo.offA;                    // A offset of tile t + 1 (t = current tile)
-    oa.issue(rA, 0, odo.offA, ldsBase + 4 * kHalfBytes, wave);
-    ob.issue(rB, 0, odo.offB, ldsBase + 6 * kHalfBytes, wave);
-    ob.issue(rB, 1, odo.offB, ldsBase + 7 * kHalfBytes, wave);
+    uint32_t offA1 = odo.offA, offB1 = odo.offB;  // offsets of tile t + 1 (t = current tile)
+    oa.issue(rA, 0, offA1, ldsBase + 4 * kHalfBytes, wave);
+    ob.issue(rB, 0, offB1, ldsBase + 6 * kHalfBytes, wave);
     int tNext = 2;                                // K-tile the odometer is about to describe
     if (tNext < nTiles) odo.advance(p.gK);
     uint32_t offA2 = odo.offA, offB2 = odo.offB;  // offsets of tile t + 2
-    CTAMD_H_VMCNT(10);                            // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
+    CTAMD_H_VMCNT(8);                             // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
 
@@ -299,10 +310,11 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     }
 
     // One phase.  P = LDS buffer of the current K-tile (compile time), Q = phase inside the tile.
-    //   load segment : fragment reads of the operand half that changes, one half-tile of LDS-DMA (the slot
-    //                  freed one phase ago), counted wait (five half-tiles stay in flight), own reads done
+    //   load segment : fragment reads of the operand half that changes, one half-tile of LDS-DMA, counted
+    //                  wait for the half-tile the NEXT phase reads (four stay in flight)
     //   barrier      : the other wave row has finished its MFMA segment / issued its half of the DMA
-    //   MFMA segment : 8 x 32x32x16 on one accumulator quadrant
+    //   MFMA segment : own fragment reads are back (their latency overlapped the barrier), 8 x 32x32x16 on
+    //                  one accumulator quadrant
     //   barrier
 #define CTAMD_H_PHASE(P, Q)                                                                        \
     {                                                                                              \
@@ -310,19 +322,19 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         if constexpr ((Q) == 0) { CTAMD_H_READ_A((P) * 4 + 0) CTAMD_H_READ_B((P) * 4 + 2, b0) }   \
         if constexpr ((Q) == 1) { CTAMD_H_READ_B((P) * 4 + 3, b1) }                                \
         if constexpr ((Q) == 2) { CTAMD_H_READ_A((P) * 4 + 1) }                                    \
-        if constexpr ((Q) == 0) oa.issue(rA, 1, offA1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
-        if constexpr ((Q) == 1) oa.issue(rA, 0, offA2, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
-        if constexpr ((Q) == 2) ob.issue(rB, 0, offB2, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);        \
+        if constexpr ((Q) == 0) ob.template issue<false>(rB, 1, offB1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 1) oa.template issue<false>(rA, 1, offA1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 2) oa.template issue<false>(rA, 0, offA2, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
         if constexpr ((Q) == 3) {                                                                  \
-            ob.issue(rB, 1, offB2, ldsBase + ((P) * 4 + 3) * kHalfBytes, wave);                    \
-            offA1 = offA2;                                                                         \
+            ob.template issue<false>(rB, 0, offB2, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
+            offA1 = offA2; offB1 = offB2;                                                          \
             ++tNext;                                                                               \
             if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
             offA2 = odo.offA; offB2 = odo.offB;                                                    \
         }                                                                                          \
-        CTAMD_H_VMCNT(10);                                                                         \
-        CTAMD_H_LGKM0();                                                                           \
+        CTAMD_H_VMCNT(8);                                                                          \
         __builtin_amdgcn_s_barrier();                                                              \
+        CTAMD_H_LGKM0();                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         CTAMD_H_FENCE_A()                                                                          \
         if constexpr ((Q) == 0 || (Q) == 3) { CTAMD_H_FENCE_B(b0) } else { CTAMD_H_FENCE_B(b1) }   \
