@@ -158,9 +158,8 @@ def main():
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak if peak else None, "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic_einsum.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
-                "kernel": "%s<%dx%dx%d,w%dx%dx%d,ring%d> (table index %d)" % (
-                    "gett_f32_stream_kernel" if desc.get("splitK", 1) > 1 and desc.get("pf", 0) >= 3 and desc.get("kernel", 0) >= 54 else "gett_f32_kernel",
-                    desc["bm"], desc["bn"], desc["bk"], desc["wm"], desc["wn"], desc["wk"], desc.get("pf", 0), desc.get("kernel", -1)),
+                "kernel": "%s<%dx%dx%d,w%dx%dx%d> (table index %d)" % (desc.get("kname", "gett_f32_kernel"), desc["bm"], desc["bn"], desc["bk"],
+                                                                       desc["wm"], desc["wn"], desc["wk"], desc.get("kernel", -1)),
                 "launches": n, "mean_us": mean_ms.value * 1e3, "min_us": min_ms.value * 1e3,
                 "algorithmic_flop_per_launch": FLOP, "algorithmic_bytes_per_launch": BYTES,
                 "hbm_equiv_TBps": BYTES / (mean_ms.value * 1e-3) / 1e12 if n else None,

@@ -324,7 +324,7 @@ cutensorStatus_t cutensorCreateElementwiseBinary(const cutensorHandle_t handle, 
                                                  cutensorOperator_t opAC, const cutensorComputeDescriptor_t descCompute) {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
-    if (opAC != CUTENSOR_OP_ADD) return CUTENSOR_STATUS_NOT_SUPPORTED;
+    if (opAC != CUTENSOR_OP_ADD && opAC != CUTENSOR_OP_MUL && opAC != CUTENSOR_OP_MAX && opAC != CUTENSOR_OP_MIN) return CUTENSOR_STATUS_NOT_SUPPORTED;
     cutensorOperationDescriptor op{};
     op.kind = OpKind::ElementwiseBinary;
     cutensorStatus_t st;
@@ -339,6 +339,35 @@ cutensorStatus_t cutensorCreateElementwiseBinary(const cutensorHandle_t handle, 
     st = plan_elementwise(op, ep, &why);
     if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateElementwiseBinary: %s", why.c_str()); return st; }
     op.movedBytes = 3.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);
+    return new_op(desc, op);
+}
+
+// elementwise_trinary.cu:174-182
+cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                  const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                  const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                                  const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                  const cutensorTensorDescriptor_t descD, const int32_t modeD[],
+                                                  cutensorOperator_t opAB, cutensorOperator_t opABC,
+                                                  const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::ElementwiseTrinary;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.B, descB, modeB, opB)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.C, descC, modeC, opC)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descD, modeD, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.opAB = opAB;
+    op.opReduce = opABC;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    EwTrinaryPlan tp;
+    std::string why;
+    st = plan_elementwise_trinary(op, tp, &why);
+    if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateElementwiseTrinary: %s", why.c_str()); return st; }
+    op.movedBytes = 4.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);   // elementwise_trinary.cu:234-238
     return new_op(desc, op);
 }
 
@@ -382,6 +411,30 @@ cutensorStatus_t cutensorOperationDescriptorSetAttribute(const cutensorHandle_t 
     if (desc == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (attr == CUTENSOR_OPERATION_DESCRIPTOR_TAG && sizeInBytes == sizeof(int32_t)) {
         desc->tag = *static_cast<const int32_t*>(buf);
+        return CUTENSOR_STATUS_SUCCESS;
+    }
+    // elementwise_permute_padding.cu:178-195: one int per output mode / one output-typed value
+    if (attr == CUTENSOR_OPERATION_DESCRIPTOR_PADDING_LEFT || attr == CUTENSOR_OPERATION_DESCRIPTOR_PADDING_RIGHT) {
+        if (desc->kind != OpKind::Permutation) return CUTENSOR_STATUS_NOT_SUPPORTED;
+        if (sizeInBytes != sizeof(int32_t) * desc->D.modes.size()) return CUTENSOR_STATUS_INVALID_VALUE;
+        const int32_t* v = static_cast<const int32_t*>(buf);
+        std::vector<int32_t>& dst = (attr == CUTENSOR_OPERATION_DESCRIPTOR_PADDING_LEFT) ? desc->padLeft : desc->padRight;
+        dst.assign(v, v + desc->D.modes.size());
+        for (int32_t x : dst) if (x < 0) { dst.clear(); return CUTENSOR_STATUS_INVALID_VALUE; }
+        return CUTENSOR_STATUS_SUCCESS;
+    }
+    if (attr == CUTENSOR_OPERATION_DESCRIPTOR_PADDING_VALUE) {
+        if (desc->kind != OpKind::Permutation) return CUTENSOR_STATUS_NOT_SUPPORTED;
+        if (sizeInBytes != dtype_size(desc->D.desc.dtype)) return CUTENSOR_STATUS_INVALID_VALUE;
+        switch (desc->D.desc.dtype) {
+            case HIP_R_32F: desc->padValue = *static_cast<const float*>(buf); break;
+            case HIP_R_64F: desc->padValue = *static_cast<const double*>(buf); break;
+            case HIP_R_16F: { uint16_t u; std::memcpy(&u, buf, 2); const uint32_t s = (u >> 15) & 1u, e = (u >> 10) & 31u, m = u & 1023u;
+                              double x = (e == 0) ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((double)(m | 1024u), (int)e - 25));
+                              desc->padValue = s ? -x : x; break; }
+            case HIP_R_16BF: { uint16_t u; std::memcpy(&u, buf, 2); const uint32_t w = (uint32_t)u << 16; float f; std::memcpy(&f, &w, 4); desc->padValue = f; break; }
+            default: return CUTENSOR_STATUS_NOT_SUPPORTED;
+        }
         return CUTENSOR_STATUS_SUCCESS;
     }
     return CUTENSOR_STATUS_NOT_SUPPORTED;
@@ -625,6 +678,37 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         pl->requiredWorkspace = pl->red.workspace;
         CT_LOG("plan: reduction variant=%d kept=%u red=%u splitR=%u perm=%d", pl->red.variant, pl->red.p.kept.total,
                pl->red.p.red.total, pl->red.p.splitR, (int)pl->red.isPermutation);
+    } else if (desc->kind == OpKind::ElementwiseTrinary) {
+        st = plan_elementwise_trinary(*desc, pl->ew3, &why);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        pl->alignB3 = desc->B.desc.alignment;
+        pl->requiredWorkspace = 0;
+        CT_LOG("plan: elementwise trinary passes=%d swapAB=%d variant(last)=%d", pl->ew3.twoPass ? 2 : 1, (int)pl->ew3.swapAB, pl->ew3.last.variant);
+    } else if (desc->kind == OpKind::Permutation && (!desc->padLeft.empty() || !desc->padRight.empty())) {
+        // The output buffer is the packed tensor of extents e + padLeft + padRight (the sample sizes it that way,
+        // elementwise_permute_padding.cu:101-103); the descriptor carries the unpadded extents.
+        const size_t nm = desc->D.modes.size();
+        std::vector<int64_t> packed(nm), padded(nm);
+        int64_t accU = 1, accP = 1, offset = 0;
+        bool isPacked = true;
+        for (size_t i = 0; i < nm; ++i) {
+            const int64_t l = desc->padLeft.empty() ? 0 : desc->padLeft[i], r = desc->padRight.empty() ? 0 : desc->padRight[i];
+            packed[i] = accU; padded[i] = accP;
+            isPacked = isPacked && (desc->D.desc.extent[i] == 1 || desc->D.desc.stride[i] == accU);
+            offset += l * accP;
+            accU *= desc->D.desc.extent[i];
+            accP *= desc->D.desc.extent[i] + l + r;
+        }
+        if (!isPacked) { delete pl; CT_LOG("cutensorCreatePlan: padding needs a packed output descriptor"); return CUTENSOR_STATUS_NOT_SUPPORTED; }
+        cutensorOperationDescriptor inner = *desc;
+        inner.D.desc.stride = padded;
+        st = plan_elementwise(inner, pl->ew, &why);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        pl->padFillElems = (uint64_t)accP;
+        pl->padOffsetElems = offset;
+        pl->padValue = desc->padValue;
+        pl->requiredWorkspace = 0;
+        CT_LOG("plan: padded permutation variant=%d fill=%llu elems offset=%lld", pl->ew.variant, (unsigned long long)pl->padFillElems, (long long)offset);
     } else {
         st = plan_elementwise(*desc, pl->ew, &why);
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
@@ -727,12 +811,15 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
 }
 
 static hipError_t run_elementwise(const EwPlan& ew, hipDataType dtype, double a, const void* A, double g,
-                                  const void* C, void* D, hipStream_t stream) {
+                                  const void* C, void* D, hipStream_t stream, const void* E = nullptr, double d = 0.0) {
     Ew2DParams p = ew.p;
     p.A = A;
-    p.C = (ew.usesC && g != 0.0) ? C : nullptr;
+    // a zero gamma drops the C term only for ADD (alpha perm(A) + 0): MUL / MAX / MIN still need it
+    p.C = (ew.usesC && (g != 0.0 || (p.opAC != 0 && p.opAC != CUTENSOR_OP_ADD))) ? C : nullptr;
     p.D = D;
+    p.E = E;
     p.alpha = (float)a; p.gamma = (float)g; p.alpha64 = a; p.gamma64 = g;
+    p.delta = (float)d; p.delta64 = d;
     return launch_elementwise(p, ew.variant, (int)dtype, stream);
 }
 
@@ -773,7 +860,13 @@ cutensorStatus_t cutensorPermute(const cutensorHandle_t handle, const cutensorPl
     if (alpha == nullptr || A == nullptr || B == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (misaligned(A, plan->alignA) || misaligned(B, plan->alignD)) return CUTENSOR_STATUS_INVALID_VALUE;
     const double a = scalar_as_double(alpha, plan->scalarType);
-    hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, B, stream);
+    hipError_t err = hipSuccess;
+    void* out = B;
+    if (plan->padFillElems != 0) {   // border (and interior, rewritten next) = padding value
+        err = launch_fill(B, plan->padFillElems, (int)plan->dtype, plan->padValue, stream);
+        out = static_cast<char*>(B) + plan->padOffsetElems * (int64_t)dtype_size(plan->dtype);
+    }
+    if (err == hipSuccess) err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, out, stream);
     if (err != hipSuccess) { CT_LOG("cutensorPermute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
 }
@@ -790,6 +883,55 @@ cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle,
     hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, g, C, D, stream);
     if (err != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
     return CUTENSOR_STATUS_SUCCESS;
+}
+
+// elementwise_trinary.cu:223-227
+cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
+                                                   const void* alpha, const void* A, const void* beta, const void* B,
+                                                   const void* gamma, const void* C, void* D, cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::ElementwiseTrinary) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || beta == nullptr || gamma == nullptr || A == nullptr || B == nullptr || C == nullptr || D == nullptr)
+        return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(B, plan->alignB3) || misaligned(C, plan->alignC) || misaligned(D, plan->alignD))
+        return CUTENSOR_STATUS_INVALID_VALUE;
+    const double a = scalar_as_double(alpha, plan->scalarType), b = scalar_as_double(beta, plan->scalarType),
+                 g = scalar_as_double(gamma, plan->scalarType);
+    const EwTrinaryPlan& t = plan->ew3;
+    hipError_t err = hipSuccess;
+    if (t.twoPass) {
+        err = run_elementwise(t.first, plan->dtype, a, A, 0.0, nullptr, D, stream);                       // D = alpha perm(A)
+        if (err == hipSuccess) err = run_elementwise(t.last, plan->dtype, b, B, g, C, D, stream, D, 1.0);  // combine in place
+    } else if (t.swapAB) {
+        err = run_elementwise(t.last, plan->dtype, a, A, g, C, D, stream, B, b);   // E = B (has D's layout)
+    } else {
+        err = run_elementwise(t.last, plan->dtype, b, B, g, C, D, stream, A, a);   // E = A
+    }
+    if (err != hipSuccess) { CT_LOG("cutensorElementwiseTrinaryExecute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction_jit.cu:134,398 — the engine has no run-time code generation (every kernel is compiled ahead of
+// time for gfx950), so its "kernel cache" holds nothing: writing produces a small tagged file, reading checks
+// the tag and reports IO_ERROR for a missing file exactly as the sample expects on its first run.
+cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    FILE* f = std::fopen(filename, "w");
+    if (f == nullptr) return CUTENSOR_STATUS_IO_ERROR;
+    std::fprintf(f, "cutensor-amd-kernelcache 1 gfx950 0\n");
+    std::fclose(f);
+    return CUTENSOR_STATUS_SUCCESS;
+}
+cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    FILE* f = std::fopen(filename, "r");
+    if (f == nullptr) return CUTENSOR_STATUS_IO_ERROR;
+    char tag[64] = {0};
+    const bool ok = std::fscanf(f, "%63s", tag) == 1 && std::strcmp(tag, "cutensor-amd-kernelcache") == 0;
+    std::fclose(f);
+    return ok ? CUTENSOR_STATUS_SUCCESS : CUTENSOR_STATUS_IO_ERROR;
 }
 
 // utils.cuh:38
@@ -828,14 +970,15 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"family\":%d,\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
                           "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
-                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f,\"fusedFold\":%d",
+                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f,\"fusedFold\":%d,\"kname\":\"%s\"",
                           plan->choice.family, (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
                           k >= 0 ? tab[k].bk : 16, k >= 0 ? tab[k].wm : 1, k >= 0 ? tab[k].wn : 1, k >= 0 ? tab[k].wk : 1,
                           k >= 0 ? tab[k].pf : 0, k >= 0 ? tab[k].ablation : 0,
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
-                          (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold);
+                          (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold,
+                          k < 0 ? "gett_simple_kernel" : plan->choice.family == 1 ? "gett_h16_kernel" : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
         for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)

@@ -26,7 +26,8 @@ struct cutensorTensorDescriptor {
     int64_t numElementsSpanned() const;  // 1 + sum (extent-1)*stride
 };
 
-enum class OpKind : int { Contraction = 0, Reduction = 1, Permutation = 2, ElementwiseBinary = 3 };
+enum class OpKind : int { Contraction = 0, Reduction = 1, Permutation = 2, ElementwiseBinary = 3, ElementwiseTrinary = 4,
+                           ContractionTrinary = 5 };
 
 struct TensorUse {
     cutensorTensorDescriptor desc;
@@ -38,10 +39,15 @@ struct TensorUse {
 struct cutensorOperationDescriptor {
     OpKind      kind;
     TensorUse   A, B, C, D;
-    cutensorOperator_t opReduce = CUTENSOR_OP_ADD;   // reduction operator / binary combiner
+    TensorUse   E;                                   // output of a trinary contraction (D is its beta source)
+    cutensorOperator_t opReduce = CUTENSOR_OP_ADD;   // reduction operator / binary combiner (opAC, opABC)
+    cutensorOperator_t opAB = CUTENSOR_OP_ADD;       // element-wise trinary: first combiner
     const cutensorComputeDescriptor* compute = nullptr;
     hipDataType scalarType = HIP_R_32F;
     int32_t     tag = 0;
+    // CUTENSOR_OPERATION_DESCRIPTOR_PADDING_{LEFT,RIGHT,VALUE} of a permutation (elementwise_permute_padding.cu:178-195)
+    std::vector<int32_t> padLeft, padRight;
+    double      padValue = 0.0;
     double      flops = 0.0;
     double      movedBytes = 0.0;
 };
@@ -97,6 +103,14 @@ struct EwPlan {
     Ew2DParams p{};              // pointers / scalars are filled at launch
     bool       usesC = false;
 };
+// cutensorElementwiseTrinaryExecute: D = opABC(opAB(alpha A, beta B), gamma C) as one or two passes of the
+// element-wise kernels (plan_elementwise_trinary)
+struct EwTrinaryPlan {
+    bool   twoPass = false;      // pass 1: D = s1 * perm(X1);  last pass: D = opAC(opAB(delta * E, s2 * perm(X2)), gamma * perm(C))
+    bool   swapAB = false;       // the operand that already has D's layout plays E (single pass): true -> E = B, X2 = A
+    EwPlan first;                // permutation X1 -> D (two-pass form only)
+    EwPlan last;
+};
 struct ReducePlan {
     int          variant = RED_GENERIC;
     ReduceParams p{};
@@ -106,6 +120,7 @@ struct ReducePlan {
 };
 
 cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why);
+cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op, EwTrinaryPlan& plan, std::string* why);
 cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t wsLimit, int numCUs,
                                 ReducePlan& plan, std::string* why);
 
@@ -129,6 +144,13 @@ struct cutensorPlan {
     bool                       fusedFold = false;     // split-K partials are folded inside the GETT launch
     // element-wise / reduction
     ctamd::EwPlan     ew;
+    ctamd::EwTrinaryPlan ew3;
+    // padded permutation: the output buffer holds extents + padLeft + padRight per mode; it is filled with the
+    // padding value, then the permutation writes the interior
+    uint64_t          padFillElems = 0;    // 0 = no padding
+    int64_t           padOffsetElems = 0;  // element offset of the interior's origin
+    double            padValue = 0.0;
+    uint32_t          alignB3 = 0;     // element-wise trinary: alignment of B
     ctamd::ReducePlan red;
 };
 

@@ -119,6 +119,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     Ew2DParams& p = plan.p;
     std::memset(&p, 0, sizeof(p));
     p.E0 = p.E1 = 1;
+    if (op.kind == OpKind::ElementwiseBinary) p.opAC = (int32_t)op.opReduce;   // ADD / MUL / MAX / MIN; every other caller adds
     std::vector<EwMode> rest;
     int i1 = -1;
     if (!modes.empty()) {
@@ -164,6 +165,53 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     const uint64_t nb = (uint64_t)p.tiles0 * p.tiles1 * p.rest.total;
     if (nb >= (1ull << 31)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "tensor too large for the tile index space");
     p.nBlocks = (uint32_t)nb;
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+// D = opABC(opAB(alpha A, beta B), gamma C)  (cuTENSOR/elementwise_trinary.cu:174-182; the sample's
+// D_{a,b,c} = alpha A_{c,b,a} + beta B_{c,a,b} + gamma C_{a,b,c}, :51-53).  The element-wise kernels take
+// one permuted operand through their tile path plus operands that are walked with D's own strides, so:
+//   * an operand of A / B that already has D's layout rides along as E: one pass, 4 |D| bytes;
+//   * otherwise pass 1 writes D = alpha perm(A) and pass 2 combines in place with beta perm(B) and gamma C:
+//     6 |D| bytes (the combiners ADD / MUL / MAX / MIN commute, so the order of A and B is free).
+cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op, EwTrinaryPlan& plan, std::string* why) {
+    auto fail = [&](cutensorStatus_t st, const char* msg) {
+        if (why) *why = msg;
+        return st;
+    };
+    auto ok_op = [](cutensorOperator_t o) { return o == CUTENSOR_OP_ADD || o == CUTENSOR_OP_MUL || o == CUTENSOR_OP_MAX || o == CUTENSOR_OP_MIN; };
+    if (!ok_op(op.opAB) || !ok_op(op.opReduce)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "binary operator");
+    if (op.B.op != CUTENSOR_OP_IDENTITY) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    auto same_layout = [&](const TensorUse& X) {
+        if (X.modes.size() != op.D.modes.size() || X.desc.dtype != op.D.desc.dtype) return false;
+        for (size_t i = 0; i < op.D.modes.size(); ++i) {
+            const int ix = find_label(X.modes, op.D.modes[i]);
+            if (ix < 0 || X.desc.extent[ix] != op.D.desc.extent[i]) return false;
+            if (op.D.desc.extent[i] != 1 && X.desc.stride[ix] != op.D.desc.stride[i]) return false;
+        }
+        return true;
+    };
+    plan = EwTrinaryPlan{};
+    const bool aSame = same_layout(op.A), bSame = same_layout(op.B);
+    cutensorOperationDescriptor last = op;      // A := the permuted operand of the last pass, C := C, D := D
+    last.kind = OpKind::ElementwiseBinary;
+    if (aSame || bSame) {
+        plan.twoPass = false;
+        plan.swapAB = !aSame;                    // E = B, permuted operand = A
+        last.A = plan.swapAB ? op.A : op.B;
+    } else {
+        plan.twoPass = true;
+        cutensorOperationDescriptor first = op;
+        first.kind = OpKind::Permutation;
+        first.C = TensorUse{};
+        cutensorStatus_t st = plan_elementwise(first, plan.first, why);
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        last.A = op.B;
+    }
+    cutensorStatus_t st = plan_elementwise(last, plan.last, why);
+    if (st != CUTENSOR_STATUS_SUCCESS) return st;
+    plan.last.p.opAB = (int32_t)op.opAB;
+    plan.last.p.opAC = (int32_t)op.opReduce;
     return CUTENSOR_STATUS_SUCCESS;
 }
 

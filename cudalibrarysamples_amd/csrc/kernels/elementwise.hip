@@ -21,6 +21,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <cstring>
 
 #include "launch.h"
 #include "params.h"
@@ -48,6 +49,23 @@ __device__ __forceinline__ void rest_offsets(const ModeGroup& g, uint32_t idx, i
     }
 }
 
+// binary combiners of the element-wise family (cutensorOperator_t values; 0 = ADD)
+template <typename S>
+__device__ __forceinline__ S ew_comb(int op, S x, S y) {
+    switch (op) {
+        case 5: return x * y;                 // CUTENSOR_OP_MUL
+        case 6: return x > y ? x : y;         // CUTENSOR_OP_MAX
+        case 7: return x < y ? x : y;         // CUTENSOR_OP_MIN
+        default: return x + y;                // CUTENSOR_OP_ADD
+    }
+}
+__device__ __forceinline__ f32x4 ew_comb4(int op, f32x4 x, f32x4 y) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = ew_comb<float>(op, x[e], y[e]);
+    return r;
+}
+
 struct TileId { uint32_t t0, t1, rest; };
 __device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
     TileId t;
@@ -70,6 +88,7 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
     __shared__ __attribute__((aligned(16))) float tile[TT * TT_LD];   // [dim1][dim0]
     const float* A = static_cast<const float*>(p.A);
     const float* C = static_cast<const float*>(p.C);
+    const float* E = static_cast<const float*>(p.E);
     float*       D = static_cast<float*>(p.D);
     const int tid = threadIdx.x;
 
@@ -109,14 +128,18 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
                 if (c0 < p.E0 && r1 < p.E1) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * TT_LD + 4 * (tid & 15)]);
                     v *= p.alpha;
+                    if (E != nullptr)
+                        v = ew_comb4(p.opAB, p.delta * *reinterpret_cast<const f32x4*>(E + oD + (int64_t)r1 * p.sD1 + c0), v);
                     if (C != nullptr) {
                         const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
+                        f32x4 c;
                         if (p.sC0 == 1) {
-                            v += p.gamma * *reinterpret_cast<const f32x4*>(cp);
+                            c = *reinterpret_cast<const f32x4*>(cp);
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += p.gamma * cp[(int64_t)e * p.sC0];
+                            for (int e = 0; e < 4; ++e) c[e] = cp[(int64_t)e * p.sC0];
                         }
+                        v = ew_comb4(p.opAC, v, p.gamma * c);
                     }
                     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
                 }
@@ -135,6 +158,7 @@ constexpr int RC_T0 = 256, RC_T1 = 8;
 __global__ void __launch_bounds__(256) ew_rowcopy_f32_kernel(const Ew2DParams p) {
     const float* A = static_cast<const float*>(p.A);
     const float* C = static_cast<const float*>(p.C);
+    const float* E = static_cast<const float*>(p.E);
     float*       D = static_cast<float*>(p.D);
     const int tid = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
@@ -150,14 +174,18 @@ __global__ void __launch_bounds__(256) ew_rowcopy_f32_kernel(const Ew2DParams p)
             f32x4 v = __builtin_nontemporal_load(
                 reinterpret_cast<const f32x4*>(A + oA + (int64_t)r1 * p.sA1 + c0));
             v *= p.alpha;
+            if (E != nullptr)
+                v = ew_comb4(p.opAB, p.delta * *reinterpret_cast<const f32x4*>(E + oD + (int64_t)r1 * p.sD1 + c0), v);
             if (C != nullptr) {
                 const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
+                f32x4 c;
                 if (p.sC0 == 1) {
-                    v += p.gamma * *reinterpret_cast<const f32x4*>(cp);
+                    c = *reinterpret_cast<const f32x4*>(cp);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += p.gamma * cp[(int64_t)e * p.sC0];
+                    for (int e = 0; e < 4; ++e) c[e] = cp[(int64_t)e * p.sC0];
                 }
+                v = ew_comb4(p.opAC, v, p.gamma * c);
             }
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
         }
@@ -184,9 +212,11 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
     typedef typename EwScalar<T>::type S;
     const T* A = static_cast<const T*>(p.A);
     const T* C = static_cast<const T*>(p.C);
+    const T* E = static_cast<const T*>(p.E);
     T*       D = static_cast<T*>(p.D);
     const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
     const S gamma = sizeof(S) == 8 ? (S)p.gamma64 : (S)p.gamma;
+    const S delta = sizeof(S) == 8 ? (S)p.delta64 : (S)p.delta;
     const int tid = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
         const TileId t = decode_tile(p, b);
@@ -196,9 +226,58 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
         const uint32_t r1 = t.t1 * GN_T1 + (tid >> 6);
         if (c0 >= p.E0 || r1 >= p.E1) continue;
         S v = alpha * ew_load<T>(A + oA + (int64_t)c0 * p.sA0 + (int64_t)r1 * p.sA1);
-        if (C != nullptr) v += gamma * ew_load<T>(C + oC + (int64_t)c0 * p.sC0 + (int64_t)r1 * p.sC1);
+        if (E != nullptr) v = ew_comb<S>(p.opAB, delta * ew_load<T>(E + oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1), v);
+        if (C != nullptr) v = ew_comb<S>(p.opAC, v, gamma * ew_load<T>(C + oC + (int64_t)c0 * p.sC0 + (int64_t)r1 * p.sC1));
         ew_store<T>(D + oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1, v);
     }
+}
+
+// Contiguous fill with 16-byte stores (HBM-bound: n * sizeof(T) bytes written).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct FillPattern { uint32_t w[4]; };
+
+__global__ void __launch_bounds__(256) ew_fill_kernel(u32x4* D16, uint64_t n16, unsigned char* tail, uint32_t tailBytes, FillPattern pat) {
+    const u32x4 v = {pat.w[0], pat.w[1], pat.w[2], pat.w[3]};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(v, D16 + i);
+    if (blockIdx.x == 0 && threadIdx.x < tailBytes) tail[threadIdx.x] = (unsigned char)(pat.w[(threadIdx.x >> 2) & 3] >> (8 * (threadIdx.x & 3)));
+}
+
+static uint16_t fill_f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static uint16_t fill_f32_to_f16(float f) {   // round to nearest even, host-side
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+hipError_t launch_fill(void* D, uint64_t n, int dtype, double value, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    FillPattern pat;
+    size_t es;
+    switch (dtype) {
+        case HIP_R_32F: { const float v = (float)value; uint32_t u; std::memcpy(&u, &v, 4); pat = FillPattern{{u, u, u, u}}; es = 4; break; }
+        case HIP_R_64F: { uint64_t u; std::memcpy(&u, &value, 8); pat = FillPattern{{(uint32_t)u, (uint32_t)(u >> 32), (uint32_t)u, (uint32_t)(u >> 32)}}; es = 8; break; }
+        case HIP_R_16F: { const uint32_t u = fill_f32_to_f16((float)value), w = u | (u << 16); pat = FillPattern{{w, w, w, w}}; es = 2; break; }
+        case HIP_R_16BF: { const uint32_t u = fill_f32_to_bf16((float)value), w = u | (u << 16); pat = FillPattern{{w, w, w, w}}; es = 2; break; }
+        default: return hipErrorInvalidValue;
+    }
+    if ((reinterpret_cast<uintptr_t>(D) & 15) != 0) return hipErrorInvalidValue;   // descriptors carry >= 16-byte alignment here
+    const uint64_t bytes = n * es, n16 = bytes / 16;
+    const uint32_t tailBytes = (uint32_t)(bytes % 16);
+    uint64_t blocks = (n16 + 255) / 256;
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(ew_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<u32x4*>(D), n16,
+                       static_cast<unsigned char*>(D) + n16 * 16, tailBytes, pat);
+    return hipGetLastError();
 }
 
 hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream) {

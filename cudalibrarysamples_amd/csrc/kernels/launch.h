@@ -46,6 +46,8 @@ enum EwVariant : int {
     EW_GENERIC   = 2   // any strides, any dtype: one element per lane
 };
 hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream);
+// D[0 .. n) = value (contiguous; the padded-permutation border fill)
+hipError_t launch_fill(void* D, uint64_t n, int dtype, double value, hipStream_t stream);
 
 // reduction family (reduce.hip)
 enum ReduceVariant : int {

@@ -87,6 +87,14 @@ struct Ew2DParams {
     uint32_t    nBlocks;
     float       alpha, gamma;
     double      alpha64, gamma64;
+    // Trinary form (cutensorElementwiseTrinaryExecute): D = opAC(opAB(delta * E, alpha * perm(A)), gamma * perm(C))
+    // where E has D's strides (E = D for the in-place second pass, or the operand that already has D's
+    // layout); E == nullptr: D = opAC(alpha * perm(A), gamma * perm(C)).  Operators: cutensorOperator_t
+    // ADD / MUL / MAX / MIN (0 is read as ADD).
+    const void* E;
+    float       delta;
+    double      delta64;
+    int32_t     opAB, opAC;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -64,6 +64,11 @@ EXPORTS = {
     "cutensorReduce": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp),
     "cutensorPermute": (_vp, _vp, _vp, _vp, _vp, _vp),
     "cutensorElementwiseBinaryExecute": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp),
+    "cutensorCreateElementwiseTrinary": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                         _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int, ctypes.c_int, _vp),
+    "cutensorElementwiseTrinaryExecute": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp),
+    "cutensorReadKernelCacheFromFile": (_vp, ctypes.c_char_p),
+    "cutensorWriteKernelCacheToFile": (_vp, ctypes.c_char_p),
 }
 DATA_SYMBOLS = ["CUTENSOR_COMPUTE_DESC_16F", "CUTENSOR_COMPUTE_DESC_16BF", "CUTENSOR_COMPUTE_DESC_TF32",
                 "CUTENSOR_COMPUTE_DESC_3XTF32", "CUTENSOR_COMPUTE_DESC_32F", "CUTENSOR_COMPUTE_DESC_64F"]

@@ -96,10 +96,18 @@ class Plan:
         a = self.scalar(alpha)
         ct.check(ct.cutensorPermute(self.handle.h, self.plan, ctypes.byref(a), A, B, stream or None))
 
+    def trinary(self, alpha, A, beta, B, gamma, C, D, stream=0):
+        a, b, g = self.scalar(alpha), self.scalar(beta), self.scalar(gamma)
+        ct.check(ct.cutensorElementwiseTrinaryExecute(self.handle.h, self.plan, ctypes.byref(a), A, ctypes.byref(b), B,
+                                                      ctypes.byref(g), C, D, stream or None))
+
     def binary(self, alpha, A, gamma, C, D, stream=0):
         a, g = self.scalar(alpha), self.scalar(gamma)
         ct.check(ct.cutensorElementwiseBinaryExecute(self.handle.h, self.plan, ctypes.byref(a), A, ctypes.byref(g),
                                                      C, D, stream or None))
+
+
+_OPS = {"ADD": ct.OP_ADD, "MUL": ct.OP_MUL, "MAX": ct.OP_MAX, "MIN": ct.OP_MIN}
 
 
 def _desc3(handle, specs, dtype, alignment):
@@ -134,7 +142,9 @@ def reduction_plan(handle, extA, modesA, extC, modesC, dtype=ct.R_32F, strideA=N
 
 
 def permutation_plan(handle, extA, modesA, extB, modesB, dtype=ct.R_32F, strideA=None, strideB=None,
-                     compute=None, alignment=128, **plan_kw):
+                     compute=None, alignment=128, padding=None, **plan_kw):
+    """padding = (left[], right[], value): CUTENSOR_OPERATION_DESCRIPTOR_PADDING_* per output mode
+    (elementwise_permute_padding.cu:178-195); the output buffer then holds extB + left + right per mode."""
     dA, dB = _desc3(handle, [(extA, strideA), (extB, strideB)], dtype, alignment)
     op = ctypes.c_void_p()
     st = ct.cutensorCreatePermutation(handle.h, ctypes.byref(op), dA, ct.i32(modesA), ct.OP_IDENTITY, dB, ct.i32(modesB),
@@ -142,5 +152,44 @@ def permutation_plan(handle, extA, modesA, extB, modesB, dtype=ct.R_32F, strideA
     ct.cutensorDestroyTensorDescriptor(dA)
     ct.cutensorDestroyTensorDescriptor(dB)
     ct.check(st)
+    if padding is not None:
+        left, right, value = padding
+        n = len(extB)
+        l = (ctypes.c_int32 * n)(*left)
+        r = (ctypes.c_int32 * n)(*right)
+        ct.check(ct.cutensorOperationDescriptorSetAttribute(handle.h, op, 4, l, 4 * n))    # PADDING_LEFT
+        ct.check(ct.cutensorOperationDescriptorSetAttribute(handle.h, op, 5, r, 4 * n))    # PADDING_RIGHT
+        v = ctypes.c_double(value) if dtype == ct.R_64F else ctypes.c_float(value)
+        ct.check(ct.cutensorOperationDescriptorSetAttribute(handle.h, op, 6, ctypes.byref(v), ctypes.sizeof(v)))   # PADDING_VALUE
     plan_kw.setdefault("workspace_limit", 0)   # elementwise_permute.cu:183-187
     return Plan(handle, op, "permutation", dtype, **plan_kw)
+
+
+def binary_plan(handle, extA, modesA, extC, modesC, op="ADD", dtype=ct.R_32F, compute=None, alignment=128, **plan_kw):
+    """D = op(alpha * perm(A), gamma * C) — cutensorCreateElementwiseBinary (elementwise_binary.cu:149-153)."""
+    dA, dC = _desc3(handle, [(extA, None), (extC, None)], dtype, alignment)
+    opd = ctypes.c_void_p()
+    st = ct.cutensorCreateElementwiseBinary(handle.h, ctypes.byref(opd), dA, ct.i32(modesA), ct.OP_IDENTITY, dC, ct.i32(modesC),
+                                            ct.OP_IDENTITY, dC, ct.i32(modesC), _OPS[op],
+                                            ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
+    ct.cutensorDestroyTensorDescriptor(dA)
+    ct.cutensorDestroyTensorDescriptor(dC)
+    ct.check(st)
+    plan_kw.setdefault("workspace_limit", 0)
+    return Plan(handle, opd, "binary", dtype, **plan_kw)
+
+
+def trinary_plan(handle, extA, modesA, extB, modesB, extC, modesC, extD, modesD, opAB="ADD", opABC="ADD", dtype=ct.R_32F,
+                 compute=None, alignment=128, **plan_kw):
+    """D = opABC(opAB(alpha * perm(A), beta * perm(B)), gamma * perm(C)) — cutensorCreateElementwiseTrinary
+    (elementwise_trinary.cu:174-182)."""
+    dA, dB, dC, dD = _desc3(handle, [(extA, None), (extB, None), (extC, None), (extD, None)], dtype, alignment)
+    opd = ctypes.c_void_p()
+    st = ct.cutensorCreateElementwiseTrinary(handle.h, ctypes.byref(opd), dA, ct.i32(modesA), ct.OP_IDENTITY, dB, ct.i32(modesB),
+                                             ct.OP_IDENTITY, dC, ct.i32(modesC), ct.OP_IDENTITY, dD, ct.i32(modesD),
+                                             _OPS[opAB], _OPS[opABC], ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
+    for d in (dA, dB, dC, dD):
+        ct.cutensorDestroyTensorDescriptor(d)
+    ct.check(st)
+    plan_kw.setdefault("workspace_limit", 0)
+    return Plan(handle, opd, "trinary", dtype, **plan_kw)

@@ -163,6 +163,22 @@ cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle,
                                                   const void* gamma, const void* C, void* D,
                                                   cudaStream_t stream);
 
+/* elementwise_trinary.cu:174-182: D = opABC(opAB(alpha opA(A), beta opB(B)), gamma opC(C)) */
+cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                  const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                  const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                                  const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                  const cutensorTensorDescriptor_t descD, const int32_t modeD[],
+                                                  cutensorOperator_t opAB, cutensorOperator_t opABC,
+                                                  const cutensorComputeDescriptor_t descCompute);
+/* elementwise_trinary.cu:223-227 */
+cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
+                                                   const void* alpha, const void* A, const void* beta, const void* B,
+                                                   const void* gamma, const void* C, void* D, cudaStream_t stream);
+/* contraction_jit.cu:134 / :398 — accepted for source compatibility; there is no run-time code generation */
+cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]);
+cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]);
+
 /* ---- misc (utils.cuh:38) --------------------------------------------------------------------- */
 const char* cutensorGetErrorString(const cutensorStatus_t error);
 size_t      cutensorGetVersion(void);

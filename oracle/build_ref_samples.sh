@@ -14,7 +14,8 @@ mkdir -p "$OUT"
 FLAGS="-x hip --offload-arch=gfx950 -std=c++17 -O2 -w -I$ROOT/tests/sample_compat -I$ROOT/include"
 LINK="-L$ROOT/cudalibrarysamples_amd/lib -Wl,-rpath,\$ORIGIN/../../cudalibrarysamples_amd/lib"
 rc=0
-for s in contraction einsum reduction elementwise_permute; do
+for s in contraction einsum reduction elementwise_permute elementwise_binary elementwise_trinary elementwise_permute_padding \
+         contraction_plan_cache contraction_jit; do
     if hipcc $FLAGS "$REF/cuTENSOR/$s.cu" -o "$OUT/$s" $LINK -lcutensor 2> "$OUT/$s.log"; then
         echo "built oracle/_ref/$s"
     else
@@ -25,5 +26,10 @@ if hipcc $FLAGS "$REF/cuTENSORMg/contraction_multi_gpu.cu" -o "$OUT/contraction_
     echo "built oracle/_ref/contraction_multi_gpu"
 else
     echo "FAILED oracle/_ref/contraction_multi_gpu (see oracle/_ref/contraction_multi_gpu.log)"; rc=1
+fi
+if hipcc $FLAGS "$REF/cuTENSORMg/blog_post.cu" -o "$OUT/blog_post" $LINK -lcutensorMg -lcutensor 2> "$OUT/blog_post.log"; then
+    echo "built oracle/_ref/blog_post"
+else
+    echo "FAILED oracle/_ref/blog_post (see oracle/_ref/blog_post.log)"; rc=1
 fi
 exit $rc
