@@ -267,6 +267,94 @@ cutensorStatus_t cutensorCreateContraction(const cutensorHandle_t handle, cutens
     return new_op(desc, op);
 }
 
+// contraction_trinary.cu:191-198: E = alpha * A * B * C + beta * D, executed as two pairwise contractions through a
+// packed intermediate T.  The pair contracted first is the one that minimises flops(first) + flops(second)
+// (the sample itself states its flop count as that sum, :65-67); T keeps every mode of the pair that the third
+// operand or the output still needs, in the order they appear in X then Y.
+cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                  const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                  const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                                  const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                  const cutensorTensorDescriptor_t descD, const int32_t modeD[], cutensorOperator_t opD,
+                                                  const cutensorTensorDescriptor_t descE, const int32_t modeE[],
+                                                  const cutensorComputeDescriptor_t descCompute) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
+    cutensorOperationDescriptor op{};
+    op.kind = OpKind::ContractionTrinary;
+    cutensorStatus_t st;
+    if ((st = fill_use(op.A, descA, modeA, opA)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.B, descB, modeB, opB)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.C, descC, modeC, opC)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.D, descD, modeD, opD)) != CUTENSOR_STATUS_SUCCESS) return st;
+    if ((st = fill_use(op.E, descE, modeE, CUTENSOR_OP_IDENTITY)) != CUTENSOR_STATUS_SUCCESS) return st;
+    op.compute = descCompute;
+    op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
+    const TensorUse* in[3] = {&op.A, &op.B, &op.C};
+    auto has = [](const std::vector<int32_t>& v, int32_t l) { return std::find(v.begin(), v.end(), l) != v.end(); };
+    double bestCost = 0.0;
+    bool found = false;
+    static const int pairs[3][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}};
+    for (const auto& pr : pairs) {
+        const TensorUse &X = *in[pr[0]], &Y = *in[pr[1]], &Z = *in[pr[2]];
+        // T: modes of X and Y still needed by Z or E
+        TensorUse T;
+        T.present = true;
+        T.desc.dtype = X.desc.dtype;
+        T.desc.alignment = 256;
+        double flops1 = 2.0, tElems = 1.0;
+        std::vector<int32_t> seen;
+        auto visit = [&](const TensorUse& U) {
+            for (size_t i = 0; i < U.modes.size(); ++i) {
+                const int32_t l = U.modes[i];
+                if (has(seen, l)) continue;
+                seen.push_back(l);
+                flops1 *= (double)U.desc.extent[i];
+                if (has(Z.modes, l) || has(op.E.modes, l)) {
+                    T.modes.push_back(l);
+                    T.desc.extent.push_back(U.desc.extent[i]);
+                    tElems *= (double)U.desc.extent[i];
+                }
+            }
+        };
+        visit(X); visit(Y);
+        T.desc.numModes = (uint32_t)T.modes.size();
+        T.desc.stride.resize(T.modes.size());
+        int64_t run = 1;
+        for (size_t i = 0; i < T.modes.size(); ++i) { T.desc.stride[i] = run; run *= T.desc.extent[i]; }
+        double flops2 = 2.0;
+        std::vector<int32_t> seen2;
+        for (const TensorUse* U : {const_cast<const TensorUse*>(&T), &Z})
+            for (size_t i = 0; i < U->modes.size(); ++i)
+                if (!has(seen2, U->modes[i])) { seen2.push_back(U->modes[i]); flops2 *= (double)U->desc.extent[i]; }
+        cutensorOperationDescriptor s1{}, s2{};
+        s1.kind = s2.kind = OpKind::Contraction;
+        s1.compute = s2.compute = descCompute;
+        s1.scalarType = s2.scalarType = op.scalarType;
+        s1.A = X; s1.B = Y; s1.C = T; s1.D = T;
+        s2.A = T; s2.B = Z; s2.C = op.D; s2.D = op.E;
+        ContractionView v1, v2;
+        std::string why;
+        if (build_contraction_view(s1, v1, &why) != CUTENSOR_STATUS_SUCCESS || build_contraction_view(s2, v2, &why) != CUTENSOR_STATUS_SUCCESS) continue;
+        s1.flops = flops1; s2.flops = flops2;
+        const double cost = flops1 + flops2 + 8.0 * tElems;   // the intermediate is written and read once
+        if (!found || cost < bestCost) {
+            found = true;
+            bestCost = cost;
+            op.sub.clear();
+            op.sub.push_back(s1);
+            op.sub.push_back(s2);
+            op.triOrder[0] = pr[0]; op.triOrder[1] = pr[1]; op.triOrder[2] = pr[2];
+            op.tBytes = (uint64_t)tElems * dtype_size(T.desc.dtype);
+            op.flops = flops1 + flops2;
+        }
+    }
+    if (!found) { CT_LOG("cutensorCreateContractionTrinary: no pairwise order is supported"); return CUTENSOR_STATUS_NOT_SUPPORTED; }
+    const double es = (double)dtype_size(op.A.desc.dtype);
+    op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.B.desc) + num_elements(op.C.desc) + num_elements(op.E.desc));
+    return new_op(desc, op);
+}
+
 // reduction.cu:141-146
 cutensorStatus_t cutensorCreateReduction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
                                          const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
@@ -486,6 +574,15 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || workspaceSizeEstimate == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     *workspaceSizeEstimate = 0;
+    if (desc->kind == OpKind::ContractionTrinary) {   // intermediate + the larger of the two pairwise needs
+        uint64_t w1 = 0, w2 = 0;
+        cutensorOperationDescriptor s1 = desc->sub[0], s2 = desc->sub[1];
+        cutensorStatus_t st = cutensorEstimateWorkspaceSize(handle, &s1, planPref, workspacePref, &w1);
+        if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorEstimateWorkspaceSize(handle, &s2, planPref, workspacePref, &w2);
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        *workspaceSizeEstimate = ((desc->tBytes + 255) & ~255ull) + std::max(w1, w2);
+        return CUTENSOR_STATUS_SUCCESS;
+    }
     if (workspacePref == CUTENSOR_WORKSPACE_MIN) return CUTENSOR_STATUS_SUCCESS;
     const uint64_t cap = (workspacePref == CUTENSOR_WORKSPACE_MAX) ? (4ull << 30) : (1ull << 30);
     if (desc->kind == OpKind::Contraction) {
@@ -592,6 +689,25 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     pl->accumulate64 = desc->compute && desc->compute->id == 5;
     std::string why;
     cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+
+    if (desc->kind == OpKind::ContractionTrinary) {
+        const uint64_t tOff = (desc->tBytes + 255) & ~255ull;
+        if (workspaceSizeLimit < tOff) { delete pl; CT_LOG("cutensorCreatePlan: trinary contraction needs %llu bytes for its intermediate", (unsigned long long)tOff); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
+        cutensorOperationDescriptor s1 = desc->sub[0], s2 = desc->sub[1];
+        cutensorPlan_t p1 = nullptr, p2 = nullptr;
+        st = cutensorCreatePlan(handle, &p1, &s1, pref, workspaceSizeLimit - tOff);
+        if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(handle, &p2, &s2, pref, workspaceSizeLimit - tOff);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete p1; delete p2; delete pl; return st; }
+        pl->sub1 = p1; pl->sub2 = p2;
+        pl->tBytes = desc->tBytes;
+        for (int i = 0; i < 3; ++i) pl->triOrder[i] = desc->triOrder[i];
+        pl->alignB3 = desc->B.desc.alignment;            // B
+        pl->alignC = desc->C.desc.alignment;             // C (third input)
+        pl->alignD = desc->E.desc.alignment;             // output E (and its beta source D)
+        pl->requiredWorkspace = tOff + std::max(p1->requiredWorkspace, p2->requiredWorkspace);
+        *plan = pl;
+        return CUTENSOR_STATUS_SUCCESS;
+    }
 
     if (desc->kind == OpKind::Contraction) {
         st = build_contraction_view(*desc, pl->view, &why);
@@ -909,6 +1025,30 @@ cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle
     }
     if (err != hipSuccess) { CT_LOG("cutensorElementwiseTrinaryExecute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
+}
+
+// contraction_trinary.cu:290-294
+cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                         const void* A, const void* B, const void* C, const void* beta, const void* D, void* E,
+                                         void* workspace, uint64_t workspaceSize, cudaStream_t stream) {
+    if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
+    if (plan == nullptr || plan->kind != OpKind::ContractionTrinary || plan->sub1 == nullptr || plan->sub2 == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || C == nullptr || E == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (workspace == nullptr || workspaceSize < plan->requiredWorkspace) return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+    if (misaligned(workspace, 256)) return CUTENSOR_STATUS_INVALID_VALUE;
+    const void* in[3] = {A, B, C};
+    const void *X = in[plan->triOrder[0]], *Y = in[plan->triOrder[1]], *Z = in[plan->triOrder[2]];
+    const uint64_t tOff = (plan->tBytes + 255) & ~255ull;
+    void* T = workspace;
+    void* ws = static_cast<char*>(workspace) + tOff;
+    const double one64 = 1.0, zero64 = 0.0;
+    const float one32 = 1.f, zero32 = 0.f;
+    const bool f64 = plan->scalarType == HIP_R_64F;
+    const void* one = f64 ? static_cast<const void*>(&one64) : static_cast<const void*>(&one32);
+    const void* zero = f64 ? static_cast<const void*>(&zero64) : static_cast<const void*>(&zero32);
+    cutensorStatus_t st = cutensorContract(handle, plan->sub1, one, X, Y, zero, T, T, ws, workspaceSize - tOff, stream);
+    if (st != CUTENSOR_STATUS_SUCCESS) return st;
+    return cutensorContract(handle, plan->sub2, alpha, T, Z, beta, D, E, ws, workspaceSize - tOff, stream);
 }
 
 // contraction_jit.cu:134,398 — the engine has no run-time code generation (every kernel is compiled ahead of

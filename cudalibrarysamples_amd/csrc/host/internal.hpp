@@ -45,6 +45,11 @@ struct cutensorOperationDescriptor {
     const cutensorComputeDescriptor* compute = nullptr;
     hipDataType scalarType = HIP_R_32F;
     int32_t     tag = 0;
+    // trinary contraction E = alpha A B C + beta D (contraction_trinary.cu:191-198) as two pairwise contractions:
+    // sub[0]: T = X * Y (packed intermediate in the workspace), sub[1]: E = alpha T * Z + beta D
+    std::vector<cutensorOperationDescriptor> sub;
+    int         triOrder[3] = {0, 1, 2};   // operand indices (0 = A, 1 = B, 2 = C) playing X, Y, Z
+    uint64_t    tBytes = 0;
     // CUTENSOR_OPERATION_DESCRIPTOR_PADDING_{LEFT,RIGHT,VALUE} of a permutation (elementwise_permute_padding.cu:178-195)
     std::vector<int32_t> padLeft, padRight;
     double      padValue = 0.0;
@@ -130,6 +135,12 @@ size_t  dtype_size(hipDataType t);
 }  // namespace ctamd
 
 struct cutensorPlan {
+    ~cutensorPlan() { delete sub1; delete sub2; }
+    // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
+    cutensorPlan* sub1 = nullptr;
+    cutensorPlan* sub2 = nullptr;
+    uint64_t    tBytes = 0;
+    int         triOrder[3] = {0, 1, 2};
     OpKind      kind;
     hipDataType dtype = HIP_R_32F;
     hipDataType scalarType = HIP_R_32F;

@@ -67,6 +67,9 @@ EXPORTS = {
     "cutensorCreateElementwiseTrinary": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
                                          _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int, ctypes.c_int, _vp),
     "cutensorElementwiseTrinaryExecute": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp),
+    "cutensorCreateContractionTrinary": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                         _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int, _vp, _i32p, _vp),
+    "cutensorContractTrinary": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp),
     "cutensorReadKernelCacheFromFile": (_vp, ctypes.c_char_p),
     "cutensorWriteKernelCacheToFile": (_vp, ctypes.c_char_p),
 }

@@ -96,6 +96,11 @@ class Plan:
         a = self.scalar(alpha)
         ct.check(ct.cutensorPermute(self.handle.h, self.plan, ctypes.byref(a), A, B, stream or None))
 
+    def contract_trinary(self, alpha, A, B, C, beta, D, E, workspace=0, workspace_size=0, stream=0):
+        a, b = self.scalar(alpha), self.scalar(beta)
+        ct.check(ct.cutensorContractTrinary(self.handle.h, self.plan, ctypes.byref(a), A, B, C, ctypes.byref(b), D, E,
+                                            workspace or None, workspace_size, stream or None))
+
     def trinary(self, alpha, A, beta, B, gamma, C, D, stream=0):
         a, b, g = self.scalar(alpha), self.scalar(beta), self.scalar(gamma)
         ct.check(ct.cutensorElementwiseTrinaryExecute(self.handle.h, self.plan, ctypes.byref(a), A, ctypes.byref(b), B,
@@ -193,3 +198,18 @@ def trinary_plan(handle, extA, modesA, extB, modesB, extC, modesC, extD, modesD,
     ct.check(st)
     plan_kw.setdefault("workspace_limit", 0)
     return Plan(handle, opd, "trinary", dtype, **plan_kw)
+
+
+def contraction_trinary_plan(handle, extA, modesA, extB, modesB, extC, modesC, extD, modesD, dtype=ct.R_32F, compute=None,
+                             alignment=128, **plan_kw):
+    """E = alpha * A * B * C + beta * D — cutensorCreateContractionTrinary (contraction_trinary.cu:191-198); E shares
+    D's descriptor as in the sample."""
+    dA, dB, dC, dD = _desc3(handle, [(extA, None), (extB, None), (extC, None), (extD, None)], dtype, alignment)
+    opd = ctypes.c_void_p()
+    st = ct.cutensorCreateContractionTrinary(handle.h, ctypes.byref(opd), dA, ct.i32(modesA), ct.OP_IDENTITY, dB, ct.i32(modesB),
+                                             ct.OP_IDENTITY, dC, ct.i32(modesC), ct.OP_IDENTITY, dD, ct.i32(modesD), ct.OP_IDENTITY,
+                                             dD, ct.i32(modesD), ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
+    for d in (dA, dB, dC, dD):
+        ct.cutensorDestroyTensorDescriptor(d)
+    ct.check(st)
+    return Plan(handle, opd, "contraction_trinary", dtype, **plan_kw)

@@ -175,6 +175,18 @@ cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle,
 cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
                                                    const void* alpha, const void* A, const void* beta, const void* B,
                                                    const void* gamma, const void* C, void* D, cudaStream_t stream);
+/* contraction_trinary.cu:191-198: E = alpha * opA(A) * opB(B) * opC(C) + beta * opD(D) */
+cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                  const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                  const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                                  const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                  const cutensorTensorDescriptor_t descD, const int32_t modeD[], cutensorOperator_t opD,
+                                                  const cutensorTensorDescriptor_t descE, const int32_t modeE[],
+                                                  const cutensorComputeDescriptor_t descCompute);
+/* contraction_trinary.cu:290-294 */
+cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                         const void* A, const void* B, const void* C, const void* beta, const void* D, void* E,
+                                         void* workspace, uint64_t workspaceSize, cudaStream_t stream);
 /* contraction_jit.cu:134 / :398 — accepted for source compatibility; there is no run-time code generation */
 cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]);
 cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]);

@@ -103,3 +103,27 @@ def test_padded_permutation(env):
     got = from_device(dD, out)
     ref = np.pad(np.einsum("whcn->cwhn", A), list(zip(left, right)), constant_values=np.float32(7.5))
     np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.75])
+def test_contraction_trinary(env, beta):
+    """D_{m,n,b,r,a} = alpha A_{m,k,a,j,b,i} B_{k,n,i} C_{r,j} + beta D (contraction_trinary.cu:44-48) at shrunk
+    extents, against numpy.einsum in fp64; fp32 tolerance as for the binary contraction (rtol 1e-4)."""
+    torch, ct, ops, h = env
+    ext = dict(m=24, a=4, b=6, n=8, r=12, k=8, i=4, j=16)
+    mA, mB, mC, mD = "mkajbi", "kni", "rj", "mnbra"
+    A = make_tensor([ext[c] for c in mA], 21, np.float32)
+    B = make_tensor([ext[c] for c in mB], 22, np.float32)
+    C = make_tensor([ext[c] for c in mC], 23, np.float32)
+    D = make_tensor([ext[c] for c in mD], 24, np.float32)
+    dA, dB, dC, dD = to_device(A), to_device(B), to_device(C), to_device(D)
+    plan = ops.contraction_trinary_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
+                                        [ext[c] for c in mD], mD)
+    assert plan.required_workspace > 0 and plan.required_workspace <= plan.workspace_estimate
+    ws = torch.empty(plan.required_workspace, dtype=torch.uint8, device="cuda")
+    plan.contract_trinary(1.1, dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), beta, dD.data_ptr(), dD.data_ptr(),
+                          ws.data_ptr(), plan.required_workspace)
+    torch.cuda.synchronize()
+    got = from_device(dD, D)
+    ref = 1.1 * np.einsum("mkajbi,kni,rj->mnbra", A.astype(np.float64), B.astype(np.float64), C.astype(np.float64)) + beta * D
+    np.testing.assert_allclose(got, ref, rtol=1e-4)
