@@ -171,3 +171,64 @@ def test_contraction_sample_full_size_sampled(env):
         m, u, n, v = (int(rng.integers(0, ext[c])) for c in "munv")
         ref = 1.1 * np.einsum("hk,kh->", A64[m, :, :, n], B64[u, :, v, :])
         assert abs(got[m, u, n, v] - ref) <= 1e-4 * abs(ref), (m, u, n, v, got[m, u, n, v], ref)
+
+
+def test_headline_in_launch_fold_matches_two_kernel_fold(built):
+    """The opt-in in-launch split-K fold (CUTENSOR_AMD_FUSED_FOLD=1) must give the same numbers as
+    the default two-kernel fold up to fp32 re-association (both sum the same 256 partials in a fixed order)."""
+    import os
+    import torch
+    from cudalibrarysamples_amd import ops
+    ext = dict(a=96, b=64, c=64, d=64, e=96)
+    h = ops.Handle()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    A = torch.rand(96 * 64 * 64 * 64, generator=g, device="cuda")
+    B = torch.rand(96 * 64 * 64 * 64, generator=g, device="cuda")
+    outs = []
+    for fused in ("0", "1"):
+        os.environ["CUTENSOR_AMD_FUSED_FOLD"] = fused
+        try:
+            plan = ops.contraction_plan(h, [ext[c] for c in "dcba"], "dcba", [ext[c] for c in "ebcd"], "ebcd",
+                                        [ext[c] for c in "ea"], "ea", workspace_limit=1 << 30)
+        finally:
+            os.environ.pop("CUTENSOR_AMD_FUSED_FOLD", None)
+        d = plan.describe()
+        assert d["fusedFold"] == int(fused), d
+        ws = torch.empty(max(plan.required_workspace, 256), dtype=torch.uint8, device="cuda")
+        C = torch.full((96 * 96,), 3.0, device="cuda")
+        for _ in range(3):   # repeated launches re-arm the counters
+            plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), plan.required_workspace)
+        torch.cuda.synchronize()
+        outs.append(C.cpu().numpy())
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-6)
+
+
+def test_contract_inside_a_captured_graph(built):
+    """cutensorContract is capture-safe (no allocation, no synchronisation): GETT + fold captured in a HIP graph
+    and replayed give the eager result bit for bit."""
+    import torch
+    from cudalibrarysamples_amd import ops
+    ext = dict(a=96, b=16, c=16, d=64, e=96)
+    h = ops.Handle()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    A = torch.rand(96 * 16 * 16 * 64, generator=g, device="cuda")
+    B = torch.rand(96 * 16 * 16 * 64, generator=g, device="cuda")
+    plan = ops.contraction_plan(h, [ext[c] for c in "dcba"], "dcba", [ext[c] for c in "ebcd"], "ebcd",
+                                [ext[c] for c in "ea"], "ea", workspace_limit=1 << 30)
+    ws = torch.empty(max(plan.required_workspace, 256), dtype=torch.uint8, device="cuda")
+    eager = torch.zeros(96 * 96, device="cuda")
+    plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, eager.data_ptr(), eager.data_ptr(), ws.data_ptr(), plan.required_workspace,
+                  torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = torch.zeros(96 * 96, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, out.data_ptr(), out.data_ptr(), ws.data_ptr(), plan.required_workspace,
+                      torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
