@@ -669,6 +669,110 @@ done:
     return best;
 }
 
+// ---- per-XCD K split for one-tile split-K plans ---------------------------------------------------------------
+// The eight XCDs of an MI355X sustain slightly different shader clocks under the fp32-MFMA streaming kernel
+// (2.00-2.07 GHz on the parts measured, stable per part, `profiles/r01b_phase_timing_einsum.json`), and with an
+// even K split the slower dies finish 1-1.5 us after the faster ones.  Once per handle the plan's own kernel is
+// run on scratch tensors with its in-kernel timestamps on; the per-XCD clock (shader cycles / wall time) becomes
+// the weight of that XCD's share of K.  Returns the packed tiles-per-slice bytes, 0 = keep the uniform split.
+static unsigned long long calibrate_xcd_split(cutensorHandle_t handle, const cutensorOperationDescriptor& op, const cutensorPlan& pl) {
+    const uint32_t splitK = pl.gett.splitK;
+    if (pl.gett.nBlocks != splitK || splitK % 8 != 0 || splitK > (uint32_t)handle->numCUs) return 0;
+    int count = 0;
+    const GettKernelInfo* tab = gett_f32_kernels(&count);
+    const GettKernelInfo& k = tab[pl.choice.kernel];
+    const uint64_t kTiles = pl.view.totK / k.bk;
+    const uint64_t perXcdSum = kTiles / (splitK / 8);            // sum over x of tiles-per-slice(x)
+    if (kTiles % (splitK / 8) != 0 || perXcdSum / 8 < 8 || perXcdSum / 8 > 200) return 0;
+    {
+        std::lock_guard<std::mutex> g(handle->mtx);
+        if (handle->xcdSpeed.empty()) {
+            handle->xcdSpeed.assign(8, 1.0);
+            const size_t es = 4;
+            auto span = [&](const cutensorTensorDescriptor& d) {
+                int64_t n = 1;
+                for (uint32_t i = 0; i < d.numModes; ++i) n += (d.extent[i] - 1) * d.stride[i];
+                return (size_t)n * es;
+            };
+            void *A = nullptr, *B = nullptr, *D = nullptr, *W = nullptr;
+            unsigned long long* T = nullptr;
+            const size_t tBytes = (size_t)splitK * 16 * sizeof(unsigned long long);
+            std::vector<unsigned long long> host((size_t)splitK * 16);
+            bool ok = hipMalloc(&A, span(op.A.desc)) == hipSuccess && hipMalloc(&B, span(op.B.desc)) == hipSuccess &&
+                      hipMalloc(&D, span(op.D.desc)) == hipSuccess && hipMalloc(&W, pl.requiredWorkspace) == hipSuccess &&
+                      hipMalloc((void**)&T, tBytes) == hipSuccess;
+            if (ok) {
+                (void)hipMemset(A, 0x3c, span(op.A.desc));
+                (void)hipMemset(B, 0x3c, span(op.B.desc));
+                (void)hipMemset(T, 0, tBytes);
+                GettParams gp = pl.gett;
+                gp.A = pl.view.swapped ? B : A;
+                gp.B = pl.view.swapped ? A : B;
+                gp.C = D; gp.D = D; gp.alpha = 1.f; gp.beta = 0.f;
+                gp.partial = static_cast<float*>(W);
+                gp.sync = nullptr;
+                gp.xcdTiles = 0;
+                for (int rep = 0; rep < 4 && ok; ++rep) {
+                    gp.timing = (rep == 3) ? T : nullptr;
+                    ok = k.launch(gp, nullptr) == hipSuccess;
+                }
+                ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(host.data(), T, tBytes, hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            if (ok) {
+                // workgroup b runs on XCD b % 8 (observed placement; only the weights depend on it)
+                double clk[8] = {0}, n[8] = {0};
+                for (uint32_t b = 0; b < splitK; ++b) {
+                    const unsigned long long* t = &host[(size_t)b * 16];
+                    const double cyc = (double)(t[4] - t[0]), wall = (double)(t[6] - t[5]);
+                    if (t[4] > t[0] && t[6] > t[5]) { clk[b & 7] += cyc / wall; n[b & 7] += 1.0; }
+                }
+                double mean = 0.0;
+                bool all = true;
+                for (int x = 0; x < 8; ++x) { all = all && n[x] > 0; if (n[x] > 0) clk[x] /= n[x]; mean += clk[x] / 8.0; }
+                if (all && mean > 0)
+                    for (int x = 0; x < 8; ++x) {
+                        const double w = clk[x] / mean;
+                        handle->xcdSpeed[x] = (w > 0.9 && w < 1.1) ? w : 1.0;   // a die 10 % off is a measurement artefact
+                    }
+                CT_LOG("xcd calibration: relative clocks %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f", handle->xcdSpeed[0], handle->xcdSpeed[1],
+                       handle->xcdSpeed[2], handle->xcdSpeed[3], handle->xcdSpeed[4], handle->xcdSpeed[5], handle->xcdSpeed[6], handle->xcdSpeed[7]);
+            } else {
+                (void)hipGetLastError();
+            }
+            if (A) (void)hipFree(A);
+            if (B) (void)hipFree(B);
+            if (D) (void)hipFree(D);
+            if (W) (void)hipFree(W);
+            if (T) (void)hipFree(T);
+        }
+    }
+    // largest-remainder apportionment of perXcdSum tiles
+    double sum = 0.0;
+    for (double w : handle->xcdSpeed) sum += w;
+    uint32_t n[8];
+    double frac[8];
+    uint64_t assigned = 0;
+    for (int x = 0; x < 8; ++x) {
+        const double ideal = (double)perXcdSum * handle->xcdSpeed[x] / sum;
+        n[x] = (uint32_t)ideal;
+        frac[x] = ideal - n[x];
+        assigned += n[x];
+    }
+    while (assigned < perXcdSum) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x) if (frac[x] > frac[best]) best = x;
+        n[best] += 1; frac[best] = -1.0; assigned += 1;
+    }
+    unsigned long long packed = 0;
+    bool uniform = true;
+    for (int x = 0; x < 8; ++x) {
+        if (n[x] == 0 || n[x] > 255) return 0;
+        uniform = uniform && n[x] == n[0];
+        packed |= (unsigned long long)n[x] << (8 * x);
+    }
+    return uniform ? 0 : packed;
+}
+
 // contraction.cu:218-222, elementwise_permute.cu:183-187 (limit 0), einsum.cu:324-329 (limit 1 GiB)
 cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_t* plan,
                                     const cutensorOperationDescriptor_t desc, const cutensorPlanPreference_t pref,
@@ -750,6 +854,17 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, pick);
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
+        pl->requiredWorkspace = pick.workspace;
+        // Per-XCD K split (one output tile, split-K over whole XCD rows): see calibrate_xcd_split
+        if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK >= 64 && pl->view.totL == 1 && pl->gett.tilesM * pl->gett.tilesN == 1) {
+            int cnt = 0;
+            const GettKernelInfo* tabf = gett_f32_kernels(&cnt);
+            const char* env = std::getenv("CUTENSOR_AMD_XCD_BALANCE");
+            // opt-in: on the parts measured the clocks differ by +-1.5 %, below the 1-tile-in-32 (3 %) granularity
+            // of the headline split, so the apportionment comes out uniform
+            if (env && env[0] == '1' && tabf[pick.kernel].fragPartials && !tabf[pick.kernel].ablation)
+                pl->gett.xcdTiles = calibrate_xcd_split(handle, *desc, *pl);
+        }
         // In-launch fold of the split-K partials: only when every workgroup of the launch owns a CU of its own
         // (they wait for each other) and the output is a plain matrix; otherwise the fold is a second kernel.
         if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK > 1) {
@@ -1110,7 +1225,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"family\":%d,\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
                           "\"kernel\":%d,\"bm\":%d,\"bn\":%d,\"bk\":%d,\"wm\":%d,\"wn\":%d,\"wk\":%d,\"pf\":%d,\"abl\":%d,\"splitK\":%u,\"kPerSlice\":%u,"
-                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f,\"fusedFold\":%d,\"kname\":\"%s\"",
+                          "\"blocks\":%u,\"workspace\":%llu,\"model_us\":%.2f,\"fusedFold\":%d,\"xcdTiles\":\"%016llx\",\"kname\":\"%s\"",
                           plan->choice.family, (unsigned long long)plan->view.totL, (unsigned long long)plan->view.totM,
                           (unsigned long long)plan->view.totN, (unsigned long long)plan->view.totK, (int)plan->view.swapped,
                           plan->view.layA, plan->view.layB, k, k >= 0 ? tab[k].bm : 16, k >= 0 ? tab[k].bn : 16,
@@ -1118,6 +1233,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           k >= 0 ? tab[k].pf : 0, k >= 0 ? tab[k].ablation : 0,
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold,
+                          (unsigned long long)plan->gett.xcdTiles,
                           k < 0 ? "gett_simple_kernel" : plan->choice.family == 1 ? "gett_h16_kernel" : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");

@@ -181,6 +181,9 @@ struct cutensorHandle {
     int logLevel = 0;
     // {arrivals, departures} counter pairs for in-launch split-K folds, 64 B apart, zeroed once; a launch
     // draws the next slot round-robin and its last workgroup re-arms it (gett_f32_stream.hip)
+    // relative sustained shader clock of the 8 XCDs under the streaming GETT kernel (measured once per handle by
+    // calibrate_xcd_split); empty = not measured, all-equal = measurement failed / disabled
+    std::vector<double> xcdSpeed;
     uint32_t* syncPool = nullptr;
     uint32_t  syncNext = 0;
     static constexpr uint32_t kSyncSlots = 256;

@@ -313,8 +313,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         for (uint32_t s : splits) {
             ContractionChoice c;
             c.kernel = i;
-            // streaming kernels walk their LDS ring in whole turns: equal slices of a multiple of S tiles
-            if (k.fragPartials && (v.totK % k.bk != 0 || kTiles % s != 0 || (kTiles / s) % (uint64_t)k.pf != 0)) continue;
+            if (k.fragPartials && v.totK % k.bk != 0) continue;   // whole K-tiles; any number of tiles per slice
             const uint64_t tilesPerSlice = (kTiles + s - 1) / s;
             c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
             c.splitK = (uint32_t)((v.totK + c.kPerSlice - 1) / c.kPerSlice);

@@ -62,6 +62,25 @@ __device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t*
     }
 }
 
+// Touch every 64-byte line of the kernel-argument segment with one burst of scalar loads and wait once.
+// hipcc fetches arguments lazily, in as many dependent rounds as the control flow has stages (8 for the
+// streaming GETT kernel), and a round that misses the scalar cache costs ~900 cycles at kernel start; after
+// this burst every later round hits.  BYTES = sizeof(the kernel's argument struct), at most 1024.
+template <int BYTES>
+__device__ __forceinline__ void prefetch_kernarg() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BYTES <= 1024, "argument block larger than the prefetch covers");
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink;   // the loaded words are never used; only lines inside the argument block are touched
+#define CTAMD_TOUCH(OFF) if constexpr (BYTES > (OFF)) asm volatile("s_load_dword %0, %1, " #OFF : "=s"(sink) : "s"(ka) : "memory");
+    CTAMD_TOUCH(0x0) CTAMD_TOUCH(0x40) CTAMD_TOUCH(0x80) CTAMD_TOUCH(0xc0) CTAMD_TOUCH(0x100) CTAMD_TOUCH(0x140)
+    CTAMD_TOUCH(0x180) CTAMD_TOUCH(0x1c0) CTAMD_TOUCH(0x200) CTAMD_TOUCH(0x240) CTAMD_TOUCH(0x280) CTAMD_TOUCH(0x2c0)
+    CTAMD_TOUCH(0x300) CTAMD_TOUCH(0x340) CTAMD_TOUCH(0x380) CTAMD_TOUCH(0x3c0)
+#undef CTAMD_TOUCH
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) :: "memory");
+#endif
+}
+
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nBlocks) {
     // Workgroup b is dispatched to XCD b % 8 (observed, used for speed only).  Give every XCD a
     // contiguous range of logical tile ids; bijective for any nBlocks.

@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
     constexpr int RED_FLOATS   = (WK > 1) ? (WK - 1) * BM * BN : 0;
     constexpr int LDS_FLOATS   = (Cfg::NBUF * STAGE_FLOATS > RED_FLOATS) ? Cfg::NBUF * STAGE_FLOATS : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -547,6 +548,7 @@ __global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(
     constexpr int RED_FLOATS = WM * WN * PER_WAVE;
     constexpr int LDS_FLOATS = (2 * STAGE_FLOATS > RED_FLOATS) ? 2 * STAGE_FLOATS : RED_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
 
     const int tid  = threadIdx.x;
     const int team = __builtin_amdgcn_readfirstlane(tid / TT);

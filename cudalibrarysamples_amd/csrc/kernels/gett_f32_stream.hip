@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     static_assert(S >= 3 && S <= 6 && S * STAGE * 4 <= 160 * 1024, "LDS ring must fit 160 KiB");
     static_assert(LOADS * (S - 1) <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) float lds[S * STAGE];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -249,11 +250,29 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     const uint32_t slice = id % p.splitK;
     const uint32_t l = id / p.splitK;
     const uint32_t m0 = mt * BM, n0 = nt * BN;
-    const uint32_t kBegin = slice * p.kPerSlice;
-    uint32_t kEnd = kBegin + p.kPerSlice;
-    if (kEnd > p.gK.total) kEnd = p.gK.total;
-    // fast-K: every tile is full; the planner guarantees nTiles % S == 0 and nTiles >= S
-    const int nTiles = (int)((kEnd - kBegin) / BK);
+    // K range of this workgroup (fast-K: every tile is full; any tile count >= 1).  Uniform split: slice *
+    // kPerSlice.  Balanced split (p.xcdTiles != 0, one output tile, splitK % 8 == 0): the slices of XCD x —
+    // ids [x q, (x+1) q), q = splitK / 8, after the XCD remap — hold xcdTiles.byte[x] tiles each, so that a
+    // die whose sustained clock is lower gets proportionally less of K (host: calibrate_xcd_split).
+    uint32_t kBegin = slice * p.kPerSlice;
+    int nTiles;
+    if (p.xcdTiles != 0) {
+        const uint32_t q = p.splitK >> 3;
+        const uint32_t x = slice / q, j = slice - x * q;
+        uint32_t first = 0, mine = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < 8; ++y) {
+            const uint32_t ny = (uint32_t)(p.xcdTiles >> (8 * y)) & 0xffu;
+            first += (y < x) ? ny * q : 0u;
+            mine = (y == x) ? ny : mine;
+        }
+        kBegin = (first + j * mine) * BK;
+        nTiles = (int)mine;
+    } else {
+        uint32_t kEnd = kBegin + p.kPerSlice;
+        if (kEnd > p.gK.total) kEnd = p.gK.total;
+        nTiles = (int)((kEnd - kBegin) / BK);
+    }
 
     if (loader) {
         // =========================== data movers ======================================================
@@ -277,14 +296,19 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         // rest of the ring is still being requested (an LDS-DMA issue that misses the TLB takes hundreds
         // of cycles, so S tiles of issue time in front of barrier #0 would be S times the start-up cost).
         issue(0);
-        issue(1);
-        CTAMD_WAIT_VMCNT(LOADS);
+        if (nTiles > 1) {
+            issue(1);
+            CTAMD_WAIT_VMCNT(LOADS);
+        } else {
+            CTAMD_WAIT_VMCNT(0);
+        }
         __builtin_amdgcn_s_barrier();                      // #0
 #pragma unroll
-        for (int T = 2; T < S; ++T) issue(T);
-        int slot = 0;
+        for (int T = 2; T < S; ++T)
+            if (T < nTiles) issue(T);
+        int slot = 0, t = 0;
         unsigned long long waitV = 0, waitB = 0;
-        for (int t = 0; t + S < nTiles; ++t) {             // outstanding: tiles t+1 .. t+S-1
+        for (; t + S < nTiles; ++t) {                      // outstanding: tiles t+1 .. t+S-1
             unsigned long long c0 = 0, c1 = 0, c2 = 0;
             if constexpr (Cfg::ABL == 3) c0 = __builtin_readcyclecounter();
             if constexpr (Cfg::ABL == 1) CTAMD_WAIT_VMCNT(0); else CTAMD_WAIT_VMCNT(LOADS * (S - 2));
@@ -297,13 +321,17 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         if constexpr (Cfg::ABL == 3) {
             if (tlog != nullptr && tid == 256) { tlog[9] = waitV; tlog[10] = waitB; }
         }
-        // the last S tiles are already on their way: S-1 more barriers with exact waits
-        if constexpr (S > 2) { CTAMD_WAIT_VMCNT(LOADS * (S - 2)); __builtin_amdgcn_s_barrier(); }
-        if constexpr (S > 3) { CTAMD_WAIT_VMCNT(LOADS * (S - 3)); __builtin_amdgcn_s_barrier(); }
-        if constexpr (S > 4) { CTAMD_WAIT_VMCNT(LOADS * (S - 4)); __builtin_amdgcn_s_barrier(); }
-        if constexpr (S > 5) { CTAMD_WAIT_VMCNT(LOADS * (S - 5)); __builtin_amdgcn_s_barrier(); }
+        // every tile is on its way: one barrier per remaining tile, waiting for exactly the tiles behind it
+        for (; t + 1 < nTiles; ++t) {
+            const int behind = nTiles - t - 2;             // tiles issued after tile t+1: 0 .. S-2
+            if (behind <= 0) CTAMD_WAIT_VMCNT(0);
+            else if (behind == 1) CTAMD_WAIT_VMCNT(LOADS);
+            else if (behind == 2) CTAMD_WAIT_VMCNT(LOADS * 2);
+            else if (behind == 3) CTAMD_WAIT_VMCNT((S > 4 ? LOADS * 3 : 0));
+            else CTAMD_WAIT_VMCNT((S > 5 ? LOADS * 4 : 0));
+            __builtin_amdgcn_s_barrier();                  // #(t+1)
+        }
         CTAMD_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();                      // #(nTiles-1)
         return;
     }
 
@@ -389,16 +417,25 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
 #define CTAMD_BODY_MID(U) CTAMD_TILE_BODY(U, false)
-#define CTAMD_BODY_END(U) CTAMD_TILE_BODY(U, (U) == S - 1)
     // compile-time unrolling over the ring slots
 #define CTAMD_FOR_SLOTS(M)                                                     \
     { M(0) M(1) M(2)                                                           \
       if constexpr (S > 3) { M(3) } if constexpr (S > 4) { M(4) }              \
       if constexpr (S > 5) { M(5) } }
-    const int groups = nTiles / S;
-    for (int g = 0; g + 1 < groups; ++g) CTAMD_FOR_SLOTS(CTAMD_BODY_MID)
+    // whole ring turns whose S tiles all have a successor, then the last 1 .. S tiles (slots 0 .. r-1)
+    int t = 0;
+    for (; t + S < nTiles; t += S) CTAMD_FOR_SLOTS(CTAMD_BODY_MID)
     stamp(2);
-    CTAMD_FOR_SLOTS(CTAMD_BODY_END)
+    const int r = nTiles - t;
+#define CTAMD_BODY_END(U) CTAMD_TILE_BODY(U, (U) == S - 1)
+#define CTAMD_BODY_TAIL(U)                                                     \
+    if (r == (U) + 1) CTAMD_TILE_BODY(U, true)                                 \
+    else if (r > (U) + 1) CTAMD_TILE_BODY(U, false)
+    if (r == S) {          // the common case (whole ring turns): straight-line code, no per-tile branch
+        CTAMD_FOR_SLOTS(CTAMD_BODY_END)
+    } else {
+        CTAMD_FOR_SLOTS(CTAMD_BODY_TAIL)
+    }
     stamp(3);
     if constexpr (Cfg::ABL == 3) {
         if (tlog != nullptr && tid == 0) tlog[8] = waitC;

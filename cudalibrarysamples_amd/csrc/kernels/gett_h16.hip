@@ -217,6 +217,7 @@ struct HOdometer {
 template <bool BF, int LA, int LB>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
     // slot index: buffer * 4 + {0: A-half 0, 1: A-half 1, 2: B-half 0, 3: B-half 1}
 
     const int tid  = threadIdx.x;

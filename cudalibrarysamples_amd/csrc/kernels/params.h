@@ -37,6 +37,7 @@ struct GettParams {
     float*      partial;  // split-K workspace: [slice][L][M][N] fp32, or nullptr
     unsigned long long* timing;   // diagnostics: 16 x uint64 per workgroup (nullptr = off)
     uint32_t*   sync;     // {arrivals, departures} of an in-launch split-K fold (streaming kernels), or nullptr
+    unsigned long long xcdTiles;  // balanced split-K (streaming kernels): byte x = K-tiles per slice on XCD x; 0 = uniform
     ModeGroup   gM, gN, gK, gL;
     float       alpha, beta;
     double      alpha64, beta64;  // same scalars at full width (fp64 data)
