@@ -84,3 +84,121 @@ def einsum(equation, a, b=None):
             ws = _workspace[a.device] = torch.empty(1 << 30, dtype=torch.uint8, device=a.device)
     plan.execute(a, b, out, ws)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Autograd, module and N-ary front ends — the counterparts of cuTENSOR/python/cutensor/torch/einsum.py:25-156
+# (EinsumFunction.forward/backward :27-69, Einsum module :98-119, EinsumGeneral :139-172) and
+# cutensor/common.py:18-28 (normalize_subscript).  Every contraction, reduction and permutation below runs
+# through `einsum()` above, i.e. through the C ABI on the GPU; nothing falls back to torch.einsum.
+# ---------------------------------------------------------------------------------------------------------------
+def normalize_subscript(subscript):
+    """'ik,kj' -> ('ik,kj->ij', True): implicit output = sorted modes that appear once (common.py:18-28)."""
+    if "->" in subscript:
+        lhs, rhs = subscript.split("->")
+    else:
+        lhs = subscript
+        rhs = "".join(sorted(s for s in set(subscript) if s != "," and subscript.count(s) == 1))
+    if "..." in lhs:
+        raise RuntimeError("Elipsis is currently unsupported")
+    return lhs + "->" + rhs, "," in lhs
+
+
+class EinsumFunction(torch.autograd.Function):
+    """out = einsum(equation, a[, b]) with gradients computed by further einsums on the engine
+    (einsum.py:27-69: d_a = einsum(C,B->A)(grad, b), d_b = einsum(A,C->B)(a, grad); unary: grad permuted back)."""
+
+    @staticmethod
+    def forward(ctx, equation, input_0, input_1=None):
+        equation, is_binary = normalize_subscript(equation)
+        if is_binary and input_1 is None:
+            raise RuntimeError("The subscript indicates two inputs, but only one was passed")
+        if not is_binary and input_1 is not None:
+            raise RuntimeError("The subscript indicates one input, but two were passed")
+        out = einsum(equation, input_0.detach(), input_1.detach() if input_1 is not None else None)
+        if is_binary:
+            ctx.save_for_backward(input_0, input_1)
+        else:
+            ctx.in_shape = tuple(input_0.shape)
+        ctx.equation, ctx.is_binary = equation, is_binary
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        lhs, mode_c = ctx.equation.split("->")
+        grad_output = grad_output.contiguous()
+        if ctx.is_binary:
+            a, b = ctx.saved_tensors
+            mode_a, mode_b = lhs.split(",")
+            d_a = _grad_einsum(mode_c, grad_output, mode_b, b.detach(), mode_a, a.shape) if ctx.needs_input_grad[1] else None
+            d_b = _grad_einsum(mode_a, a.detach(), mode_c, grad_output, mode_b, b.shape) if ctx.needs_input_grad[2] else None
+            return None, d_a, d_b
+        d_in = _grad_einsum(mode_c, grad_output, None, None, lhs, ctx.in_shape) if ctx.needs_input_grad[1] else None
+        return None, d_in, None
+
+
+def _grad_einsum(m0, t0, m1, t1, m_out, out_shape):
+    """einsum(m0[,m1] -> m_out); modes of m_out that neither operand carries (they were summed away in the
+    forward pass) are broadcast afterwards — a stride-0 view, no copy."""
+    present = [c for c in m_out if c in m0 or (m1 is not None and c in m1)]
+    eq = m0 + ("," + m1 if m1 is not None else "") + "->" + "".join(present)
+    g = einsum(eq, t0, t1)
+    if len(present) == len(m_out):
+        return g
+    view = [out_shape[i] if c in present else 1 for i, c in enumerate(m_out)]
+    return g.reshape(view).expand(out_shape)
+
+
+class Einsum(torch.nn.Module):
+    """torch.nn.Module wrapper (einsum.py:98-119)."""
+
+    def __init__(self, equation):
+        super().__init__()
+        self.equation = equation
+
+    def forward(self, input_0, input_1=None):
+        return EinsumFunction.apply(self.equation, input_0, input_1)
+
+
+def _compute_target_tensor(in0, in1, target, rest):
+    """Modes the pairwise intermediate must keep: those still needed by the remaining operands or the output,
+    output modes in output order (einsum.py:122-136)."""
+    rest = "".join(rest) + target
+    result = []
+    for m in in0 + in1:
+        if m in rest and m not in result:
+            result.append(m)
+    keep = sorted((m for m in result if m in target), key=target.index)
+    it = iter(keep)
+    return "".join(next(it) if m in target else m for m in result)
+
+
+def EinsumGeneral(equation, *tensors, **kwargs):
+    """N-ary einsum as a sequence of pairwise EinsumFunction calls along numpy's contraction path
+    (einsum.py:139-172); differentiable end to end."""
+    import numpy as np
+    tensors = list(tensors)
+    equation, _ = normalize_subscript(equation)
+    lhs, target = equation.split("->")
+    eqs = lhs.split(",")
+    if len(eqs) != len(tensors):
+        raise RuntimeError("The subscript indicates %d inputs, but %d were passed" % (len(eqs), len(tensors)))
+    if len(tensors) == 1:
+        return EinsumFunction.apply(eqs[0] + "->" + target, tensors[0])
+    path = np.einsum_path(equation, *[np.broadcast_to(np.nan, t.shape) for t in tensors], **kwargs)[0][1:]
+    result = None
+    for step in path:
+        if len(step) == 1:
+            result = EinsumFunction.apply(eqs[step[0]] + "->" + target, tensors[step[0]])
+            continue
+        i, j = sorted(step)
+        in0, in1 = tensors[i], tensors[j]
+        e0, e1 = eqs[i], eqs[j]
+        for k in (j, i):
+            tensors.pop(k)
+            eqs.pop(k)
+        tgt = target if not tensors else _compute_target_tensor(e0, e1, target, eqs)
+        result = EinsumFunction.apply(e0 + "," + e1 + "->" + tgt, in0, in1)
+        tensors.append(result)
+        eqs.append(tgt)
+    return result

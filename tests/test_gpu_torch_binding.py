@@ -1,0 +1,97 @@
+"""GPU regression suite of the PyTorch front end: the reference's own test list,
+cuTENSOR/python/cutensor/torch/einsum_test.py:47-160 (forward AND both gradients of EinsumFunction against
+torch.einsum) and :163-238 (EinsumGeneral, N-ary, gradients), real dtypes.  The checker is torch.einsum on the
+CPU in float64 (the reference compares with torch.einsum on its GPU); tolerance = the reference's
+rtol 5e-3 / atol 6e-3 (:42), tightened to rtol 2e-4 for float32."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BINARY = [  # einsum_test.py:49-118 (complex cases are out of scope)
+    ("test0", (48, 37), (37, 74), "ik,kj->ij", "float32"),
+    ("test2", (50, 50, 50, 20), (50, 50, 50, 20), "likm,lkjm->lij", "float32"),
+    ("test3", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "float32"),
+    ("test4", (50, 50), (50, 50), "ik,kj->ij", "float16"),
+    ("test5", (50, 50, 50), (50, 50, 50), "lik,lkj->lij", "float16"),
+    ("test7", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "float16"),
+    ("test8", (2, 5, 50, 2), (5, 2, 50, 2), "mlik,lkjm", "float64"),
+    ("test8_bf16", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "bfloat16"),
+]
+GENERAL = [  # einsum_test.py:165-196
+    ("g0", [(50, 60), (60, 40)], "ik,kj->ji", "float32"),
+    ("g1", [(50, 60), (60, 7), (7, 8)], "ik,kl,lj->ij", "float32"),
+    ("g2", [(50, 60), (60, 7), (7, 8)], "ik,kl,lj", "float32"),
+    ("g4", [(50, 60)], "ij->ji", "float32"),
+]
+
+
+@pytest.fixture(scope="module")
+def te(built):
+    import torch
+    assert torch.cuda.is_available()
+    from cudalibrarysamples_amd import torch_einsum
+    return torch, torch_einsum
+
+
+def _close(torch, got, ref, dtype):
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got.double().cpu(), ref, rtol=5e-3, atol=6e-3)
+    if dtype in ("float32", "float64"):
+        torch.testing.assert_close(got.double().cpu(), ref, rtol=2e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("name,a_size,b_size,equation,dtype", BINARY, ids=[c[0] for c in BINARY])
+def test_einsum_function_forward_and_gradients(te, name, a_size, b_size, equation, dtype):
+    torch, tein = te
+    torch.manual_seed(0)
+    dt = getattr(torch, dtype)
+    scale = 1.0 if dtype in ("float32", "float64") else 0.25    # keep 16-bit sums of 50*20 terms inside the reference's atol
+    A = (torch.randn(*a_size) * scale).to(dt).cuda().requires_grad_(True)
+    B = (torch.randn(*b_size) * scale).to(dt).cuda().requires_grad_(True)
+    out = tein.EinsumFunction.apply(equation, A, B)
+    out.backward(torch.ones_like(out))
+    rA = A.detach().double().cpu().requires_grad_(True)
+    rB = B.detach().double().cpu().requires_grad_(True)
+    ref = torch.einsum(equation, rA, rB)
+    ref.backward(torch.ones_like(ref))
+    _close(torch, out.detach(), ref.detach(), dtype)
+    _close(torch, A.grad, rA.grad, dtype)
+    _close(torch, B.grad, rB.grad, dtype)
+
+
+@pytest.mark.parametrize("name,sizes,equation,dtype", GENERAL, ids=[c[0] for c in GENERAL])
+def test_einsum_general_forward_and_gradients(te, name, sizes, equation, dtype):
+    torch, tein = te
+    torch.manual_seed(1)
+    ts = [torch.randn(*s).cuda().requires_grad_(True) for s in sizes]
+    out = tein.EinsumGeneral(equation, *ts)
+    out.backward(torch.ones_like(out))
+    rs = [t.detach().double().cpu().requires_grad_(True) for t in ts]
+    ref = torch.einsum(equation, *rs)
+    ref.backward(torch.ones_like(ref))
+    _close(torch, out.detach(), ref.detach(), dtype)
+    for t, r in zip(ts, rs):
+        _close(torch, t.grad, r.grad, dtype)
+
+
+def test_module_and_reduction_gradient_broadcast(te):
+    """Einsum module (einsum.py:98-119) and a unary reduction whose gradient is a broadcast (einsum.cu:451 'nij->ji')."""
+    torch, tein = te
+    torch.manual_seed(2)
+    A = torch.randn(6, 10, 12).cuda().requires_grad_(True)
+    out = tein.Einsum("nij->ji")(A)
+    out.backward(torch.arange(out.numel(), dtype=torch.float32, device="cuda").reshape(out.shape))
+    rA = A.detach().double().cpu().requires_grad_(True)
+    ref = torch.einsum("nij->ji", rA)
+    ref.backward(torch.arange(ref.numel(), dtype=torch.float64).reshape(ref.shape))
+    _close(torch, out.detach(), ref.detach(), "float32")
+    _close(torch, A.grad, rA.grad, "float32")
+
+
+def test_argument_count_errors(te):
+    torch, tein = te
+    a = torch.zeros(3, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        tein.EinsumFunction.apply("ik,kj->ij", a)
+    with pytest.raises(RuntimeError):
+        tein.EinsumFunction.apply("ij->ji", a, a)
