@@ -574,6 +574,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || workspaceSizeEstimate == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     *workspaceSizeEstimate = 0;
+    if (desc->kind == OpKind::BlockSparseContraction) return blocksparse_estimate(handle, *desc, workspaceSizeEstimate);
     if (desc->kind == OpKind::ContractionTrinary) {   // intermediate + the larger of the two pairwise needs
         uint64_t w1 = 0, w2 = 0;
         cutensorOperationDescriptor s1 = desc->sub[0], s2 = desc->sub[1];
@@ -794,6 +795,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     std::string why;
     cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
 
+    if (desc->kind == OpKind::BlockSparseContraction) {
+        st = blocksparse_plan(handle, *desc, workspaceSizeLimit, pl);
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        *plan = pl;
+        return CUTENSOR_STATUS_SUCCESS;
+    }
     if (desc->kind == OpKind::ContractionTrinary) {
         const uint64_t tOff = (desc->tBytes + 255) & ~255ull;
         if (workspaceSizeLimit < tOff) { delete pl; CT_LOG("cutensorCreatePlan: trinary contraction needs %llu bytes for its intermediate", (unsigned long long)tOff); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }

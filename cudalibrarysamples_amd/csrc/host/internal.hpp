@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,7 +28,7 @@ struct cutensorTensorDescriptor {
 };
 
 enum class OpKind : int { Contraction = 0, Reduction = 1, Permutation = 2, ElementwiseBinary = 3, ElementwiseTrinary = 4,
-                           ContractionTrinary = 5 };
+                           ContractionTrinary = 5, BlockSparseContraction = 6 };
 
 struct TensorUse {
     cutensorTensorDescriptor desc;
@@ -36,8 +37,11 @@ struct TensorUse {
     bool                     present = false;
 };
 
+namespace ctamd { struct BlockSparseOp; struct BlockSparsePlan; }
+
 struct cutensorOperationDescriptor {
     OpKind      kind;
+    std::shared_ptr<ctamd::BlockSparseOp> bs;        // block-sparse contraction (host/blocksparse.cpp)
     TensorUse   A, B, C, D;
     TensorUse   E;                                   // output of a trinary contraction (D is its beta source)
     cutensorOperator_t opReduce = CUTENSOR_OP_ADD;   // reduction operator / binary combiner (opAC, opABC)
@@ -129,6 +133,9 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
 cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t wsLimit, int numCUs,
                                 ReducePlan& plan, std::string* why);
 
+cutensorStatus_t blocksparse_estimate(cutensorHandle_t handle, const cutensorOperationDescriptor& desc, uint64_t* ws);
+cutensorStatus_t blocksparse_plan(cutensorHandle_t handle, const cutensorOperationDescriptor& desc, uint64_t wsLimit, cutensorPlan* pl);
+
 FastDiv make_fastdiv(uint32_t d);
 size_t  dtype_size(hipDataType t);
 
@@ -137,6 +144,7 @@ size_t  dtype_size(hipDataType t);
 struct cutensorPlan {
     ~cutensorPlan() { delete sub1; delete sub2; }
     // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
+    std::shared_ptr<ctamd::BlockSparsePlan> bsp;     // block-sparse contraction: dense plans + block-pair task list
     cutensorPlan* sub1 = nullptr;
     cutensorPlan* sub2 = nullptr;
     uint64_t    tBytes = 0;

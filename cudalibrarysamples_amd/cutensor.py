@@ -70,6 +70,13 @@ EXPORTS = {
     "cutensorCreateContractionTrinary": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
                                          _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int, _vp, _i32p, _vp),
     "cutensorContractTrinary": (_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp),
+    "cutensorCreateBlockSparseTensorDescriptor": (_vp, ctypes.POINTER(_vp), ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32),
+                                                  _i64p, _i32p, _i64p, ctypes.c_int),
+    "cutensorDestroyBlockSparseTensorDescriptor": (_vp,),
+    "cutensorCreateBlockSparseContraction": (_vp, ctypes.POINTER(_vp), _vp, _i32p, ctypes.c_int, _vp, _i32p, ctypes.c_int,
+                                             _vp, _i32p, ctypes.c_int, _vp, _i32p, _vp),
+    "cutensorBlockSparseContract": (_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                    _vp, ctypes.c_uint64, _vp),
     "cutensorReadKernelCacheFromFile": (_vp, ctypes.c_char_p),
     "cutensorWriteKernelCacheToFile": (_vp, ctypes.c_char_p),
 }

@@ -187,6 +187,28 @@ cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle,
 cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
                                          const void* A, const void* B, const void* C, const void* beta, const void* D, void* E,
                                          void* workspace, uint64_t workspaceSize, cudaStream_t stream);
+/* ---- block-sparse tensors (blocksparse.cu) ----------------------------------------------------------
+ * A tensor is a set of dense blocks: every mode is cut into sections (extent[] lists the section extents mode by
+ * mode), a block is addressed by one section index per mode (nonZeroCoordinates[block * numModes + mode]) and lives
+ * behind its own device pointer; stride == NULL: every block packed column-major. blocksparse.cu:102-107 */
+cutensorStatus_t cutensorCreateBlockSparseTensorDescriptor(cutensorHandle_t handle, cutensorBlockSparseTensorDescriptor_t* desc,
+                                                           const uint32_t numModes, const uint64_t numNonZeroBlocks,
+                                                           const uint32_t numSectionsPerMode[], const int64_t extent[],
+                                                           const int32_t nonZeroCoordinates[], const int64_t stride[],
+                                                           cudaDataType_t dataType);
+cutensorStatus_t cutensorDestroyBlockSparseTensorDescriptor(cutensorBlockSparseTensorDescriptor_t desc);
+/* blocksparse.cu:177-182 */
+cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
+                                                      const cutensorBlockSparseTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
+                                                      const cutensorBlockSparseTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
+                                                      const cutensorBlockSparseTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
+                                                      const cutensorBlockSparseTensorDescriptor_t descD, const int32_t modeD[],
+                                                      const cutensorComputeDescriptor_t descCompute);
+/* blocksparse.cu:206-209: A, B, C, D are host arrays of device pointers, one per non-zero block */
+cutensorStatus_t cutensorBlockSparseContract(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
+                                             const void* const A[], const void* const B[], const void* beta,
+                                             const void* const C[], void* const D[], void* workspace, uint64_t workspaceSize,
+                                             cudaStream_t stream);
 /* contraction_jit.cu:134 / :398 — accepted for source compatibility; there is no run-time code generation */
 cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]);
 cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]);

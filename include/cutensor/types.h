@@ -177,6 +177,7 @@ typedef struct cutensorTensorDescriptor*    cutensorTensorDescriptor_t;
 typedef struct cutensorOperationDescriptor* cutensorOperationDescriptor_t;
 typedef struct cutensorPlanPreference*      cutensorPlanPreference_t;
 typedef struct cutensorPlan*                cutensorPlan_t;
+typedef struct cutensorBlockSparseTensorDescriptor* cutensorBlockSparseTensorDescriptor_t;   /* blocksparse.cu:64 */
 
 /* Compute descriptors are opaque pointers to library-owned constants and are used as values
  * (contraction.cu:40, einsum.cu:39,46,53). */

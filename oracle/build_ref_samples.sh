@@ -15,7 +15,7 @@ FLAGS="-x hip --offload-arch=gfx950 -std=c++17 -O2 -w -I$ROOT/tests/sample_compa
 LINK="-L$ROOT/cudalibrarysamples_amd/lib -Wl,-rpath,\$ORIGIN/../../cudalibrarysamples_amd/lib"
 rc=0
 for s in contraction einsum reduction elementwise_permute elementwise_binary elementwise_trinary elementwise_permute_padding \
-         contraction_plan_cache contraction_jit contraction_trinary; do
+         contraction_plan_cache contraction_jit contraction_trinary blocksparse; do
     if hipcc $FLAGS "$REF/cuTENSOR/$s.cu" -o "$OUT/$s" $LINK -lcutensor 2> "$OUT/$s.log"; then
         echo "built oracle/_ref/$s"
     else
