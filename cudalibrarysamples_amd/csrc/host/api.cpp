@@ -40,12 +40,15 @@ int log_level() {
 #define CT_LOG(...) do { if (log_level() > 0) { std::fprintf(stderr, "[cutensor-amd] " __VA_ARGS__); std::fputc('\n', stderr); } } while (0)
 
 bool supported_dtype(hipDataType t) {
-    return t == HIP_R_32F || t == HIP_R_64F || t == HIP_R_16F || t == HIP_R_16BF;
+    // complex data is accepted for contractions only (mode-table kernel); the element-wise / reduction planners
+    // answer NOT_SUPPORTED for it
+    return t == HIP_R_32F || t == HIP_R_64F || t == HIP_R_16F || t == HIP_R_16BF || t == HIP_C_32F || t == HIP_C_64F;
 }
 
 // scalar type of alpha/beta for a data type + compute descriptor (einsum.cu:40,47,54;
 // torch/einsum.cc:39): fp64 data -> fp64 scalars, everything else -> fp32 scalars.
 hipDataType scalar_type_for(hipDataType data, const cutensorComputeDescriptor* c) {
+    if (data == HIP_C_32F || data == HIP_C_64F) return data;   // contraction_jit.cu:205: complex scalars for complex data
     if (data == HIP_R_64F || (c && c->id == 5)) return HIP_R_64F;
     return HIP_R_32F;
 }
@@ -81,9 +84,15 @@ std::string problem_key(const cutensorOperationDescriptor& op) {
     return ss.str();
 }
 
-double scalar_as_double(const void* s, hipDataType t) {
+double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
     if (s == nullptr) return 0.0;
-    return t == HIP_R_64F ? *static_cast<const double*>(s) : (double)*static_cast<const float*>(s);
+    return (t == HIP_R_64F || t == HIP_C_64F) ? *static_cast<const double*>(s) : (double)*static_cast<const float*>(s);
+}
+double scalar_imag(const void* s, hipDataType t) {
+    if (s == nullptr) return 0.0;
+    if (t == HIP_C_64F) return static_cast<const double*>(s)[1];
+    if (t == HIP_C_32F) return (double)static_cast<const float*>(s)[1];
+    return 0.0;
 }
 
 bool misaligned(const void* p, uint32_t a) { return a > 1 && (reinterpret_cast<uintptr_t>(p) % a) != 0; }
@@ -590,7 +599,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         ContractionView v;
         cutensorStatus_t st = build_contraction_view(*desc, v, nullptr);
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
-        if (v.dtype != HIP_R_32F) return CUTENSOR_STATUS_SUCCESS;
+        if (v.dtype != HIP_R_32F || v.wide) return CUTENSOR_STATUS_SUCCESS;
         // the largest workspace any of the best few candidates would like to have
         std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs);
         uint64_t want = 0;
@@ -823,6 +832,42 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     if (desc->kind == OpKind::Contraction) {
         st = build_contraction_view(*desc, pl->view, &why);
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (pl->view.wide) {
+            // mode-table kernel: output modes (L, M, N), then contracted modes, in device memory owned by the plan
+            const ContractionView& v = pl->view;
+            std::vector<WideMode> tab;
+            uint64_t outTotal = 1;
+            for (const std::vector<CanonMode>* g : {&v.L, &v.M, &v.N})
+                for (const CanonMode& m : *g) {
+                    tab.push_back(WideMode{make_fastdiv((uint32_t)m.extent), m.sA, m.sB, m.sC, m.sD});
+                    outTotal *= (uint64_t)m.extent;
+                }
+            pl->wide.nOut = (uint32_t)tab.size();
+            for (const CanonMode& m : v.K) tab.push_back(WideMode{make_fastdiv((uint32_t)m.extent), m.sA, m.sB, 0, 0});
+            pl->wide.nK = (uint32_t)v.K.size();
+            pl->wide.outTotal = outTotal;
+            pl->wide.kTotal = (uint32_t)v.totK;
+            // conjugation flags follow the operands into their kernel roles (kernel-A is the user's B when swapped)
+            const bool cA = desc->A.op == CUTENSOR_OP_CONJ, cB = desc->B.op == CUTENSOR_OP_CONJ;
+            pl->wide.conjA = v.swapped ? cB : cA;
+            pl->wide.conjB = v.swapped ? cA : cB;
+            pl->wide.conjC = desc->C.op == CUTENSOR_OP_CONJ;
+            void* dev = nullptr;
+            if (hipMalloc(&dev, std::max<size_t>(tab.size(), 1) * sizeof(WideMode)) != hipSuccess ||
+                (!tab.empty() && hipMemcpy(dev, tab.data(), tab.size() * sizeof(WideMode), hipMemcpyHostToDevice) != hipSuccess)) {
+                (void)hipGetLastError();
+                if (dev) (void)hipFree(dev);
+                delete pl;
+                return CUTENSOR_STATUS_ALLOC_FAILED;
+            }
+            pl->wide.modes = static_cast<const WideMode*>(dev);
+            pl->choice = ContractionChoice{};
+            pl->choice.kernel = -2;
+            pl->requiredWorkspace = 0;
+            CT_LOG("plan: contraction with %u output + %u contracted unfusable modes -> mode-table kernel", pl->wide.nOut, pl->wide.nK);
+            *plan = pl;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
         const bool mfmaPath = pl->view.dtype == HIP_R_32F && !pl->accumulate64;
         ContractionChoice pick;   // kernel = -1: simple kernel
         if (mfmaPath) {
@@ -958,6 +1003,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     return CUTENSOR_STATUS_SUCCESS;
 }
 
+cutensorPlan::~cutensorPlan() {
+    delete sub1;
+    delete sub2;
+    if (wide.modes != nullptr) (void)hipFree(const_cast<ctamd::WideMode*>(wide.modes));
+}
+
 cutensorStatus_t cutensorDestroyPlan(cutensorPlan_t plan) {
     delete plan;
     return CUTENSOR_STATUS_SUCCESS;
@@ -984,9 +1035,11 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     if (plan == nullptr || plan->kind != OpKind::Contraction) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     const double a = scalar_as_double(alpha, plan->scalarType), b = scalar_as_double(beta, plan->scalarType);
-    if (b != 0.0 && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    const double aIm = scalar_imag(alpha, plan->scalarType), bIm = scalar_imag(beta, plan->scalarType);
+    const bool betaZero = (b == 0.0 && bIm == 0.0);
+    if (!betaZero && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (misaligned(A, plan->alignA) || misaligned(B, plan->alignB) || misaligned(D, plan->alignD) ||
-        (b != 0.0 && misaligned(C, plan->alignC)))
+        (!betaZero && misaligned(C, plan->alignC)))
         return CUTENSOR_STATUS_INVALID_VALUE;
     if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
         return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
@@ -994,13 +1047,19 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     GettParams p = plan->gett;
     p.A = plan->view.swapped ? B : A;
     p.B = plan->view.swapped ? A : B;
-    p.C = (b != 0.0) ? C : D;
+    p.C = (!betaZero) ? C : D;
     p.D = D;
     p.alpha = (float)a; p.beta = (float)b;
     p.alpha64 = a; p.beta64 = b;
     p.timing = g_timingBuffer;
     hipError_t err;
-    if (plan->choice.kernel < 0) {
+    if (plan->choice.kernel == -2) {
+        WideParams w = plan->wide;
+        w.A = p.A; w.B = p.B; w.C = p.C; w.D = D;
+        w.alpha = p.alpha; w.beta = p.beta; w.alpha64 = a; w.beta64 = b;
+        w.alphaIm = aIm; w.betaIm = bIm;
+        err = launch_gett_wide(w, (int)plan->dtype, plan->accumulate64, stream);
+    } else if (plan->choice.kernel < 0) {
         p.partial = nullptr;
         err = launch_gett_simple(p, (int)plan->dtype, plan->accumulate64, stream);
     } else if (plan->choice.family == 1) {
@@ -1241,7 +1300,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold,
                           (unsigned long long)plan->gett.xcdTiles,
-                          k < 0 ? "gett_simple_kernel" : plan->choice.family == 1 ? "gett_h16_kernel" : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
+                          k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 1 ? "gett_h16_kernel" : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
         for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)
@@ -1312,7 +1371,7 @@ int ctamdCountCandidates(const cutensorHandle_t handle, const cutensorOperationD
     if (handle == nullptr || desc == nullptr || desc->kind != OpKind::Contraction) return -1;
     ContractionView v;
     if (build_contraction_view(*desc, v, nullptr) != CUTENSOR_STATUS_SUCCESS) return -1;
-    if (v.dtype != HIP_R_32F) return 0;
+    if (v.dtype != HIP_R_32F || v.wide) return 0;
     return (int)rank_contraction_choices(v, wsLimit, handle->numCUs).size();
 }
 

@@ -85,6 +85,8 @@ struct ContractionView {
     int      layA = LAY_S, layB = LAY_S; // best layout each operand admits
     hipDataType dtype = HIP_R_32F;
     uint64_t totL = 1, totM = 1, totN = 1, totK = 1;
+    bool     wide = false;               // a group has more than kMaxGroupModes unfusable modes (or >= 2^31 elements):
+                                         // only the mode-table kernel (gett_wide_kernel) can run it
 };
 
 // One executable choice for a contraction.
@@ -142,7 +144,8 @@ size_t  dtype_size(hipDataType t);
 }  // namespace ctamd
 
 struct cutensorPlan {
-    ~cutensorPlan() { delete sub1; delete sub2; }
+    ~cutensorPlan();
+    ctamd::WideParams wide{};        // mode-table contraction (view.wide): .modes is device memory owned by this plan
     // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
     std::shared_ptr<ctamd::BlockSparsePlan> bsp;     // block-sparse contraction: dense plans + block-pair task list
     cutensorPlan* sub1 = nullptr;

@@ -213,11 +213,20 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     v.totL = group_total(v.L); v.totM = group_total(v.M);
     v.totN = group_total(v.N); v.totK = group_total(v.K);
     const uint64_t lim = (1ull << 31) - 1;
-    if (v.totL > lim || v.totM > lim || v.totN > lim || v.totK > lim)
-        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "a fused mode group exceeds 2^31-1 elements");
-    if ((int)v.L.size() > kMaxGroupModes || (int)v.M.size() > kMaxGroupModes ||
-        (int)v.N.size() > kMaxGroupModes || (int)v.K.size() > kMaxGroupModes)
-        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 4 unfusable modes in one group");
+    if (v.totK > lim) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "the contracted modes span more than 2^31-1 elements");
+    if (v.totL > lim || v.totM > lim || v.totN > lim || (int)v.L.size() > kMaxGroupModes || (int)v.M.size() > kMaxGroupModes ||
+        (int)v.N.size() > kMaxGroupModes || (int)v.K.size() > kMaxGroupModes) {
+        // more digits than the tiled kernels' argument block describes: the mode-table kernel takes it
+        if (v.L.size() + v.M.size() + v.N.size() + v.K.size() > 128) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "more than 128 unfusable modes");
+        v.wide = true;
+        v.layA = v.layB = LAY_S;
+        return CUTENSOR_STATUS_SUCCESS;
+    }
+    if (v.dtype == HIP_C_32F || v.dtype == HIP_C_64F) {   // complex data: the mode-table kernel is the only one that multiplies it
+        v.wide = true;
+        v.layA = v.layB = LAY_S;
+        return CUTENSOR_STATUS_SUCCESS;
+    }
 
     // ---- operand layouts: 16-byte lanes = 4 fp32 or 8 bf16/fp16 elements ------------------------
     const int64_t vec = (dtype_size(v.dtype) == 2) ? 8 : 4;

@@ -76,6 +76,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     };
     const TensorUse &A = op.A, &C = op.C, &D = op.D;
     const bool usesC = C.present;
+    if (D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex element-wise operations");
     if (dup_labels(A.modes) || dup_labels(D.modes) || (usesC && dup_labels(C.modes)))
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
     if (A.desc.dtype != D.desc.dtype || (usesC && C.desc.dtype != D.desc.dtype))
@@ -222,6 +223,7 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
         return st;
     };
     const TensorUse &A = op.A, &C = op.C, &D = op.D;
+    if (D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex reductions");
     if (dup_labels(A.modes) || dup_labels(D.modes)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
     if (C.modes != D.modes) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "modes of C and D differ");
     if (C.desc.extent != D.desc.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extents of C and D differ");

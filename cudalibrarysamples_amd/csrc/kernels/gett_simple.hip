@@ -92,6 +92,119 @@ __global__ void __launch_bounds__(256) gett_simple_kernel(const GettParams p) {
     gs_store<T>(D + gs_offset<1>(p.gM, m) + gs_offset<1>(p.gN, n), (double)val);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide-mode contraction: one output element per lane, the mode table is read through wave-uniform indices
+// (scalar loads).  Output index -> digits once per element (64-bit arithmetic), contracted index -> digits per
+// k with multiply-high divisions.  Correctness path for tensors the tiled kernels cannot describe.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename S>
+__global__ void __launch_bounds__(256) gett_wide_kernel(const WideParams p) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.outTotal) return;
+    int64_t oA = 0, oB = 0, oC = 0, oD = 0;
+    uint64_t rem = e;
+    for (uint32_t i = 0; i < p.nOut; ++i) {
+        const WideMode m = p.modes[i];
+        const uint64_t q = rem / m.div.d;
+        const int64_t digit = (int64_t)(rem - q * m.div.d);
+        oA += digit * m.sA; oB += digit * m.sB; oC += digit * m.sC; oD += digit * m.sD;
+        rem = q;
+    }
+    const T* A = static_cast<const T*>(p.A) + oA;
+    const T* B = static_cast<const T*>(p.B) + oB;
+    S acc = (S)0;
+    for (uint32_t k = 0; k < p.kTotal; ++k) {
+        int64_t ka = 0, kb = 0;
+        uint32_t r = k;
+        for (uint32_t i = 0; i < p.nK; ++i) {
+            const WideMode m = p.modes[p.nOut + i];
+            const uint32_t q = (m.div.d < 2) ? r : gs_fast_div(r, m.div);
+            const int64_t digit = (int64_t)(r - q * m.div.d);
+            ka += digit * m.sA; kb += digit * m.sB;
+            r = q;
+        }
+        acc += (S)gs_load<T>(A + ka) * (S)gs_load<T>(B + kb);
+    }
+    const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
+    const S beta  = sizeof(S) == 8 ? (S)p.beta64 : (S)p.beta;
+    S val = alpha * acc;
+    if (beta != (S)0) val += beta * (S)gs_load<T>(static_cast<const T*>(p.C) + oC);
+    gs_store<T>(static_cast<T*>(p.D) + oD, (double)val);
+}
+
+// Complex data: D = alpha * op(A) * op(B) + beta * op(C) with op = identity or conjugate
+// (cuTENSOR/contraction_jit.cu:31-41: std::complex<float> tensors and scalars).  R = float or double.
+template <typename R>
+__global__ void __launch_bounds__(256) gett_wide_complex_kernel(const WideParams p) {
+    struct Cx { R re, im; };
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.outTotal) return;
+    int64_t oA = 0, oB = 0, oC = 0, oD = 0;
+    uint64_t rem = e;
+    for (uint32_t i = 0; i < p.nOut; ++i) {
+        const WideMode m = p.modes[i];
+        const uint64_t q = rem / m.div.d;
+        const int64_t digit = (int64_t)(rem - q * m.div.d);
+        oA += digit * m.sA; oB += digit * m.sB; oC += digit * m.sC; oD += digit * m.sD;
+        rem = q;
+    }
+    const Cx* A = static_cast<const Cx*>(p.A) + oA;
+    const Cx* B = static_cast<const Cx*>(p.B) + oB;
+    const R sa = p.conjA ? (R)-1 : (R)1, sb = p.conjB ? (R)-1 : (R)1;
+    R accRe = 0, accIm = 0;
+    for (uint32_t k = 0; k < p.kTotal; ++k) {
+        int64_t ka = 0, kb = 0;
+        uint32_t r = k;
+        for (uint32_t i = 0; i < p.nK; ++i) {
+            const WideMode m = p.modes[p.nOut + i];
+            const uint32_t q = (m.div.d < 2) ? r : gs_fast_div(r, m.div);
+            const int64_t digit = (int64_t)(r - q * m.div.d);
+            ka += digit * m.sA; kb += digit * m.sB;
+            r = q;
+        }
+        const Cx a = A[ka], b = B[kb];
+        const R aim = sa * a.im, bim = sb * b.im;
+        accRe += a.re * b.re - aim * bim;
+        accIm += a.re * bim + aim * b.re;
+    }
+    const R alRe = (R)p.alpha64, alIm = (R)p.alphaIm, beRe = (R)p.beta64, beIm = (R)p.betaIm;
+    Cx out;
+    out.re = alRe * accRe - alIm * accIm;
+    out.im = alRe * accIm + alIm * accRe;
+    if (beRe != (R)0 || beIm != (R)0) {
+        Cx c = static_cast<const Cx*>(p.C)[oC];
+        if (p.conjC) c.im = -c.im;
+        out.re += beRe * c.re - beIm * c.im;
+        out.im += beRe * c.im + beIm * c.re;
+    }
+    static_cast<Cx*>(p.D)[oD] = out;
+}
+
+template <typename T, typename S>
+static void launch_wide_t(const WideParams& p, hipStream_t stream) {
+    const uint64_t blocks = (p.outTotal + 255) / 256;
+    hipLaunchKernelGGL((gett_wide_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+}
+
+hipError_t launch_gett_wide(const WideParams& p, int dtype, bool accumulate64, hipStream_t stream) {
+    if (p.outTotal == 0) return hipSuccess;
+    if ((p.outTotal + 255) / 256 >= (1ull << 31)) return hipErrorInvalidValue;
+    switch (dtype) {
+        case HIP_R_32F:  if (accumulate64) launch_wide_t<float, double>(p, stream); else launch_wide_t<float, float>(p, stream); break;
+        case HIP_R_64F:  launch_wide_t<double, double>(p, stream); break;
+        case HIP_R_16F:  launch_wide_t<__half, float>(p, stream); break;
+        case HIP_R_16BF: launch_wide_t<__hip_bfloat16, float>(p, stream); break;
+        case HIP_C_32F:
+            hipLaunchKernelGGL(gett_wide_complex_kernel<float>, dim3((unsigned)((p.outTotal + 255) / 256)), dim3(256), 0, stream, p);
+            break;
+        case HIP_C_64F:
+            hipLaunchKernelGGL(gett_wide_complex_kernel<double>, dim3((unsigned)((p.outTotal + 255) / 256)), dim3(256), 0, stream, p);
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <typename T, typename S>
 static void launch_simple_t(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gett_simple_kernel<T, S>), dim3(p.nBlocks), dim3(256), 0, stream, p);

@@ -39,6 +39,9 @@ const GettKernelInfo* gett_h16_kernels(int* count);
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,
                               hipStream_t stream);
 
+// any number of modes (mode table in device memory), one output element per lane
+hipError_t launch_gett_wide(const WideParams& p, int dtype /*hipDataType*/, bool accumulate64, hipStream_t stream);
+
 // element-wise family (elementwise.hip)
 enum EwVariant : int {
     EW_TRANSPOSE = 0,  // sD0 == 1 and sA1 == 1: 64x64 LDS tile, 16-byte lanes on both sides

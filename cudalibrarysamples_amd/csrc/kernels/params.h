@@ -53,6 +53,31 @@ struct GettParams {
     int64_t     cStrideL[kMaxGroupModes];
 };
 
+// ---------------------------------------------------------------------------------------------
+// Contractions with more unfusable modes per group than kMaxGroupModes (e.g. the 25-mode extent-2 tensors of
+// cuTENSOR/contraction_jit.cu:50-56): the mode list lives in device memory instead of the argument block.
+// Entries [0, nOut) are the output modes in any order, entries [nOut, nOut + nK) the contracted modes.
+// ---------------------------------------------------------------------------------------------
+struct WideMode {
+    FastDiv div;                 // extent as divisor (contracted modes are decoded with it; d = extent)
+    int64_t sA, sB, sC, sD;      // element strides (0 where the tensor does not carry the mode)
+};
+struct WideParams {
+    const void* A;
+    const void* B;
+    const void* C;
+    void*       D;
+    const WideMode* modes;       // device memory, owned by the plan
+    uint32_t    nOut, nK;
+    uint64_t    outTotal;        // product of the output extents
+    uint32_t    kTotal;          // product of the contracted extents (< 2^31)
+    float       alpha, beta;
+    double      alpha64, beta64;
+    // complex data (HIP_C_32F / HIP_C_64F): imaginary parts of the scalars, conjugation of each input
+    double      alphaIm, betaIm;
+    int32_t     conjA, conjB, conjC;
+};
+
 // Second stage of split-K: D = alpha * sum_s partial[s] + beta * C
 struct SplitKReduceParams {
     const float* partial;

@@ -20,9 +20,11 @@ lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
 # ---- enums (include/cutensor/types.h) ----------------------------------------------------------
 R_32F, R_64F, R_16F, R_16BF = 0, 1, 2, 14
+C_32F, C_64F = 4, 5   # complex data: contractions only (mode-table kernel)
 STATUS_SUCCESS, STATUS_NOT_INITIALIZED, STATUS_INVALID_VALUE = 0, 1, 7
 STATUS_NOT_SUPPORTED, STATUS_INSUFFICIENT_WORKSPACE, STATUS_IO_ERROR = 15, 19, 21
 OP_IDENTITY, OP_ADD, OP_MUL, OP_MAX, OP_MIN = 1, 3, 5, 6, 7
+OP_CONJ = 9
 ALGO_DEFAULT, ALGO_DEFAULT_PATIENT = -1, -6
 WORKSPACE_MIN, WORKSPACE_DEFAULT, WORKSPACE_MAX = 1, 2, 3
 JIT_MODE_NONE = 0

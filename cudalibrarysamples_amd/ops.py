@@ -9,7 +9,7 @@ import ctypes
 
 from . import cutensor as ct
 
-_DTYPE_COMPUTE = {ct.R_32F: "32F", ct.R_64F: "64F", ct.R_16F: "16F", ct.R_16BF: "16BF"}
+_DTYPE_COMPUTE = {ct.R_32F: "32F", ct.R_64F: "64F", ct.R_16F: "16F", ct.R_16BF: "16BF", ct.C_32F: "32F", ct.C_64F: "64F"}
 
 
 class Handle:
@@ -68,6 +68,10 @@ class Plan:
         self.scalar_type = st_type.value
 
     def scalar(self, x):
+        if self.scalar_type == ct.C_32F:
+            return (ctypes.c_float * 2)(complex(x).real, complex(x).imag)
+        if self.scalar_type == ct.C_64F:
+            return (ctypes.c_double * 2)(complex(x).real, complex(x).imag)
         return ctypes.c_double(x) if self.scalar_type == ct.R_64F else ctypes.c_float(x)
 
     def describe(self):
@@ -120,12 +124,13 @@ def _desc3(handle, specs, dtype, alignment):
 
 
 def contraction_plan(handle, extA, modesA, extB, modesB, extC, modesC, dtype=ct.R_32F, strideA=None,
-                     strideB=None, strideC=None, strideD=None, compute=None, alignment=128, **plan_kw):
+                     strideB=None, strideC=None, strideD=None, compute=None, alignment=128, opA=ct.OP_IDENTITY,
+                     opB=ct.OP_IDENTITY, opC=ct.OP_IDENTITY, **plan_kw):
     dA, dB, dC = _desc3(handle, [(extA, strideA), (extB, strideB), (extC, strideC)], dtype, alignment)
     dD = tensor_descriptor(handle, extC, strideD, dtype, alignment) if strideD is not None else dC
     op = ctypes.c_void_p()
-    st = ct.cutensorCreateContraction(handle.h, ctypes.byref(op), dA, ct.i32(modesA), ct.OP_IDENTITY, dB, ct.i32(modesB),
-                                      ct.OP_IDENTITY, dC, ct.i32(modesC), ct.OP_IDENTITY, dD, ct.i32(modesC),
+    st = ct.cutensorCreateContraction(handle.h, ctypes.byref(op), dA, ct.i32(modesA), opA, dB, ct.i32(modesB),
+                                      opB, dC, ct.i32(modesC), opC, dD, ct.i32(modesC),
                                       ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
     for d in {id(x): x for x in (dA, dB, dC, dD)}.values():
         ct.cutensorDestroyTensorDescriptor(d)

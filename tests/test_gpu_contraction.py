@@ -232,3 +232,62 @@ def test_contract_inside_a_captured_graph(built):
         graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_many_mode_contraction_uses_the_mode_table_kernel(built, dtype):
+    """Tensors with many small unfusable modes (the shape class of cuTENSOR/contraction_jit.cu:50-56: 25 / 13 / 24
+    modes of extent 2) exceed the four digits per group of the tiled kernels and run on the mode-table kernel;
+    parity against numpy.einsum in fp64 (fp32: rtol 1e-5 at K = 64)."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    # A: 14 modes, B: 10, C: 12; six contracted modes; neighbouring modes are swapped so that nothing fuses
+    mA = "badcfehgjilknm"
+    mB = "ponmlkqrst"[::-1]
+    mC = "".join(c for c in "abcdefghijopqrst" if (c in mA) != (c in mB))   # free modes in sorted order: (b,a) in A vs (a,b) in C ...
+    ext = {c: (3 if c in "aq" else 2) for c in set(mA + mB)}
+    np_dt = np.float32 if dtype == "float32" else np.float64
+    A = make_tensor([ext[c] for c in mA], 31, np_dt, -1, 1)
+    B = make_tensor([ext[c] for c in mB], 32, np_dt, -1, 1)
+    C = make_tensor([ext[c] for c in mC], 33, np_dt, -1, 1)
+    dA, dB, dC = to_device(A), to_device(B), to_device(C)
+    cdt = ct.R_32F if dtype == "float32" else ct.R_64F
+    plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC, dtype=cdt)
+    d = plan.describe()
+    assert d["kname"] == "gett_wide_kernel", d
+    plan.contract(1.5, dA.data_ptr(), dB.data_ptr(), -0.5, dC.data_ptr(), dC.data_ptr())
+    torch.cuda.synchronize()
+    got = from_device(dC, C)
+    ref = 1.5 * np.einsum("%s,%s->%s" % (mA, mB, mC), A.astype(np.float64), B.astype(np.float64)) - 0.5 * C
+    np.testing.assert_allclose(got, ref, rtol=1e-5 if dtype == "float32" else 1e-13, atol=1e-5 if dtype == "float32" else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_complex_contraction_with_conjugation(built, dtype):
+    """Complex data (cuTENSOR/contraction_jit.cu:31-41, std::complex<float> tensors and scalars) runs on the mode-table
+    kernel: D = alpha * conj(A) * B + beta * C with complex alpha / beta against numpy in complex128."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    rng = np.random.default_rng(41)
+    ext = dict(m=12, n=9, k=7, l=3)
+    np_dt = np.complex64 if dtype == "complex64" else np.complex128
+    def rnd(modes):
+        shape = [ext[c] for c in modes]
+        return (rng.random(shape) - 0.5 + 1j * (rng.random(shape) - 0.5)).astype(np_dt).copy(order="F")
+    A, B, C = rnd("mkl"), rnd("knl"), rnd("mnl")
+    tdt = torch.complex64 if dtype == "complex64" else torch.complex128
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x.ravel(order="K"))).to(tdt).cuda()
+    dA, dB, dC = dev(A), dev(B), dev(C)
+    cdt = ct.C_32F if dtype == "complex64" else ct.C_64F
+    plan = ops.contraction_plan(h, [ext[c] for c in "mkl"], "mkl", [ext[c] for c in "knl"], "knl", [ext[c] for c in "mnl"], "mnl",
+                                dtype=cdt, opA=ct.OP_CONJ)
+    assert plan.scalar_type == cdt
+    assert plan.describe()["kname"] == "gett_wide_kernel"
+    alpha, beta = 1.1 - 0.3j, 0.25 + 0.5j
+    plan.contract(alpha, dA.data_ptr(), dB.data_ptr(), beta, dC.data_ptr(), dC.data_ptr())
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy().reshape(C.shape, order="F")
+    ref = alpha * np.einsum("mkl,knl->mnl", np.conj(A).astype(np.complex128), B.astype(np.complex128)) + beta * C
+    np.testing.assert_allclose(got, ref, rtol=2e-5 if dtype == "complex64" else 1e-13, atol=2e-6 if dtype == "complex64" else 1e-13)

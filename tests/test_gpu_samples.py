@@ -12,10 +12,9 @@ pytestmark = pytest.mark.gpu
 
 REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 SAMPLES = ["contraction", "einsum", "reduction", "elementwise_permute", "elementwise_binary", "elementwise_trinary",
-           "elementwise_permute_padding", "contraction_plan_cache", "contraction_trinary", "blocksparse", "contraction_multi_gpu"]
-# contraction_jit.cu builds and links (cutensorRead/WriteKernelCacheToFile are exported) but its 25-mode extent-2
-# tensors need more than 4 unfusable modes per group -> CUTENSOR_STATUS_NOT_SUPPORTED from cutensorCreatePlan
-# (out of scope).
+           "elementwise_permute_padding", "contraction_plan_cache", "contraction_trinary", "blocksparse", "contraction_jit", "contraction_multi_gpu"]
+# contraction_jit.cu: its 25-mode extent-2 tensors run on the mode-table kernel (gett_wide_kernel); JIT mode is accepted and
+# ignored (every kernel is ahead-of-time compiled), the kernel-cache file calls succeed with an empty cache.
 
 
 @pytest.mark.parametrize("name", SAMPLES)
