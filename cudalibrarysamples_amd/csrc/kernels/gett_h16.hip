@@ -37,6 +37,7 @@
 // |A| + |B| + |D| (16-bit elements).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "params.h"
 #include "launch.h"
@@ -214,7 +215,9 @@ struct HOdometer {
     }
 };
 
-template <bool BF, int LA, int LB>
+// TIMED (measurement-only instantiation, selected with CUTENSOR_AMD_H16_TIMED=1): waves 0 and 4 of workgroup 0
+// record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
+template <bool BF, int LA, int LB, bool TIMED = false>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     prefetch_kernarg<(int)sizeof(GettParams)>();
@@ -317,9 +320,14 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     //   MFMA segment : own fragment reads are back (their latency overlapped the barrier), 8 x 32x32x16 on
     //                  one accumulator quadrant
     //   barrier
+#define CTAMD_H_STAMP(Q, I)                                                                        \
+    if constexpr (TIMED) {                                                                         \
+        if (tstamp && t8 == 8 && lane == 0) tstamp[(Q) * 7 + (I)] = __builtin_readcyclecounter();  \
+    }
 #define CTAMD_H_PHASE(P, Q)                                                                        \
     {                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        CTAMD_H_STAMP(Q, 0)                                                                        \
         if constexpr ((Q) == 0) { CTAMD_H_READ_A((P) * 4 + 0) CTAMD_H_READ_B((P) * 4 + 2, b0) }   \
         if constexpr ((Q) == 1) { CTAMD_H_READ_B((P) * 4 + 3, b1) }                                \
         if constexpr ((Q) == 2) { CTAMD_H_READ_A((P) * 4 + 1) }                                    \
@@ -333,9 +341,13 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
             if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
             offA2 = odo.offA; offB2 = odo.offB;                                                    \
         }                                                                                          \
+        CTAMD_H_STAMP(Q, 1)                                                                        \
         CTAMD_H_VMCNT(8);                                                                          \
+        CTAMD_H_STAMP(Q, 2)                                                                        \
         __builtin_amdgcn_s_barrier();                                                              \
+        CTAMD_H_STAMP(Q, 3)                                                                        \
         CTAMD_H_LGKM0();                                                                           \
+        CTAMD_H_STAMP(Q, 4)                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         CTAMD_H_FENCE_A()                                                                          \
         if constexpr ((Q) == 0 || (Q) == 3) { CTAMD_H_FENCE_B(b0) } else { CTAMD_H_FENCE_B(b1) }   \
@@ -346,13 +358,20 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         if constexpr ((Q) == 3) { CTAMD_H_MFMA(1, 0, b0) CTAMD_H_FENCE_ACC(1, 0) }                 \
         __builtin_amdgcn_s_setprio(0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        CTAMD_H_STAMP(Q, 5)                                                                        \
         __builtin_amdgcn_s_barrier();                                                              \
+        CTAMD_H_STAMP(Q, 6)                                                                        \
     }
 #define CTAMD_H_TILE(P) CTAMD_H_PHASE(P, 0) CTAMD_H_PHASE(P, 1) CTAMD_H_PHASE(P, 2) CTAMD_H_PHASE(P, 3)
 
+    unsigned long long* tstamp = nullptr;
+    int t8 = 0;
+    if constexpr (TIMED) {
+        if (p.timing != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4)) tstamp = p.timing + (wave >> 2) * 32;
+    }
     int t = 0;
-    for (; t + 1 < nTiles; t += 2) { CTAMD_H_TILE(0) CTAMD_H_TILE(1) }
-    if (t < nTiles) { CTAMD_H_TILE(0) }
+    for (; t + 1 < nTiles; t += 2) { t8 = t; CTAMD_H_TILE(0) t8 = t + 1; CTAMD_H_TILE(1) }
+    if (t < nTiles) { t8 = t; CTAMD_H_TILE(0) }
     if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
     CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive the workgroup
 
@@ -404,7 +423,11 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
+    if (timed && BF && LA == LAY_K && LB == LAY_F)
+        hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
