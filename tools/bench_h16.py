@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--layout", default="mk,kn")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands: cycle efficiency without the data-dependent power limit "
+                                                         "(never a quotable number, MI355X guide rule 25)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -29,6 +31,9 @@ def main():
     g.manual_seed(1)
     A = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(tdt)
     B = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(tdt)
+    if args.zeros:
+        A.zero_()
+        B.zero_()
     D = torch.empty((n, n), device="cuda", dtype=tdt)
     h = ops.Handle()
     plan = ops.contraction_plan(h, [n, n], mA, [n, n], mB, [n, n], "mn", dtype=cdt)
@@ -54,7 +59,7 @@ def main():
     peak = 256 * 4096 * 2.4e9
     # spot check against torch (rocBLAS is used here only as a checker of the bench's own output)
     ref = (A[:, :64].float().t() @ B[:64, :].float().t()) if False else None
-    print(json.dumps({"workload": "bf16 contraction %s,%s->mn n=%d" % (mA, mB, n), "dtype": args.dtype, "plan": desc,
+    print(json.dumps({"workload": "bf16 contraction %s,%s->mn n=%d%s" % (mA, mB, n, " ZERO-FILLED" if args.zeros else ""), "dtype": args.dtype, "plan": desc,
                       "ms_per_call": ms, "kernel_mean_ms": mean_ms.value, "kernel_min_ms": min_ms.value,
                       "tflops": flop / ms / 1e9, "kernel_tflops": flop / mean_ms.value / 1e9,
                       "frac_of_bf16_mfma_peak": flop / (mean_ms.value * 1e-3) / peak,
