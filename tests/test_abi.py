@@ -148,3 +148,110 @@ def test_einsum_helper_parsing(ct):
             n = ct.lib.ctamdEinsumOutputShape(e, out, 64)
             assert [out[i] for i in range(n)] == ref["output_shape"], eq
         ct.lib.ctamdEinsumDestroy(e)
+
+
+def _op_attr_float(ct, h, op, attr):
+    v = ctypes.c_float(0)
+    ct.check(ct.cutensorOperationDescriptorGetAttribute(h.h, op, attr, ctypes.byref(v), 4))
+    return v.value
+
+
+def test_trinary_contraction_pair_order_and_workspace(ct, ops):
+    """contraction_trinary.cu:44-67: D_{m,n,b,r,a} = A_{m,k,a,j,b,i} B_{k,n,i} C_{r,j}; the sample states the work as
+    flops(A*B) + flops((AB)*C) (:65-67) — the planner must find that order, and the workspace estimate must hold
+    the packed intermediate T_{m,a,j,b,n}."""
+    h = ops.Handle()
+    ext = dict(m=256, a=32, b=32, n=64, r=64, k=8, i=8, j=64)
+    mA, mB, mC, mD = "mkajbi", "kni", "rj", "mnbra"
+    dA, dB, dC, dD = [ops.tensor_descriptor(h, [ext[c] for c in m]) for m in (mA, mB, mC, mD)]
+    op = ctypes.c_void_p()
+    ct.check(ct.cutensorCreateContractionTrinary(h.h, ctypes.byref(op), dA, ct.i32(mA), ct.OP_IDENTITY, dB, ct.i32(mB), ct.OP_IDENTITY,
+                                                 dC, ct.i32(mC), ct.OP_IDENTITY, dD, ct.i32(mD), ct.OP_IDENTITY, dD, ct.i32(mD),
+                                                 ct.compute_desc("32F")))
+    e = ext
+    first = 2.0 * e["m"] * e["a"] * e["b"] * e["j"] * e["n"] * e["k"] * e["i"]
+    second = 2.0 * e["m"] * e["a"] * e["b"] * e["n"] * e["r"] * e["j"]
+    flops = _op_attr_float(ct, h, op, ct.OPERATION_DESCRIPTOR_FLOPS) if hasattr(ct, "OPERATION_DESCRIPTOR_FLOPS") else _op_attr_float(ct, h, op, 2)
+    assert abs(flops - (first + second)) / (first + second) < 1e-6
+    est = ctypes.c_uint64(0)
+    ct.check(ct.cutensorEstimateWorkspaceSize(h.h, op, None, ct.WORKSPACE_DEFAULT, ctypes.byref(est)))
+    t_bytes = 4 * e["m"] * e["a"] * e["j"] * e["b"] * e["n"]
+    assert est.value >= t_bytes
+    mn = ctypes.c_uint64(0)
+    ct.check(ct.cutensorEstimateWorkspaceSize(h.h, op, None, ct.WORKSPACE_MIN, ctypes.byref(mn)))
+    assert t_bytes <= mn.value <= est.value
+    ct.cutensorDestroyOperationDescriptor(op)
+
+
+def test_elementwise_trinary_descriptor_and_operator_checks(ct, ops):
+    """elementwise_trinary.cu:174-182; ADD/MUL/MAX/MIN combiners are served, anything else is NOT_SUPPORTED."""
+    h = ops.Handle()
+    ext = dict(a=40, b=20, c=30)
+    d = {m: ops.tensor_descriptor(h, [ext[c] for c in m]) for m in ("cba", "cab", "abc")}
+    for opAB, opABC, want in ((ct.OP_ADD, ct.OP_ADD, ct.STATUS_SUCCESS), (ct.OP_MUL, ct.OP_MAX, ct.STATUS_SUCCESS), (2, ct.OP_ADD, 15)):
+        op = ctypes.c_void_p()
+        st = ct.cutensorCreateElementwiseTrinary(h.h, ctypes.byref(op), d["cba"], ct.i32("cba"), ct.OP_IDENTITY, d["cab"], ct.i32("cab"),
+                                                 ct.OP_IDENTITY, d["abc"], ct.i32("abc"), ct.OP_IDENTITY, d["abc"], ct.i32("abc"),
+                                                 opAB, opABC, ct.compute_desc("32F"))
+        assert st == want
+        if st == ct.STATUS_SUCCESS:
+            moved = _op_attr_float(ct, h, op, 3)      # MOVED_BYTES: 4 |D| (elementwise_trinary.cu:234-238)
+            assert moved == 4.0 * 4 * 40 * 20 * 30
+            ct.cutensorDestroyOperationDescriptor(op)
+
+
+def test_many_mode_and_complex_contractions_are_accepted(ct, ops):
+    """contraction_jit.cu:31-56: 25 / 13 / 24 modes of extent 2, complex<float> data, complex scalar type."""
+    h = ops.Handle()
+    mC = [0, 1, 2, 3, 4, 6, 8, 9, 25, 26, 10, 12, 14, 27, 15, 28, 17, 19, 29, 20, 21, 30, 23, 24]
+    mA = [0, 2, 1, 4, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 19, 21, 22, 23, 24]
+    mB = [25, 26, 27, 28, 29, 30, 5, 7, 11, 13, 16, 18, 22]
+    dA, dB, dC = [ops.tensor_descriptor(h, [2] * len(m), dtype=ct.C_32F) for m in (mA, mB, mC)]
+    op = ctypes.c_void_p()
+    ct.check(ct.cutensorCreateContraction(h.h, ctypes.byref(op), dA, ct.i32(mA), ct.OP_IDENTITY, dB, ct.i32(mB), ct.OP_IDENTITY,
+                                          dC, ct.i32(mC), ct.OP_IDENTITY, dC, ct.i32(mC), ct.compute_desc("3XTF32")))
+    st = ctypes.c_int(0)
+    ct.check(ct.cutensorOperationDescriptorGetAttribute(h.h, op, ct.OPERATION_DESCRIPTOR_SCALAR_TYPE, ctypes.byref(st), 4))
+    assert st.value == ct.C_32F                     # contraction_jit.cu:205
+    est = ctypes.c_uint64(1)
+    ct.check(ct.cutensorEstimateWorkspaceSize(h.h, op, None, ct.WORKSPACE_DEFAULT, ctypes.byref(est)))
+    assert est.value == 0                           # the mode-table kernel needs no workspace
+    ct.cutensorDestroyOperationDescriptor(op)
+    # complex element-wise operations are not served
+    p = ctypes.c_void_p()
+    assert ct.cutensorCreatePermutation(h.h, ctypes.byref(p), dA, ct.i32(mA), ct.OP_IDENTITY, dA, ct.i32(mA), ct.compute_desc("32F")) == 15
+
+
+def test_blocksparse_descriptor_validation(ct, ops):
+    """blocksparse.cu:102-107: section index out of range / non-positive section extent are INVALID_VALUE."""
+    h = ops.Handle()
+    nsec = (ctypes.c_uint32 * 2)(2, 2)
+    d = ctypes.c_void_p()
+    ok = ct.cutensorCreateBlockSparseTensorDescriptor(h.h, ctypes.byref(d), 2, 2, nsec, ct.i64([4, 5, 6, 7]), ct.i32([0, 0, 1, 1]), None, ct.R_64F)
+    assert ok == ct.STATUS_SUCCESS
+    assert ct.cutensorDestroyBlockSparseTensorDescriptor(d) == ct.STATUS_SUCCESS
+    bad = ct.cutensorCreateBlockSparseTensorDescriptor(h.h, ctypes.byref(d), 2, 1, nsec, ct.i64([4, 5, 6, 7]), ct.i32([0, 2]), None, ct.R_64F)
+    assert bad == ct.STATUS_INVALID_VALUE
+    bad = ct.cutensorCreateBlockSparseTensorDescriptor(h.h, ctypes.byref(d), 2, 1, nsec, ct.i64([4, 0, 6, 7]), ct.i32([0, 0]), None, ct.R_64F)
+    assert bad == ct.STATUS_INVALID_VALUE
+
+
+def test_padding_attributes(ct, ops):
+    """elementwise_permute_padding.cu:178-195: one int per output mode; wrong sizes are INVALID_VALUE; non-permutation
+    descriptors refuse the attribute."""
+    h = ops.Handle()
+    dA = ops.tensor_descriptor(h, [8, 6, 4])
+    dC = ops.tensor_descriptor(h, [4, 8, 6])
+    op = ctypes.c_void_p()
+    ct.check(ct.cutensorCreatePermutation(h.h, ctypes.byref(op), dA, ct.i32("whc"), ct.OP_IDENTITY, dC, ct.i32("cwh"), ct.compute_desc("32F")))
+    pad = (ctypes.c_int32 * 3)(0, 1, 2)
+    assert ct.cutensorOperationDescriptorSetAttribute(h.h, op, 4, pad, 12) == ct.STATUS_SUCCESS
+    assert ct.cutensorOperationDescriptorSetAttribute(h.h, op, 5, pad, 8) == ct.STATUS_INVALID_VALUE
+    v = ctypes.c_float(1.5)
+    assert ct.cutensorOperationDescriptorSetAttribute(h.h, op, 6, ctypes.byref(v), 4) == ct.STATUS_SUCCESS
+    ct.cutensorDestroyOperationDescriptor(op)
+    red = ctypes.c_void_p()
+    dR = ops.tensor_descriptor(h, [8])
+    ct.check(ct.cutensorCreateReduction(h.h, ctypes.byref(red), dA, ct.i32("whc"), ct.OP_IDENTITY, dR, ct.i32("w"), ct.OP_IDENTITY, dR, ct.i32("w"),
+                                        ct.OP_ADD, ct.compute_desc("32F")))
+    assert ct.cutensorOperationDescriptorSetAttribute(h.h, red, 4, pad, 12) == 15
