@@ -100,6 +100,7 @@ bool misaligned(const void* p, uint32_t a) { return a > 1 && (reinterpret_cast<u
 // Optional per-kernel timing of the dominant (GETT) kernel with HIP events recorded on the caller's
 // stream, for bench.py's roofline line.  Off by default; see ctamdProfileBegin/End below.
 unsigned long long* g_timingBuffer = nullptr;   // diagnostics: see ctamdSetTimingBuffer
+bool g_skipFold = false;                        // diagnostics: see ctamdSetSplitKFold
 
 struct KernelProfile {
     bool enabled = false;
@@ -1096,7 +1097,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             std::lock_guard<std::mutex> g(g_prof.mtx);
             g_prof.events.emplace_back(e0, e1);
         }
-        if (err == hipSuccess && plan->choice.splitK > 1 && !plan->fusedFold) {
+        if (err == hipSuccess && plan->choice.splitK > 1 && !plan->fusedFold && !g_skipFold) {
             SplitKReduceParams r = plan->skr;
             r.partial = static_cast<float*>(workspace);
             r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
@@ -1322,6 +1323,11 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
 // Diagnostics: device buffer of 8 x uint64 per workgroup that the GETT kernel fills with phase
 // timestamps (shader clock and wall clock); nullptr switches it off.
 void ctamdSetTimingBuffer(void* deviceBuffer) { g_timingBuffer = static_cast<unsigned long long*>(deviceBuffer); }
+
+// Diagnostics: enabled = 0 makes cutensorContract launch the GETT kernel only (the split-K partials stay unfolded, D is
+// not written) so that a stream of back-to-back GETT launches can be timed with one event pair — per-launch event
+// pairs put a ~6 us idle gap after every kernel and the chip leaves its steady clock state.  Never used by the samples.
+void ctamdSetSplitKFold(int enabled) { g_skipFold = (enabled == 0); }
 
 // Per-kernel timing of the GETT kernel inside cutensorContract: Begin() arms it, End() synchronises the
 // recorded event pairs and returns the number of launches and their mean / min duration in ms.

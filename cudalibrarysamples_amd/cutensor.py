@@ -97,6 +97,8 @@ lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
 lib.ctamdSetTimingBuffer.argtypes = [_vp]
 lib.ctamdSetTimingBuffer.restype = None
+lib.ctamdSetSplitKFold.argtypes = [ctypes.c_int]
+lib.ctamdSetSplitKFold.restype = None
 lib.ctamdProfileBegin.restype = None
 lib.ctamdProfileEnd.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 lib.ctamdEinsumCreate.argtypes = [ctypes.c_char_p, _i64p, ctypes.c_int, _i64p, ctypes.c_int, ctypes.c_int]
