@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=8192)
-    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--dtype", default="bfloat16")
     ap.add_argument("--layout", default="mk,kn")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands: cycle efficiency without the data-dependent power limit "
@@ -39,7 +39,7 @@ def main():
     plan = ops.contraction_plan(h, [n, n], mA, [n, n], mB, [n, n], "mn", dtype=cdt)
     desc = plan.describe()
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(3):
+    for _ in range(60):   # ~50 ms: past the device's clock ramp (cold vs steady state)
         plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
