@@ -755,7 +755,12 @@ static hipError_t launch_stream(const GettParams& p, hipStream_t stream) {
     XS(64, 64, LAY_F, LAY_F, 4)         \
     XS(64, 64, LAY_K, LAY_F, 4)         \
     XS(64, 64, LAY_F, LAY_K, 4)         \
-    XS(64, 64, LAY_K, LAY_K, 4)
+    XS(64, 64, LAY_K, LAY_K, 4)         \
+    XS(96, 96, LAY_F, LAY_F, 3)         \
+    XS(96, 96, LAY_F, LAY_K, 3)         \
+    XS(96, 96, LAY_K, LAY_K, 3)         \
+    XS(128, 128, LAY_F, LAY_F, 3)       \
+    XS(128, 128, LAY_K, LAY_F, 3)
 
 #define CTAMD_STREAM_ENTRY(bm, bn, la, lb, s) \
     {bm, bn, kStreamBK, 2, 2, 1, la, lb, 512, s, 1, 0, &launch_stream<StreamCfg<bm, bn, la, lb, s>>, 1},
