@@ -600,6 +600,11 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         ContractionView v;
         cutensorStatus_t st = build_contraction_view(*desc, v, nullptr);
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        if (!v.wide && (v.dtype == HIP_R_16BF || v.dtype == HIP_R_16F)) {   // split-K partials of the 16-bit MFMA kernel
+            ContractionChoice hc;
+            if (pick_h16_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
         if (v.dtype != HIP_R_32F || v.wide) return CUTENSOR_STATUS_SUCCESS;
         // the largest workspace any of the best few candidates would like to have
         std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs);
@@ -904,7 +909,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 pick = ch[idx];
             }
         }
-        if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, pick);
+        if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, workspaceSizeLimit, handle->numCUs, pick);
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
         pl->requiredWorkspace = pick.workspace;
@@ -1066,7 +1071,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     } else if (plan->choice.family == 1) {
         int count = 0;
         const GettKernelInfo* tab = gett_h16_kernels(&count);
-        p.partial = nullptr;
+        p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
@@ -1075,6 +1080,12 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             (void)hipEventRecord(e1, stream);
             std::lock_guard<std::mutex> g(g_prof.mtx);
             g_prof.events.emplace_back(e0, e1);
+        }
+        if (err == hipSuccess && plan->choice.splitK > 1) {
+            SplitKReduceParams r = plan->skr;
+            r.partial = static_cast<float*>(workspace);
+            r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
+            err = launch_splitk_reduce(r, stream);
         }
     } else {
         int count = 0;

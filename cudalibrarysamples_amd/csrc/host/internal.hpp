@@ -104,7 +104,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
 // Ranked candidate list (best first) under a workspace limit.
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
                                                         int numCUs);
-bool pick_h16_choice(const ContractionView& v, ContractionChoice& c);
+bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
 void fill_gett_params(const ContractionView& v, const ContractionChoice& c, GettParams& p,
                       SplitKReduceParams& r);
 

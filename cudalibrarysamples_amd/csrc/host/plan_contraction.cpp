@@ -366,7 +366,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 // 16-bit data (bf16 / fp16, fp32 accumulation): one kernel shape (256 x 256 x 64, gett_h16.hip), picked
 // when both operands admit 16-byte lanes, the fastest contracted mode holds whole 64-deep K-tiles and
 // both operands can be addressed with 32-bit byte offsets.  Returns false -> the simple kernel runs.
-bool pick_h16_choice(const ContractionView& v, ContractionChoice& c) {
+bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c) {
     if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
     if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
     if (v.K.empty() || v.K.front().extent % 64 != 0 || v.totK % 64 != 0) return false;
@@ -383,11 +383,21 @@ bool pick_h16_choice(const ContractionView& v, ContractionChoice& c) {
     c.family = 1;
     c.kernel = (v.dtype == HIP_R_16BF ? 0 : 4) + (v.layA == LAY_F ? 2 : 0) + (v.layB == LAY_F ? 1 : 0);
     if (c.kernel >= count) return false;
-    c.splitK = 1;
-    c.kPerSlice = (uint32_t)v.totK;
-    c.workspace = 0;
     const double tiles = std::ceil((double)v.totM / tab[c.kernel].bm) * std::ceil((double)v.totN / tab[c.kernel].bn) * (double)v.totL;
-    c.estimateUs = std::ceil(tiles / 256.0) * (2.0 * tab[c.kernel].bm * tab[c.kernel].bn * (double)v.totK) / (4096.0 * 2.4e9 * 0.6) * 1e6;
+    // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
+    const uint64_t kTiles = v.totK / 64;
+    uint64_t split = 1;
+    if (tiles * 2.0 <= (double)numCUs && kTiles >= 8) {
+        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
+        const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
+        while (split > 1 && split * perSliceBytes > wsLimit) --split;
+        if (split < 2) split = 1;
+    }
+    const uint64_t tilesPerSlice = (kTiles + split - 1) / split;
+    c.splitK = (uint32_t)((kTiles + tilesPerSlice - 1) / tilesPerSlice);
+    c.kPerSlice = (uint32_t)(tilesPerSlice * 64);
+    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
+    c.estimateUs = std::ceil(tiles * c.splitK / (double)numCUs) * (2.0 * tab[c.kernel].bm * tab[c.kernel].bn * (double)c.kPerSlice) / (4096.0 * 2.4e9 * 0.5) * 1e6;
     return true;
 }
 
@@ -442,6 +452,7 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
     r.splitK = c.splitK;
     r.tilesM = p.tilesM; r.tilesN = p.tilesN;
     r.fragTM = (uint32_t)bm / 32u; r.fragTN = (uint32_t)bn / 32u;
+    r.outType = (c.family == 1) ? (v.dtype == HIP_R_16BF ? 1 : 2) : 0;
 }
 
 }  // namespace ctamd

@@ -783,8 +783,25 @@ __global__ void __launch_bounds__(512) splitk_reduce_kernel(const SplitKReducePa
     group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
     group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
     float val = p.alpha * sum;
-    if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[oCl + oCm + oCn];
-    static_cast<float*>(p.D)[oDl + oDm + oDn] = val;
+    if (p.outType == 0) {
+        if (p.beta != 0.f) val += p.beta * static_cast<const float*>(p.C)[oCl + oCm + oCn];
+        static_cast<float*>(p.D)[oDl + oDm + oDn] = val;
+    } else {   // 16-bit data of the gett_h16 kernels: fp32 partials, one rounding of the result
+        const bool bf = p.outType == 1;
+        if (p.beta != 0.f) {
+            const uint16_t c = static_cast<const uint16_t*>(p.C)[oCl + oCm + oCn];
+            val += p.beta * (bf ? __uint_as_float((uint32_t)c << 16) : (float)__builtin_bit_cast(_Float16, c));
+        }
+        uint16_t out;
+        if (bf) {
+            uint32_t u = __float_as_uint(val);
+            if ((u & 0x7fffffffu) > 0x7f800000u) out = (uint16_t)((u >> 16) | 0x40u);
+            else { u += 0x7fffu + ((u >> 16) & 1u); out = (uint16_t)(u >> 16); }
+        } else {
+            out = __builtin_bit_cast(uint16_t, (_Float16)val);
+        }
+        static_cast<uint16_t*>(p.D)[oDl + oDm + oDn] = out;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -187,11 +187,16 @@ struct HOdometer {
     uint32_t j0, n0, j1, e1, hi;
     uint32_t offA, offB, stepA, stepB, wrapA, wrapB;
     __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ __forceinline__ void init(const ModeGroup& gK) {
+    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
         const uint32_t E0 = gK.div[0].d;
         n0 = sgpr(E0 / kHBK);
         e1 = sgpr(gK.div[1].d);
-        j0 = 0; j1 = 0; hi = 0; offA = 0; offB = 0;
+        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
+        j0 = sgpr((k0 - q0 * E0) / kHBK);
+        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
+        j1 = sgpr(q0 - hi * e1);
+        offA = sgpr(group_offset32<0>(gK, k0) * 2u);
+        offB = sgpr(group_offset32<1>(gK, k0) * 2u);
         stepA = sgpr((uint32_t)((int64_t)kHBK * gK.stride[0][0]) * 2u);
         stepB = sgpr((uint32_t)((int64_t)kHBK * gK.stride[1][0]) * 2u);
         wrapA = sgpr((uint32_t)gK.stride[0][1] * 2u - (n0 - 1) * stepA);
@@ -232,6 +237,9 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     //      at a time form an 8 x 4 block (12 operand panels for 32 tiles) ---------------------------------
     uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
     const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;          // split-K: slice-major ids (splitK == 1: slice = 0)
+    id -= slice * tilesAll;
     const uint32_t l = id / tilesMN;
     id -= l * tilesMN;
     const uint32_t perGroup = 8u * p.tilesN;
@@ -240,7 +248,10 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
-    const int nTiles = (int)(p.gK.total / kHBK);
+    // K range of this slice in K-tiles (fast-K: every tile is full)
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
     const HRsrc rA = h_make_rsrc(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l));
     const HRsrc rB = h_make_rsrc(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l));
@@ -255,7 +266,7 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     const uint32_t offFa0 = h_offF(lane, 2 * wr), offFa1 = h_offF(lane, 2 * wr + 1), offFb = h_offF(lane, wc);
 
     HOdometer odo;
-    odo.init(p.gK);
+    odo.init(p.gK, tile0 * kHBK);
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
 
     // ---- prologue: K-tile 0 and the first halves of K-tile 1, in consumption order ---------------------
@@ -375,6 +386,28 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
     CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive the workgroup
 
+    // ---- split-K: fp32 partial tile, row-major [slice][l][m][n] (32 lanes x 4 B contiguous along n); the fold
+    //      (splitk_reduce_kernel, 16-bit output) applies alpha / beta -------------------------------------------
+    if (p.partial != nullptr) {
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t na = n0 + 32 * wc + (lane & 31), nb = na + 128;
+                    if (na < Nt) P[(size_t)m * Nt + na] = c0[r];
+                    if (nb < Nt) P[(size_t)m * Nt + nb] = c1[r];
+                }
+            }
+        };
+        store_partial(acc[0][0][0], acc[0][0][1], m0 + 64 * wr);
+        store_partial(acc[0][1][0], acc[0][1][1], m0 + 64 * wr + 32);
+        store_partial(acc[1][0][0], acc[1][0][1], m0 + 128 + 64 * wr);
+        store_partial(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
+        return;
+    }
     // ---- epilogue: D = alpha * acc + beta * C, 16-bit stores (32 lanes x 2 B contiguous along n) -------
     const uint16_t* C = static_cast<const uint16_t*>(p.C);
     uint16_t*       D = static_cast<uint16_t*>(p.D);

@@ -92,6 +92,7 @@ struct SplitKReduceParams {
     // accumulator-order partials (streaming kernels): output tile grid and 16x16 fragments per wave
     uint32_t     tilesM, tilesN;
     uint32_t     fragTM, fragTN;
+    int32_t      outType;        // C / D element type of the row-major fold: 0 = fp32, 1 = bf16, 2 = fp16
 };
 
 // ---------------------------------------------------------------------------------------------

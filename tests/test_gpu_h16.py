@@ -46,7 +46,8 @@ def _run(env, ext, mA, mB, mC, dtype_name="bfloat16", alpha=1.0, beta=0.0, seed=
     d = plan.describe()
     if expect_mfma:
         assert d["family"] == 1 and d["kernel"] >= 0, d
-    plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr())
+    ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
     torch.cuda.synchronize()
     # oracle on the rounded inputs: fp64 einsum over the reversed (row-major) views
     rA, rB, rC = mA[::-1], mB[::-1], mC[::-1]
@@ -119,3 +120,40 @@ def test_full_size_8192_sampled(env):
     got = D1[ni, mi].double().cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.15)     # |sum of 8192 U(-1,1)^2 terms| ~ 30; atol covers cancellation
     np.testing.assert_array_equal((D1.float() * 2).cpu().numpy(), D2.float().cpu().numpy())   # exact: scaling by 2 commutes with rounding
+
+
+@pytest.mark.parametrize("dims", [(96, 96, 4096), (264, 120, 1536), (512, 256, 8192)])
+def test_split_k_for_small_outputs(env, dims):
+    """Few output tiles and a long K: the 16-bit kernel splits K over the idle CUs (fp32 partials in the workspace,
+    folded with one rounding to the 16-bit type)."""
+    torch, ct, ops, h = env
+    m, n, k = dims
+    tdt = torch.bfloat16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    A = (torch.rand((k, m), generator=g, device="cuda") * 2 - 1).to(tdt)      # A[m,k] column-major
+    B = (torch.rand((n, k), generator=g, device="cuda") * 2 - 1).to(tdt)      # B[k,n] column-major
+    C = (torch.rand((n, m), generator=g, device="cuda") * 2 - 1).to(tdt)
+    D = torch.empty_like(C)
+    plan = ops.contraction_plan(h, [m, k], "mk", [k, n], "kn", [m, n], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
+    d = plan.describe()
+    assert d["family"] == 1 and d["splitK"] > 1 and plan.required_workspace > 0, d
+    ws = torch.empty(plan.required_workspace, dtype=torch.uint8, device="cuda")
+    plan.contract(1.25, A.data_ptr(), B.data_ptr(), -0.5, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
+    torch.cuda.synchronize()
+    ref = 1.25 * (B.double().cpu() @ A.double().cpu()) - 0.5 * C.double().cpu()     # [n][m] = sum_k B[n][k] A[k][m]
+    np.testing.assert_allclose(D.double().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=0.1)
+    # without workspace the same plan falls back to one slice
+    plan1 = ops.contraction_plan(h, [m, k], "mk", [k, n], "kn", [m, n], "mn", dtype=ct.R_16BF, workspace_limit=0)
+    assert plan1.describe()["splitK"] == 1 and plan1.required_workspace == 0
+    D1 = torch.empty_like(C)
+    plan1.contract(1.25, A.data_ptr(), B.data_ptr(), -0.5, C.data_ptr(), D1.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(D1.double().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=0.1)
+
+
+def test_headline_einsum_shape_in_bf16(env):
+    """'abcd,dcbe->ae' (einsum.cu helper view) with 16-bit data: one 96 x 96 output tile, K = b*c*d split over the CUs."""
+    got, ref, d = _run(env, dict(a=96, b=16, c=16, d=64, e=96), "dcba", "ebcd", "ea", seed=23)
+    assert d["splitK"] > 1, d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.25)
