@@ -18,6 +18,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <complex>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -51,9 +52,25 @@ template <> struct EinsumTypeTraits<__hip_bfloat16> {
     typedef float ScalarType;
 };
 
+// complex data (python/cutensor/torch/einsum_test.py:56-68: complex64 / complex128 cases): contractions only
+template <> struct EinsumTypeTraits<std::complex<float>> {
+    static cutensorDataType_t dataType() { return CUTENSOR_C_32F; }
+    static cutensorComputeDescriptor_t computeDesc() { return CUTENSOR_COMPUTE_DESC_32F; }
+    typedef std::complex<float> ScalarType;
+};
+template <> struct EinsumTypeTraits<std::complex<double>> {
+    static cutensorDataType_t dataType() { return CUTENSOR_C_64F; }
+    static cutensorComputeDescriptor_t computeDesc() { return CUTENSOR_COMPUTE_DESC_64F; }
+    typedef std::complex<double> ScalarType;
+};
+
 template <typename ComputeType, typename IntType, int kMaxNumModes_>
 class Einsum {
 public:
+    // conjugate an operand inside the contraction (python/einsum.h: the conjA / conjB arguments the PyTorch binding
+    // uses for complex gradients, torch/einsum.py:50-61); call before plan() / execute()
+    void setConjugate(bool conjA, bool conjB) { conjA_ = conjA; conjB_ = conjB; }
+
     Einsum(const std::string& equation, const std::vector<IntType>& A_shape,
            const std::vector<IntType>& B_shape = std::vector<IntType>()) {
         if (equation.find("...") != std::string::npos) return;   // broadcasting: not supported
@@ -139,7 +156,8 @@ public:
                   cutensorCreatePlanPreference(handle, &pref, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE) == CUTENSOR_STATUS_SUCCESS;
         if (ok && !modesB_.empty()) {
             ok = cutensorCreateTensorDescriptor(handle, &dB, (uint32_t)modesB_.size(), extentB_.data(), nullptr, type, kAlignment) == CUTENSOR_STATUS_SUCCESS &&
-                 cutensorCreateContraction(handle, &op, dA, modesA_.data(), CUTENSOR_OP_IDENTITY, dB, modesB_.data(), CUTENSOR_OP_IDENTITY,
+                 cutensorCreateContraction(handle, &op, dA, modesA_.data(), conjA_ ? CUTENSOR_OP_CONJ : CUTENSOR_OP_IDENTITY, dB, modesB_.data(),
+                                           conjB_ ? CUTENSOR_OP_CONJ : CUTENSOR_OP_IDENTITY,
                                            dC, modesC_.data(), CUTENSOR_OP_IDENTITY, dC, modesC_.data(), compute) == CUTENSOR_STATUS_SUCCESS;
         } else if (ok) {
             ok = cutensorCreateReduction(handle, &op, dA, modesA_.data(), CUTENSOR_OP_IDENTITY, dC, modesC_.data(), CUTENSOR_OP_IDENTITY,
@@ -182,6 +200,7 @@ public:
 private:
     static const size_t kWorksize_ = 1024ULL * 1024ULL * 1024ULL;   // 1 GiB, as einsum.cu:380
     bool isInitialized_ = false;
+    bool conjA_ = false, conjB_ = false;
     std::vector<int32_t> modesA_, modesB_, modesC_;
     std::vector<int64_t> extentA_, extentB_, extentC_;
     cutensorPlan_t plan_ = nullptr;

@@ -17,6 +17,7 @@ struct Base {
     virtual uint64_t required() const = 0;
     virtual bool exec(cutensorHandle_t h, const void* A, const void* B, void* C, void* w, hipStream_t s) = 0;
     virtual cutensorPlan_t raw() const = 0;
+    virtual void conj(bool a, bool b) = 0;
 };
 template <typename T>
 struct Impl : Base {
@@ -30,6 +31,7 @@ struct Impl : Base {
         return e.execute(h, A, B, C, w, s);
     }
     cutensorPlan_t raw() const override { return e.rawPlan(); }
+    void conj(bool a, bool b) override { e.setConjugate(a, b); }
 };
 }  // namespace
 
@@ -43,10 +45,13 @@ void* ctamdEinsumCreate(const char* equation, const int64_t* shapeA, int nA, con
         case HIP_R_64F:  return static_cast<Base*>(new (std::nothrow) Impl<double>(equation, a, b));
         case HIP_R_16F:  return static_cast<Base*>(new (std::nothrow) Impl<__half>(equation, a, b));
         case HIP_R_16BF: return static_cast<Base*>(new (std::nothrow) Impl<__hip_bfloat16>(equation, a, b));
+        case HIP_C_32F:  return static_cast<Base*>(new (std::nothrow) Impl<std::complex<float>>(equation, a, b));
+        case HIP_C_64F:  return static_cast<Base*>(new (std::nothrow) Impl<std::complex<double>>(equation, a, b));
         default: return nullptr;
     }
 }
 void ctamdEinsumDestroy(void* e) { delete static_cast<Base*>(e); }
+void ctamdEinsumSetConjugate(void* e, int conjA, int conjB) { if (e) static_cast<Base*>(e)->conj(conjA != 0, conjB != 0); }
 int ctamdEinsumIsInitialized(void* e) { return e && static_cast<Base*>(e)->init() ? 1 : 0; }
 int ctamdEinsumOutputShape(void* e, int64_t* out, int cap) {
     if (!e) return -1;

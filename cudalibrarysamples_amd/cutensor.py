@@ -103,6 +103,8 @@ lib.ctamdProfileBegin.restype = None
 lib.ctamdProfileEnd.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 lib.ctamdEinsumCreate.argtypes = [ctypes.c_char_p, _i64p, ctypes.c_int, _i64p, ctypes.c_int, ctypes.c_int]
 lib.ctamdEinsumCreate.restype = _vp
+lib.ctamdEinsumSetConjugate.argtypes = [_vp, ctypes.c_int, ctypes.c_int]
+lib.ctamdEinsumSetConjugate.restype = None
 lib.ctamdEinsumDestroy.argtypes = [_vp]
 lib.ctamdEinsumDestroy.restype = None
 lib.ctamdEinsumIsInitialized.argtypes = [_vp]

@@ -10,7 +10,8 @@ import torch
 
 from . import cutensor as ct
 
-_TORCH2CT = {torch.float32: ct.R_32F, torch.float64: ct.R_64F, torch.float16: ct.R_16F, torch.bfloat16: ct.R_16BF}
+_TORCH2CT = {torch.float32: ct.R_32F, torch.float64: ct.R_64F, torch.float16: ct.R_16F, torch.bfloat16: ct.R_16BF,
+             torch.complex64: ct.C_32F, torch.complex128: ct.C_64F}   # complex: binary contractions only
 
 _handle = None
 
@@ -29,11 +30,13 @@ def get_handle():
 class EinsumPlan:
     """Parsed + planned equation for fixed shapes/dtype (plan()/execute() split of python/einsum.h)."""
 
-    def __init__(self, equation, a_shape, b_shape, dtype):
+    def __init__(self, equation, a_shape, b_shape, dtype, conj_a=False, conj_b=False):
         self.e = ct.lib.ctamdEinsumCreate(equation.encode(), ct.i64(list(a_shape)), len(a_shape),
                                           ct.i64(list(b_shape)), len(b_shape), _TORCH2CT[dtype])
         if not self.e or not ct.lib.ctamdEinsumIsInitialized(self.e):
             raise ValueError("cutensor einsum: '%s' not supported for shapes %s, %s" % (equation, tuple(a_shape), tuple(b_shape)))
+        if conj_a or conj_b:
+            ct.lib.ctamdEinsumSetConjugate(self.e, int(conj_a), int(conj_b))
         out = (ctypes.c_int64 * 64)()
         n = ct.lib.ctamdEinsumOutputShape(self.e, out, 64)
         self.output_shape = [out[i] for i in range(n)]
@@ -65,16 +68,17 @@ _plans = {}
 _workspace = {}
 
 
-def einsum(equation, a, b=None):
-    """out = einsum(equation, a[, b]) on the GPU holding `a`.  Inputs must be contiguous."""
+def einsum(equation, a, b=None, conj_a=False, conj_b=False):
+    """out = einsum(equation, a[, b]) on the GPU holding `a`.  Inputs must be contiguous.  conj_a / conj_b conjugate an
+    operand inside the contraction (python/cutensor/torch/einsum.py:50-61 uses them for complex gradients)."""
     if not a.is_cuda:
         raise RuntimeError("cutensor einsum runs on the GPU only (there is no CPU path)")
     a = a.contiguous()
     b = b.contiguous() if b is not None else None
-    key = (equation, tuple(a.shape), tuple(b.shape) if b is not None else (), a.dtype)
+    key = (equation, tuple(a.shape), tuple(b.shape) if b is not None else (), a.dtype, bool(conj_a), bool(conj_b))
     plan = _plans.get(key)
     if plan is None:
-        plan = _plans[key] = EinsumPlan(equation, a.shape, b.shape if b is not None else (), a.dtype)
+        plan = _plans[key] = EinsumPlan(equation, a.shape, b.shape if b is not None else (), a.dtype, conj_a, conj_b)
     out = torch.empty(plan.output_shape, dtype=a.dtype, device=a.device)
     ws = None
     if plan.required_workspace:
@@ -130,19 +134,20 @@ class EinsumFunction(torch.autograd.Function):
         if ctx.is_binary:
             a, b = ctx.saved_tensors
             mode_a, mode_b = lhs.split(",")
-            d_a = _grad_einsum(mode_c, grad_output, mode_b, b.detach(), mode_a, a.shape) if ctx.needs_input_grad[1] else None
-            d_b = _grad_einsum(mode_a, a.detach(), mode_c, grad_output, mode_b, b.shape) if ctx.needs_input_grad[2] else None
+            cj = torch.is_complex(a) or torch.is_complex(b)      # einsum.py:53-61: conjugate the saved operand
+            d_a = _grad_einsum(mode_c, grad_output, mode_b, b.detach(), mode_a, a.shape, False, cj) if ctx.needs_input_grad[1] else None
+            d_b = _grad_einsum(mode_a, a.detach(), mode_c, grad_output, mode_b, b.shape, cj, False) if ctx.needs_input_grad[2] else None
             return None, d_a, d_b
         d_in = _grad_einsum(mode_c, grad_output, None, None, lhs, ctx.in_shape) if ctx.needs_input_grad[1] else None
         return None, d_in, None
 
 
-def _grad_einsum(m0, t0, m1, t1, m_out, out_shape):
+def _grad_einsum(m0, t0, m1, t1, m_out, out_shape, conj0=False, conj1=False):
     """einsum(m0[,m1] -> m_out); modes of m_out that neither operand carries (they were summed away in the
     forward pass) are broadcast afterwards — a stride-0 view, no copy."""
     present = [c for c in m_out if c in m0 or (m1 is not None and c in m1)]
     eq = m0 + ("," + m1 if m1 is not None else "") + "->" + "".join(present)
-    g = einsum(eq, t0, t1)
+    g = einsum(eq, t0, t1, conj0, conj1)
     if len(present) == len(m_out):
         return g
     view = [out_shape[i] if c in present else 1 for i, c in enumerate(m_out)]

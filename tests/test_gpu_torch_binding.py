@@ -7,8 +7,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BINARY = [  # einsum_test.py:49-118 (complex cases are out of scope)
+BINARY = [  # einsum_test.py:49-118
     ("test0", (48, 37), (37, 74), "ik,kj->ij", "float32"),
+    ("test0_complex", (50, 50), (50, 50), "ik,kj->ij", "complex64"),
+    ("test1_complex", (50, 50, 50), (50, 50, 50), "lik,lkj->lij", "complex128"),
     ("test2", (50, 50, 50, 20), (50, 50, 50, 20), "likm,lkjm->lij", "float32"),
     ("test3", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "float32"),
     ("test4", (50, 50), (50, 50), "ik,kj->ij", "float16"),
@@ -21,6 +23,7 @@ GENERAL = [  # einsum_test.py:165-196
     ("g0", [(50, 60), (60, 40)], "ik,kj->ji", "float32"),
     ("g1", [(50, 60), (60, 7), (7, 8)], "ik,kl,lj->ij", "float32"),
     ("g2", [(50, 60), (60, 7), (7, 8)], "ik,kl,lj", "float32"),
+    ("g3_complex", [(50, 60), (60, 7), (7, 8)], "ik,kl,lj->ij", "complex64"),
     ("g4", [(50, 60)], "ij->ji", "float32"),
 ]
 
@@ -33,8 +36,16 @@ def te(built):
     return torch, torch_einsum
 
 
+def _wide(torch, dtype):
+    return torch.complex128 if dtype.startswith("complex") else torch.float64
+
+
 def _close(torch, got, ref, dtype):
     assert got.shape == ref.shape
+    if dtype.startswith("complex"):   # einsum_test.py:37-40: real and imaginary parts separately
+        _close(torch, torch.real(got), torch.real(ref), "float32" if dtype == "complex64" else "float64")
+        _close(torch, torch.imag(got), torch.imag(ref), "float32" if dtype == "complex64" else "float64")
+        return
     torch.testing.assert_close(got.double().cpu(), ref, rtol=5e-3, atol=6e-3)
     if dtype in ("float32", "float64"):
         torch.testing.assert_close(got.double().cpu(), ref, rtol=2e-4, atol=2e-3)
@@ -45,13 +56,13 @@ def test_einsum_function_forward_and_gradients(te, name, a_size, b_size, equatio
     torch, tein = te
     torch.manual_seed(0)
     dt = getattr(torch, dtype)
-    scale = 1.0 if dtype in ("float32", "float64") else 0.25    # keep 16-bit sums of 50*20 terms inside the reference's atol
-    A = (torch.randn(*a_size) * scale).to(dt).cuda().requires_grad_(True)
-    B = (torch.randn(*b_size) * scale).to(dt).cuda().requires_grad_(True)
+    scale = 0.25 if dtype in ("float16", "bfloat16") else 1.0   # keep 16-bit sums of 50*20 terms inside the reference's atol
+    A = (torch.randn(*a_size, dtype=dt if dt.is_complex else torch.float32) * scale).to(dt).cuda().requires_grad_(True)
+    B = (torch.randn(*b_size, dtype=dt if dt.is_complex else torch.float32) * scale).to(dt).cuda().requires_grad_(True)
     out = tein.EinsumFunction.apply(equation, A, B)
     out.backward(torch.ones_like(out))
-    rA = A.detach().double().cpu().requires_grad_(True)
-    rB = B.detach().double().cpu().requires_grad_(True)
+    rA = A.detach().to(_wide(torch, dtype)).cpu().requires_grad_(True)
+    rB = B.detach().to(_wide(torch, dtype)).cpu().requires_grad_(True)
     ref = torch.einsum(equation, rA, rB)
     ref.backward(torch.ones_like(ref))
     _close(torch, out.detach(), ref.detach(), dtype)
@@ -63,10 +74,11 @@ def test_einsum_function_forward_and_gradients(te, name, a_size, b_size, equatio
 def test_einsum_general_forward_and_gradients(te, name, sizes, equation, dtype):
     torch, tein = te
     torch.manual_seed(1)
-    ts = [torch.randn(*s).cuda().requires_grad_(True) for s in sizes]
+    dt = getattr(torch, dtype)
+    ts = [torch.randn(*s, dtype=dt).cuda().requires_grad_(True) for s in sizes]
     out = tein.EinsumGeneral(equation, *ts)
     out.backward(torch.ones_like(out))
-    rs = [t.detach().double().cpu().requires_grad_(True) for t in ts]
+    rs = [t.detach().to(_wide(torch, dtype)).cpu().requires_grad_(True) for t in ts]
     ref = torch.einsum(equation, *rs)
     ref.backward(torch.ones_like(ref))
     _close(torch, out.detach(), ref.detach(), dtype)
