@@ -972,7 +972,8 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
         pl->alignB3 = desc->B.desc.alignment;
         pl->requiredWorkspace = 0;
-        CT_LOG("plan: elementwise trinary passes=%d swapAB=%d variant(last)=%d", pl->ew3.twoPass ? 2 : 1, (int)pl->ew3.swapAB, pl->ew3.last.variant);
+        CT_LOG("plan: elementwise trinary passes=%d swapAB=%d bothPermuted=%d variant(last)=%d", pl->ew3.twoPass ? 2 : 1, (int)pl->ew3.swapAB,
+               (int)pl->ew3.bothPermuted, pl->ew3.last.variant);
     } else if (desc->kind == OpKind::Permutation && (!desc->padLeft.empty() || !desc->padRight.empty())) {
         // The output buffer is the packed tensor of extents e + padLeft + padRight (the sample sizes it that way,
         // elementwise_permute_padding.cu:101-103); the descriptor carries the unpadded extents.
@@ -1208,7 +1209,13 @@ cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle
                  g = scalar_as_double(gamma, plan->scalarType);
     const EwTrinaryPlan& t = plan->ew3;
     hipError_t err = hipSuccess;
-    if (t.twoPass) {
+    if (t.bothPermuted) {
+        Ew2DParams q = t.last.p;
+        q.A = A; q.X = B; q.D = D; q.E = nullptr;
+        q.C = (t.last.usesC && (g != 0.0 || (q.opAC != 0 && q.opAC != CUTENSOR_OP_ADD))) ? C : nullptr;
+        q.alpha = (float)a; q.alpha64 = a; q.xi = (float)b; q.xi64 = b; q.gamma = (float)g; q.gamma64 = g;
+        err = launch_elementwise(q, t.last.variant, (int)plan->dtype, stream);
+    } else if (t.twoPass) {
         err = run_elementwise(t.first, plan->dtype, a, A, 0.0, nullptr, D, stream);                       // D = alpha perm(A)
         if (err == hipSuccess) err = run_elementwise(t.last, plan->dtype, b, B, g, C, D, stream, D, 1.0);  // combine in place
     } else if (t.swapAB) {

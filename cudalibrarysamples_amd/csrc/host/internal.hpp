@@ -113,12 +113,14 @@ struct EwPlan {
     int        variant = EW_GENERIC;
     Ew2DParams p{};              // pointers / scalars are filled at launch
     bool       usesC = false;
+    bool       usesX = false;    // second permuted operand (trinary, both operands permuted)
 };
 // cutensorElementwiseTrinaryExecute: D = opABC(opAB(alpha A, beta B), gamma C) as one or two passes of the
 // element-wise kernels (plan_elementwise_trinary)
 struct EwTrinaryPlan {
     bool   twoPass = false;      // pass 1: D = s1 * perm(X1);  last pass: D = opAC(opAB(delta * E, s2 * perm(X2)), gamma * perm(C))
     bool   swapAB = false;       // the operand that already has D's layout plays E (single pass): true -> E = B, X2 = A
+    bool   bothPermuted = false; // single pass with two LDS tiles: A through the tile path, B as the second tile operand
     EwPlan first;                // permutation X1 -> D (two-pass form only)
     EwPlan last;
 };

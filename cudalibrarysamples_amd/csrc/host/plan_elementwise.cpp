@@ -17,6 +17,7 @@ namespace {
 struct EwMode {
     int64_t extent;
     int64_t sA = 0, sD = 0, sC = 0;
+    int64_t sX = 0;   // second permuted operand (element-wise trinary), 0 when unused
 };
 
 int find_label(const std::vector<int32_t>& modes, int32_t l) {
@@ -37,7 +38,7 @@ void fuse(std::vector<EwMode>& g, bool useC) {
     for (const EwMode& m : g) {
         if (!out.empty()) {
             EwMode& p = out.back();
-            bool ok = (m.sA == p.sA * p.extent) && (m.sD == p.sD * p.extent);
+            bool ok = (m.sA == p.sA * p.extent) && (m.sD == p.sD * p.extent) && (m.sX == p.sX * p.extent);
             if (useC) ok = ok && (m.sC == p.sC * p.extent);
             if (ok && p.extent * m.extent < (1ll << 31)) {
                 p.extent *= m.extent;
@@ -76,6 +77,9 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     };
     const TensorUse &A = op.A, &C = op.C, &D = op.D;
     const bool usesC = C.present;
+    // second permuted operand: only the trinary planner passes a descriptor of kind ElementwiseBinary with B present
+    const bool usesX = op.kind == OpKind::ElementwiseBinary && op.B.present;
+    if (usesX && (op.B.desc.dtype != D.desc.dtype || dup_labels(op.B.modes))) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "second permuted operand");
     if (D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex element-wise operations");
     if (dup_labels(A.modes) || dup_labels(D.modes) || (usesC && dup_labels(C.modes)))
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
@@ -101,6 +105,13 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
             if (A.desc.extent[ia] != m.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extent mismatch between A and output");
             m.sA = A.desc.stride[ia];
         }   // absent => stride 0 (broadcast)
+        if (usesX) {
+            const int ix = find_label(op.B.modes, D.modes[i]);
+            if (ix >= 0) {
+                if (op.B.desc.extent[ix] != m.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extent mismatch between B and output");
+                m.sX = op.B.desc.stride[ix];
+            }
+        }
         if (usesC) {
             const int ic = find_label(C.modes, D.modes[i]);
             if (ic >= 0) {
@@ -126,7 +137,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     if (!modes.empty()) {
         const EwMode& m0 = modes[0];
         if (m0.extent >= (1ll << 31)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mode extent >= 2^31");
-        p.E0 = (uint32_t)m0.extent; p.sA0 = m0.sA; p.sD0 = m0.sD; p.sC0 = m0.sC;
+        p.E0 = (uint32_t)m0.extent; p.sA0 = m0.sA; p.sD0 = m0.sD; p.sC0 = m0.sC; p.sX0 = m0.sX;
         if (modes.size() > 1) {
             i1 = 1;
             if (m0.sA != 1) {   // partner dim = A's fastest remaining mode
@@ -134,12 +145,13 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
                     if (modes[i].sA != 0 && (modes[i1].sA == 0 || modes[i].sA < modes[i1].sA)) i1 = (int)i;
             }
             const EwMode& m1 = modes[i1];
-            p.E1 = (uint32_t)m1.extent; p.sA1 = m1.sA; p.sD1 = m1.sD; p.sC1 = m1.sC;
+            p.E1 = (uint32_t)m1.extent; p.sA1 = m1.sA; p.sD1 = m1.sD; p.sC1 = m1.sC; p.sX1 = m1.sX;
         }
         for (size_t i = 1; i < modes.size(); ++i)
             if ((int)i != i1) rest.push_back(modes[i]);
     }
     if (!fill_rest(p.rest, rest)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "too many unfusable modes");
+    for (size_t i = 0; i < rest.size(); ++i) p.restX[i] = rest[i].sX;
 
     // ---- variant --------------------------------------------------------------------------
     const bool f32 = D.desc.dtype == HIP_R_32F;
@@ -152,13 +164,19 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     const bool cOK = !usesC || p.sC0 != 1 || (mult4(p.sC1));
     plan.variant = EW_GENERIC;
     int t0 = 64, t1 = 4;
+    bool xOK = true;   // the transposing variant reads X exactly like A: 16-byte lanes along dim1
+    if (usesX) {
+        xOK = op.B.desc.alignment % 16 == 0 && p.sX1 == 1 && mult4(p.sX0);
+        for (const EwMode& m : rest) xOK = xOK && mult4(m.sX);
+    }
     if (f32 && aligned && restOK && cOK && p.sD0 == 1 && p.E0 % 4 == 0) {
-        if (i1 >= 0 && p.sA1 == 1 && p.sA0 != 1 && p.E1 % 4 == 0 && mult4(p.sA0) && mult4(p.sD1)) {
+        if (i1 >= 0 && p.sA1 == 1 && p.sA0 != 1 && p.E1 % 4 == 0 && mult4(p.sA0) && mult4(p.sD1) && xOK) {
             plan.variant = EW_TRANSPOSE; t0 = 64; t1 = 64;
-        } else if (p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
+        } else if (!usesX && p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
             plan.variant = EW_ROWCOPY; t0 = 256; t1 = 8;
         }
     }
+    plan.usesX = usesX;
     p.tiles0 = (p.E0 + t0 - 1) / t0;
     p.tiles1 = (p.E1 + t1 - 1) / t1;
     p.divTiles0 = make_fastdiv(p.tiles0);
@@ -196,11 +214,27 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
     const bool aSame = same_layout(op.A), bSame = same_layout(op.B);
     cutensorOperationDescriptor last = op;      // A := the permuted operand of the last pass, C := C, D := D
     last.kind = OpKind::ElementwiseBinary;
+    last.B = TensorUse{};                        // no second tile operand in these forms
     if (aSame || bSame) {
         plan.twoPass = false;
         plan.swapAB = !aSame;                    // E = B, permuted operand = A
         last.A = plan.swapAB ? op.A : op.B;
     } else {
+        // both permuted: one pass if the tile decomposition of (B -> D) also reads A with 16-byte lanes (the sample's
+        // A_{c,b,a}, B_{c,a,b} -> D_{a,b,c} share the partner mode c), 4 |D| bytes instead of 6
+        cutensorOperationDescriptor both = op;
+        both.kind = OpKind::ElementwiseBinary;
+        both.A = op.A;            // tile path
+        both.B = op.B;            // second tile (X)
+        EwPlan one;
+        if (plan_elementwise(both, one, nullptr) == CUTENSOR_STATUS_SUCCESS && one.usesX && one.variant == EW_TRANSPOSE) {
+            plan.twoPass = false;
+            plan.bothPermuted = true;
+            plan.last = one;
+            plan.last.p.opAB = (int32_t)op.opAB;
+            plan.last.p.opAC = (int32_t)op.opReduce;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
         plan.twoPass = true;
         cutensorOperationDescriptor first = op;
         first.kind = OpKind::Permutation;

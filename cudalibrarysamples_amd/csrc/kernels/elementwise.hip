@@ -66,6 +66,18 @@ __device__ __forceinline__ f32x4 ew_comb4(int op, f32x4 x, f32x4 y) {
     return r;
 }
 
+// offset of a rest index in the second permuted operand X (explicit stride array, same digits as rest_offsets)
+__device__ __forceinline__ int64_t rest_offset_x(const ModeGroup& g, const int64_t* sx, uint32_t idx) {
+    int64_t o = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t q = __umulhi(idx, g.div[i].magic) >> g.div[i].shift;
+        o += (int64_t)(idx - q * g.div[i].d) * sx[i];
+        idx = q;
+    }
+    return o;
+}
+
 struct TileId { uint32_t t0, t1, rest; };
 __device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
     TileId t;
@@ -84,8 +96,13 @@ __device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
 constexpr int TT = 64;          // tile edge
 constexpr int TT_LD = TT + 4;   // LDS row stride (floats), keeps rows 16-byte aligned
 
+// HASX: second permuted operand through a second LDS tile (a separate instantiation, so that the plain permutation
+// keeps its 17-KiB footprint and 8 workgroups per CU)
+template <bool HASX>
 __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams p) {
     __shared__ __attribute__((aligned(16))) float tile[TT * TT_LD];   // [dim1][dim0]
+    __shared__ __attribute__((aligned(16))) float tileX[HASX ? TT * TT_LD : 4];
+    const float* X = HASX ? static_cast<const float*>(p.X) : nullptr;
     const float* A = static_cast<const float*>(p.A);
     const float* C = static_cast<const float*>(p.C);
     const float* E = static_cast<const float*>(p.E);
@@ -116,6 +133,20 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
                 const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
                 *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * TT_LD + 4 * (tid >> 4)]) = o;
             }
+            if constexpr (HASX) {
+                const int64_t oX = rest_offset_x(p.rest, p.restX, t.rest);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (c1 < p.E1 && (r0 + r) < p.E0)
+                        in[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + oX + (int64_t)(r0 + r) * p.sX0 + c1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
+                    *reinterpret_cast<f32x4*>(&tileX[(4 * (tid & 15) + j) * TT_LD + 4 * (tid >> 4)]) = o;
+                }
+            }
         }
         __syncthreads();
         // ---- write: lane -> (dim0 float4 c0 = tid%16, dim1 row = tid/16 + 16*pass)
@@ -128,6 +159,8 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
                 if (c0 < p.E0 && r1 < p.E1) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * TT_LD + 4 * (tid & 15)]);
                     v *= p.alpha;
+                    if constexpr (HASX)
+                        v = ew_comb4(p.opAB, p.xi * *reinterpret_cast<const f32x4*>(&tileX[lr * TT_LD + 4 * (tid & 15)]), v);
                     if (E != nullptr)
                         v = ew_comb4(p.opAB, p.delta * *reinterpret_cast<const f32x4*>(E + oD + (int64_t)r1 * p.sD1 + c0), v);
                     if (C != nullptr) {
@@ -227,6 +260,11 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
         if (c0 >= p.E0 || r1 >= p.E1) continue;
         S v = alpha * ew_load<T>(A + oA + (int64_t)c0 * p.sA0 + (int64_t)r1 * p.sA1);
         if (E != nullptr) v = ew_comb<S>(p.opAB, delta * ew_load<T>(E + oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1), v);
+        if (p.X != nullptr) {
+            const S xi = sizeof(S) == 8 ? (S)p.xi64 : (S)p.xi;
+            v = ew_comb<S>(p.opAB, xi * ew_load<T>(static_cast<const T*>(p.X) + rest_offset_x(p.rest, p.restX, t.rest) +
+                                                  (int64_t)c0 * p.sX0 + (int64_t)r1 * p.sX1), v);
+        }
         if (C != nullptr) v = ew_comb<S>(p.opAC, v, gamma * ew_load<T>(C + oC + (int64_t)c0 * p.sC0 + (int64_t)r1 * p.sC1));
         ew_store<T>(D + oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1, v);
     }
@@ -288,7 +326,8 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
     const unsigned cap = 256u * 8u * 16u;
     if (grid > cap) grid = cap;
     if (variant == EW_TRANSPOSE && dtype == HIP_R_32F) {
-        hipLaunchKernelGGL(ew_transpose_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+        if (p.X != nullptr) hipLaunchKernelGGL(ew_transpose_f32_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+        else                hipLaunchKernelGGL(ew_transpose_f32_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_32F) {
         hipLaunchKernelGGL(ew_rowcopy_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_GENERIC) {

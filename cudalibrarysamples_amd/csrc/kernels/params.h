@@ -122,6 +122,14 @@ struct Ew2DParams {
     float       delta;
     double      delta64;
     int32_t     opAB, opAC;
+    // Second permuted operand (element-wise trinary whose A and B are both permuted but share the tile modes):
+    // D = opAC(opAB(xi * perm(X), alpha * perm(A)), gamma * perm(C)); X == nullptr: unused.  X is walked with its own
+    // strides through the same tile decomposition as A (a second LDS tile in the transposing variant).
+    const void* X;
+    int64_t     sX0, sX1;
+    int64_t     restX[kMaxGroupModes];
+    float       xi;
+    double      xi64;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -127,3 +127,15 @@ def test_contraction_trinary(env, beta):
     got = from_device(dD, D)
     ref = 1.1 * np.einsum("mkajbi,kni,rj->mnbra", A.astype(np.float64), B.astype(np.float64), C.astype(np.float64)) + beta * D
     np.testing.assert_allclose(got, ref, rtol=1e-4)
+
+
+def test_both_operands_permuted_single_pass(env):
+    """A_{c,b,a} and B_{c,a,b} share the partner mode c of the output tile (elementwise_trinary.cu:51-53): one pass with
+    two LDS tiles; must agree with the two-pass result bit for bit is not required (same operations, same order), but
+    it is: (alpha A + beta B) + gamma C in fp32 either way."""
+    got, ref, plan = _trinary(env, dict(a=400, b=200, c=300), "cba", "cab", "abc", "abc", 1.1, 1.3, 1.2)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)
+    got, ref, plan = _trinary(env, dict(a=68, b=36, c=44), "cba", "cab", "abc", "abc", 1.0, 1.0, 1.0, "MAX", "MUL")
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)
+    got, ref, plan = _trinary(env, dict(a=66, b=35, c=44), "cba", "cab", "abc", "abc", 0.5, 2.0, -1.0)   # ragged a (66 % 4 != 0): generic path
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)
