@@ -152,6 +152,12 @@ def test_split_k_for_small_outputs(env, dims):
     np.testing.assert_allclose(D1.double().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=0.1)
 
 
+def test_split_k_fp16(env):
+    got, ref, d = _run(env, dict(m=96, n=120, k=2048), "km", "nk", "mn", dtype_name="float16", alpha=0.5, beta=1.0, seed=25)
+    assert d["family"] == 1 and d["splitK"] > 1, d
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-2)
+
+
 def test_headline_einsum_shape_in_bf16(env):
     """'abcd,dcbe->ae' (einsum.cu helper view) with 16-bit data: one 96 x 96 output tile, K = b*c*d split over the CUs."""
     got, ref, d = _run(env, dict(a=96, b=16, c=16, d=64, e=96), "dcba", "ebcd", "ea", seed=23)
