@@ -992,6 +992,9 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (!isPacked) { delete pl; CT_LOG("cutensorCreatePlan: padding needs a packed output descriptor"); return CUTENSOR_STATUS_NOT_SUPPORTED; }
         cutensorOperationDescriptor inner = *desc;
         inner.D.desc.stride = padded;
+        // the interior starts `offset` elements into the buffer: keep the 16-byte-lane variants only if that is lane-aligned
+        const int64_t lane = 16 / (int64_t)dtype_size(desc->D.desc.dtype);
+        if (offset % lane != 0) inner.D.desc.alignment = (uint32_t)dtype_size(desc->D.desc.dtype);
         st = plan_elementwise(inner, pl->ew, &why);
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
         pl->padFillElems = (uint64_t)accP;

@@ -154,10 +154,13 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     for (size_t i = 0; i < rest.size(); ++i) p.restX[i] = rest[i].sX;
 
     // ---- variant --------------------------------------------------------------------------
-    const bool f32 = D.desc.dtype == HIP_R_32F;
+    // vector paths: fp32 (4-element lanes) and bf16 / fp16 (8-element lanes); "mult4" = multiple of the lane width
+    const bool h16 = D.desc.dtype == HIP_R_16BF || D.desc.dtype == HIP_R_16F;
+    const bool f32 = D.desc.dtype == HIP_R_32F || (h16 && !usesX);
+    const int64_t vec = h16 ? 8 : 4;
     const bool aligned = (A.desc.alignment % 16 == 0) && (D.desc.alignment % 16 == 0) &&
                          (!usesC || C.desc.alignment % 16 == 0);
-    auto mult4 = [](int64_t s) { return s % 4 == 0; };
+    auto mult4 = [vec](int64_t s) { return s % vec == 0; };
     bool restOK = true;
     for (const EwMode& m : rest) restOK = restOK && mult4(m.sA) && mult4(m.sD) && (!usesC || mult4(m.sC));
     // C is read with 16-byte lanes only when it is contiguous along dim0; otherwise element-wise
@@ -169,11 +172,11 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
         xOK = op.B.desc.alignment % 16 == 0 && p.sX1 == 1 && mult4(p.sX0);
         for (const EwMode& m : rest) xOK = xOK && mult4(m.sX);
     }
-    if (f32 && aligned && restOK && cOK && p.sD0 == 1 && p.E0 % 4 == 0) {
-        if (i1 >= 0 && p.sA1 == 1 && p.sA0 != 1 && p.E1 % 4 == 0 && mult4(p.sA0) && mult4(p.sD1) && xOK) {
+    if (f32 && aligned && restOK && cOK && p.sD0 == 1 && p.E0 % vec == 0) {
+        if (i1 >= 0 && p.sA1 == 1 && p.sA0 != 1 && p.E1 % vec == 0 && mult4(p.sA0) && mult4(p.sD1) && xOK) {
             plan.variant = EW_TRANSPOSE; t0 = 64; t1 = 64;
         } else if (!usesX && p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
-            plan.variant = EW_ROWCOPY; t0 = 256; t1 = 8;
+            plan.variant = EW_ROWCOPY; t0 = h16 ? 512 : 256; t1 = 8;
         }
     }
     plan.usesX = usesX;

@@ -226,6 +226,136 @@ __global__ void __launch_bounds__(256) ew_rowcopy_f32_kernel(const Ew2DParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// 16-bit data (bf16 / fp16), same two shapes: 16-byte lanes = 8 elements, arithmetic in fp32.
+//   EW_ROWCOPY   tile = 512 dim0 elements (64 lanes x 8) x 8 dim1 rows
+//   EW_TRANSPOSE tile = 64 x 64 elements; LDS image [dim1][dim0] with an odd row pitch (65 elements), filled and
+//                drained with 2-byte LDS accesses (16 + 16 per lane and tile — a few hundred LDS cycles against
+//                ~2 k cycles of HBM time for the tile's 16 KiB), HBM sees 128-byte segments on both sides
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4e __attribute__((ext_vector_type(4)));
+
+template <bool BF> __device__ __forceinline__ float h16_to_f32(uint16_t v) {
+    if constexpr (BF) return __uint_as_float((uint32_t)v << 16);
+    else return (float)__builtin_bit_cast(_Float16, v);
+}
+template <bool BF> __device__ __forceinline__ uint16_t f32_to_h16(float f) {
+    if constexpr (BF) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    } else {
+        return __builtin_bit_cast(uint16_t, (_Float16)f);
+    }
+}
+template <bool BF> __device__ __forceinline__ void h16_unpack(u32x4e v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = h16_to_f32<BF>((uint16_t)(v[i] & 0xffffu)); f[2 * i + 1] = h16_to_f32<BF>((uint16_t)(v[i] >> 16)); }
+}
+template <bool BF> __device__ __forceinline__ u32x4e h16_pack(const float (&f)[8]) {
+    u32x4e v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f32_to_h16<BF>(f[2 * i]) | ((uint32_t)f32_to_h16<BF>(f[2 * i + 1]) << 16);
+    return v;
+}
+// out = opAC(opAB(delta * E, alpha * a), gamma * C) on 8 elements starting at D-offset offD (dim0 contiguous)
+template <bool BF>
+__device__ __forceinline__ u32x4e h16_combine(const Ew2DParams& p, const float (&a)[8], const uint16_t* E, const uint16_t* C,
+                                              int64_t offD, int64_t offC) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p.alpha * a[i];
+    if (E != nullptr) {
+        float e[8];
+        h16_unpack<BF>(*reinterpret_cast<const u32x4e*>(E + offD), e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ew_comb<float>(p.opAB, p.delta * e[i], v[i]);
+    }
+    if (C != nullptr) {
+        float c[8];
+        if (p.sC0 == 1) {
+            h16_unpack<BF>(*reinterpret_cast<const u32x4e*>(C + offC), c);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c[i] = h16_to_f32<BF>(C[offC + (int64_t)i * p.sC0]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ew_comb<float>(p.opAC, v[i], p.gamma * c[i]);
+    }
+    return h16_pack<BF>(v);
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256) ew_rowcopy_h16_kernel(const Ew2DParams p) {
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    const uint16_t* E = static_cast<const uint16_t*>(p.E);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * 512 + 8 * (tid & 63);
+        if (c0 >= p.E0) continue;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t r1 = t.t1 * 8 + (tid >> 6) * 2 + r;
+            if (r1 >= p.E1) continue;
+            float a[8];
+            h16_unpack<BF>(__builtin_nontemporal_load(reinterpret_cast<const u32x4e*>(A + oA + (int64_t)r1 * p.sA1 + c0)), a);
+            const int64_t offD = oD + (int64_t)r1 * p.sD1 + c0;
+            const u32x4e out = h16_combine<BF>(p, a, E, C, offD, oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0);
+            __builtin_nontemporal_store(out, reinterpret_cast<u32x4e*>(D + offD));
+        }
+    }
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256) ew_transpose_h16_kernel(const Ew2DParams p) {
+    constexpr int PITCH = 65;
+    __shared__ uint16_t tile[64 * PITCH];   // [dim1][dim0]
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    const uint16_t* E = static_cast<const uint16_t*>(p.E);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t i0 = t.t0 * 64, i1 = t.t1 * 64;
+        // read: unit u = 8 dim1 elements of one dim0 row (8 lanes cover a 128-byte segment)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + 256 * k;
+            const uint32_t r0 = u >> 3, c1 = 8 * (u & 7);
+            u32x4e v = {0u, 0u, 0u, 0u};
+            if (i0 + r0 < p.E0 && i1 + c1 < p.E1)
+                v = __builtin_nontemporal_load(reinterpret_cast<const u32x4e*>(A + oA + (int64_t)(i0 + r0) * p.sA0 + i1 + c1));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[(c1 + j) * PITCH + r0] = (uint16_t)(v[j >> 1] >> (16 * (j & 1)));
+        }
+        __syncthreads();
+        // write: unit u = 8 dim0 elements of one dim1 row
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + 256 * k;
+            const uint32_t lr = u >> 3, c0 = 8 * (u & 7);
+            if (i0 + c0 < p.E0 && i1 + lr < p.E1) {
+                float a[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = h16_to_f32<BF>(tile[lr * PITCH + c0 + j]);
+                const int64_t offD = oD + (int64_t)(i1 + lr) * p.sD1 + i0 + c0;
+                const u32x4e out = h16_combine<BF>(p, a, E, C, offD, oC + (int64_t)(i1 + lr) * p.sC1 + (int64_t)(i0 + c0) * p.sC0);
+                __builtin_nontemporal_store(out, reinterpret_cast<u32x4e*>(D + offD));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // EW_GENERIC: any strides / dtype.  Tile = 64 dim0 elements x 4 dim1 rows, one element per lane.
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_T0 = 64, GN_T1 = 4;
@@ -330,6 +460,14 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
         else                hipLaunchKernelGGL(ew_transpose_f32_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_32F) {
         hipLaunchKernelGGL(ew_rowcopy_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_TRANSPOSE && dtype == HIP_R_16BF) {
+        hipLaunchKernelGGL(ew_transpose_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_TRANSPOSE && dtype == HIP_R_16F) {
+        hipLaunchKernelGGL(ew_transpose_h16_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_ROWCOPY && dtype == HIP_R_16BF) {
+        hipLaunchKernelGGL(ew_rowcopy_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_ROWCOPY && dtype == HIP_R_16F) {
+        hipLaunchKernelGGL(ew_rowcopy_h16_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_GENERIC) {
         switch (dtype) {
             case HIP_R_32F:  hipLaunchKernelGGL(ew_generic_kernel<float>, dim3(grid), dim3(256), 0, stream, p); break;

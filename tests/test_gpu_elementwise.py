@@ -120,3 +120,39 @@ def test_large_2d_transpose_roundtrip(env):
     torch.cuda.synchronize()
     assert torch.equal(a, c)
     assert torch.equal(b.view(n, n), a.view(n, n).t().contiguous().view(n, n))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_16bit_vector_permutes_are_exact(built, dtype):
+    """bf16 / fp16 permutations through the 8-element-lane kernels (transposing and row-copy variants) and the generic
+    fallback: bit-exact for alpha = 1; binary add (alpha A + gamma C, fp32 arithmetic, one rounding) within 1 ulp."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    tdt = getattr(torch, dtype)
+    cdt = ct.R_16BF if dtype == "bfloat16" else ct.R_16F
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    cases = [
+        (dict(a=136, b=24, c=72), "abc", "cba", 0),     # full reversal: transposing variant
+        (dict(a=128, b=40, c=64), "abc", "acb", 1),     # shared fastest mode: row copy
+        (dict(a=136, b=24, c=72), "abc", "cab", 0),
+        (dict(a=37, b=5, c=11), "abc", "cba", 2),       # odd extents: generic
+    ]
+    for ext, mA, mD, want in cases:
+        eA, eD = [ext[c] for c in mA], [ext[c] for c in mD]
+        A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)      # column-major tensor == reversed row-major
+        D = torch.zeros(eD[::-1], device="cuda", dtype=tdt)
+        plan = ops.permutation_plan(h, eA, mA, eD, mD, dtype=cdt)
+        assert plan.describe()["variant"] == want, (plan.describe(), ext, mA, mD)
+        plan.permute(1.0, A.data_ptr(), D.data_ptr())
+        torch.cuda.synchronize()
+        ref = torch.einsum("%s->%s" % (mA[::-1], mD[::-1]), A)
+        assert torch.equal(D, ref), (ext, mA, mD)
+        # binary: D = 0.5 * perm(A) + 2 * C
+        C = (torch.rand(eD[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        bp = ops.binary_plan(h, eA, mA, eD, mD, dtype=cdt)
+        bp.binary(0.5, A.data_ptr(), 2.0, C.data_ptr(), D.data_ptr())
+        torch.cuda.synchronize()
+        refb = (0.5 * ref.float() + 2.0 * C.float()).to(tdt)
+        torch.testing.assert_close(D.float(), refb.float(), rtol=1e-2 if dtype == "bfloat16" else 2e-3, atol=1e-2)
