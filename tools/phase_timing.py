@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--algo", type=int, default=-1)
     ap.add_argument("--b", type=int, default=64)
+    ap.add_argument("--cold", action="store_true")
     ap.add_argument("--dump", type=str, default="", help="save the raw per-workgroup timing records (.npy)")
     args = ap.parse_args()
     import torch
@@ -33,7 +34,7 @@ def main():
     d = p.describe()
     ws = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     tbuf = torch.zeros(d["blocks"] * 16, dtype=torch.int64, device="cuda")
-    for _ in range(5):
+    for _ in range(5 if args.cold else 1500):   # steady clock state by default; --cold: 5 warm-up calls
         p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
     torch.cuda.synchronize()
     ct.lib.ctamdSetTimingBuffer(tbuf.data_ptr())
