@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of cutensorContract (fp32 and bf16) against torch.einsum in fp64 on the GPU: random mode
+counts, extents (biased to the 16-byte-lane / K-tile conditions of the MFMA kernels, but not only), mode orders,
+alpha / beta, workspace limits.  Not part of the test suite; run on a GPU box to look for rare shape bugs."""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--aligned", action="store_true", help="extents that satisfy the 16-byte-lane / whole-K-tile conditions of the "
+                                                           "streaming fp32 and the 16-bit MFMA kernels")
+    args = ap.parse_args()
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    rnd = random.Random(args.seed)
+    h = ops.Handle()
+    fails = 0
+    kinds = {}
+    for case in range(args.cases):
+        dtype = rnd.choice(["float32", "float32", "bfloat16"])
+        nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
+        labels = list("abcdefghij")
+        rnd.shuffle(labels)
+        M, N, K, L = [labels.pop() for _ in range(nM)], [labels.pop() for _ in range(nN)], [labels.pop() for _ in range(nK)], [labels.pop() for _ in range(nL)]
+        ext = {}
+        table = ((M, [8, 16, 24, 40, 96, 100, 7]), (N, [8, 16, 32, 48, 96, 13]), (K, [4, 8, 32, 64, 64, 96, 5]), (L, [2, 3]))
+        if args.aligned:
+            table = ((M, [8, 16, 24, 40, 96, 104, 264]), (N, [8, 16, 32, 48, 96, 120]), (K, [64, 64, 128, 192]), (L, [2, 3]))
+        for g, choices in table:
+            for c in g:
+                ext[c] = rnd.choice(choices)
+        mA, mB, mC = M + K + L, N + K + L, M + N + L
+        for m in (mA, mB, mC):
+            rnd.shuffle(m)
+        mA, mB, mC = "".join(mA), "".join(mB), "".join(mC)
+        elems = lambda m: eval("*".join(str(ext[c]) for c in m))
+        if max(elems(mA), elems(mB), elems(mC)) > (1 << 24):
+            continue
+        tdt = getattr(torch, dtype)
+        A = (torch.rand([ext[c] for c in mA][::-1], device="cuda") * 2 - 1).to(tdt)
+        B = (torch.rand([ext[c] for c in mB][::-1], device="cuda") * 2 - 1).to(tdt)
+        C = (torch.rand([ext[c] for c in mC][::-1], device="cuda") * 2 - 1).to(tdt)
+        D = C.clone()
+        alpha, beta = rnd.choice([1.0, 0.5, -1.25]), rnd.choice([0.0, 0.0, 1.0, -0.5])
+        limit = rnd.choice([0, 1 << 20, 1 << 28])
+        try:
+            plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
+                                        dtype=ct.R_32F if dtype == "float32" else ct.R_16BF, workspace_limit=limit)
+        except ct.CuTensorError as e:
+            print("case %d: plan refused (%s) %s,%s->%s %s" % (case, e, mA, mB, mC, ext))
+            fails += 1
+            continue
+        d = plan.describe()
+        kinds[(d.get("kname"), d["splitK"] > 1)] = kinds.get((d.get("kname"), d["splitK"] > 1), 0) + 1
+        ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
+        torch.cuda.synchronize()
+        ref = alpha * torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.double(), B.double()) + beta * C.double()
+        err = (D.double() - ref).abs()
+        ktot = 1
+        for c in K:
+            ktot *= ext[c]
+        tol = (2e-5 if dtype == "float32" else 1e-2) * (1.0 + ref.abs()) + (1e-5 if dtype == "float32" else 4e-3) * ktot ** 0.5   # fp32 sequential accumulation: ~eps * K * |partial sums|
+        if not bool((err <= tol).all()):
+            fails += 1
+            print("case %d MISMATCH max err %.3e: %s,%s->%s %s %s alpha %g beta %g limit %d plan %s" % (
+                case, float(err.max()), mA, mB, mC, ext, dtype, alpha, beta, limit, d))
+        plan.destroy()
+    print("cases %d, failures %d, kernels used: %s" % (args.cases, fails, kinds))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
