@@ -1,9 +1,9 @@
 #!/bin/bash
 # Builds the reference's OWN sample drivers, from the sources where they lie under /root/reference,
-# against OUR libcutensor.so / libcutensorMg.so.  Nothing is copied into the repository: outputs go to
+# against OUR libcutensor.so / libcutensorMg.so / libcutensorMp.so.  Nothing is copied into the repository: outputs go to
 # oracle/_ref/ (git-ignored, but shipped to the GPU box with the snapshot).  The sources are compiled
-# unmodified with `hipcc -x hip`; tests/sample_compat/ supplies <cuda_runtime.h>/<cuda_fp16.h> for the
-# runtime names the samples call themselves.  The reference's build system (Makefile/CMake, needs nvcc
+# unmodified with `hipcc -x hip`; tests/sample_compat/ supplies <cuda_runtime.h>/<cuda_fp16.h> (and, for the
+# cutensorMp sample, <mpi.h>/<nccl.h>/<cuComplex.h>/<cuda_profiler_api.h>) for the names the samples call themselves.  The reference's build system (Makefile/CMake, needs nvcc
 # and the closed libcutensor) is not used.
 set -u
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -31,5 +31,10 @@ if hipcc $FLAGS "$REF/cuTENSORMg/blog_post.cu" -o "$OUT/blog_post" $LINK -lcuten
     echo "built oracle/_ref/blog_post"
 else
     echo "FAILED oracle/_ref/blog_post (see oracle/_ref/blog_post.log)"; rc=1
+fi
+if hipcc $FLAGS "$REF/cutensorMp/cutensorMp_contraction.cu" -o "$OUT/cutensorMp_contraction" $LINK -lcutensorMp -lcutensor -L/opt/rocm/lib -lrccl 2> "$OUT/cutensorMp_contraction.log"; then
+    echo "built oracle/_ref/cutensorMp_contraction"
+else
+    echo "FAILED oracle/_ref/cutensorMp_contraction (see oracle/_ref/cutensorMp_contraction.log)"; rc=1
 fi
 exit $rc

@@ -26,6 +26,7 @@ struct cudaDeviceProp : public hipDeviceProp_t {};   /* the Mg sample writes `st
 #define cudaMallocHost              hipHostMalloc
 #define cudaFreeHost                hipHostFree
 #define cudaMemcpy                  hipMemcpy
+#define cudaMemset                  hipMemset
 #define cudaMemcpyAsync             hipMemcpyAsync
 #define cudaMemcpy2DAsync           hipMemcpy2DAsync
 #define cudaMemcpyHostToDevice      hipMemcpyHostToDevice

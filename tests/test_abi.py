@@ -25,7 +25,7 @@ def ops(built):
 def _declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(cutensor(?:Mg)?[A-Z]\w*)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:cutensor(?:Mg|Mp)?|ctamdMp)[A-Z]\w*)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported(ct):
@@ -41,6 +41,22 @@ def test_mg_symbols_exported(built):
     mg = ctypes.CDLL(os.path.join(ROOT, "cudalibrarysamples_amd", "lib", "libcutensorMg.so"))
     for n in _declared_functions("cutensorMg.h"):
         assert hasattr(mg, n), "libcutensorMg.so does not export %s" % n
+
+
+def test_mp_symbols_exported(built):
+    mp = ctypes.CDLL(os.path.join(ROOT, "cudalibrarysamples_amd", "lib", "libcutensorMp.so"))
+    names = _declared_functions("cutensorMp.h")
+    assert "cutensorMpContract" in names and "cutensorMpCreateTensorDescriptor" in names and "ctamdMpLocalWorldCreate" in names
+    for n in names:
+        assert hasattr(mp, n), "libcutensorMp.so does not export %s" % n
+    # Destroy*(NULL) is tolerated, and nothing below needs a device
+    for n in ("cutensorMpDestroyPlan", "cutensorMpDestroyTensorDescriptor", "cutensorMpDestroyOperationDescriptor",
+              "cutensorMpDestroyPlanPreference", "cutensorMpDestroy"):
+        assert getattr(mp, n)(None) == 0
+    world = ctypes.c_void_p()
+    assert mp.ctamdMpLocalWorldCreate(ctypes.byref(world), 4) == 0 and world.value
+    assert mp.ctamdMpLocalWorldCreate(ctypes.byref(ctypes.c_void_p()), 0) != 0
+    assert mp.ctamdMpLocalWorldDestroy(world) == 0
 
 
 def test_lifecycle_and_null_tolerance(ct):

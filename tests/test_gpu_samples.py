@@ -37,3 +37,16 @@ def test_blog_post_scaling_harness(built):
     r = subprocess.run([exe, "1", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "blog_post exited %d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "rror" not in (r.stdout + r.stderr).replace("No such file or directory", ""), r.stdout[-2000:]
+
+
+def test_cutensormp_sample_single_rank(built):
+    """cutensorMp/cutensorMp_contraction.cu, unmodified, as one rank on a one-rank RCCL communicator (bootstrap through
+    tests/sample_compat/mpi.h).  Its default equation (:241) holds 2^36 complex elements in A alone — a multi-node
+    size — so the run passes a smaller equation of the same family through the sample's own --eq switch (:243-252)."""
+    exe = os.path.join(REF, "cutensorMp_contraction")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/cutensorMp_contraction was not built (reference tree absent at build time)")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([exe, "--eq", "abcdefghijEFGHIJKLMN,abcdefghijABCD->EFGHIJKLMNABCD"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, "cutensorMp_contraction exited %d\nstdout:\n%s\nstderr:\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "completed successfully" in r.stdout, r.stdout[-2000:]
