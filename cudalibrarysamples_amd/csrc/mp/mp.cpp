@@ -16,10 +16,18 @@
 //      own block — the result needs no scatter and beta * C needs no exchange.
 // The local contraction therefore always sees dense, packed operands (the GETT engine's fast layouts); the price
 // is that a contracted mode distributed over ranks is gathered rather than reduced.
+//
+// Second algorithm ("stationary inputs, reduce the result") for the opposite shape — A and B distributed identically
+// along contracted modes only, e.g. the headline einsum with K cut over the ranks: every rank contracts its own K
+// slice in place (no operand moves at all) into a full-size partial of C, and ONE RCCL collective finishes the job:
+// ncclAllReduce when C is replicated, ncclReduceScatter (destination blocks packed into equal slots) when C is
+// distributed.  beta * C enters the sum exactly once (rank 0 for a replicated C, the owner's block otherwise).
+// Every rank picks the algorithm from the same global byte counts, so the choice needs no communication.
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -60,7 +68,20 @@ public:
     virtual bool send(const void* buf, size_t bytes, int peer, hipStream_t s) = 0;
     virtual bool recv(void* buf, size_t bytes, int peer, hipStream_t s) = 0;
     virtual bool end(hipStream_t s) = 0;
+    // sums of `count` elements of the real type `t`; scratch: `count` elements, used by transports that need it
+    virtual bool all_reduce(void* buf, size_t count, hipDataType t, void* scratch, hipStream_t s) = 0;
+    virtual bool reduce_scatter(const void* send, void* recv, size_t countPerRank, hipDataType t, hipStream_t s) = 0;
+    virtual bool needs_scratch() const { return false; }
 };
+
+ncclDataType_t nccl_type(hipDataType t) {
+    switch (t) {
+        case HIP_R_16F: return ncclFloat16;
+        case HIP_R_16BF: return ncclBfloat16;
+        case HIP_R_64F: return ncclFloat64;
+        default: return ncclFloat32;
+    }
+}
 
 class RcclTransport : public Transport {
 public:
@@ -75,6 +96,12 @@ public:
         return ncclRecv(buf, bytes, ncclInt8, peer, comm_, s) == ncclSuccess;
     }
     bool end(hipStream_t) override { return ncclGroupEnd() == ncclSuccess; }
+    bool all_reduce(void* buf, size_t count, hipDataType t, void*, hipStream_t s) override {
+        return ncclAllReduce(buf, buf, count, nccl_type(t), ncclSum, comm_, s) == ncclSuccess;
+    }
+    bool reduce_scatter(const void* send, void* recv, size_t countPerRank, hipDataType t, hipStream_t s) override {
+        return ncclReduceScatter(send, recv, countPerRank, nccl_type(t), ncclSum, comm_, s) == ncclSuccess;
+    }
 private:
     ncclComm_t comm_;
     int rank_, size_;
@@ -90,7 +117,17 @@ struct LocalWorld {
     std::condition_variable cv;
     std::map<std::tuple<int, int, uint64_t>, Msg> box;   // (src, dst, sequence number of the pair)
     std::vector<uint64_t> sendSeq, recvSeq;              // [src * nranks + dst]
-    explicit LocalWorld(int n) : nranks(n), sendSeq((size_t)n * n, 0), recvSeq((size_t)n * n, 0) {}
+    std::vector<const void*> published;                  // collectives: every rank's buffer
+    int arrived = 0;
+    uint64_t generation = 0;
+    explicit LocalWorld(int n) : nranks(n), sendSeq((size_t)n * n, 0), recvSeq((size_t)n * n, 0), published((size_t)n, nullptr) {}
+    // host barrier of the rank threads; false when a rank never arrives
+    bool barrier(int timeoutS) {
+        std::unique_lock<std::mutex> lock(mu);
+        const uint64_t gen = generation;
+        if (++arrived == nranks) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        return cv.wait_for(lock, std::chrono::seconds(timeoutS), [&] { return generation != gen; });
+    }
 };
 
 class LocalTransport : public Transport {
@@ -143,8 +180,61 @@ public:
         sent_.clear(); pending_.clear();
         return ok;
     }
+    // Collectives: stream-synchronous on purpose (this transport exists for verification, not speed).  Every rank
+    // publishes its buffer, sums all of them slot-wise with the engine's own element-wise ADD, and nobody touches a
+    // published buffer again before every rank has finished reading it.
+    void set_engine(cutensorHandle_t h) { engine_ = h; }
+    bool needs_scratch() const override { return true; }
+    bool all_reduce(void* buf, size_t count, hipDataType t, void* scratch, hipStream_t s) override {
+        if (!publish(buf, s)) return false;
+        bool ok = sum_slots(scratch, 0, count, t, s);
+        ok = hipStreamSynchronize(s) == hipSuccess && ok;
+        ok = w_->barrier(kPeerTimeoutS) && ok;      // every rank has read every buffer
+        ok = ok && hipMemcpyAsync(buf, scratch, count * real_size(t), hipMemcpyDeviceToDevice, s) == hipSuccess;
+        return ok;
+    }
+    bool reduce_scatter(const void* send, void* recv, size_t countPerRank, hipDataType t, hipStream_t s) override {
+        if (!publish(send, s)) return false;
+        bool ok = sum_slots(recv, (size_t)rank_ * countPerRank, countPerRank, t, s);
+        ok = hipStreamSynchronize(s) == hipSuccess && ok;
+        return w_->barrier(kPeerTimeoutS) && ok;
+    }
 private:
     static constexpr int kPeerTimeoutS = 60;
+    static size_t real_size(hipDataType t) { return t == HIP_R_64F ? 8 : (t == HIP_R_32F ? 4 : 2); }
+    bool publish(const void* buf, hipStream_t s) {
+        if (hipStreamSynchronize(s) != hipSuccess) return false;
+        { std::lock_guard<std::mutex> lock(w_->mu); w_->published[(size_t)rank_] = buf; }
+        return w_->barrier(kPeerTimeoutS);
+    }
+    // dst[0..count) = sum over ranks q of published[q][offset .. offset + count)
+    bool sum_slots(void* dst, size_t offset, size_t count, hipDataType t, hipStream_t s) {
+        const size_t es = real_size(t);
+        const int64_t ext[1] = {(int64_t)count};
+        const int32_t lab[1] = {0};
+        cutensorTensorDescriptor_t d = nullptr;
+        cutensorOperationDescriptor_t op = nullptr;
+        cutensorPlan_t plan = nullptr;
+        cutensorStatus_t st = cutensorCreateTensorDescriptor(engine_, &d, 1, ext, nullptr, t, (uint32_t)es);
+        if (st == CUTENSOR_STATUS_SUCCESS)
+            st = cutensorCreateElementwiseBinary(engine_, &op, d, lab, CUTENSOR_OP_IDENTITY, d, lab, CUTENSOR_OP_IDENTITY, d, lab, CUTENSOR_OP_ADD,
+                                                 t == HIP_R_64F ? CUTENSOR_COMPUTE_DESC_64F : CUTENSOR_COMPUTE_DESC_32F);
+        if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(engine_, &plan, op, nullptr, 0);
+        const float onef = 1.f;
+        const double oned = 1.0;
+        const void* one = t == HIP_R_64F ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
+        bool ok = st == CUTENSOR_STATUS_SUCCESS;
+        for (int q = 0; q < w_->nranks && ok; ++q) {
+            const char* src = static_cast<const char*>(w_->published[(size_t)q]) + offset * es;
+            if (q == 0) ok = hipMemcpyAsync(dst, src, count * es, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            else ok = cutensorElementwiseBinaryExecute(engine_, plan, one, src, one, dst, dst, s) == CUTENSOR_STATUS_SUCCESS;
+        }
+        cutensorDestroyPlan(plan);
+        cutensorDestroyOperationDescriptor(op);
+        cutensorDestroyTensorDescriptor(d);
+        return ok;
+    }
+    cutensorHandle_t engine_ = nullptr;
     struct Pending { void* buf; size_t bytes; int peer; };
     size_t peer_index(int peer) const { return (size_t)peer * w_->nranks + rank_; }
     LocalWorld* w_;
@@ -297,6 +387,23 @@ struct OperandPlan {
     std::vector<CopyOp> localCopies; // own block -> staging
 };
 
+// "stationary inputs, reduce the result" (see the header of this file)
+struct ReducePlan {
+    bool replicatedC = false;
+    bool direct = false;             // replicated C, packed: contract and all-reduce in the user's D
+    int64_t stageOff = 0, stageBytes = 0;     // the full-size partial of C
+    CopyOp cIn;                      // beta != 0: the rank's (block of) C -> partial
+    CopyOp out;                      // replicated, not direct: reduced partial -> D
+    bool packDirect = false;         // the destination blocks are already equal contiguous slots of the partial
+    std::vector<CopyOp> pack;        // partial -> slot q of the send region
+    int64_t sendOff = 0, sendBytes = 0, slotElems = 0;
+    bool recvDirect = false;         // the rank's D block is a packed slot: reduce-scatter straight into it
+    int64_t recvOff = 0, recvBytes = 0;
+    CopyOp unpack;                   // received slot -> D block
+    int64_t scratchOff = 0, scratchBytes = 0;
+    int64_t cInDstOff = 0;           // element offset of the own block inside the partial
+};
+
 }  // namespace
 
 struct cutensorMpHandle {
@@ -324,7 +431,14 @@ struct cutensorMpPlan {
     uint64_t contractionWs = 0;
     int64_t sendBytes = 0, recvBytes = 0, stageBytes = 0;
     uint64_t requiredDevice = 0;
+    bool reduce = false;                    // algorithm: false = gather operands, true = reduce the result
+    ReducePlan red;
+    int64_t gatherTotal = 0, reduceTotal = 0;   // bytes on the wire over all ranks, per algorithm (the selection rule)
     ~cutensorMpPlan() {
+        cutensorDestroyPlan(red.cIn.plan);
+        cutensorDestroyPlan(red.out.plan);
+        cutensorDestroyPlan(red.unpack.plan);
+        for (CopyOp& c : red.pack) cutensorDestroyPlan(c.plan);
         for (Transfer& t : sends) cutensorDestroyPlan(t.pack.plan);
         for (Transfer& t : recvs) cutensorDestroyPlan(t.unpack.plan);
         for (OperandPlan& o : in) for (CopyOp& c : o.localCopies) cutensorDestroyPlan(c.plan);
@@ -375,6 +489,215 @@ uint32_t alignment_of(int64_t byteOffset) {
     uint32_t a = 256;
     while (a > 1 && (byteOffset % a) != 0) a >>= 1;
     return a;
+}
+
+
+// ---- algorithm selection and the reduce plan ---------------------------------------------------------------------
+// Bytes every rank would receive under the gather algorithm, summed over ranks.
+int64_t gather_traffic(const cutensorMpOperationDescriptor& d, const std::vector<Box>& cBox, int world, int64_t es) {
+    int64_t total = 0;
+    const MpTensor* X[2] = {&d.A, &d.B};
+    for (int k = 0; k < 2; ++k) {
+        const MpTensor& x = *X[k];
+        if (x.replicated()) continue;
+        for (int q = 0; q < world; ++q) {
+            if (cBox[(size_t)q].empty()) continue;
+            const Box need = needed_box(d, k, cBox[(size_t)q]);
+            for (int64_t c = 0; c < x.numCells; ++c)
+                if (x.owner[(size_t)c] != q) total += intersect(need, cell_box(x, c)).volume() * es;
+        }
+    }
+    return total;
+}
+
+// The reduce algorithm applies when A and B are cut along contracted modes only and every rank holds the same
+// non-empty K range of both.
+bool reduce_applicable(const cutensorMpOperationDescriptor& d, int world) {
+    if (d.A.replicated() || d.B.replicated() || world < 2) return false;
+    const MpTensor* X[2] = {&d.A, &d.B};
+    const std::vector<int32_t>* M[2] = {&d.mA, &d.mB};
+    for (int k = 0; k < 2; ++k)
+        for (uint32_t i = 0; i < X[k]->n; ++i) {
+            if (X[k]->p[i] == 1) continue;
+            if (find_label(d.mC, (*M[k])[i]) >= 0) return false;            // a free / batch mode is cut
+            if (find_label(*M[1 - k], (*M[k])[i]) < 0) return false;
+        }
+    for (int r = 0; r < world; ++r) {
+        const Box a = cell_box(d.A, cell_of_rank(d.A, r)), b = cell_box(d.B, cell_of_rank(d.B, r));
+        if (a.empty() || b.empty()) return false;
+        for (uint32_t i = 0; i < d.A.n; ++i) {
+            const int j = find_label(d.mB, d.mA[i]);
+            if (j >= 0 && (a.lo[i] != b.lo[(size_t)j] || a.hi[i] != b.hi[(size_t)j])) return false;
+        }
+    }
+    return true;
+}
+
+// a box that is one contiguous run of a packed tensor of extents `full`
+bool contiguous_in(const Box& b, const std::vector<int64_t>& full) {
+    bool partialSeen = false;
+    for (size_t i = 0; i < full.size(); ++i) {
+        const int64_t sz = b.hi[i] - b.lo[i];
+        if (partialSeen && sz != 1) return false;
+        if (sz != full[i]) partialSeen = true;
+    }
+    return true;
+}
+
+cutensorStatus_t build_reduce_plan(cutensorMpHandle* handle, cutensorMpPlan* pl, const std::vector<Box>& cBox, uint64_t devLimit) {
+    const cutensorMpOperationDescriptor& d = pl->desc;
+    ReducePlan& R = pl->red;
+    cutensorHandle_t h = handle->h;
+    const int me = pl->rank, world = pl->nranks;
+    const int64_t es = (int64_t)elem_size(d.C.dtype);
+    const std::vector<int64_t> full = d.C.extent;
+    const std::vector<int64_t> pStride = packed_strides(full);
+    Box whole; whole.lo.assign(d.C.n, 0); whole.hi = full;
+    const int64_t cElems = whole.volume();
+    const Box myC = cBox[(size_t)me];
+    cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+    int64_t off = 0;
+    auto region = [&](int64_t bytes, int64_t& at) { at = off; off += round_up(bytes, 256); };
+
+    R.replicatedC = d.C.replicated();
+    if (R.replicatedC) {
+        R.direct = d.C.packed && d.C.bs == d.C.extent;
+        if (!R.direct) {
+            R.stageBytes = cElems * es;
+            region(R.stageBytes, R.stageOff);
+            st = make_copy(h, d.C.dtype, copy_modes(whole, d.C.elemStride, pStride), R.cIn);
+            if (st == CUTENSOR_STATUS_SUCCESS) st = make_copy(h, d.C.dtype, copy_modes(whole, pStride, d.C.elemStride), R.out);
+            if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        }
+        if (handle->transport->needs_scratch()) { R.scratchBytes = cElems * es; region(R.scratchBytes, R.scratchOff); }
+    } else {
+        R.stageBytes = cElems * es;
+        region(R.stageBytes, R.stageOff);
+        if (!myC.empty()) {
+            st = make_copy(h, d.C.dtype, copy_modes(myC, d.C.elemStride, pStride), R.cIn);
+            if (st != CUTENSOR_STATUS_SUCCESS) return st;
+            R.cInDstOff = box_offset(myC, whole, pStride);
+        }
+        for (int q = 0; q < world; ++q) R.slotElems = std::max(R.slotElems, cBox[(size_t)q].volume());
+        R.slotElems = std::max<int64_t>(R.slotElems, 1);
+        R.packDirect = true;
+        for (int q = 0; q < world; ++q) {
+            const Box& b = cBox[(size_t)q];
+            if (b.empty() || b.volume() != R.slotElems || !contiguous_in(b, full) || box_offset(b, whole, pStride) != q * R.slotElems)
+                R.packDirect = false;
+        }
+        if (!R.packDirect) {
+            R.sendBytes = (int64_t)world * R.slotElems * es;
+            region(R.sendBytes, R.sendOff);
+            R.pack.resize((size_t)world);
+            for (int q = 0; q < world; ++q) {
+                const Box& b = cBox[(size_t)q];
+                if (b.empty()) continue;
+                st = make_copy(h, d.C.dtype, copy_modes(b, pStride, packed_strides(sizes(b))), R.pack[(size_t)q]);
+                if (st != CUTENSOR_STATUS_SUCCESS) return st;
+                for (auto& l : R.pack[(size_t)q].launches) { l.first += box_offset(b, whole, pStride); l.second += (int64_t)q * R.slotElems; }
+            }
+        }
+        R.recvDirect = !myC.empty() && d.C.packed && sizes(myC) == d.C.bs && myC.volume() == R.slotElems;
+        if (!R.recvDirect) {
+            R.recvBytes = R.slotElems * es;
+            region(R.recvBytes, R.recvOff);
+            if (!myC.empty()) {
+                st = make_copy(h, d.C.dtype, copy_modes(myC, packed_strides(sizes(myC)), d.C.elemStride), R.unpack);
+                if (st != CUTENSOR_STATUS_SUCCESS) return st;
+            }
+        }
+    }
+    const uint64_t fixed = (uint64_t)off;
+    if (fixed > devLimit) return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+
+    // the local contraction: own blocks of A and B in place, the partial (or the user's D) as packed full-size C
+    const Box aBox = cell_box(d.A, cell_of_rank(d.A, me)), bBox = cell_box(d.B, cell_of_rank(d.B, me));
+    const std::vector<int64_t> extA = sizes(aBox), extB = sizes(bBox);
+    cutensorTensorDescriptor_t dT[3] = {nullptr, nullptr, nullptr};
+    st = cutensorCreateTensorDescriptor(h, &dT[0], d.A.n, extA.data(), d.A.elemStride.data(), d.A.dtype, 256);
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreateTensorDescriptor(h, &dT[1], d.B.n, extB.data(), d.B.elemStride.data(), d.B.dtype, 256);
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreateTensorDescriptor(h, &dT[2], d.C.n, full.data(), pStride.data(), d.C.dtype, 256);
+    cutensorOperationDescriptor_t op = nullptr;
+    cutensorPlanPreference_t pp = nullptr;
+    if (st == CUTENSOR_STATUS_SUCCESS)
+        st = cutensorCreateContraction(h, &op, dT[0], d.mA.data(), d.opA, dT[1], d.mB.data(), d.opB, dT[2], d.mC.data(), d.opC,
+                                       dT[2], d.mC.data(), d.compute);
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlanPreference(h, &pp, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE);
+    uint64_t want = 0;
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorEstimateWorkspaceSize(h, op, pp, CUTENSOR_WORKSPACE_DEFAULT, &want);
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &pl->contraction, op, pp, std::min<uint64_t>(want, devLimit - fixed));
+    if (st == CUTENSOR_STATUS_SUCCESS)
+        st = cutensorPlanGetAttribute(h, pl->contraction, CUTENSOR_PLAN_REQUIRED_WORKSPACE, &pl->contractionWs, sizeof(uint64_t));
+    cutensorDestroyOperationDescriptor(op);
+    cutensorDestroyPlanPreference(pp);
+    for (auto t : dT) cutensorDestroyTensorDescriptor(t);
+    if (st != CUTENSOR_STATUS_SUCCESS) return st;
+    pl->stageBytes = off;    // everything before the contraction workspace
+    pl->compute = true;
+    pl->requiredDevice = fixed + (uint64_t)round_up((int64_t)pl->contractionWs, 256);
+    return CUTENSOR_STATUS_SUCCESS;
+}
+
+bool scalar_is_zero(const void* x, hipDataType t) {
+    switch (t) {
+        case HIP_R_64F: return *static_cast<const double*>(x) == 0.0;
+        case HIP_C_64F: return static_cast<const double*>(x)[0] == 0.0 && static_cast<const double*>(x)[1] == 0.0;
+        case HIP_C_32F: return static_cast<const float*>(x)[0] == 0.f && static_cast<const float*>(x)[1] == 0.f;
+        default: return *static_cast<const float*>(x) == 0.f;
+    }
+}
+
+cutensorStatus_t run_reduce(cutensorMpHandle* handle, const cutensorMpPlan* plan, const void* alpha, const void* A, const void* B,
+                            const void* beta, const void* C, void* D, char* ws) {
+    const cutensorMpOperationDescriptor& d = plan->desc;
+    const ReducePlan& R = plan->red;
+    cutensorHandle_t h = handle->h;
+    hipStream_t s = handle->stream;
+    Transport& tp = *handle->transport;
+    const hipDataType dt = d.C.dtype, rt = real_type(dt);
+    const int64_t es = (int64_t)elem_size(dt);
+    const size_t perElem = is_complex(dt) ? 2 : 1;
+    const double zero[2] = {0.0, 0.0};                  // a zero scalar of every scalar type
+    const bool haveBeta = !scalar_is_zero(beta, dt);
+    char* ctrWs = ws + plan->stageBytes;
+    int64_t cElems = 1;
+    for (int64_t e : d.C.extent) cElems *= e;
+    cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+    if (C == nullptr) C = D;
+
+    if (R.replicatedC) {
+        char* T = R.direct ? static_cast<char*>(D) : ws + R.stageOff;
+        const bool mine = haveBeta && plan->rank == 0;  // beta * C enters the sum once
+        if (!R.direct && mine) { st = run_copy(h, R.cIn, dt, C, T, s); if (st != CUTENSOR_STATUS_SUCCESS) return st; }
+        const void* cIn = R.direct ? C : T;
+        st = cutensorContract(h, plan->contraction, alpha, A, B, mine ? beta : zero, cIn, T, ctrWs, plan->contractionWs, s);
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        if (!tp.all_reduce(T, (size_t)cElems * perElem, rt, ws + R.scratchOff, s)) return CUTENSOR_STATUS_EXECUTION_FAILED;
+        if (!R.direct) st = run_copy(h, R.out, dt, T, D, s);
+        return st;
+    }
+    char* P = ws + R.stageOff;
+    const bool mine = haveBeta && R.cIn.plan != nullptr;
+    if (haveBeta) {
+        if (hipMemsetAsync(P, 0, (size_t)(cElems * es), s) != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
+        if (mine) { st = run_copy(h, R.cIn, dt, C, P + R.cInDstOff * es, s); if (st != CUTENSOR_STATUS_SUCCESS) return st; }
+    }
+    st = cutensorContract(h, plan->contraction, alpha, A, B, haveBeta ? beta : zero, P, P, ctrWs, plan->contractionWs, s);
+    if (st != CUTENSOR_STATUS_SUCCESS) return st;
+    const char* send = P;
+    if (!R.packDirect) {
+        send = ws + R.sendOff;
+        for (const CopyOp& c : R.pack) {
+            if (c.plan == nullptr) continue;
+            st = run_copy(h, c, dt, P, ws + R.sendOff, s);
+            if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        }
+    }
+    char* recv = R.recvDirect ? static_cast<char*>(D) : ws + R.recvOff;
+    if (!tp.reduce_scatter(send, recv, (size_t)R.slotElems * perElem, rt, s)) return CUTENSOR_STATUS_EXECUTION_FAILED;
+    if (!R.recvDirect && R.unpack.plan != nullptr) st = run_copy(h, R.unpack, dt, recv, D, s);
+    return st;
 }
 
 }  // namespace
@@ -428,9 +751,12 @@ cutensorStatus_t ctamdMpCreateOnLocalWorld(cutensorMpHandle_t* handle, void* wor
     if (handle == nullptr || w == nullptr || rank < 0 || rank >= w->nranks) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorMpHandle* h = new (std::nothrow) cutensorMpHandle();
     if (h == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
-    h->transport = new (std::nothrow) LocalTransport(w, rank);
+    LocalTransport* lt = new (std::nothrow) LocalTransport(w, rank);
+    h->transport = lt;
     if (h->transport == nullptr) { delete h; return CUTENSOR_STATUS_ALLOC_FAILED; }
-    return finish_handle(h, localDevice, stream, handle);
+    cutensorStatus_t st = finish_handle(h, localDevice, stream, handle);
+    if (st == CUTENSOR_STATUS_SUCCESS) lt->set_engine((*handle)->h);
+    return st;
 }
 
 // cutensorMp_contraction.cu:474-483
@@ -579,6 +905,27 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
         cBox[(size_t)q] = cell_box(d.C, c);
     }
     pl->compute = !cBox[(size_t)me].empty();
+
+    // ---- algorithm: identical inputs on every rank, hence an identical choice -------------------------------------
+    {
+        int64_t cElems = 1;
+        for (int64_t e : d.C.extent) cElems *= e;
+        pl->gatherTotal = gather_traffic(d, cBox, world, es);
+        // ring all-reduce moves ~2 |C| per rank, reduce-scatter ~|C|
+        pl->reduceTotal = (int64_t)world * cElems * es * (d.C.replicated() ? 2 : 1);
+        bool useReduce = reduce_applicable(d, world) && pl->reduceTotal < pl->gatherTotal;
+        if (const char* force = std::getenv("CUTENSORMP_AMD_ALGO")) {       // tests: "gather" / "reduce" on every rank
+            if (std::strcmp(force, "gather") == 0) useReduce = false;
+            else if (std::strcmp(force, "reduce") == 0) useReduce = reduce_applicable(d, world);
+        }
+        if (useReduce) {
+            pl->reduce = true;
+            st = build_reduce_plan(handle, pl, cBox, devLimit);
+            if (st != CUTENSOR_STATUS_SUCCESS) return bail(st);
+            *plan = pl;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
+    }
 
     // ---- transfers: (tensor, receiver q, cell c) in a fixed order both sides agree on ------------------------
     int64_t sendOff = 0, recvOff = 0;
@@ -736,6 +1083,7 @@ cutensorStatus_t cutensorMpContract(const cutensorMpHandle_t handle, const cuten
     char* ctrWs = stageBase + plan->stageBytes;
     const void* user[2] = {A, B};
     cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+    if (plan->reduce) return run_reduce(handle, plan, alpha, A, B, beta, C, D, ws);
 
     // 1. pack what other ranks need from this rank's blocks
     for (const Transfer& t : plan->sends) {
@@ -788,6 +1136,10 @@ size_t ctamdMpDescribePlan(const cutensorMpPlan_t plan, char* buf, size_t bufSiz
     char tmp[256];
     auto add = [&](const char* fmt, auto... a) { std::snprintf(tmp, sizeof(tmp), fmt, a...); j += tmp; };
     add("\"rank\": %d, \"nranks\": %d, \"compute\": %s, ", plan->rank, plan->nranks, plan->compute ? "true" : "false");
+    add("\"algorithm\": \"%s\", \"gatherTotal\": %lld, \"reduceTotal\": %lld, ", plan->reduce ? "reduce" : "gather",
+        (long long)plan->gatherTotal, (long long)plan->reduceTotal);
+    add("\"reduceDirect\": %s, \"packDirect\": %s, \"recvDirect\": %s, ", plan->red.direct ? "true" : "false",
+        plan->red.packDirect ? "true" : "false", plan->red.recvDirect ? "true" : "false");
     add("\"stagedA\": %s, \"stagedB\": %s, ", plan->in[0].staged ? "true" : "false", plan->in[1].staged ? "true" : "false");
     add("\"sendBytes\": %lld, \"recvBytes\": %lld, \"stageBytes\": %lld, \"contractionWorkspace\": %llu, \"requiredDevice\": %llu, ",
         (long long)plan->sendBytes, (long long)plan->recvBytes, (long long)plan->stageBytes,

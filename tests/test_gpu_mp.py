@@ -184,6 +184,46 @@ def test_mp_contraction_over_local_world(mp, case):
     run_case(mp, eq, ext, dist, nranks, dtype, alpha, beta)
 
 
+REDUCE_CASES = [
+    # name, eq, extents, (distA, distB, distC), nranks, dtype, alpha, beta
+    ("C replicated: all-reduce in the user's D", "mk,kn->mn", dict(m=48, k=128, n=40), ({"k": 4}, {"k": 4}, {}), 4, "f32", 1.0, 0.5),
+    ("C cut along its last mode: slots are slabs", "mk,kn->mn", dict(m=64, k=96, n=48), ({"k": 2}, {"k": 2}, {"n": 2}), 2, "f32", 0.7, 0.5),
+    ("C cut along its first mode: packed slots", "mk,kn->mn", dict(m=64, k=96, n=48), ({"k": 2}, {"k": 2}, {"m": 2}), 2, "f32", 1.0, 0.0),
+    ("ragged 2x2 grid of C, two contracted modes cut", "mkl,lkn->mn", dict(m=50, k=12, l=10, n=27), ({"k": 2, "l": 2}, {"l": 2, "k": 2}, {"m": 2, "n": 2}), 4, "f32", 1.0, 0.25,
+     [None, [0, 2, 1, 3], None]),   # B's grid is (l, k): this rank order gives every rank the same (k, l) block of A and B
+    ("the headline einsum, shrunk, K cut over four ranks", "dcba,ebcd->ea", dict(a=24, b=16, c=8, d=16, e=24), ({"b": 4}, {"b": 4}, {}), 4, "f32", 1.0, 0.0),
+    ("complex", "mk,kn->mn", dict(m=20, k=64, n=12), ({"k": 2}, {"k": 2}, {"n": 2}), 2, "c64", 1.0, 0.5),
+    ("bf16", "mk,kn->mn", dict(m=128, k=512, n=64), ({"k": 2}, {"k": 2}, {}), 2, "bf16", 1.0, 0.0),
+    ("fp64, three ranks, one with an empty block of C", "mk,kn->mn", dict(m=4, k=90, n=16), ({"k": 3}, {"k": 3}, {"m": 3}), 3, "f64", 1.0, 0.5),
+]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("algo", ["reduce", "gather"])
+@pytest.mark.parametrize("case", REDUCE_CASES, ids=[c[0] for c in REDUCE_CASES])
+def test_mp_contracted_mode_distributed_both_algorithms(mp, monkeypatch, case, algo):
+    """A and B cut along contracted modes only: the result is either reduced (all-reduce / reduce-scatter of partials,
+    no operand moves) or the operands are gathered; both must give the reference answer on the same inputs."""
+    _, eq, ext, dist, nranks, dtype, alpha, beta = case[:8]
+    monkeypatch.setenv("CUTENSORMP_AMD_ALGO", algo)
+    d = run_case(mp, eq, ext, dist, nranks, dtype, alpha, beta, ranks=case[8] if len(case) > 8 else None)
+    assert all(x["algorithm"] == algo for x in d), d[0]
+    if algo == "reduce":
+        assert all(x["sends"] == [] and x["recvs"] == [] for x in d)        # no operand leaves its rank
+
+
+@pytest.mark.timeout(300)
+def test_mp_algorithm_choice_follows_the_byte_counts(mp):
+    """Tiny C, long K: reduce.  Free mode cut, K whole: gather (nothing to reduce).  K cut but C as large as the
+    operands: gather wins the byte count."""
+    d = run_case(mp, "dcba,ebcd->ea", dict(a=24, b=16, c=8, d=16, e=24), ({"b": 2}, {"b": 2}, {}), 2)
+    assert all(x["algorithm"] == "reduce" and x["reduceTotal"] < x["gatherTotal"] and x["reduceDirect"] for x in d)
+    d = run_case(mp, "mk,kn->mn", dict(m=64, k=32, n=16), ({"m": 2}, {}, {"m": 2}), 2)
+    assert all(x["algorithm"] == "gather" for x in d)
+    d = run_case(mp, "mk,kn->mn", dict(m=256, k=4, n=256), ({"k": 2}, {"k": 2}, {}), 2)
+    assert all(x["algorithm"] == "gather" and x["reduceTotal"] >= x["gatherTotal"] for x in d)
+
+
 @pytest.mark.timeout(300)
 def test_mp_sample_style_complex_many_modes(mp):
     """The shape family of the sample (:241: complex<float>, every extent 2, dozens of modes), two ranks, one
