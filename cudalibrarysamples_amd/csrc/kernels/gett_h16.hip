@@ -117,16 +117,17 @@ __device__ __forceinline__ uint16_t h_from_float(float f, bool bf) {
 // ---------------------------------------------------------------------------------------------
 // One operand (A rows or B columns) of the streamed K-tile.
 // ---------------------------------------------------------------------------------------------
-template <int LAY>
+template <int LAY, int NW = 8>
 struct HOperand {
-    uint32_t src[2][2];   // byte offset of this lane's 16-byte unit: [half-tile][piece i of this wave], tile k0 = 0
+    static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
+    uint32_t src[2][kPieces];   // byte offset of this lane's 16-byte unit: [half-tile][piece i of this wave], tile k0 = 0
 
     __device__ __forceinline__ void init(const ModeGroup& gFree, uint32_t strideK0, uint32_t row0, int wave, int lane) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = wave + 8 * i;                      // 1-KiB piece of the half-tile
+            for (int i = 0; i < kPieces; ++i) {
+                const int c = wave + NW * i;                     // 1-KiB piece of the half-tile
                 if constexpr (LAY == LAY_K) {
                     const int r = 8 * c + (lane >> 3), p = lane & 7;
                     const int u = p ^ ((r >> 1) & 7);
@@ -145,8 +146,12 @@ struct HOperand {
 
     template <bool PAD = true>
     __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t tileBytes, uint32_t slotByte, int wave) const {
-        h_dma16<PAD>(X, src[h][0], tileBytes, slotByte + (uint32_t)wave * 1024u);
-        h_dma16<PAD>(X, src[h][1], tileBytes, slotByte + (uint32_t)(wave + 8) * 1024u);
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) h_dma16<PAD>(X, src[h][i], tileBytes, slotByte + (uint32_t)(wave + NW * i) * 1024u);
+    }
+    template <bool PAD = true>
+    __device__ __forceinline__ void issue_piece(HRsrc X, int h, int i, uint32_t tileBytes, uint32_t slotByte, int wave) const {
+        h_dma16<PAD>(X, src[h][i], tileBytes, slotByte + (uint32_t)(wave + NW * i) * 1024u);
     }
 };
 
@@ -454,6 +459,228 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     store_frag(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
 }
 
+
+// =====================================================================================================
+// Four-wave variant (one wave per SIMD, 512 registers per lane): same 256 x 256 x 64 tile, LDS images and
+// source-side swizzles as above; 4 waves as 2 (M) x 2 (N), a wave owns a 128 x 128 quadrant = 4 x 4
+// accumulator fragments (256 registers).  Per K-tile a wave issues 64 MFMAs, reads 32 fragments (half the LDS
+// traffic per MFMA of the 2 x 4 arrangement) and stages 16 KiB by LDS-DMA; nothing is handed from wave to
+// wave, so there is ONE barrier per K-tile instead of eight:
+//   k-steps 0..2 : fragment reads of step s + 1 interleaved with the 16 MFMAs of step s (two register sets);
+//   k-step  3    : own reads of this buffer are back, own pieces of tile t + 1 have landed -> barrier; now
+//                  the buffer of tile t is free and the buffer of tile t + 1 complete: first fragment reads of
+//                  tile t + 1 and the 16 LDS-DMA pieces of tile t + 2 (one per MFMA) beside the last 16 MFMAs.
+// The matrix pipe only waits for the skew between the four waves at that barrier.
+// =====================================================================================================
+// ABL (measurement only, wrong results): 1 = no LDS-DMA in the main loop, 2 = LDS-DMA issued but never waited for,
+// 3 = no barrier / waits at the tile boundary.
+template <bool BF, int LA, int LB, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    const HRsrc rA = h_make_rsrc(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l));
+    const HRsrc rB = h_make_rsrc(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l));
+    HOperand<LA, 4> oa;
+    HOperand<LB, 4> ob;
+    oa.init(p.gM, (uint32_t)p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, (uint32_t)p.gK.stride[1][0], n0, wave, lane);
+
+    uint32_t offK[4], offF[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { offK[s] = h_offK(lane, s); offF[s] = h_offF(lane, s); }
+
+    HOdometer odo;
+    odo.init(p.gK, tile0 * kHBK);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // piece n = 0..15 of a K-tile for this wave: operand half q = n >> 2 (A0, A1, B0, B1), piece i = n & 3
+#define CTAMD_W4_DMA(P, N, PAD)                                                                                     \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        if constexpr (q_ < 2) oa.template issue_piece<PAD>(rA, q_, i_, odo.offA, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave); \
+        else ob.template issue_piece<PAD>(rB, q_ - 2, i_, odo.offB, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave);   \
+    }
+#define CTAMD_W4_STAGE(P, PAD)                                                                                      \
+    CTAMD_W4_DMA(P, 0, PAD) CTAMD_W4_DMA(P, 1, PAD) CTAMD_W4_DMA(P, 2, PAD) CTAMD_W4_DMA(P, 3, PAD)                \
+    CTAMD_W4_DMA(P, 4, PAD) CTAMD_W4_DMA(P, 5, PAD) CTAMD_W4_DMA(P, 6, PAD) CTAMD_W4_DMA(P, 7, PAD)                \
+    CTAMD_W4_DMA(P, 8, PAD) CTAMD_W4_DMA(P, 9, PAD) CTAMD_W4_DMA(P, 10, PAD) CTAMD_W4_DMA(P, 11, PAD)              \
+    CTAMD_W4_DMA(P, 12, PAD) CTAMD_W4_DMA(P, 13, PAD) CTAMD_W4_DMA(P, 14, PAD) CTAMD_W4_DMA(P, 15, PAD)
+
+    // ---- prologue: K-tiles 0 and 1 ------------------------------------------------------------------------
+    CTAMD_W4_STAGE(0, true)
+    if (1 < nTiles) odo.advance(p.gK);           // past the end the last tile is re-staged (never read)
+    CTAMD_W4_DMA(1, 0, true) CTAMD_W4_DMA(1, 1, true) CTAMD_W4_DMA(1, 2, true) CTAMD_W4_DMA(1, 3, true)
+    CTAMD_W4_DMA(1, 4, true) CTAMD_W4_DMA(1, 5, true) CTAMD_W4_DMA(1, 6, true) CTAMD_W4_DMA(1, 7, true)
+    int tNext = 1;                                // K-tile the odometer describes (its second half goes out in k-step 0)
+    CTAMD_H_VMCNT(8);                             // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s & 1
+
+    const char* const aSlot0 = lds + wr * kHalfBytes;          // A-half wr of buffer 0 (buffer 1: + 4 slots)
+    const char* const bSlot0 = lds + (2 + wc) * kHalfBytes;    // B-half wc of buffer 0
+    // fragment f = 0..7 of k-step S from buffer P into register set SET: f < 4 -> B columns 32 f (all four feed the first
+    // MFMAs of a step), else A rows 32 (f - 4)
+#define CTAMD_W4_READ(P, S, SET, F)                                                                                 \
+    {                                                                                                              \
+        if constexpr (ABL >= 4 && (P) < 2) {}                                                                      \
+        else if constexpr ((F) < 4) b[SET][F] = h_read_frag<LB>(bSlot0 + (P) * 4 * kHalfBytes, 32 * (F), S, offK, offF[F]);          \
+        else a[SET][(F) - 4] = h_read_frag<LA>(aSlot0 + (P) * 4 * kHalfBytes, 32 * ((F) - 4), S, offK, offF[(F) - 4]);        \
+    }
+#define CTAMD_W4_MFMA(SET, M) acc[(M) >> 2][(M) & 3] = h_mfma<BF>(a[SET][(M) >> 2], b[SET][(M) & 3], acc[(M) >> 2][(M) & 3]);
+    // k-step S < 3: one fragment read of step S + 1 per two MFMAs of step S; k-step 0 also carries the second half
+    // (pieces 8..15) of the tile being staged into the other buffer
+#define CTAMD_W4_PAIR(P, S, F)                                                                                      \
+    CTAMD_W4_READ(P, (S) + 1, ((S) + 1) & 1, F) CTAMD_W4_MFMA((S) & 1, 2 * (F))                                    \
+    if constexpr ((S) == 0 && ABL != 1 && ABL != 4) CTAMD_W4_DMA((P) ^ 1, 8 + (F), false)                          \
+    CTAMD_W4_MFMA((S) & 1, 2 * (F) + 1)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_W4_STEP(P, S)                                                                                         \
+    CTAMD_W4_PAIR(P, S, 0) CTAMD_W4_PAIR(P, S, 1) CTAMD_W4_PAIR(P, S, 2) CTAMD_W4_PAIR(P, S, 3)                    \
+    CTAMD_W4_PAIR(P, S, 4) CTAMD_W4_PAIR(P, S, 5) CTAMD_W4_PAIR(P, S, 6) CTAMD_W4_PAIR(P, S, 7)
+    // k-step 3: reads of the next tile's step 0 (other buffer), the first half (pieces 0..7) of tile t + 2 into this
+    // buffer, MFMAs of step 3 — a read and a piece alternate, one per MFMA
+#define CTAMD_W4_LAST2(P, F)                                                                                        \
+    CTAMD_W4_READ((P) ^ 1, 0, 0, F)                                                                                \
+    CTAMD_W4_MFMA(1, 2 * (F)) __builtin_amdgcn_sched_barrier(0);                                                   \
+    if constexpr (ABL != 1 && ABL != 4) CTAMD_W4_DMA(P, F, false)                                                  \
+    CTAMD_W4_MFMA(1, 2 * (F) + 1) __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_W4_TILE(P)                                                                                            \
+    CTAMD_W4_STEP(P, 0)                                                                                            \
+    ++tNext;                                                                                                       \
+    if (tNext < nTiles) odo.advance(p.gK);                                                                         \
+    CTAMD_W4_STEP(P, 1) CTAMD_W4_STEP(P, 2)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if constexpr (ABL != 3) CTAMD_H_LGKM0();                                                                       \
+    if constexpr (ABL != 2 && ABL != 3) CTAMD_H_VMCNT(0);                                                          \
+    if constexpr (ABL != 3) __builtin_amdgcn_s_barrier();                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_W4_LAST2(P, 0) CTAMD_W4_LAST2(P, 1) CTAMD_W4_LAST2(P, 2) CTAMD_W4_LAST2(P, 3)                            \
+    CTAMD_W4_LAST2(P, 4) CTAMD_W4_LAST2(P, 5) CTAMD_W4_LAST2(P, 6) CTAMD_W4_LAST2(P, 7)
+
+    // first fragments of tile 0
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        b[0][f] = h_read_frag<LB>(bSlot0, 32 * f, 0, offK, offF[f]);
+        a[0][f] = h_read_frag<LA>(aSlot0, 32 * f, 0, offK, offF[f]);
+        if constexpr (ABL >= 4) { b[1][f] = b[0][f]; a[1][f] = a[0][f]; }
+    }
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_W4_TILE(0) CTAMD_W4_TILE(1) }
+    if (t < nTiles) { CTAMD_W4_TILE(0) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t n = nW + (lane & 31);
+                    float* row = P + (size_t)m * Nt;
+                    if (n < Nt) row[n] = c0[r];
+                    if (n + 32 < Nt) row[n + 32] = c1[r];
+                    if (n + 64 < Nt) row[n + 64] = c2[r];
+                    if (n + 96 < Nt) row[n + 96] = c3[r];
+                }
+            }
+        };
+        store_partial(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
+        store_partial(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
+        store_partial(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
+        store_partial(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
+        return;
+    }
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    const float alpha = p.alpha, beta = p.beta;
+    int64_t offDn[4], offCn[4];
+    bool    okN[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t n = nW + 32 * j + (lane & 31);
+        okN[j] = n < Ntot;
+        offDn[j] = 0; offCn[j] = 0;
+        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    }
+    auto store_one = [&](float v, int64_t offD, int64_t offC) {
+        float val = alpha * v;
+        if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
+        D[offD] = h_from_float(val, BF);
+    };
+    auto store_row = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < Mtot) {
+                int64_t offDm, offCm;
+                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+                if (okN[0]) store_one(c0[r], offDm + offDn[0], offCm + offCn[0]);
+                if (okN[1]) store_one(c1[r], offDm + offDn[1], offCm + offCn[1]);
+                if (okN[2]) store_one(c2[r], offDm + offDn[2], offCm + offCn[2]);
+                if (okN[3]) store_one(c3[r], offDm + offDn[3], offCm + offCn[3]);
+            }
+        }
+    };
+    store_row(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
+    store_row(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
+    store_row(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
+    store_row(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4(const GettParams& p, hipStream_t stream) {
+    static const int abl = [] { const char* e = getenv("CUTENSOR_AMD_H16_ABL"); return e ? atoi(e) : 0; }();
+    if constexpr (BF && LA == LAY_K && LB == LAY_K) {
+        if (abl == 1) { hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB, 1>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (abl == 2) { hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB, 2>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (abl == 3) { hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB, 3>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (abl == 4) { hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (abl == 5) { hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+    }
+    hipLaunchKernelGGL((gett_h16w4_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
@@ -467,11 +694,18 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
 // bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F)
 #define CTAMD_H16_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 0, &launch_h16<bf, la, lb>, 0},
+#define CTAMD_H16W4_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 2, 1, 0, &launch_h16w4<bf, la, lb>, 0},
 static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16_ENTRY(false, LAY_K, LAY_K) CTAMD_H16_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16_ENTRY(false, LAY_F, LAY_K) CTAMD_H16_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16_ENTRY(false, LAY_F, LAY_K) CTAMD_H16_ENTRY(false, LAY_F, LAY_F)
+    // entries 8..15: the four-wave variant, same order
+    CTAMD_H16W4_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16_kernels(int* count) {
     *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));

@@ -163,3 +163,18 @@ def test_headline_einsum_shape_in_bf16(env):
     got, ref, d = _run(env, dict(a=96, b=16, c=16, d=64, e=96), "dcba", "ebcd", "ea", seed=23)
     assert d["splitK"] > 1, d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.25)
+
+
+def test_four_wave_variant_parity(built):
+    """The opt-in four-wave kernels (CUTENSOR_AMD_H16_WAVES=4, gett_h16w4_kernel: one wave per SIMD, 128 x 128 per wave,
+    one barrier per K-tile) must give the same answers: the GEMM-like, multi-mode and split-K cases of this file in a
+    child process that plans with the variant (the planner reads the switch once per process)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CUTENSOR_AMD_H16_WAVES="4")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "gemm_like or multi_mode or split_k or alpha_beta", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
