@@ -296,6 +296,7 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
         // pure permutation (einsum.cu:449-450 routes "nij->ijn" here): D = alpha*perm(A) + beta*C
         cutensorOperationDescriptor e = op;
         e.kind = OpKind::ElementwiseBinary;
+        e.opReduce = CUTENSOR_OP_ADD;   // nothing is reduced: opReduce (MAX / MIN / MUL) must not become the A-with-C combiner
         e.C.present = true;
         plan.isPermutation = true;
         return plan_elementwise(e, plan.perm, why);

@@ -106,6 +106,22 @@ def test_reduce_as_permutation_with_beta(env):
     assert_close(from_device(dC, C), ref, rtol=1e-6, what="reduce-as-permute")
 
 
+def test_max_min_reduction_over_unit_extents_still_adds_beta_c(env):
+    """A MAX / MIN reduction whose reduced modes all have extent 1 degenerates to a permutation; D must stay
+    alpha * A + beta * C — the reduction operator must not turn into the operator that joins A and C
+    (found by tools/fuzz_elementwise.py)."""
+    ct, ops, h, torch = env
+    eA, eC = [5, 1, 16, 12], [12, 5, 16]
+    A, C = make_tensor(eA, 51, lo=-1.0, hi=1.0), make_tensor(eC, 52, lo=-1.0, hi=1.0)
+    for op in (ct.OP_MAX, ct.OP_MIN, ct.OP_MUL):
+        p = ops.reduction_plan(h, eA, "ebgh", eC, "heg", op_reduce=op)
+        dA, dD = to_device(A), to_device(C)
+        p.reduce(-1.25, dA.data_ptr(), -0.5, dD.data_ptr(), dD.data_ptr(), 0, 0, 0)
+        torch.cuda.synchronize()
+        ref = -1.25 * np.transpose(A[:, 0, :, :], (2, 0, 1)) - 0.5 * C
+        assert_close(from_device(dD, C), ref, rtol=1e-6, atol=1e-6, what="unit-extent reduction, op %d" % op)
+
+
 def test_large_2d_transpose_roundtrip(env):
     """Size-independent property at a large size: transposing twice is the identity (bit-exact), and
     a checksum of the transposed tensor equals the checksum of the input."""
