@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--aligned", action="store_true", help="extents that satisfy the 16-byte-lane / whole-K-tile conditions of the "
                                                            "streaming fp32 and the 16-bit MFMA kernels")
+    ap.add_argument("--all-types", action="store_true", help="also fp64, fp16 and complex<float> (the functional kernels)")
+    ap.add_argument("--strided", action="store_true", help="give a third of the tensors padded (non-packed) strides")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -24,7 +26,7 @@ def main():
     fails = 0
     kinds = {}
     for case in range(args.cases):
-        dtype = rnd.choice(["float32", "float32", "bfloat16"])
+        dtype = rnd.choice(["float32", "float32", "bfloat16"] + (["float64", "float16", "complex64"] if args.all_types else []))
         nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
         labels = list("abcdefghij")
         rnd.shuffle(labels)
@@ -44,15 +46,35 @@ def main():
         if max(elems(mA), elems(mB), elems(mC)) > (1 << 24):
             continue
         tdt = getattr(torch, dtype)
-        A = (torch.rand([ext[c] for c in mA][::-1], device="cuda") * 2 - 1).to(tdt)
-        B = (torch.rand([ext[c] for c in mB][::-1], device="cuda") * 2 - 1).to(tdt)
-        C = (torch.rand([ext[c] for c in mC][::-1], device="cuda") * 2 - 1).to(tdt)
-        D = C.clone()
+
+        def make(m):
+            """Tensor with modes m (first fastest); with --strided sometimes a view into a buffer with padded extents.
+            Returns (torch view, column-major element strides or None)."""
+            e = [ext[c] for c in m]
+            pad = [rnd.choice([0, 0, 1, 3, 8]) if (args.strided and rnd.random() < 0.35) else 0 for _ in e]
+            full = [x + p_ for x, p_ in zip(e, pad)]
+            if tdt.is_complex:
+                base = torch.complex(torch.rand(full[::-1], device="cuda") * 2 - 1, torch.rand(full[::-1], device="cuda") * 2 - 1).to(tdt)
+            else:
+                base = (torch.rand(full[::-1], device="cuda") * 2 - 1).to(tdt)
+            view = base[tuple(slice(0, x) for x in e[::-1])]
+            if not any(pad):
+                return view, None
+            strides, run = [], 1
+            for x in full:
+                strides.append(run)
+                run *= x
+            return view, strides
+
+        (A, sA), (B, sB), (C, sC) = make(mA), make(mB), make(mC)
+        D = C.clone() if sC is None else C          # strided output: written in place (C aliases D, contraction.cu:264)
+        C0 = C.clone()
         alpha, beta = rnd.choice([1.0, 0.5, -1.25]), rnd.choice([0.0, 0.0, 1.0, -0.5])
         limit = rnd.choice([0, 1 << 20, 1 << 28])
         try:
+            cdt = {"float32": ct.R_32F, "bfloat16": ct.R_16BF, "float64": ct.R_64F, "float16": ct.R_16F, "complex64": ct.C_32F}[dtype]
             plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
-                                        dtype=ct.R_32F if dtype == "float32" else ct.R_16BF, workspace_limit=limit)
+                                        dtype=cdt, workspace_limit=limit, strideA=sA, strideB=sB, strideC=sC)
         except ct.CuTensorError as e:
             print("case %d: plan refused (%s) %s,%s->%s %s" % (case, e, mA, mB, mC, ext))
             fails += 1
@@ -62,12 +84,16 @@ def main():
         ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
         plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
         torch.cuda.synchronize()
-        ref = alpha * torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.double(), B.double()) + beta * C.double()
-        err = (D.double() - ref).abs()
+        wide = torch.complex128 if tdt.is_complex else torch.float64
+        ref = alpha * torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.to(wide), B.to(wide)) + beta * C0.to(wide)
+        err = (D.to(wide) - ref).abs()
         ktot = 1
         for c in K:
             ktot *= ext[c]
-        tol = (2e-5 if dtype == "float32" else 1e-2) * (1.0 + ref.abs()) + (1e-5 if dtype == "float32" else 4e-3) * ktot ** 0.5   # fp32 sequential accumulation: ~eps * K * |partial sums|
+        rel, absk = {"float32": (2e-5, 1e-5), "complex64": (4e-5, 2e-5), "float64": (1e-12, 1e-13), "float16": (2e-3, 1e-3),
+                     "bfloat16": (1e-2, 4e-3)}[dtype]
+        # sequential accumulation: ~eps * sqrt(K) steps, each relative to partial sums that themselves grow like sqrt(K)
+        tol = rel * (1.0 + ref.abs()) + absk * ktot ** 0.5 + rel * 1e-3 * ktot
         if not bool((err <= tol).all()):
             fails += 1
             print("case %d MISMATCH max err %.3e: %s,%s->%s %s %s alpha %g beta %g limit %d plan %s" % (
