@@ -44,6 +44,20 @@ def main():
     def rand(m, ext, tdt):
         return (torch.rand(shape(m, ext) or [1], device="cuda", dtype=torch.float64) * 2 - 1).to(tdt).reshape(shape(m, ext))
 
+    def rand_strided(m, ext, tdt):
+        """(view, column-major element strides or None): sometimes a view into a buffer with padded extents."""
+        e = [ext[c] for c in m]
+        pad = [rnd.choice([0, 0, 1, 3, 4, 8]) if rnd.random() < 0.4 else 0 for _ in e]
+        if not e or not any(pad):
+            return rand(m, ext, tdt), None
+        full = [x + p_ for x, p_ in zip(e, pad)]
+        base = (torch.rand(full[::-1], device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+        strides, run = [], 1
+        for x in full:
+            strides.append(run)
+            run *= x
+        return base[tuple(slice(0, x) for x in e[::-1])], strides
+
     def check(kind, got, ref, tol, scale, what):
         nonlocal fails
         err = float((got.double() - ref).abs().max()) if ref.numel() else 0.0
@@ -71,23 +85,26 @@ def main():
             if kind == "permute":
                 mA = "".join(labels)
                 mB = "".join(rnd.sample(labels, n))
-                A = rand(mA, ext, tdt)
-                B = torch.empty(shape(mB, ext), device="cuda", dtype=tdt)
-                plan = ops.permutation_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, dtype=cdt)
+                (A, sA), (B, sB) = rand_strided(mA, ext, tdt), rand_strided(mB, ext, tdt)
+                align = rnd.choice([128, 128, 16, A.element_size()])
+                plan = ops.permutation_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, dtype=cdt, strideA=sA, strideB=sB,
+                                            alignment=align)
                 plan.permute(alpha, A.data_ptr(), B.data_ptr())
                 torch.cuda.synchronize()
-                check(kind, B, alpha * as_modes(A.double(), mA, mB, ext), tol, 1.25, "%s->%s %s %s" % (mA, mB, ext, dtype))
+                check(kind, B, alpha * as_modes(A.double(), mA, mB, ext), tol, 1.25,
+                      "%s->%s %s %s strides %s %s align %d" % (mA, mB, ext, dtype, sA, sB, align))
             elif kind == "reduce":
                 mA = "".join(labels)
                 kept = rnd.sample(labels, rnd.randint(0, n - 1)) if n > 1 else []
                 mC = "".join(kept)
                 op = rnd.choice(["ADD", "ADD", "MAX", "MIN"])
-                A = rand(mA, ext, tdt)
-                C = rand(mC, ext, tdt)
-                D = C.clone()
-                plan = ops.reduction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mC], mC, dtype=cdt, op_reduce=ops._OPS[op])
+                (A, sA), (D, sC) = rand_strided(mA, ext, tdt), rand_strided(mC, ext, tdt)
+                C = D.clone()                      # D aliases C in the call (reduction.cu:219-222); C keeps the input values
+                align = rnd.choice([128, 128, 16, A.element_size()])
+                plan = ops.reduction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mC], mC, dtype=cdt, op_reduce=ops._OPS[op],
+                                          strideA=sA, strideC=sC, alignment=align)
                 ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
-                plan.reduce(alpha, A.data_ptr(), gamma, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
+                plan.reduce(alpha, A.data_ptr(), gamma, D.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
                 torch.cuda.synchronize()
                 red_dims = [i for i, c in enumerate(list(mA)[::-1]) if c not in kept]
                 a64 = A.double()
@@ -104,7 +121,7 @@ def main():
                     volC *= ext[c]
                 nred = vol // volC
                 check(kind, D, ref, tol, 1.25 * (nred ** 0.5 if op == "ADD" else 1.0) + 1.0,
-                      "%s->%s %s %s %s alpha %g beta %g" % (mA, mC, op, ext, dtype, alpha, gamma))
+                      "%s->%s %s %s %s alpha %g beta %g strides %s %s align %d" % (mA, mC, op, ext, dtype, alpha, gamma, sA, sC, align))
             elif kind == "binary":
                 mC = "".join(labels)
                 mA = "".join(rnd.sample(labels, n))
