@@ -299,7 +299,8 @@ struct CopyOp {
     std::vector<std::pair<int64_t, int64_t>> launches;   // (src, dst) element offsets added to the base pointers
 };
 
-cutensorStatus_t try_copy_plan(cutensorHandle_t h, hipDataType dtype, const std::vector<CMode>& modes, cutensorPlan_t* plan) {
+cutensorStatus_t try_copy_plan(cutensorHandle_t h, hipDataType dtype, const std::vector<CMode>& modes, uint32_t alignSrc, uint32_t alignDst,
+                               cutensorPlan_t* plan) {
     // complex data is copied as pairs of reals: a leading stride-1 mode of extent 2
     const hipDataType rt = real_type(dtype);
     const int64_t scale = is_complex(dtype) ? 2 : 1;
@@ -309,9 +310,8 @@ cutensorStatus_t try_copy_plan(cutensorHandle_t h, hipDataType dtype, const std:
     for (const CMode& m : modes) { ext.push_back(m.extent); sS.push_back(m.sSrc * scale); sD.push_back(m.sDst * scale); lab.push_back((int32_t)lab.size() + 1); }
     cutensorTensorDescriptor_t dS = nullptr, dD = nullptr;
     cutensorOperationDescriptor_t op = nullptr;
-    const uint32_t align = (uint32_t)elem_size(rt);   // sub-boxes start anywhere: no vector-lane promise
-    cutensorStatus_t st = cutensorCreateTensorDescriptor(h, &dS, (uint32_t)ext.size(), ext.data(), sS.data(), rt, align);
-    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreateTensorDescriptor(h, &dD, (uint32_t)ext.size(), ext.data(), sD.data(), rt, align);
+    cutensorStatus_t st = cutensorCreateTensorDescriptor(h, &dS, (uint32_t)ext.size(), ext.data(), sS.data(), rt, alignSrc);
+    if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreateTensorDescriptor(h, &dD, (uint32_t)ext.size(), ext.data(), sD.data(), rt, alignDst);
     if (st == CUTENSOR_STATUS_SUCCESS)
         st = cutensorCreatePermutation(h, &op, dS, lab.data(), CUTENSOR_OP_IDENTITY, dD, lab.data(),
                                        rt == HIP_R_64F ? CUTENSOR_COMPUTE_DESC_64F : CUTENSOR_COMPUTE_DESC_32F);
@@ -322,9 +322,20 @@ cutensorStatus_t try_copy_plan(cutensorHandle_t h, hipDataType dtype, const std:
     return st;
 }
 
-// Builds the copy of a box; when the element-wise planner rejects the view (too many unfusable modes) the
-// smallest group is peeled into a host loop over launches of the remaining view.
-cutensorStatus_t make_copy(cutensorHandle_t h, hipDataType dtype, std::vector<CMode> modes, CopyOp& op) {
+// Largest power of two <= 256 dividing every byte offset: what the copy may promise about its pointers (the bases it is
+// added to — hipMalloc'ed user blocks, 256-byte-aligned workspace regions — are 256-byte aligned).
+uint32_t common_alignment(const std::vector<std::pair<int64_t, int64_t>>& launches, bool second, int64_t es) {
+    uint32_t a = 256;
+    for (const auto& l : launches) {
+        const int64_t bytes = (second ? l.second : l.first) * es;
+        while (a > 1 && (bytes % a) != 0) a >>= 1;
+    }
+    return std::max<uint32_t>(a, (uint32_t)std::min<int64_t>(es, 16));
+}
+
+// Builds the copy of a box that starts srcBase / dstBase elements into its buffers; when the element-wise planner rejects
+// the view (too many unfusable modes) the smallest group is peeled into a host loop over launches of the remaining view.
+cutensorStatus_t make_copy(cutensorHandle_t h, hipDataType dtype, std::vector<CMode> modes, CopyOp& op, int64_t srcBase = 0, int64_t dstBase = 0) {
     // drop unit modes, fuse modes that are contiguous in both tensors
     std::vector<CMode> g;
     for (const CMode& m : modes) {
@@ -332,9 +343,10 @@ cutensorStatus_t make_copy(cutensorHandle_t h, hipDataType dtype, std::vector<CM
         if (!g.empty() && m.sSrc == g.back().sSrc * g.back().extent && m.sDst == g.back().sDst * g.back().extent) { g.back().extent *= m.extent; continue; }
         g.push_back(m);
     }
-    op.launches.assign(1, std::make_pair<int64_t, int64_t>(0, 0));
+    const int64_t es = (int64_t)elem_size(dtype);
+    op.launches.assign(1, std::make_pair(srcBase, dstBase));
     for (;;) {
-        cutensorStatus_t st = try_copy_plan(h, dtype, g, &op.plan);
+        cutensorStatus_t st = try_copy_plan(h, dtype, g, common_alignment(op.launches, false, es), common_alignment(op.launches, true, es), &op.plan);
         if (st == CUTENSOR_STATUS_SUCCESS) return st;
         if (st != CUTENSOR_STATUS_NOT_SUPPORTED || g.empty()) return st;
         size_t k = 0;
@@ -401,7 +413,6 @@ struct ReducePlan {
     int64_t recvOff = 0, recvBytes = 0;
     CopyOp unpack;                   // received slot -> D block
     int64_t scratchOff = 0, scratchBytes = 0;
-    int64_t cInDstOff = 0;           // element offset of the own block inside the partial
 };
 
 }  // namespace
@@ -574,9 +585,8 @@ cutensorStatus_t build_reduce_plan(cutensorMpHandle* handle, cutensorMpPlan* pl,
         R.stageBytes = cElems * es;
         region(R.stageBytes, R.stageOff);
         if (!myC.empty()) {
-            st = make_copy(h, d.C.dtype, copy_modes(myC, d.C.elemStride, pStride), R.cIn);
+            st = make_copy(h, d.C.dtype, copy_modes(myC, d.C.elemStride, pStride), R.cIn, 0, box_offset(myC, whole, pStride));
             if (st != CUTENSOR_STATUS_SUCCESS) return st;
-            R.cInDstOff = box_offset(myC, whole, pStride);
         }
         for (int q = 0; q < world; ++q) R.slotElems = std::max(R.slotElems, cBox[(size_t)q].volume());
         R.slotElems = std::max<int64_t>(R.slotElems, 1);
@@ -593,9 +603,9 @@ cutensorStatus_t build_reduce_plan(cutensorMpHandle* handle, cutensorMpPlan* pl,
             for (int q = 0; q < world; ++q) {
                 const Box& b = cBox[(size_t)q];
                 if (b.empty()) continue;
-                st = make_copy(h, d.C.dtype, copy_modes(b, pStride, packed_strides(sizes(b))), R.pack[(size_t)q]);
+                st = make_copy(h, d.C.dtype, copy_modes(b, pStride, packed_strides(sizes(b))), R.pack[(size_t)q],
+                               box_offset(b, whole, pStride), (int64_t)q * R.slotElems);
                 if (st != CUTENSOR_STATUS_SUCCESS) return st;
-                for (auto& l : R.pack[(size_t)q].launches) { l.first += box_offset(b, whole, pStride); l.second += (int64_t)q * R.slotElems; }
             }
         }
         R.recvDirect = !myC.empty() && d.C.packed && sizes(myC) == d.C.bs && myC.volume() == R.slotElems;
@@ -681,7 +691,7 @@ cutensorStatus_t run_reduce(cutensorMpHandle* handle, const cutensorMpPlan* plan
     const bool mine = haveBeta && R.cIn.plan != nullptr;
     if (haveBeta) {
         if (hipMemsetAsync(P, 0, (size_t)(cElems * es), s) != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
-        if (mine) { st = run_copy(h, R.cIn, dt, C, P + R.cInDstOff * es, s); if (st != CUTENSOR_STATUS_SUCCESS) return st; }
+        if (mine) { st = run_copy(h, R.cIn, dt, C, P, s); if (st != CUTENSOR_STATUS_SUCCESS) return st; }
     }
     st = cutensorContract(h, plan->contraction, alpha, A, B, haveBeta ? beta : zero, P, P, ctrWs, plan->contractionWs, s);
     if (st != CUTENSOR_STATUS_SUCCESS) return st;
@@ -957,9 +967,9 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
                     t.direct = x.packed && part == cb && sizes(cb) == x.bs;
                     if (!t.direct) {
                         t.sendOff = sendOff; sendOff += round_up(t.bytes, 256);
-                        st = make_copy(h, x.dtype, copy_modes(part, userStride, packed_strides(sizes(part))), t.pack);
+                        st = make_copy(h, x.dtype, copy_modes(part, userStride, packed_strides(sizes(part))), t.pack,
+                                       box_offset(part, cb, userStride), 0);
                         if (st != CUTENSOR_STATUS_SUCCESS) return bail(st);
-                        for (auto& l : t.pack.launches) l.first += box_offset(part, cb, userStride);
                     }
                     pl->sends.push_back(std::move(t));
                 } else {
@@ -988,16 +998,16 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
         const Box own = intersect(o.need, myCell);
         if (!own.empty()) {
             CopyOp c;
-            st = make_copy(h, x.dtype, copy_modes(own, x.elemStride, stStride), c);
+            st = make_copy(h, x.dtype, copy_modes(own, x.elemStride, stStride), c, box_offset(own, myCell, x.elemStride),
+                           box_offset(own, o.need, stStride));
             if (st != CUTENSOR_STATUS_SUCCESS) return bail(st);
-            for (auto& l : c.launches) { l.first += box_offset(own, myCell, x.elemStride); l.second += box_offset(own, o.need, stStride); }
             o.localCopies.push_back(std::move(c));
         }
         for (Transfer& t : pl->recvs) {
             if (t.tensor != k || t.inPlace) continue;
-            st = make_copy(h, x.dtype, copy_modes(t.box, packed_strides(sizes(t.box)), stStride), t.unpack);
+            st = make_copy(h, x.dtype, copy_modes(t.box, packed_strides(sizes(t.box)), stStride), t.unpack, 0,
+                           box_offset(t.box, o.need, stStride));
             if (st != CUTENSOR_STATUS_SUCCESS) return bail(st);
-            for (auto& l : t.unpack.launches) l.second += box_offset(t.box, o.need, stStride);
         }
     }
     pl->stageBytes = stageOff;
