@@ -658,17 +658,40 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
             gp.C = D; gp.D = D; gp.alpha = 1.f; gp.beta = 0.f;
             gp.partial = ch[i].splitK > 1 ? static_cast<float*>(W) : nullptr;
             rp.partial = static_cast<float*>(W); rp.C = D; rp.D = D; rp.alpha = 1.f; rp.beta = 0.f;
+            // one launch = GETT kernel + (for split-K) the fold that matches the kernel's partial layout
+            auto once = [&]() -> bool {
+                if (tab[ch[i].kernel].launch(gp, nullptr) != hipSuccess) return false;
+                if (ch[i].splitK > 1) {
+                    const hipError_t e = tab[ch[i].kernel].fragPartials ? launch_splitk_reduce_frag(rp, nullptr) : launch_splitk_reduce(rp, nullptr);
+                    if (e != hipSuccess) return false;
+                }
+                return true;
+            };
             float ms = 1e30f;
-            for (int rep = 0; rep < 4; ++rep) {
+            bool ok = once() && hipDeviceSynchronize() == hipSuccess;
+            if (ok && i == 0) {
+                // clock ramp: a cold MI355X runs the first ~15-20 ms of a kernel stream ~10 % slower than its steady state
+                // (DESIGN.md section 6); without this the first candidates would be timed against a handicap
                 (void)hipEventRecord(e0, nullptr);
-                if (tab[ch[i].kernel].launch(gp, nullptr) != hipSuccess) break;
-                if (ch[i].splitK > 1 && launch_splitk_reduce(rp, nullptr) != hipSuccess) break;
+                float spent = 0.f;
+                for (int guard = 0; ok && spent < 20.f && guard < 4000; ++guard) {
+                    for (int r = 0; r < 8 && ok; ++r) ok = once();
+                    (void)hipEventRecord(e1, nullptr);
+                    ok = ok && hipEventSynchronize(e1) == hipSuccess;
+                    (void)hipEventElapsedTime(&spent, e0, e1);
+                }
+            }
+            for (int rep = 0; ok && rep < 3; ++rep) {        // best of three batches of launches issued back to back
+                const int batch = 8;
+                (void)hipEventRecord(e0, nullptr);
+                for (int r = 0; r < batch && ok; ++r) ok = once();
                 (void)hipEventRecord(e1, nullptr);
-                if (hipEventSynchronize(e1) != hipSuccess) break;
+                if (!ok || hipEventSynchronize(e1) != hipSuccess) { ok = false; break; }
                 float t = 0.f;
                 (void)hipEventElapsedTime(&t, e0, e1);
-                if (rep > 0) ms = std::min(ms, t);
+                ms = std::min(ms, t / batch);
             }
+            if (!ok) { (void)hipGetLastError(); ms = 1e30f; }
             CT_LOG("autotune: cand %zu kernel %d (%dx%dx%d) splitK %u -> %.3f us (model %.1f us)", i, ch[i].kernel,
                    tab[ch[i].kernel].bm, tab[ch[i].kernel].bn, tab[ch[i].kernel].bk, ch[i].splitK, ms * 1e3, ch[i].estimateUs);
             if (ms < bestMs) { bestMs = ms; best = (int)i; }

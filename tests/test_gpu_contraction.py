@@ -291,3 +291,12 @@ def test_complex_contraction_with_conjugation(built, dtype):
     got = dC.cpu().numpy().reshape(C.shape, order="F")
     ref = alpha * np.einsum("mkl,knl->mnl", np.conj(A).astype(np.complex128), B.astype(np.complex128)) + beta * C
     np.testing.assert_allclose(got, ref, rtol=2e-5 if dtype == "complex64" else 1e-13, atol=2e-6 if dtype == "complex64" else 1e-13)
+
+
+def test_patient_algo_measures_candidates_and_stays_correct(env):
+    """CUTENSOR_ALGO_DEFAULT_PATIENT: plan creation times the ranked candidates (GETT kernel + the fold that matches its
+    partial layout) on scratch tensors and keeps the fastest; results must not depend on which one won."""
+    ct, ops, h, torch = env
+    d = run_contraction(env, dict(a=96, b=64, c=16, d=64, e=96), "dcba", "ebcd", "ea", algo=ct.ALGO_DEFAULT_PATIENT, ws_limit=1 << 30)
+    assert d["kernel"] >= 0 and d["splitK"] >= 1
+    run_contraction(env, dict(m=192, n=160, k=256), "km", "kn", "mn", alpha=0.5, beta=0.25, algo=ct.ALGO_DEFAULT_PATIENT)
