@@ -300,3 +300,47 @@ def test_patient_algo_measures_candidates_and_stays_correct(env):
     d = run_contraction(env, dict(a=96, b=64, c=16, d=64, e=96), "dcba", "ebcd", "ea", algo=ct.ALGO_DEFAULT_PATIENT, ws_limit=1 << 30)
     assert d["kernel"] >= 0 and d["splitK"] >= 1
     run_contraction(env, dict(m=192, n=160, k=256), "km", "kn", "mn", alpha=0.5, beta=0.25, algo=ct.ALGO_DEFAULT_PATIENT)
+
+
+def test_one_handle_shared_by_threads(built):
+    """A process-wide handle is shared by framework threads (python/einsum.h:484-502): planning (with the plan cache on)
+    and execution from four threads at once, each on its own stream, must give every thread its own correct result."""
+    import threading
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle(plan_cache=64)
+    shapes = [dict(m=96, n=64, k=512), dict(m=100, n=36, k=52), dict(m=256, n=256, k=128), dict(m=64, n=48, k=4096)]
+    errors = []
+
+    def body(tid):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            for it in range(6):
+                ext = shapes[(tid + it) % len(shapes)]
+                mA, mB, mC = ("km", "kn", "mn") if (tid + it) % 2 else ("mk", "nk", "mn")
+                eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+                A, B = make_tensor(eA, 100 * tid + it), make_tensor(eB, 100 * tid + it + 50)
+                p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 26,
+                                         algo=ct.ALGO_DEFAULT_PATIENT if it == 0 else ct.ALGO_DEFAULT)
+                dA, dB = to_device(A), to_device(B)
+                dC = torch.zeros(int(np.prod(eC)), dtype=torch.float32, device="cuda")
+                ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                p.contract(1.0, dA.data_ptr(), dB.data_ptr(), 0.0, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), p.required_workspace,
+                           stream.cuda_stream)
+                stream.synchronize()
+                ref = np.zeros(eC, dtype=np.float32, order="F")
+                oracle.contract(A, mA, B, mB, ref, mC)
+                got = np.reshape(dC.cpu().numpy(), eC, order="F")
+                assert_close(got, ref, rtol=1e-4, atol=1e-4 * float(np.abs(ref).max()), what="thread %d iteration %d" % (tid, it))
+                p.destroy()
+        except BaseException as e:   # noqa: BLE001 — reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=body, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
