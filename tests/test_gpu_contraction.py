@@ -344,3 +344,37 @@ def test_one_handle_shared_by_threads(built):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("mA", ["km", "mk"])
+def test_operand_larger_than_4_gib(built, mA):
+    """Maximum sizes: an operand whose span exceeds 2^32 bytes (5.4 GB) must take the kernels with 64-bit offsets (the
+    LDS-DMA ring kernels address 32-bit byte offsets and are excluded by the planner).  Checked by fp64 dot products of
+    sampled outputs and by linearity in alpha."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    M, N, K = 1024, 64, 5 << 18
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    # column-major "km" = torch [M][K] (k contiguous); "mk" = torch [K][M]
+    A = torch.rand((M, K) if mA == "km" else (K, M), generator=g, device="cuda", dtype=torch.float32)
+    B = torch.rand((N, K), generator=g, device="cuda", dtype=torch.float32)       # "kn": k contiguous
+    assert A.numel() * 4 > (1 << 32)
+    C = torch.empty((N, M), device="cuda", dtype=torch.float32)                    # "mn": m contiguous
+    p = ops.contraction_plan(h, [K, M] if mA == "km" else [M, K], mA, [K, N], "kn", [M, N], "mn", workspace_limit=1 << 30)
+    d = p.describe()
+    assert d["kname"] != "gett_f32_stream_kernel", d
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    rows = [0, 1, 17, 511, 512, 1000, M - 1]
+    Arows = (A[rows, :] if mA == "km" else A[:, rows].t()).double()
+    ref = B.double() @ Arows.t()                                                    # [N][len(rows)]
+    got = C[:, rows].double()
+    rel = float(((got - ref).abs() / ref.abs()).max())
+    assert rel < 2e-4, (rel, d)          # K = 1.3 M terms accumulated in fp32 by up to 256 split-K slices
+    C2 = torch.empty_like(C)
+    p.contract(-0.5, A.data_ptr(), B.data_ptr(), 0.0, C2.data_ptr(), C2.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    assert torch.equal(C2, C * -0.5)
