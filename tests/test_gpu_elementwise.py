@@ -190,3 +190,19 @@ def test_permute_tensor_larger_than_4_gib(env):
     torch.cuda.synchronize()
     assert torch.equal(back, A)
     assert torch.equal(T[::4099, ::977], A.t()[::4099, ::977])
+
+
+def test_reduce_tensor_larger_than_4_gib(env):
+    """Maximum sizes: row sums and column sums of a 5.4-GB matrix (both reduction kernels walk 64-bit offsets)."""
+    ct, ops, h, torch = env
+    a, b = 1 << 15, 40960
+    A = torch.rand((b, a), device="cuda", dtype=torch.float32)        # column-major [a, b]
+    for kept, ext, dim in (("a", [a], 0), ("b", [b], 1)):
+        p = ops.reduction_plan(h, [a, b], "ab", ext, kept)
+        D = torch.zeros(ext[0], device="cuda", dtype=torch.float32)
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        p.reduce(1.0, A.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace)
+        torch.cuda.synchronize()
+        ref = A.sum(dim=dim, dtype=torch.float64)
+        rel = float(((D.double() - ref).abs() / ref).max())
+        assert rel < 2e-5, (kept, rel, p.describe())
