@@ -370,13 +370,20 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
     if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
     if (v.K.empty() || v.K.front().extent % 64 != 0 || v.totK % 64 != 0) return false;
-    auto span_bytes = [&](bool slotA) {
+    // The 16-bit kernels address an operand with 32-bit byte offsets relative to a 64-bit base that moves with the workgroup
+    // tile, the wave and the K-tile (gett_h16.hip, HOperand / HOdometer): what has to stay below 2^31 bytes is the span of
+    // ONE 256-row x 64-k tile, whatever the size of the tensor.
+    auto tile_span_bytes = [&](bool slotA) {
         uint64_t n = 1;
-        for (const std::vector<CanonMode>* g : {slotA ? &v.M : &v.N, &v.K})
-            for (const CanonMode& m : *g) n += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(slotA ? m.sA : m.sB);
+        for (const CanonMode& m : (slotA ? v.M : v.N))
+            n += (uint64_t)(std::min<int64_t>(m.extent, 256) - 1) * (uint64_t)std::llabs(slotA ? m.sA : m.sB);
+        n += 64ull * (uint64_t)std::llabs(slotA ? v.K.front().sA : v.K.front().sB);
         return n * 2ull;
     };
-    if (span_bytes(true) >= (1ull << 32) - (1ull << 20) || span_bytes(false) >= (1ull << 32) - (1ull << 20)) return false;
+    if (tile_span_bytes(true) >= (1ull << 31) || tile_span_bytes(false) >= (1ull << 31)) return false;
+    for (const std::vector<CanonMode>* g : {&v.M, &v.N, &v.K})       // relative offsets are unsigned
+        for (const CanonMode& m : *g)
+            if (m.sA < 0 || m.sB < 0) return false;
     int count = 0;
     const GettKernelInfo* tab = gett_h16_kernels(&count);
     c = ContractionChoice{};

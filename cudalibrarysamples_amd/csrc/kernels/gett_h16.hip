@@ -60,30 +60,43 @@ typedef float    f32x16 __attribute__((ext_vector_type(16)));
 // not provably uniform is silently given VGPRs.
 typedef int HRsrc __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ HRsrc h_make_rsrc(const void* base) {
-    const uint64_t b = (uint64_t)(uintptr_t)base;
+__device__ __forceinline__ uint64_t h_uniform64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// descriptor whose base is the (wave-uniform) byte address `addr`
+__device__ __forceinline__ HRsrc h_make_rsrc(uint64_t addr) {
     HRsrc r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+    r[0] = (int)(uint32_t)addr;
+    r[1] = (int)((uint32_t)(addr >> 32) & 0xffffu);
     r[2] = -1;
     r[3] = 0x00020000;
     return r;
+}
+__device__ __forceinline__ int64_t h_wave_min(int64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
 }
 
 // 64 lanes x 16 B -> the 1-KiB LDS piece at byte address ldsByte (wave-uniform).  Hidden from the
 // compiler's wait-count bookkeeping on purpose: completion is counted by hand (CTAMD_H_VMCNT).
 // s_nop 4: the SGPR operands may come straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).
 template <bool PAD = true>
-__device__ __forceinline__ void h_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, uint32_t ldsByte) {
+__device__ __forceinline__ void h_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t ldsByte) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (PAD)
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc) : "memory");
     else   // main loop: every SGPR operand was produced by the scalar ALU, or long ago
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc), "s"(tileBytes) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc) : "memory");
 #else
-    (void)rsrc; (void)laneBytes; (void)tileBytes; (void)ldsByte;
+    (void)rsrc; (void)laneBytes; (void)ldsByte;
 #endif
 }
 
@@ -120,9 +133,15 @@ __device__ __forceinline__ uint16_t h_from_float(float f, bool bf) {
 template <int LAY, int NW = 8>
 struct HOperand {
     static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
-    uint32_t src[2][kPieces];   // byte offset of this lane's 16-byte unit: [half-tile][piece i of this wave], tile k0 = 0
+    // Byte offset of this lane's 16-byte unit, [half-tile][piece i of this wave], for the K-tile at k = 0 — relative to
+    // `base`, the smallest such offset in the wave: a workgroup tile spans far less than 2^32 bytes whatever the size of
+    // the tensor, and `base` (64 bits, wave-uniform) goes into the buffer descriptor.
+    uint32_t src[2][kPieces];
+    uint64_t base;
 
-    __device__ __forceinline__ void init(const ModeGroup& gFree, uint32_t strideK0, uint32_t row0, int wave, int lane) {
+    __device__ __forceinline__ void init(const ModeGroup& gFree, int64_t strideK0, uint32_t row0, int wave, int lane) {
+        int64_t off[2][kPieces];
+        int64_t mn = INT64_MAX;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -133,25 +152,33 @@ struct HOperand {
                     const int u = p ^ ((r >> 1) & 7);
                     uint32_t row = row0 + 128 * h + r;
                     if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
-                    src[h][i] = (group_offset32<0>(gFree, row) + 8u * (uint32_t)u) * 2u;
+                    off[h][i] = (group_offset<0>(gFree, row) + 8 * u) * 2;
                 } else {
                     const int kk = 4 * c + (lane >> 4), p = lane & 15;
                     const int u = p ^ (4 * ((lane >> 4) & 3));
                     uint32_t row = row0 + 128 * h + 8 * u;
                     if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
-                    src[h][i] = (group_offset32<0>(gFree, row) + (uint32_t)kk * strideK0) * 2u;
+                    off[h][i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
                 }
+                mn = off[h][i] < mn ? off[h][i] : mn;
             }
+        const int64_t mnW = (int64_t)h_uniform64((uint64_t)h_wave_min(mn));
+        base = (uint64_t)mnW;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) src[h][i] = (uint32_t)(off[h][i] - mnW);
     }
 
+    // X: descriptor of (operand + batch offset + this wave's base + the K-tile's offset)
     template <bool PAD = true>
-    __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t tileBytes, uint32_t slotByte, int wave) const {
+    __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t slotByte, int wave) const {
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) h_dma16<PAD>(X, src[h][i], tileBytes, slotByte + (uint32_t)(wave + NW * i) * 1024u);
+        for (int i = 0; i < kPieces; ++i) h_dma16<PAD>(X, src[h][i], slotByte + (uint32_t)(wave + NW * i) * 1024u);
     }
     template <bool PAD = true>
-    __device__ __forceinline__ void issue_piece(HRsrc X, int h, int i, uint32_t tileBytes, uint32_t slotByte, int wave) const {
-        h_dma16<PAD>(X, src[h][i], tileBytes, slotByte + (uint32_t)(wave + NW * i) * 1024u);
+    __device__ __forceinline__ void issue_piece(HRsrc X, int h, int i, uint32_t slotByte, int wave) const {
+        h_dma16<PAD>(X, src[h][i], slotByte + (uint32_t)(wave + NW * i) * 1024u);
     }
 };
 
@@ -190,7 +217,7 @@ __device__ __forceinline__ s16x8 h_read_frag(const char* slot, int rb, int s, co
 // fastest contracted digit's extent is a multiple of kHBK, so a tile never straddles a digit boundary.
 struct HOdometer {
     uint32_t j0, n0, j1, e1, hi;
-    uint32_t offA, offB, stepA, stepB, wrapA, wrapB;
+    uint64_t offA, offB, stepA, stepB, wrapA, wrapB;      // bytes, modulo 2^64
     __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
         const uint32_t E0 = gK.div[0].d;
@@ -200,12 +227,12 @@ struct HOdometer {
         j0 = sgpr((k0 - q0 * E0) / kHBK);
         hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
         j1 = sgpr(q0 - hi * e1);
-        offA = sgpr(group_offset32<0>(gK, k0) * 2u);
-        offB = sgpr(group_offset32<1>(gK, k0) * 2u);
-        stepA = sgpr((uint32_t)((int64_t)kHBK * gK.stride[0][0]) * 2u);
-        stepB = sgpr((uint32_t)((int64_t)kHBK * gK.stride[1][0]) * 2u);
-        wrapA = sgpr((uint32_t)gK.stride[0][1] * 2u - (n0 - 1) * stepA);
-        wrapB = sgpr((uint32_t)gK.stride[1][1] * 2u - (n0 - 1) * stepB);
+        offA = h_uniform64((uint64_t)(group_offset<0>(gK, k0) * 2));
+        offB = h_uniform64((uint64_t)(group_offset<1>(gK, k0) * 2));
+        stepA = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[0][0] * 2));
+        stepB = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[1][0] * 2));
+        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
+        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
     }
     __device__ __forceinline__ void advance(const ModeGroup& gK) {
         const bool c0 = (j0 + 1 == n0);
@@ -218,8 +245,8 @@ struct HOdometer {
             hi += 1;
             const uint32_t k = hi * e1 * gK.div[0].d;
             if (k < gK.total) {
-                offA = sgpr(group_offset32<0>(gK, k) * 2u);
-                offB = sgpr(group_offset32<1>(gK, k) * 2u);
+                offA = h_uniform64((uint64_t)(group_offset<0>(gK, k) * 2));
+                offB = h_uniform64((uint64_t)(group_offset<1>(gK, k) * 2));
             }
         }
     }
@@ -258,12 +285,14 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
-    const HRsrc rA = h_make_rsrc(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l));
-    const HRsrc rB = h_make_rsrc(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l));
+    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
     HOperand<LA> oa;
     HOperand<LB> ob;
-    oa.init(p.gM, (uint32_t)p.gK.stride[0][0], m0, wave, lane);
-    ob.init(p.gN, (uint32_t)p.gK.stride[1][0], n0, wave, lane);
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    bA += oa.base;                                 // descriptor base = operand + batch offset + this wave's smallest piece offset
+    bB += ob.base;
 
     uint32_t offK[4];
 #pragma unroll
@@ -282,17 +311,17 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     //   q = 2: A-half 0 of tile t + 2     q = 3: B-half 0 of tile t + 2
     // A half-tile is first read at least five phases after it was issued and the wait in front of each
     // phase's first barrier leaves four half-tiles (8 LDS-DMA instructions of this wave) in flight.
-    oa.issue(rA, 0, odo.offA, ldsBase + 0 * kHalfBytes, wave);
-    ob.issue(rB, 0, odo.offB, ldsBase + 2 * kHalfBytes, wave);
-    ob.issue(rB, 1, odo.offB, ldsBase + 3 * kHalfBytes, wave);
-    oa.issue(rA, 1, odo.offA, ldsBase + 1 * kHalfBytes, wave);
+    oa.issue(h_make_rsrc(bA + odo.offA), 0, ldsBase + 0 * kHalfBytes, wave);
+    ob.issue(h_make_rsrc(bB + odo.offB), 0, ldsBase + 2 * kHalfBytes, wave);
+    ob.issue(h_make_rsrc(bB + odo.offB), 1, ldsBase + 3 * kHalfBytes, wave);
+    oa.issue(h_make_rsrc(bA + odo.offA), 1, ldsBase + 1 * kHalfBytes, wave);
     if (1 < nTiles) odo.advance(p.gK);
-    uint32_t offA1 = odo.offA, offB1 = odo.offB;  // offsets of tile t + 1 (t = current tile)
-    oa.issue(rA, 0, offA1, ldsBase + 4 * kHalfBytes, wave);
-    ob.issue(rB, 0, offB1, ldsBase + 6 * kHalfBytes, wave);
+    uint64_t offA1 = odo.offA, offB1 = odo.offB;  // offsets of tile t + 1 (t = current tile)
+    oa.issue(h_make_rsrc(bA + offA1), 0, ldsBase + 4 * kHalfBytes, wave);
+    ob.issue(h_make_rsrc(bB + offB1), 0, ldsBase + 6 * kHalfBytes, wave);
     int tNext = 2;                                // K-tile the odometer is about to describe
     if (tNext < nTiles) odo.advance(p.gK);
-    uint32_t offA2 = odo.offA, offB2 = odo.offB;  // offsets of tile t + 2
+    uint64_t offA2 = odo.offA, offB2 = odo.offB;  // offsets of tile t + 2
     CTAMD_H_VMCNT(8);                             // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
@@ -347,11 +376,11 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         if constexpr ((Q) == 0) { CTAMD_H_READ_A((P) * 4 + 0) CTAMD_H_READ_B((P) * 4 + 2, b0) }   \
         if constexpr ((Q) == 1) { CTAMD_H_READ_B((P) * 4 + 3, b1) }                                \
         if constexpr ((Q) == 2) { CTAMD_H_READ_A((P) * 4 + 1) }                                    \
-        if constexpr ((Q) == 0) ob.template issue<false>(rB, 1, offB1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
-        if constexpr ((Q) == 1) oa.template issue<false>(rA, 1, offA1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
-        if constexpr ((Q) == 2) oa.template issue<false>(rA, 0, offA2, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
+        if constexpr ((Q) == 0) ob.template issue<false>(h_make_rsrc(bB + offB1), 1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 1) oa.template issue<false>(h_make_rsrc(bA + offA1), 1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 2) oa.template issue<false>(h_make_rsrc(bA + offA2), 0, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
         if constexpr ((Q) == 3) {                                                                  \
-            ob.template issue<false>(rB, 0, offB2, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
+            ob.template issue<false>(h_make_rsrc(bB + offB2), 0, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
             offA1 = offA2; offB1 = offB2;                                                          \
             ++tNext;                                                                               \
             if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
@@ -500,12 +529,14 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
-    const HRsrc rA = h_make_rsrc(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l));
-    const HRsrc rB = h_make_rsrc(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l));
+    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
     HOperand<LA, 4> oa;
     HOperand<LB, 4> ob;
-    oa.init(p.gM, (uint32_t)p.gK.stride[0][0], m0, wave, lane);
-    ob.init(p.gN, (uint32_t)p.gK.stride[1][0], n0, wave, lane);
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    bA += oa.base;                                 // descriptor base = operand + batch offset + this wave's smallest piece offset
+    bB += ob.base;
 
     uint32_t offK[4], offF[4];
 #pragma unroll
@@ -519,8 +550,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
 #define CTAMD_W4_DMA(P, N, PAD)                                                                                     \
     {                                                                                                              \
         constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
-        if constexpr (q_ < 2) oa.template issue_piece<PAD>(rA, q_, i_, odo.offA, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave); \
-        else ob.template issue_piece<PAD>(rB, q_ - 2, i_, odo.offB, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave);   \
+        if constexpr (q_ < 2) oa.template issue_piece<PAD>(h_make_rsrc(bA + odo.offA), q_, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave); \
+        else ob.template issue_piece<PAD>(h_make_rsrc(bB + odo.offB), q_ - 2, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave);   \
     }
 #define CTAMD_W4_STAGE(P, PAD)                                                                                      \
     CTAMD_W4_DMA(P, 0, PAD) CTAMD_W4_DMA(P, 1, PAD) CTAMD_W4_DMA(P, 2, PAD) CTAMD_W4_DMA(P, 3, PAD)                \
@@ -684,10 +715,13 @@ static hipError_t launch_h16w4(const GettParams& p, hipStream_t stream) {
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
-    if (timed && BF && LA == LAY_K && LB == LAY_F)
-        hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(512), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps
+        if (timed) {
+            hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcutensor.so")
+# CUTENSOR_AMD_LIBRARY: another build of the same library (A/B measurements of two source revisions on one box)
+LIB_PATH = os.environ.get("CUTENSOR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libcutensor.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

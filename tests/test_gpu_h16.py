@@ -178,3 +178,32 @@ def test_four_wave_variant_parity(built):
                        capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("mA", ["km", "mk"])
+def test_bf16_operand_larger_than_4_gib(built, mA):
+    """Maximum sizes: a 5.2-GB bf16 operand stays on the MFMA kernel — its 32-bit lane offsets are relative to a 64-bit
+    base that moves with the workgroup tile, the wave and the K-tile.  fp64 dot products of sampled outputs."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    M, N, K = 2048, 256, 5 << 18
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    A = (torch.rand((M, K) if mA == "km" else (K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+    B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)      # "kn"
+    assert A.numel() * 2 > (1 << 32)
+    C = torch.empty((N, M), device="cuda", dtype=torch.bfloat16)                          # "mn"
+    p = ops.contraction_plan(h, [K, M] if mA == "km" else [M, K], mA, [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF,
+                             workspace_limit=1 << 30)
+    d = p.describe()
+    assert d["kname"] in ("gett_h16_kernel", "gett_h16w4_kernel"), d
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    rows = [0, 1, 127, 128, 1000, 1023, 1024, M - 1]        # first / last rows of several 256-row tiles
+    Arows = (A[rows, :] if mA == "km" else A[:, rows].t()).double()
+    ref = B.double() @ Arows.t()
+    got = C[:, rows].double()
+    err = float((got - ref).abs().max())
+    assert err <= 8e-3 * float(ref.abs().max()) + 1e-2, (err, float(ref.abs().max()), d)
