@@ -84,6 +84,7 @@ public:
         const size_t lhsEnd = implicit ? eq.size() : arrow;
         std::string sA, sB, sC;
         if (comma != std::string::npos && comma < lhsEnd) {
+            hasB_ = true;   // two operands even when the second is a scalar ("i,->i": zero modes, e.g. a gradient of "i,i->")
             sA = eq.substr(0, comma);
             sB = eq.substr(comma + 1, lhsEnd - comma - 1);
         } else {
@@ -154,7 +155,7 @@ public:
         bool ok = cutensorCreateTensorDescriptor(handle, &dA, (uint32_t)modesA_.size(), extentA_.data(), nullptr, type, kAlignment) == CUTENSOR_STATUS_SUCCESS &&
                   cutensorCreateTensorDescriptor(handle, &dC, (uint32_t)modesC_.size(), extentC_.data(), nullptr, type, kAlignment) == CUTENSOR_STATUS_SUCCESS &&
                   cutensorCreatePlanPreference(handle, &pref, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE) == CUTENSOR_STATUS_SUCCESS;
-        if (ok && !modesB_.empty()) {
+        if (ok && hasB_) {
             ok = cutensorCreateTensorDescriptor(handle, &dB, (uint32_t)modesB_.size(), extentB_.data(), nullptr, type, kAlignment) == CUTENSOR_STATUS_SUCCESS &&
                  cutensorCreateContraction(handle, &op, dA, modesA_.data(), conjA_ ? CUTENSOR_OP_CONJ : CUTENSOR_OP_IDENTITY, dB, modesB_.data(),
                                            conjB_ ? CUTENSOR_OP_CONJ : CUTENSOR_OP_IDENTITY,
@@ -183,7 +184,7 @@ public:
         if (!plan(handle, kWorksize_)) return false;
         typename EinsumTypeTraits<ComputeType>::ScalarType alpha = 1, beta = 0;
         cutensorStatus_t st;
-        if (!modesB_.empty())
+        if (hasB_)
             st = cutensorContract(handle, plan_, &alpha, A_raw, B_raw, &beta, C_raw, C_raw, work_raw, kWorksize_, stream);
         else
             st = cutensorReduce(handle, plan_, &alpha, A_raw, &beta, C_raw, C_raw, work_raw, kWorksize_, stream);
@@ -200,6 +201,7 @@ public:
 private:
     static const size_t kWorksize_ = 1024ULL * 1024ULL * 1024ULL;   // 1 GiB, as einsum.cu:380
     bool isInitialized_ = false;
+    bool hasB_ = false;
     bool conjA_ = false, conjB_ = false;
     std::vector<int32_t> modesA_, modesB_, modesC_;
     std::vector<int64_t> extentA_, extentB_, extentC_;

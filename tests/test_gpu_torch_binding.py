@@ -107,3 +107,23 @@ def test_argument_count_errors(te):
         tein.EinsumFunction.apply("ik,kj->ij", a)
     with pytest.raises(RuntimeError):
         tein.EinsumFunction.apply("ij->ji", a, a)
+
+
+def test_scalar_output_gradients_use_a_scalar_second_operand(te):
+    """A dot product 'i,i->' differentiates into 'i,->i' and ',i->i': two operands, one of them a 0-dim tensor.  The helper
+    must still contract (and scale by the scalar), not fall back to the one-operand path (found by tools/fuzz_einsum.py)."""
+    torch, tein = te
+    torch.manual_seed(3)
+    a = torch.randn(37, device="cuda")
+    s = torch.tensor(2.5, device="cuda")
+    assert torch.allclose(tein.einsum("i,->i", a, s), a * 2.5)
+    assert torch.allclose(tein.einsum(",i->i", s, a), a * 2.5)
+    for eq, shapes in (("i,i->", [(16,), (16,)]), ("ie,ei", [(24, 2), (2, 24)])):
+        A = torch.randn(*shapes[0], device="cuda", requires_grad=True)
+        B = torch.randn(*shapes[1], device="cuda", requires_grad=True)
+        out = tein.EinsumFunction.apply(eq, A, B)
+        out.backward(torch.tensor(1.5, device="cuda"))
+        rA, rB = A.detach().double().requires_grad_(True), B.detach().double().requires_grad_(True)
+        torch.einsum(eq, rA, rB).backward(torch.tensor(1.5, device="cuda", dtype=torch.float64))
+        _close(torch, A.grad, rA.grad.cpu(), "float32")
+        _close(torch, B.grad, rB.grad.cpu(), "float32")
