@@ -719,7 +719,16 @@ static cutensorStatus_t finish_handle(cutensorMpHandle* h, int localDevice, hipS
     h->stream = stream;
     int saved = -1;
     (void)hipGetDevice(&saved);
-    if (hipSetDevice(localDevice) != hipSuccess) { (void)hipGetLastError(); delete h; return CUTENSOR_STATUS_INVALID_VALUE; }
+    if (hipSetDevice(localDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        int count = 0;
+        const bool noGpu = hipGetDeviceCount(&count) != hipSuccess || count == 0;
+        (void)hipGetLastError();
+        // a machine without any GPU can still build and inspect plans (the planner of the single-GPU library works there
+        // too); execution fails in the first HIP call.  A wrong device index on a machine with GPUs is an error.
+        if (!noGpu) { delete h; return CUTENSOR_STATUS_INVALID_VALUE; }
+        h->device = -1;
+    }
     cutensorStatus_t st = cutensorCreate(&h->h);
     if (saved >= 0) (void)hipSetDevice(saved);
     if (st != CUTENSOR_STATUS_SUCCESS) { delete h; return st; }
@@ -892,7 +901,7 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
     const uint64_t devLimit = pref ? pref->devLimit : (1ull << 62);
     int saved = -1;
     (void)hipGetDevice(&saved);
-    (void)hipSetDevice(handle->device);
+    if (handle->device >= 0) (void)hipSetDevice(handle->device);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{saved};
 
     cutensorMpPlan* pl = new (std::nothrow) cutensorMpPlan();
@@ -1076,9 +1085,10 @@ cutensorStatus_t cutensorMpContract(const cutensorMpHandle_t handle, const cuten
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (plan->requiredDevice > 0 && workspaceDevice == nullptr) return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+    if (handle->device < 0) return CUTENSOR_STATUS_ARCH_MISMATCH;   // plan-only handle of a machine without a GPU
     int saved = -1;
     (void)hipGetDevice(&saved);
-    (void)hipSetDevice(handle->device);
+    if (handle->device >= 0) (void)hipSetDevice(handle->device);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{saved};
 
     const cutensorMpOperationDescriptor& d = plan->desc;
