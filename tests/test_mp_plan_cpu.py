@@ -114,3 +114,56 @@ def test_headline_einsum_k_sharded_over_eight_ranks_reduces(cmp, monkeypatch):
         assert p["reduceTotal"] == 8 * 96 * 96 * 4 * 2
         assert p["gatherTotal"] == 8 * 7 * 2 * (96 * 64 * 64 * 64 * 4 // 8)
         assert p["sendBytes"] == 0 and p["recvBytes"] == 0
+
+
+def test_descriptor_and_operation_validation(cmp):
+    """Error behaviour of the Mp descriptors (status codes, nothing crashes): grids that do not match the world, rank lists
+    that are not permutations, block-cyclic layouts, D distributed differently from C, extent mismatches."""
+    cm, ct = cmp
+    world = cm.LocalWorld(4)
+    try:
+        h = ctypes.c_void_p()
+        cm.check(cm.ctamdMpCreateOnLocalWorld(ctypes.byref(h), world.ptr, 1, 0, None))
+
+        def desc(ext, p, ranks=None, block=None, n=4, dtype=None):
+            d = ctypes.c_void_p()
+            st = cm.cutensorMpCreateTensorDescriptor(h, ctypes.byref(d), len(ext), ct.i64(ext), None, ct.i64(block) if block else None, None,
+                                                     ct.i64(p), n, ct.i32(ranks) if ranks else None, dtype or ct.R_32F)
+            return st, d
+
+        assert desc([64, 32], [2, 2])[0] == 0
+        assert desc([64, 32], [1, 1])[0] == 0                                 # one cell: replicated
+        assert desc([64, 32], [2, 1])[0] == ct.STATUS_INVALID_VALUE           # 2 cells in a world of 4
+        assert desc([64, 32], [4, 2], n=8)[0] == ct.STATUS_INVALID_VALUE      # 8 cells
+        assert desc([64, 32], [2, 2], ranks=[0, 1, 1, 3])[0] == ct.STATUS_INVALID_VALUE   # not a permutation
+        assert desc([64, 32], [2, 2], ranks=[0, 1, 2, 4])[0] == ct.STATUS_INVALID_VALUE   # rank outside the world
+        assert desc([64, 32], [2, 2], block=[16, 16])[0] == ct.STATUS_NOT_SUPPORTED       # block-cyclic (two blocks per rank)
+        assert desc([64, 32], [2, 2], block=[32, 16])[0] == 0                             # the default blocks, spelled out
+        assert desc([0, 32], [2, 2])[0] == ct.STATUS_INVALID_VALUE
+        assert cm.cutensorMpCreateTensorDescriptor(None, ctypes.byref(ctypes.c_void_p()), 1, ct.i64([4]), None, None, None, ct.i64([1]), 1, None,
+                                                   ct.R_32F) == ct.STATUS_NOT_INITIALIZED
+
+        (_, dA), (_, dB), (_, dC) = desc([64, 32], [4, 1]), desc([32, 48], [1, 1]), desc([64, 48], [4, 1])
+        (_, dD2), (_, dBad) = desc([64, 48], [1, 4]), desc([31, 48], [1, 1])
+        lab = [ct.i32("mk"), ct.i32("kn"), ct.i32("mn")]
+        op = ctypes.c_void_p()
+        args = lambda a, b, c, d_: (h, ctypes.byref(op), a, lab[0], ct.OP_IDENTITY, b, lab[1], ct.OP_IDENTITY, c, lab[2], ct.OP_IDENTITY, d_, lab[2],
+                                    ct.compute_desc("32F"))
+        assert cm.cutensorMpCreateContraction(*args(dA, dB, dC, dC)) == 0
+        assert cm.cutensorMpCreateContraction(*args(dA, dB, dC, dD2)) == ct.STATUS_NOT_SUPPORTED     # D laid out differently from C
+        assert cm.cutensorMpCreateContraction(*args(dA, dBad, dC, dC)) == ct.STATUS_INVALID_VALUE    # k: 32 vs 31
+        assert cm.cutensorMpCreateContraction(*args(dA, None, dC, dC)) == ct.STATUS_INVALID_VALUE
+        pref = ctypes.c_void_p()
+        assert cm.cutensorMpCreatePlanPreference(h, ctypes.byref(pref), 7, 1 << 20, 0) == ct.STATUS_NOT_SUPPORTED   # unknown algorithm
+        cm.check(cm.cutensorMpCreatePlanPreference(h, ctypes.byref(pref), cm.ALGO_DEFAULT, 1024, 0))
+        plan = ctypes.c_void_p()
+        # a 1-KiB device budget: enough when every operand box is local (nothing is staged), not for a gathered case
+        assert cm.cutensorMpCreatePlan(h, ctypes.byref(plan), op, pref) == 0
+        cm.check(cm.cutensorMpDestroyPlan(plan))
+        (_, dAk), (_, dBk) = desc([64, 32], [1, 4]), desc([32, 48], [4, 1])
+        (_, dCr) = desc([64, 48], [2, 2])
+        assert cm.cutensorMpCreateContraction(*args(dAk, dBk, dCr, dCr)) == 0
+        assert cm.cutensorMpCreatePlan(h, ctypes.byref(plan), op, pref) == ct.STATUS_INSUFFICIENT_WORKSPACE
+        cm.check(cm.cutensorMpDestroy(h))
+    finally:
+        world.close()
