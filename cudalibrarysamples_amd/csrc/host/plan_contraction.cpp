@@ -389,8 +389,14 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c = ContractionChoice{};
     c.family = 1;
     c.kernel = (v.dtype == HIP_R_16BF ? 0 : 4) + (v.layA == LAY_F ? 2 : 0) + (v.layB == LAY_F ? 1 : 0);
-    // entries 8..15: four waves per workgroup (one per SIMD), 0..7: eight waves (two rows, ping-pong)
-    static const int variant = [] { const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES"); return (e && e[0] == '4') ? 8 : 0; }();
+    // entries 0..7: eight waves, two rows alternated by barriers (ping-pong); 8..15: four waves per workgroup (one per
+    // SIMD); 16..23: eight free-running waves, one barrier per K-tile
+    static const int variant = [] {
+        const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
+        if (e && e[0] == '4') return 8;
+        if (e && e[0] == 'f') return 16;
+        return 0;
+    }();
     c.kernel += variant;
     if (c.kernel >= count) return false;
     const double tiles = std::ceil((double)v.totM / tab[c.kernel].bm) * std::ceil((double)v.totN / tab[c.kernel].bn) * (double)v.totL;

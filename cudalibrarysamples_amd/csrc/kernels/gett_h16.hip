@@ -698,6 +698,224 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
     store_row(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
 }
 
+
+// =====================================================================================================
+// Free-running eight-wave variant (CUTENSOR_AMD_H16_WAVES=f): the tile, LDS images and source-side swizzles of the
+// kernels above, 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 4 x 2 accumulator fragments (128 registers) and
+// stages 8 KiB per K-tile.  Unlike gett_h16_kernel the two waves of a SIMD are NOT alternated by barriers: every wave
+// runs the four-wave kernel's software pipeline (fragment reads of k-step s + 1 and its share of the LDS-DMA pieces
+// interleaved with the 8 MFMAs of k-step s, two register sets), the SIMD's arbiter fills one wave's read / DMA-issue
+// slots with the other wave's MFMAs, and the workgroup meets ONCE per K-tile — in front of k-step 3, whose 8 MFMAs
+// (operands already in registers) are issued after the barrier and cover the first fragment reads of the next tile.
+// NP3 = LDS-DMA pieces (of the wave's 8 per K-tile) issued in k-step 3 right after the barrier frees the buffer; the
+// rest go out in k-step 0 of the next tile.
+// =====================================================================================================
+template <bool BF, int LA, int LB, int NP3 = 4>
+__global__ void __launch_bounds__(512, 2) gett_h16fr_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
+    HOperand<LA, 8> oa;
+    HOperand<LB, 8> ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    bA += oa.base;
+    bB += ob.base;
+
+    uint32_t offK[4], offFa[4], offFb[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { offK[s] = h_offK(lane, s); offFa[s] = h_offF(lane, s); }
+    offFb[0] = h_offF(lane, 2 * (wc & 1));
+    offFb[1] = h_offF(lane, 2 * (wc & 1) + 1);
+
+    HOdometer odo;
+    odo.init(p.gK, tile0 * kHBK);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // piece n = 0..7 of a K-tile for this wave: operand half q = n >> 1 (A0, A1, B0, B1), piece i = n & 1
+#define CTAMD_FR_DMA(P, N, PAD)                                                                                     \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 1, i_ = (N) & 1;                                                                 \
+        if constexpr (q_ < 2) oa.template issue_piece<PAD>(h_make_rsrc(bA + odo.offA), q_, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave); \
+        else ob.template issue_piece<PAD>(h_make_rsrc(bB + odo.offB), q_ - 2, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave);   \
+    }
+#define CTAMD_FR_DMA_IF(P, N, PAD) if constexpr ((N) >= 0 && (N) < 8) CTAMD_FR_DMA(P, ((N) >= 0 && (N) < 8 ? (N) : 0), PAD)
+
+    // ---- prologue: K-tile 0 and the first NP3 pieces of K-tile 1 -----------------------------------------------
+    CTAMD_FR_DMA(0, 0, true) CTAMD_FR_DMA(0, 1, true) CTAMD_FR_DMA(0, 2, true) CTAMD_FR_DMA(0, 3, true)
+    CTAMD_FR_DMA(0, 4, true) CTAMD_FR_DMA(0, 5, true) CTAMD_FR_DMA(0, 6, true) CTAMD_FR_DMA(0, 7, true)
+    if (1 < nTiles) odo.advance(p.gK);           // past the end the last tile is re-staged (never read)
+    CTAMD_FR_DMA_IF(1, NP3 > 0 ? 0 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 1 ? 1 : -1, true)
+    CTAMD_FR_DMA_IF(1, NP3 > 2 ? 2 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 3 ? 3 : -1, true)
+    CTAMD_FR_DMA_IF(1, NP3 > 4 ? 4 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 5 ? 5 : -1, true)
+    CTAMD_FR_DMA_IF(1, NP3 > 6 ? 6 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 7 ? 7 : -1, true)
+    int tNext = 1;                                // K-tile the odometer describes
+    CTAMD_H_VMCNT(NP3);                           // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][2];                       // two register sets: k-step s uses set s & 1
+
+    const char* const aSlot0 = lds + wr * kHalfBytes;                 // A-half wr of buffer 0 (buffer 1: + 4 slots)
+    const char* const bSlot0 = lds + (2 + (wc >> 1)) * kHalfBytes;    // B-half wc >> 1 of buffer 0
+    const int bRow = 64 * (wc & 1);                                   // this wave's columns inside the B half
+    // fragment f = 0..5 of k-step S from buffer P into register set SET: f < 2 -> B columns bRow + 32 f, else A rows 32 (f - 2)
+#define CTAMD_FR_READ(P, S, SET, F)                                                                                 \
+    {                                                                                                              \
+        if constexpr ((F) < 2) b[SET][F] = h_read_frag<LB>(bSlot0 + (P) * 4 * kHalfBytes, bRow + 32 * (F), S, offK, offFb[F]);          \
+        else a[SET][(F) - 2] = h_read_frag<LA>(aSlot0 + (P) * 4 * kHalfBytes, 32 * ((F) - 2), S, offK, offFa[(F) - 2]);        \
+    }
+#define CTAMD_FR_MFMA(SET, M) acc[(M) >> 1][(M) & 1] = h_mfma<BF>(a[SET][(M) >> 1], b[SET][(M) & 1], acc[(M) >> 1][(M) & 1]);
+    // group G = 0..3 of k-step S < 3: reads of step S + 1 (G = 0: both B fragments, G = 1: A rows 0-63, G = 2, 3: one A
+    // fragment each), two MFMAs of step S, and in k-step 0 one of the pieces NP3.. of the tile going into the other buffer
+#define CTAMD_FR_GROUP(P, S, G)                                                                                     \
+    if constexpr ((G) == 0) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 0) CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 1) } \
+    if constexpr ((G) == 1) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 2) CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 3) } \
+    if constexpr ((G) == 2) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 4) }                                         \
+    if constexpr ((G) == 3) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 5) }                                         \
+    CTAMD_FR_MFMA((S) & 1, 2 * (G))                                                                                \
+    if constexpr ((S) == 0) { CTAMD_FR_DMA_IF((P) ^ 1, NP3 + (G), false) }                                          \
+    CTAMD_FR_MFMA((S) & 1, 2 * (G) + 1)                                                                            \
+    if constexpr ((S) == 0) { CTAMD_FR_DMA_IF((P) ^ 1, NP3 + 4 + (G), false) }                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_FR_STEP(P, S) CTAMD_FR_GROUP(P, S, 0) CTAMD_FR_GROUP(P, S, 1) CTAMD_FR_GROUP(P, S, 2) CTAMD_FR_GROUP(P, S, 3)
+    // k-step 3 (after the barrier): reads of the next tile's step 0 from the other buffer, pieces 0 .. NP3 - 1 of tile t + 2
+    // into this buffer, MFMAs of step 3
+#define CTAMD_FR_LAST(P, G)                                                                                         \
+    if constexpr ((G) == 0) { CTAMD_FR_READ((P) ^ 1, 0, 0, 0) CTAMD_FR_READ((P) ^ 1, 0, 0, 1) }                     \
+    if constexpr ((G) == 1) { CTAMD_FR_READ((P) ^ 1, 0, 0, 2) CTAMD_FR_READ((P) ^ 1, 0, 0, 3) }                     \
+    if constexpr ((G) == 2) { CTAMD_FR_READ((P) ^ 1, 0, 0, 4) }                                                     \
+    if constexpr ((G) == 3) { CTAMD_FR_READ((P) ^ 1, 0, 0, 5) }                                                     \
+    CTAMD_FR_MFMA(1, 2 * (G))                                                                                      \
+    if constexpr (NP3 <= 4) { CTAMD_FR_DMA_IF(P, (G) < NP3 ? (G) : -1, false) }                                     \
+    else { CTAMD_FR_DMA_IF(P, 2 * (G) < NP3 ? 2 * (G) : -1, false) }                                               \
+    CTAMD_FR_MFMA(1, 2 * (G) + 1)                                                                                  \
+    if constexpr (NP3 > 4) { CTAMD_FR_DMA_IF(P, 2 * (G) + 1 < NP3 ? 2 * (G) + 1 : -1, false) }                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_FR_TILE(P)                                                                                            \
+    CTAMD_FR_STEP(P, 0)                                                                                            \
+    ++tNext;                                                                                                       \
+    if (tNext < nTiles) odo.advance(p.gK);                                                                         \
+    CTAMD_FR_STEP(P, 1) CTAMD_FR_STEP(P, 2)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_H_LGKM0();                                                                                               \
+    CTAMD_H_VMCNT(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_FR_LAST(P, 0) CTAMD_FR_LAST(P, 1) CTAMD_FR_LAST(P, 2) CTAMD_FR_LAST(P, 3)
+
+    // first fragments of tile 0
+    CTAMD_FR_READ(0, 0, 0, 0) CTAMD_FR_READ(0, 0, 0, 1) CTAMD_FR_READ(0, 0, 0, 2)
+    CTAMD_FR_READ(0, 0, 0, 3) CTAMD_FR_READ(0, 0, 0, 4) CTAMD_FR_READ(0, 0, 0, 5)
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_FR_TILE(0) CTAMD_FR_TILE(1) }
+    if (t < nTiles) { CTAMD_FR_TILE(0) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 64 * wc;     // this wave's 128 x 64 block
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t n = nW + (lane & 31);
+                    float* row = P + (size_t)m * Nt;
+                    if (n < Nt) row[n] = c0[r];
+                    if (n + 32 < Nt) row[n + 32] = c1[r];
+                }
+            }
+        };
+        store_partial(acc[0][0], acc[0][1], mW);
+        store_partial(acc[1][0], acc[1][1], mW + 32);
+        store_partial(acc[2][0], acc[2][1], mW + 64);
+        store_partial(acc[3][0], acc[3][1], mW + 96);
+        return;
+    }
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    const float alpha = p.alpha, beta = p.beta;
+    int64_t offDn[2], offCn[2];
+    bool    okN[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t n = nW + 32 * j + (lane & 31);
+        okN[j] = n < Ntot;
+        offDn[j] = 0; offCn[j] = 0;
+        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    }
+    auto store_one = [&](float v, int64_t offD, int64_t offC) {
+        float val = alpha * v;
+        if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
+        D[offD] = h_from_float(val, BF);
+    };
+    auto store_row = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < Mtot) {
+                int64_t offDm, offCm;
+                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+                if (okN[0]) store_one(c0[r], offDm + offDn[0], offCm + offCn[0]);
+                if (okN[1]) store_one(c1[r], offDm + offDn[1], offCm + offCn[1]);
+            }
+        }
+    };
+    store_row(acc[0][0], acc[0][1], mW);
+    store_row(acc[1][0], acc[1][1], mW + 32);
+    store_row(acc[2][0], acc[2][1], mW + 64);
+    store_row(acc[3][0], acc[3][1], mW + 96);
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16fr(const GettParams& p, hipStream_t stream) {
+    static const int np3 = [] { const char* e = getenv("CUTENSOR_AMD_H16_NP3"); return e ? atoi(e) : 4; }();
+    if (np3 == 8) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 8>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else if (np3 == 0) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 0>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else if (np3 == 1) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 1>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else if (np3 == 2) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 2>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4(const GettParams& p, hipStream_t stream) {
     static const int abl = [] { const char* e = getenv("CUTENSOR_AMD_H16_ABL"); return e ? atoi(e) : 0; }();
@@ -730,6 +948,8 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 0, &launch_h16<bf, la, lb>, 0},
 #define CTAMD_H16W4_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 2, 1, 0, &launch_h16w4<bf, la, lb>, 0},
+#define CTAMD_H16FR_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 2, 1, 0, &launch_h16fr<bf, la, lb>, 0},
 static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)
@@ -739,7 +959,12 @@ static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16W4_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16W4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16W4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_F, LAY_F)
+    // entries 16..23: the free-running eight-wave variant, same order
+    CTAMD_H16FR_ENTRY(true, LAY_K, LAY_K) CTAMD_H16FR_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16FR_ENTRY(true, LAY_F, LAY_K) CTAMD_H16FR_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16FR_ENTRY(false, LAY_K, LAY_K) CTAMD_H16FR_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16FR_ENTRY(false, LAY_F, LAY_K) CTAMD_H16FR_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16_kernels(int* count) {
     *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));

@@ -2,29 +2,40 @@
 //
 // Serves the call sequence of cuTENSORMg/contraction_multi_gpu.cu (create handle :151, block-cyclic
 // tensor descriptors :195-217, contraction descriptor / find / workspace / plan :228-250,
-// cutensorMgContraction :328-332).  Built entirely on the public single-GPU ABI (include/cutensor.h),
-// HIP and RCCL.
+// cutensorMgContraction :328-332) and of cuTENSORMg/blog_post.cu (:131-145, :286-302).  Built entirely
+// on the public single-GPU ABI (include/cutensor.h), HIP and RCCL.
 //
-// Algorithm ("shard the largest free mode, gather the rest"):
-//   1. The largest free mode p of C is cut into one contiguous shard per handle device; shards are
-//      further cut at p's block boundaries so that every piece lies inside one block.
-//   2. Each device gathers the grid cells it needs into its workspace, laid out [cell][cell buffer]:
-//      all cells of the operand that does not carry p (an all-gather), the cells of the other
-//      operand (and of C when beta != 0) whose p-coordinate it owns.  Cells are whole, contiguous
-//      device buffers, so the exchange is plain contiguous transfers: RCCL send/recv pairs inside
-//      one ncclGroup over xGMI when every handle device is distinct, device-local copies otherwise.
-//   3. The gathered [cell][w, lb] image *is* a tensor: mode i of extent E_i becomes three modes
-//      (w_i within a block, c_i grid coordinate, lb_i local block) with strides
-//      (elementStride_i, cellElems * cellStride_i, blockStride_i).  The local contraction is one
-//      cutensorContract per piece on these views — the GETT engine needs no redistribution kernel.
-//   4. Every piece of C is copied from the staging image into the owning cell's buffer by an
-//      identity cutensorPermute on strided views (peer stores over xGMI when the owner is remote).
+// Algorithm ("shard the largest free mode, gather the rest, overlap the gather with the first pieces"):
+//   1. The largest free mode p of C (carried by exactly one operand X) is cut into one contiguous shard
+//      per handle device; shards are cut again at p's block boundaries so that every piece lies in one block.
+//   2. The other operand Y does not carry p: every device needs all of it (an all-gather).  When Y is
+//      distributed along a free mode q, the device's work is cut along q's grid coordinate as well: the
+//      coordinates whose cells the device already holds come first (no remote dependency), the remote ones
+//      follow in contiguous runs, so the first local contraction starts while the gather is in flight.
+//   3. An operand view that touches a single grid cell living on the computing device is read (or, for D,
+//      written) in place.  Everything else is staged in the device's workspace as an image [cell][cell
+//      buffer]: local cells by device copies on the device's own stream, remote cells over xGMI by RCCL
+//      ncclSend / ncclRecv pairs inside ONE ncclGroup per wave on a separate communication stream per
+//      device (or by peer copies on several streams: CUTENSORMG_AMD_TRANSPORT=peer, and when RCCL is not
+//      available).  Every wave records an event; a piece waits only for the waves that carry its cells.
+//   4. The staged image *is* a tensor: mode i becomes (w_i inside a block, block-index digits) with strides
+//      (elementStride_i, cellElems * cellStride_i per grid digit, blockStride_i per local-block digit); the
+//      local contraction is one cutensorContract per piece on these strided views — no redistribution kernel.
+//   5. Pieces alternate between the caller's stream and an auxiliary stream per device (two local
+//      contractions in flight hide each other's tails); staged pieces of C are copied to the owners' cells
+//      by identity cutensorPermute on strided views (peer stores over xGMI when the owner is remote).
+//
+// Shared modes must have the same block size in every tensor that carries them; their device counts may
+// differ when they divide each other (e.g. B distributed along j, C not): the block index is then split
+// into common mixed-radix digits.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
 #include <set>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -56,14 +67,46 @@ size_t elem_size(hipDataType t) {
     }
 }
 
-struct Piece {                // a sub-range of the sharded mode handled by one device
-    int dev = 0;              // index into the handle's device list
-    int64_t lo = 0, hi = 0;   // global index range [lo, hi)
+constexpr int kMaxDigits = 6;      // block-index digits per label (labels of the local views: 8 * label + digit, 7 = w)
+constexpr int kComputeStreams = 2; // caller's stream + one auxiliary stream per device
+
+// Mixed-radix split of a label's block index b = sum digit_j * prod_{i<j} f_i, fine enough that every tensor's
+// (grid coordinate, local block) split is a prefix: dc_T = f_0 * ... * f_{t-1}.
+struct Radix {
+    int64_t blockSize = 1, numBlocks = 1;
+    std::vector<int64_t> f;        // digit extents, least significant first (may be empty: one block)
+};
+
+struct OperandUse {               // how one piece sees one tensor (0 = A, 1 = B, 2 = C/D)
+    bool direct = false;          // the view touches one cell that lives on the computing device: used in place
+    int cell = -1;                // that cell
+    int64_t off = 0;              // element offset of the view (inside the staging image, or inside the cell)
+    std::vector<int> cells;       // staged: the cells the view touches
+};
+
+struct Piece {
+    int dev = 0;                  // index into the handle's device list
+    int64_t lo = 0, hi = 0;       // range of the sharded mode p
+    int64_t q0 = 0, q1 = 0;       // range of q's grid coordinate (q1 == 0: q is not cut)
+    int stream = 0;               // 0 = caller's stream, 1 = auxiliary stream
     cutensorPlan_t plan = nullptr;
     uint64_t planWs = 0;
-    int64_t offA = 0, offB = 0, offC = 0;      // element offsets of the views in the staging images
+    OperandUse use[3];
     struct Scatter { int cell; int64_t off; cutensorPlan_t plan; };
-    std::vector<Scatter> scatter;              // staging C -> owner cell
+    std::vector<Scatter> scatter; // staged C -> owner cells
+    std::vector<int> waitEvents;  // transfer events (indices into the plan's event table) this piece waits for
+    double flops = 0.0;
+};
+
+struct Transfer {                 // one cell copied into a device's staging image
+    int tensor = 0, cell = 0;
+    int dst = 0;                  // handle device index that receives
+    int src = -1;                 // handle device index of the owner (-1: the owner is not in the handle)
+    int32_t ownerDevice = 0;      // HIP device id of the owner
+    bool local = false;           // owner is the receiving device: device copy on the caller's stream
+    int wave = 0;                 // remote transfers: RCCL group / event index on the receiver
+    int64_t bytes = 0;
+    int event = -1;               // index into the plan's event table (remote transfers)
 };
 
 }  // namespace
@@ -72,7 +115,11 @@ struct cutensorMgHandle {
     std::vector<int32_t> devices;
     std::vector<cutensorHandle_t> handles;
     bool distinct = true;
+    bool haveDevice = false;         // false: no GPU visible — descriptors and plans only (CPU tests)
     std::vector<ncclComm_t> comms;   // one per handle device when distinct and > 1
+    // execution resources, created on first use: [device][k]
+    std::vector<std::vector<hipStream_t>> commStreams;
+    std::vector<hipStream_t> auxStreams;
 };
 struct cutensorMgTensorDescriptor { MgTensor t; };
 struct cutensorMgContractionDescriptor {
@@ -83,19 +130,25 @@ struct cutensorMgContractionDescriptor {
 struct cutensorMgContractionFind { cutensorMgAlgo_t algo; };
 struct cutensorMgContractionPlan {
     cutensorMgContractionDescriptor desc;
-    std::vector<Piece> pieces;
-    // per handle device: cells to gather (tensor 0 = A, 1 = B, 2 = C)
-    std::vector<std::vector<int>> need[3];
+    std::vector<Piece> pieces;                 // execution order per device
+    std::vector<Transfer> transfers;
+    int numWaves = 0;
     int64_t stagingBytes[3] = {0, 0, 0};
-    std::vector<int64_t> wsBytes;    // required per device
-    uint64_t contractionWs = 0;
+    uint64_t contractionWs = 0;                // per compute stream
+    int pLabel = -1, qLabel = -1;
+    bool useRccl = false;
+    // events (created on first execution): per device {start, localReady, auxDone, commDone[k]...}, then one per (device, wave)
+    std::vector<hipEvent_t> events;
+    int evPerDevice = 0;
+    int commPerDevice = 1;
+    const cutensorMgHandle* owner = nullptr;
 };
 
 namespace {
 
 class DeviceGuard {   // the caller's current device is restored (contraction_multi_gpu.cu:320-346)
 public:
-    DeviceGuard() { if (hipGetDevice(&saved_) != hipSuccess) saved_ = -1; }
+    DeviceGuard() { if (hipGetDevice(&saved_) != hipSuccess) { saved_ = -1; (void)hipGetLastError(); } }
     ~DeviceGuard() { if (saved_ >= 0) (void)hipSetDevice(saved_); }
 private:
     int saved_ = -1;
@@ -113,37 +166,104 @@ int device_rank(const cutensorMgHandle* h, int32_t dev) {
     return -1;
 }
 
-// View of tensor T (staging image layout [cell][cell buffer]) for the local contraction.
-// Mode `shard` (index in T, or -1) is restricted to [lo, hi); every other mode i becomes up to three
-// sub-modes labelled 3*labelIndex + {0,1,2}.
 struct View {
     std::vector<int64_t> extent, stride;
     std::vector<int32_t> modes;
     int64_t offset = 0;
 };
 
+// Restriction of a label inside a view: the sharded mode p is pinned to [lo, hi) inside block `block`; q's digit
+// `digit` is cut to [c0, c1).
+struct Restrict {
+    int pLabel = -1; int64_t lo = 0, hi = 0;
+    int qLabel = -1; int qDigit = -1; int64_t c0 = 0, c1 = 0;
+};
+
+// digits of tensor t's mode i below `split` are grid-coordinate digits, the rest local-block digits
+int grid_digits(const Radix& r, int64_t dc) {
+    int64_t prod = 1;
+    int k = 0;
+    while (prod < dc && k < (int)r.f.size()) prod *= r.f[k++];
+    return k;
+}
+
+// View of tensor T for a piece.  staging: strides of the [cell][cell buffer] image (grid digits step by whole cell
+// images); otherwise the view is relative to one cell buffer and grid digits must be pinned (they contribute no offset).
 View make_view(const MgTensor& t, const std::vector<int32_t>& labels, const std::vector<int32_t>& universe,
-               int shard, int64_t lo, int64_t hi, bool stagingLayout) {
+               const std::vector<Radix>& radix, const Restrict& rs, bool staging) {
     View v;
     for (uint32_t i = 0; i < t.n; ++i) {
         const int li = find_label(universe, labels[i]);
-        const int64_t cellStep = stagingLayout ? t.cellElems * t.cellStride[i] : 0;
-        if ((int)i == shard) {
-            const int64_t b = lo / t.blockSize[i];            // global block of the piece
-            const int64_t c = b % t.deviceCount[i], lb = b / t.deviceCount[i];
-            v.offset += c * cellStep + lb * t.blockStride[i] + (lo - b * t.blockSize[i]) * t.elemStride[i];
-            if (hi - lo > 1) { v.extent.push_back(hi - lo); v.stride.push_back(t.elemStride[i]); v.modes.push_back(3 * li); }
-            continue;
+        const Radix& r = radix[li];
+        const int nGrid = grid_digits(r, t.deviceCount[i]);
+        const bool isP = li == rs.pLabel, isQ = li == rs.qLabel;
+        // w: position inside a block
+        if (isP) {
+            const int64_t block = rs.lo / r.blockSize;
+            v.offset += (rs.lo - block * r.blockSize) * t.elemStride[i];
+            if (rs.hi - rs.lo > 1) { v.extent.push_back(rs.hi - rs.lo); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
+        } else if (r.blockSize > 1) {
+            v.extent.push_back(r.blockSize); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7);
         }
-        if (t.blockSize[i] > 1) { v.extent.push_back(t.blockSize[i]); v.stride.push_back(t.elemStride[i]); v.modes.push_back(3 * li); }
-        if (stagingLayout && t.deviceCount[i] > 1) { v.extent.push_back(t.deviceCount[i]); v.stride.push_back(cellStep); v.modes.push_back(3 * li + 1); }
-        if (t.localBlocks[i] > 1) { v.extent.push_back(t.localBlocks[i]); v.stride.push_back(t.blockStride[i]); v.modes.push_back(3 * li + 2); }
+        // block-index digits
+        int64_t rest = isP ? rs.lo / r.blockSize : 0;
+        int64_t gridStep = t.cellElems * t.cellStride[i], localStep = t.blockStride[i];
+        for (int j = 0; j < (int)r.f.size(); ++j) {
+            const bool grid = j < nGrid;
+            const int64_t step = grid ? gridStep : localStep;
+            if (grid && !staging) {           // cell-relative view: the cell is chosen by the caller, its coordinate is no mode
+                if (isP) rest /= r.f[j];
+                gridStep *= r.f[j];
+                continue;
+            }
+            if (isP) {
+                v.offset += (rest % r.f[j]) * step;
+                rest /= r.f[j];
+            } else if (isQ && j == rs.qDigit) {
+                v.offset += rs.c0 * step;
+                if (rs.c1 - rs.c0 > 1) { v.extent.push_back(rs.c1 - rs.c0); v.stride.push_back(step); v.modes.push_back(8 * li + j); }
+            } else if (r.f[j] > 1) {
+                v.extent.push_back(r.f[j]); v.stride.push_back(step); v.modes.push_back(8 * li + j);
+            }
+            if (grid) gridStep *= r.f[j]; else localStep *= r.f[j];
+        }
     }
     return v;
 }
 
+// Grid cells of tensor T the restricted view touches.
+std::vector<int> cells_of(const MgTensor& t, const std::vector<int32_t>& labels, const std::vector<int32_t>& universe,
+                          const std::vector<Radix>& radix, const Restrict& rs) {
+    std::vector<int> out;
+    for (int64_t c = 0; c < t.numCells; ++c) {
+        bool want = true;
+        for (uint32_t i = 0; i < t.n && want; ++i) {
+            const int li = find_label(universe, labels[i]);
+            const int64_t coord = (c / t.cellStride[i]) % t.deviceCount[i];
+            if (li == rs.pLabel) {
+                want = coord == (rs.lo / radix[li].blockSize) % t.deviceCount[i];
+            } else if (li == rs.qLabel && rs.qDigit >= 0 && rs.qDigit < grid_digits(radix[li], t.deviceCount[i])) {
+                // q's cut digit is a grid digit of this tensor: its value inside the cell coordinate
+                int64_t below = 1;
+                for (int j = 0; j < rs.qDigit; ++j) below *= radix[li].f[j];
+                const int64_t d = (coord / below) % radix[li].f[rs.qDigit];
+                want = d >= rs.c0 && d < rs.c1;
+            }
+        }
+        if (want) out.push_back((int)c);
+    }
+    return out;
+}
+
+uint32_t align_of(int64_t offsetBytes, size_t es) {   // pointer alignment a view at this byte offset of a 256-byte aligned base keeps
+    uint32_t a = 256;
+    while (a > es && (offsetBytes % a) != 0) a >>= 1;
+    return std::max<uint32_t>(a, (uint32_t)es);
+}
+
 cutensorStatus_t make_desc(cutensorHandle_t h, const View& v, hipDataType type, cutensorTensorDescriptor_t* d) {
-    return cutensorCreateTensorDescriptor(h, d, (uint32_t)v.extent.size(), v.extent.data(), v.stride.data(), type, 16);
+    const uint32_t a = std::min<uint32_t>(align_of(v.offset * (int64_t)elem_size(type), elem_size(type)), 16u);
+    return cutensorCreateTensorDescriptor(h, d, (uint32_t)v.extent.size(), v.extent.data(), v.stride.data(), type, a);
 }
 
 cutensorComputeDescriptor_t compute_desc(cutensorComputeType_t c) {
@@ -172,6 +292,11 @@ void destroy_pieces(std::vector<Piece>& pieces) {
     pieces.clear();
 }
 
+bool env_is(const char* name, const char* value) {
+    const char* e = std::getenv(name);
+    return e != nullptr && std::strcmp(e, value) == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,20 +309,21 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
     if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
     cutensorMgHandle* h = new (std::nothrow) cutensorMgHandle();
     if (h == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+    h->haveDevice = count > 0;
     h->devices.assign(devices, devices + numDevices);
     std::set<int32_t> uniq(h->devices.begin(), h->devices.end());
     h->distinct = uniq.size() == h->devices.size();
     for (int32_t d : h->devices) {
-        if (d < 0 || (count > 0 && d >= count)) { delete h; return CUTENSOR_STATUS_INVALID_VALUE; }
+        if (d < 0 || (count > 0 && d >= count)) { cutensorMgDestroy(h); return CUTENSOR_STATUS_INVALID_VALUE; }
         if (count > 0) (void)hipSetDevice(d);
         cutensorHandle_t ch = nullptr;
-        if (cutensorCreate(&ch) != CUTENSOR_STATUS_SUCCESS) { delete h; return CUTENSOR_STATUS_ALLOC_FAILED; }
+        if (cutensorCreate(&ch) != CUTENSOR_STATUS_SUCCESS) { cutensorMgDestroy(h); return CUTENSOR_STATUS_ALLOC_FAILED; }
         h->handles.push_back(ch);
         if (count > 0)
             for (int32_t o : uniq)
                 if (o != d) { (void)hipDeviceEnablePeerAccess(o, 0); (void)hipGetLastError(); }   // xGMI peer mapping
     }
-    if (count > 0 && h->distinct && numDevices > 1) {
+    if (count > 0 && h->distinct && numDevices > 1 && !env_is("CUTENSORMG_AMD_TRANSPORT", "peer")) {
         h->comms.resize(numDevices);
         std::vector<int> devs(h->devices.begin(), h->devices.end());
         if (ncclCommInitAll(h->comms.data(), (int)numDevices, devs.data()) != ncclSuccess) h->comms.clear();
@@ -209,6 +335,12 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
 // contraction_multi_gpu.cu:383
 cutensorStatus_t cutensorMgDestroy(cutensorMgHandle_t handle) {
     if (handle == nullptr) return CUTENSOR_STATUS_SUCCESS;
+    DeviceGuard guard;
+    for (size_t g = 0; g < handle->commStreams.size(); ++g) {
+        if (handle->haveDevice) (void)hipSetDevice(handle->devices[g]);
+        for (hipStream_t s : handle->commStreams[g]) (void)hipStreamDestroy(s);
+        if (g < handle->auxStreams.size() && handle->auxStreams[g]) (void)hipStreamDestroy(handle->auxStreams[g]);
+    }
     for (ncclComm_t c : handle->comms) (void)ncclCommDestroy(c);
     for (cutensorHandle_t h : handle->handles) cutensorDestroy(h);
     delete handle;
@@ -292,13 +424,16 @@ cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t 
                         d->C.deviceCount == d->D.deviceCount && d->C.elemStride == d->D.elemStride &&
                         d->C.blockStride == d->D.blockStride && d->C.devices == d->D.devices;
     if (!sameCD || d->A.dtype != d->B.dtype || d->A.dtype != d->C.dtype) { delete d; return CUTENSOR_STATUS_NOT_SUPPORTED; }
-    // a mode shared by two tensors must be blocked identically in both
+    // a mode shared by two tensors must be cut into the same blocks in both, and the two device counts must divide one
+    // another (the block index then has common mixed-radix digits)
     auto check = [&](const MgTensor& x, const std::vector<int32_t>& mx, const MgTensor& y, const std::vector<int32_t>& my) {
         for (uint32_t i = 0; i < x.n; ++i) {
             const int j = find_label(my, mx[i]);
             if (j < 0) continue;
             if (x.extent[i] != y.extent[j]) return CUTENSOR_STATUS_INVALID_VALUE;
-            if (x.blockSize[i] != y.blockSize[j] || x.deviceCount[i] != y.deviceCount[j]) return CUTENSOR_STATUS_NOT_SUPPORTED;
+            if (x.blockSize[i] != y.blockSize[j]) return CUTENSOR_STATUS_NOT_SUPPORTED;
+            const int64_t a = x.deviceCount[i], b = y.deviceCount[j];
+            if (a % b != 0 && b % a != 0) return CUTENSOR_STATUS_NOT_SUPPORTED;
         }
         return CUTENSOR_STATUS_SUCCESS;
     };
@@ -332,8 +467,10 @@ cutensorStatus_t cutensorMgDestroyContractionFind(cutensorMgContractionFind_t fi
     return CUTENSOR_STATUS_SUCCESS;
 }
 
-static const uint64_t kLocalContractionWs = 256ull << 20;   // split-K scratch offered to every local plan
+static const uint64_t kLocalContractionWs = 128ull << 20;   // split-K scratch offered to every local plan (per compute stream)
 
+// Upper bound of the staging images (whether a tensor needs staging at all is decided by the plan; the workspace
+// query must not be smaller than what any plan of this descriptor can ask for).
 static void staging_sizes(const cutensorMgContractionDescriptor& d, int64_t out[3]) {
     const size_t es = elem_size(d.A.dtype);
     auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
@@ -352,7 +489,7 @@ cutensorStatus_t cutensorMgContractionGetWorkspace(const cutensorMgHandle_t hand
     int64_t s[3];
     staging_sizes(*desc, s);
     for (size_t i = 0; i < handle->devices.size(); ++i)
-        deviceWorkspaceSize[i] = s[0] + s[1] + s[2] + (int64_t)kLocalContractionWs;
+        deviceWorkspaceSize[i] = s[0] + s[1] + s[2] + (int64_t)(kComputeStreams * kLocalContractionWs);
     *hostWorkspaceSize = 0;
     return CUTENSOR_STATUS_SUCCESS;
 }
@@ -368,23 +505,49 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     cutensorMgContractionPlan* pl = new (std::nothrow) cutensorMgContractionPlan();
     if (pl == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
     pl->desc = *desc;
+    pl->owner = handle;
     const cutensorMgContractionDescriptor& d = pl->desc;
     const int nDev = (int)handle->devices.size();
+    const size_t es = elem_size(d.A.dtype);
     staging_sizes(d, pl->stagingBytes);
     const int64_t fixed = pl->stagingBytes[0] + pl->stagingBytes[1] + pl->stagingBytes[2];
-    pl->wsBytes.assign(nDev, fixed);
     uint64_t ctrWs = kLocalContractionWs;
     for (int g = 0; g < nDev; ++g) {
         if (deviceWorkspaceSize[g] < fixed) { delete pl; return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
-        ctrWs = std::min<uint64_t>(ctrWs, (uint64_t)(deviceWorkspaceSize[g] - fixed));
+        ctrWs = std::min<uint64_t>(ctrWs, (uint64_t)(deviceWorkspaceSize[g] - fixed) / kComputeStreams / 256 * 256);
     }
     pl->contractionWs = ctrWs;
+    pl->useRccl = !handle->comms.empty();
 
-    // ---- label universe and the mode to shard -------------------------------------------------
+    // ---- label universe, block-index digits per label ----------------------------------------------
+    const MgTensor* T[3] = {&d.A, &d.B, &d.C};
+    const std::vector<int32_t>* M[3] = {&d.mA, &d.mB, &d.mC};
     std::vector<int32_t> universe;
-    for (auto* m : {&d.mA, &d.mB, &d.mC})
-        for (int32_t l : *m)
+    for (int k = 0; k < 3; ++k)
+        for (int32_t l : *M[k])
             if (find_label(universe, l) < 0) universe.push_back(l);
+    std::vector<Radix> radix(universe.size());
+    for (size_t li = 0; li < universe.size(); ++li) {
+        std::set<int64_t> dcs;
+        Radix& r = radix[li];
+        for (int k = 0; k < 3; ++k) {
+            const int i = find_label(*M[k], universe[li]);
+            if (i < 0) continue;
+            r.blockSize = T[k]->blockSize[i];
+            r.numBlocks = T[k]->extent[i] / T[k]->blockSize[i];
+            dcs.insert(T[k]->deviceCount[i]);
+        }
+        int64_t prev = 1;
+        for (int64_t dc : dcs) {          // ascending; each divides the next (checked by the contraction descriptor)
+            if (dc % prev != 0) { delete pl; return CUTENSOR_STATUS_NOT_SUPPORTED; }
+            if (dc / prev > 1) r.f.push_back(dc / prev);
+            prev = dc;
+        }
+        if (r.numBlocks / prev > 1) r.f.push_back(r.numBlocks / prev);
+        if ((int)r.f.size() > kMaxDigits) { delete pl; return CUTENSOR_STATUS_NOT_SUPPORTED; }
+    }
+
+    // ---- the mode to shard (p) and the mode that orders the gather (q) --------------------------------
     int pC = -1;   // index in C of the largest mode that is free (in exactly one of A / B) — else any C mode
     for (int pass = 0; pass < 2 && pC < 0; ++pass)
         for (uint32_t i = 0; i < d.C.n; ++i) {
@@ -392,14 +555,33 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             if (pass == 0 && inA == inB) continue;
             if (pC < 0 || d.C.extent[i] > d.C.extent[pC]) pC = (int)i;
         }
-    const int32_t pLabel = pC >= 0 ? d.mC[pC] : 0;
-    const int pA = pC >= 0 ? find_label(d.mA, pLabel) : -1;
-    const int pB = pC >= 0 ? find_label(d.mB, pLabel) : -1;
+    const int pLi = pC >= 0 ? find_label(universe, d.mC[pC]) : -1;
+    pl->pLabel = pC >= 0 ? d.mC[pC] : -1;
+    // Y = the operand that does not carry p (gathered whole); q = Y's free mode with the largest device count whose
+    // grid coordinate is ONE digit in Y (so that a run of coordinates is a box)
+    int yK = -1;
+    if (pC >= 0) yK = find_label(d.mA, d.mC[pC]) >= 0 ? 1 : 0;
+    if (pC >= 0 && find_label(d.mA, d.mC[pC]) >= 0 && find_label(d.mB, d.mC[pC]) >= 0) yK = -1;   // batch mode: both carry it
+    int qLi = -1, qDigit = -1;
+    int64_t qCount = 1;
+    if (yK >= 0 && !env_is("CUTENSORMG_AMD_QSPLIT", "0")) {
+        const MgTensor& Y = *T[yK];
+        for (uint32_t i = 0; i < Y.n; ++i) {
+            const int32_t l = (*M[yK])[i];
+            if (find_label(d.mC, l) < 0 || Y.deviceCount[i] <= 1) continue;
+            const int li = find_label(universe, l);
+            const int nGrid = grid_digits(radix[li], Y.deviceCount[i]);
+            if (nGrid != 1) continue;
+            if (Y.deviceCount[i] > qCount) { qCount = Y.deviceCount[i]; qLi = li; qDigit = 0; }
+        }
+    }
+    pl->qLabel = qLi >= 0 ? universe[qLi] : -1;
 
-    // ---- pieces: one shard per device, cut at block boundaries ---------------------------------
-    std::vector<Piece> pieces;
+    // ---- pieces: one shard of p per device, cut at block boundaries, then runs of q's coordinate -------
+    struct Shard { int dev; int64_t lo, hi; };
+    std::vector<Shard> shards;
     if (pC < 0) {
-        Piece p; p.dev = 0; pieces.push_back(p);
+        shards.push_back(Shard{0, 0, 0});
     } else {
         const int64_t E = d.C.extent[pC], bs = d.C.blockSize[pC];
         int64_t per = (E + nDev - 1) / nDev;
@@ -408,81 +590,197 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             int64_t lo = (int64_t)g * per, hi = std::min<int64_t>(E, lo + per);
             while (lo < hi) {
                 const int64_t cut = std::min<int64_t>(hi, (lo / bs + 1) * bs);
-                Piece p; p.dev = g; p.lo = lo; p.hi = cut;
-                pieces.push_back(p);
+                shards.push_back(Shard{g, lo, cut});
                 lo = cut;
             }
         }
     }
+    double flopsAll = 2.0;
+    for (size_t li = 0; li < universe.size(); ++li) flopsAll *= (double)(radix[li].blockSize * radix[li].numBlocks);
 
-    // ---- which cells each device gathers --------------------------------------------------------
-    const MgTensor* T[3] = {&d.A, &d.B, &d.C};
-    const int shardIdx[3] = {pA, pB, pC};
-    for (int k = 0; k < 3; ++k) pl->need[k].assign(nDev, std::vector<int>());
+    auto restrict_of = [&](const Shard& s, int64_t c0, int64_t c1) {
+        Restrict rs;
+        if (pC >= 0) { rs.pLabel = pLi; rs.lo = s.lo; rs.hi = s.hi; }
+        if (qLi >= 0 && c1 > c0) { rs.qLabel = qLi; rs.qDigit = qDigit; rs.c0 = c0; rs.c1 = c1; }
+        return rs;
+    };
+    // is every cell of tensor k that the restricted view touches local to device g?
+    auto all_local = [&](int k, const Restrict& rs, int g) {
+        for (int c : cells_of(*T[k], *M[k], universe, radix, rs))
+            if (T[k]->devices[c] != handle->devices[g]) return false;
+        return true;
+    };
+    int wavesWanted = 1;
+    if (const char* e = std::getenv("CUTENSORMG_AMD_WAVES")) wavesWanted = std::max(1, std::atoi(e));
+
+    std::vector<Piece> pieces;
+    int numWaves = 0;
     for (int g = 0; g < nDev; ++g) {
-        std::set<int64_t> coords;   // grid coordinates of mode p touched by device g
-        for (const Piece& p : pieces)
-            if (p.dev == g && pC >= 0) coords.insert((p.lo / d.C.blockSize[pC]) % d.C.deviceCount[pC]);
-        const bool active = std::any_of(pieces.begin(), pieces.end(), [&](const Piece& p) { return p.dev == g; });
-        if (!active) continue;
+        std::vector<Piece> mine;
+        for (const Shard& s : shards) {
+            if (s.dev != g) continue;
+            if (qLi < 0) {
+                Piece p; p.dev = g; p.lo = s.lo; p.hi = s.hi;
+                mine.push_back(p);
+                continue;
+            }
+            // class of each q coordinate: -1 = everything this coordinate needs of Y is already on the device, else the
+            // gather wave that brings it (ring distance from the device's own position, wavesWanted waves)
+            std::vector<int> cls((size_t)qCount);
+            for (int64_t c = 0; c < qCount; ++c) {
+                const Restrict rs = restrict_of(s, c, c + 1);
+                if (all_local(yK, rs, g)) { cls[(size_t)c] = -1; continue; }
+                const int64_t dist = ((c - g) % qCount + qCount) % qCount;      // 1 .. qCount - 1 for the usual one-cell-per-device layout
+                cls[(size_t)c] = (int)std::min<int64_t>(wavesWanted - 1, (dist > 0 ? dist - 1 : 0) * wavesWanted / std::max<int64_t>(1, qCount - 1));
+            }
+            // maximal runs of equal class, local runs first, then by wave
+            struct Run { int64_t c0, c1; int cls; };
+            std::vector<Run> runs;
+            for (int64_t c = 0; c < qCount;) {
+                int64_t e = c + 1;
+                while (e < qCount && cls[(size_t)e] == cls[(size_t)c]) ++e;
+                runs.push_back(Run{c, e, cls[(size_t)c]});
+                c = e;
+            }
+            std::stable_sort(runs.begin(), runs.end(), [](const Run& a, const Run& b) { return a.cls < b.cls; });
+            for (const Run& r : runs) {
+                Piece p; p.dev = g; p.lo = s.lo; p.hi = s.hi; p.q0 = r.c0; p.q1 = r.c1;
+                mine.push_back(p);
+            }
+        }
+        for (size_t i = 0; i < mine.size(); ++i) mine[i].stream = (int)(i % kComputeStreams);
+        pieces.insert(pieces.end(), mine.begin(), mine.end());
+    }
+
+    // ---- operand uses, transfers ------------------------------------------------------------------------
+    std::map<std::pair<int, std::pair<int, int>>, int> have;   // (device, (tensor, cell)) -> transfer index
+    bool staged[3] = {false, false, false};
+    for (Piece& p : pieces) {
+        const Shard s{p.dev, p.lo, p.hi};
+        const Restrict rs = restrict_of(s, p.q0, p.q1);
+        p.flops = flopsAll;
+        if (pC >= 0) p.flops *= (double)(p.hi - p.lo) / (double)d.C.extent[pC];
+        if (qLi >= 0) p.flops *= (double)(p.q1 - p.q0) / (double)qCount;
         for (int k = 0; k < 3; ++k) {
-            const MgTensor& t = *T[k];
-            for (int64_t c = 0; c < t.numCells; ++c) {
-                bool want = true;
-                if (shardIdx[k] >= 0) {
-                    const int64_t coord = (c / t.cellStride[shardIdx[k]]) % t.deviceCount[shardIdx[k]];
-                    want = coords.count(coord) > 0;
-                }
-                if (want) pl->need[k][g].push_back((int)c);
+            OperandUse& u = p.use[k];
+            u.cells = cells_of(*T[k], *M[k], universe, radix, rs);
+            u.direct = u.cells.size() == 1 && T[k]->devices[u.cells[0]] == handle->devices[p.dev] &&
+                       !env_is("CUTENSORMG_AMD_DIRECT", "0");
+            if (u.direct) { u.cell = u.cells[0]; continue; }
+            staged[k] = true;
+            for (int c : u.cells) {
+                const auto key = std::make_pair(p.dev, std::make_pair(k, c));
+                if (have.count(key)) continue;
+                Transfer t;
+                t.tensor = k; t.cell = c; t.dst = p.dev;
+                t.ownerDevice = T[k]->devices[c];
+                t.src = device_rank(handle, t.ownerDevice);
+                t.local = t.ownerDevice == handle->devices[p.dev];
+                t.bytes = T[k]->cellElems * (int64_t)es;
+                have[key] = (int)pl->transfers.size();
+                pl->transfers.push_back(t);
             }
         }
     }
+    // waves of the remote transfers: in the order the pieces of the receiving device first need them
+    {
+        std::vector<int> nextWave((size_t)nDev, 0);
+        std::vector<std::vector<int>> order((size_t)nDev);   // remote transfer indices per device in first-use order
+        std::set<int> seen;
+        for (const Piece& p : pieces)
+            for (int k = 0; k < 3; ++k) {
+                if (p.use[k].direct) continue;
+                for (int c : p.use[k].cells) {
+                    const int ti = have[std::make_pair(p.dev, std::make_pair(k, c))];
+                    if (pl->transfers[(size_t)ti].local || seen.count(ti)) continue;
+                    seen.insert(ti);
+                    order[(size_t)p.dev].push_back(ti);
+                }
+            }
+        for (int g = 0; g < nDev; ++g) {
+            const size_t n = order[(size_t)g].size();
+            const size_t perWave = std::max<size_t>(1, (n + (size_t)wavesWanted - 1) / (size_t)wavesWanted);
+            for (size_t i = 0; i < n; ++i) {
+                Transfer& t = pl->transfers[(size_t)order[(size_t)g][i]];
+                t.wave = (int)(i / perWave);
+                numWaves = std::max(numWaves, t.wave + 1);
+            }
+        }
+    }
+    pl->numWaves = numWaves;
+    pl->commPerDevice = pl->useRccl ? 1 : std::max(1, std::min(7, nDev - 1));
+    pl->evPerDevice = 3 + pl->commPerDevice + numWaves * (pl->useRccl ? 1 : pl->commPerDevice);
+    for (Transfer& t : pl->transfers) {
+        if (t.local) continue;
+        // RCCL: one event per (device, wave); peer copies: one event per (device, wave, comm stream)
+        t.event = t.dst * pl->evPerDevice + 3 + pl->commPerDevice + t.wave * (pl->useRccl ? 1 : pl->commPerDevice);
+    }
+    if (!pl->useRccl) {   // spread a wave's peer copies over the communication streams
+        std::map<std::pair<int, int>, int> n;
+        for (Transfer& t : pl->transfers) {
+            if (t.local) continue;
+            int& k = n[std::make_pair(t.dst, t.wave)];
+            t.event += k % pl->commPerDevice;
+            ++k;
+        }
+    }
+    for (Piece& p : pieces) {
+        std::set<int> ev;
+        for (int k = 0; k < 3; ++k) {
+            if (p.use[k].direct) continue;
+            for (int c : p.use[k].cells) {
+                const Transfer& t = pl->transfers[(size_t)have[std::make_pair(p.dev, std::make_pair(k, c))]];
+                if (!t.local) ev.insert(t.event);
+            }
+        }
+        p.waitEvents.assign(ev.begin(), ev.end());
+    }
+    for (int k = 0; k < 3; ++k)
+        if (!staged[k]) pl->stagingBytes[k] = 0;
 
     // ---- local plans ----------------------------------------------------------------------------
     const cutensorComputeDescriptor_t cd = compute_desc(d.compute);
     cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
     for (Piece& p : pieces) {
-        (void)hipSetDevice(handle->devices[p.dev]);
-        (void)hipGetLastError();
+        if (handle->haveDevice) { (void)hipSetDevice(handle->devices[p.dev]); (void)hipGetLastError(); }
         cutensorHandle_t h = handle->handles[p.dev];
-        const View vA = make_view(d.A, d.mA, universe, pA, p.lo, p.hi, true);
-        const View vB = make_view(d.B, d.mB, universe, pB, p.lo, p.hi, true);
-        const View vC = make_view(d.C, d.mC, universe, pC, p.lo, p.hi, true);
-        p.offA = vA.offset; p.offB = vB.offset; p.offC = vC.offset;
-        cutensorTensorDescriptor_t dA = nullptr, dB = nullptr, dC = nullptr;
+        const Shard s{p.dev, p.lo, p.hi};
+        const Restrict rs = restrict_of(s, p.q0, p.q1);
+        View v[3];
+        for (int k = 0; k < 3; ++k) {
+            v[k] = make_view(*T[k], *M[k], universe, radix, rs, !p.use[k].direct);
+            p.use[k].off = v[k].offset;
+        }
+        cutensorTensorDescriptor_t dT[3] = {nullptr, nullptr, nullptr};
         cutensorOperationDescriptor_t op = nullptr;
         cutensorPlanPreference_t pref = nullptr;
-        st = make_desc(h, vA, d.A.dtype, &dA);
-        if (st == CUTENSOR_STATUS_SUCCESS) st = make_desc(h, vB, d.B.dtype, &dB);
-        if (st == CUTENSOR_STATUS_SUCCESS) st = make_desc(h, vC, d.C.dtype, &dC);
+        for (int k = 0; k < 3 && st == CUTENSOR_STATUS_SUCCESS; ++k) st = make_desc(h, v[k], T[k]->dtype, &dT[k]);
         if (st == CUTENSOR_STATUS_SUCCESS)
-            st = cutensorCreateContraction(h, &op, dA, vA.modes.data(), CUTENSOR_OP_IDENTITY, dB, vB.modes.data(), CUTENSOR_OP_IDENTITY,
-                                           dC, vC.modes.data(), CUTENSOR_OP_IDENTITY, dC, vC.modes.data(), cd);
+            st = cutensorCreateContraction(h, &op, dT[0], v[0].modes.data(), CUTENSOR_OP_IDENTITY, dT[1], v[1].modes.data(), CUTENSOR_OP_IDENTITY,
+                                           dT[2], v[2].modes.data(), CUTENSOR_OP_IDENTITY, dT[2], v[2].modes.data(), cd);
         if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlanPreference(h, &pref, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE);
         if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &p.plan, op, pref, pl->contractionWs);
         if (st == CUTENSOR_STATUS_SUCCESS)
             st = cutensorPlanGetAttribute(h, p.plan, CUTENSOR_PLAN_REQUIRED_WORKSPACE, &p.planWs, sizeof(p.planWs));
         cutensorDestroyOperationDescriptor(op);
         cutensorDestroyPlanPreference(pref);
-        cutensorDestroyTensorDescriptor(dA);
-        cutensorDestroyTensorDescriptor(dB);
-        cutensorDestroyTensorDescriptor(dC);
+        for (int k = 0; k < 3; ++k) cutensorDestroyTensorDescriptor(dT[k]);
         if (st != CUTENSOR_STATUS_SUCCESS) break;
+        if (p.use[2].direct) continue;
         // scatter plans: the piece's region inside every cell of C it touches (cell-relative strides)
-        const View cellView = make_view(d.C, d.mC, universe, pC, p.lo, p.hi, false);
-        const int64_t coord = pC >= 0 ? (p.lo / d.C.blockSize[pC]) % d.C.deviceCount[pC] : 0;
-        for (int64_t c = 0; c < d.C.numCells && st == CUTENSOR_STATUS_SUCCESS; ++c) {
-            if (pC >= 0 && (c / d.C.cellStride[pC]) % d.C.deviceCount[pC] != coord) continue;
+        const View cellView = make_view(d.C, d.mC, universe, radix, rs, false);
+        for (int c : p.use[2].cells) {
             cutensorTensorDescriptor_t ds = nullptr;
             cutensorOperationDescriptor_t po = nullptr;
-            Piece::Scatter s{(int)c, cellView.offset, nullptr};
+            Piece::Scatter sc{c, cellView.offset, nullptr};
             st = make_desc(h, cellView, d.C.dtype, &ds);
             if (st == CUTENSOR_STATUS_SUCCESS)
                 st = cutensorCreatePermutation(h, &po, ds, cellView.modes.data(), CUTENSOR_OP_IDENTITY, ds, cellView.modes.data(), cd);
-            if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &s.plan, po, nullptr, 0);
+            if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &sc.plan, po, nullptr, 0);
             cutensorDestroyOperationDescriptor(po);
             cutensorDestroyTensorDescriptor(ds);
-            if (st == CUTENSOR_STATUS_SUCCESS) p.scatter.push_back(s);
+            if (st != CUTENSOR_STATUS_SUCCESS) break;
+            p.scatter.push_back(sc);
         }
         if (st != CUTENSOR_STATUS_SUCCESS) break;
     }
@@ -499,8 +797,41 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
 cutensorStatus_t cutensorMgDestroyContractionPlan(cutensorMgContractionPlan_t plan) {
     if (plan == nullptr) return CUTENSOR_STATUS_SUCCESS;
     destroy_pieces(plan->pieces);
+    if (!plan->events.empty() && plan->owner != nullptr) {
+        DeviceGuard guard;
+        const int nDev = (int)plan->owner->devices.size();
+        for (int g = 0; g < nDev; ++g) {
+            (void)hipSetDevice(plan->owner->devices[g]);
+            for (int i = 0; i < plan->evPerDevice; ++i)
+                if (plan->events[(size_t)(g * plan->evPerDevice + i)]) (void)hipEventDestroy(plan->events[(size_t)(g * plan->evPerDevice + i)]);
+        }
+    }
     delete plan;
     return CUTENSOR_STATUS_SUCCESS;
+}
+
+// Streams and events of the execution engine (created on first use; the Mg model is one host thread).
+static bool ensure_runtime(cutensorMgHandle* h, cutensorMgContractionPlan* pl) {
+    const int nDev = (int)h->devices.size();
+    if (h->commStreams.size() != (size_t)nDev) { h->commStreams.assign((size_t)nDev, {}); h->auxStreams.assign((size_t)nDev, nullptr); }
+    for (int g = 0; g < nDev; ++g) {
+        if (hipSetDevice(h->devices[g]) != hipSuccess) return false;
+        while ((int)h->commStreams[(size_t)g].size() < pl->commPerDevice) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+            h->commStreams[(size_t)g].push_back(s);
+        }
+        if (h->auxStreams[(size_t)g] == nullptr && hipStreamCreateWithFlags(&h->auxStreams[(size_t)g], hipStreamNonBlocking) != hipSuccess) return false;
+    }
+    if (pl->events.empty()) {
+        pl->events.assign((size_t)(nDev * pl->evPerDevice), nullptr);
+        for (int g = 0; g < nDev; ++g) {
+            if (hipSetDevice(h->devices[g]) != hipSuccess) return false;
+            for (int i = 0; i < pl->evPerDevice; ++i)
+                if (hipEventCreateWithFlags(&pl->events[(size_t)(g * pl->evPerDevice + i)], hipEventDisableTiming) != hipSuccess) return false;
+        }
+    }
+    return true;
 }
 
 // contraction_multi_gpu.cu:328-332
@@ -513,79 +844,185 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
     if (plan == nullptr || alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr ||
         workspaceDevice == nullptr || streams == nullptr)
         return CUTENSOR_STATUS_INVALID_VALUE;
+    if (!handle->haveDevice) return CUTENSOR_STATUS_ARCH_MISMATCH;   // plan-only handle (no GPU visible)
     DeviceGuard guard;
-    const cutensorMgContractionDescriptor& d = plan->desc;
+    cutensorMgContractionPlan* pl = plan;
+    const cutensorMgContractionDescriptor& d = pl->desc;
     const int nDev = (int)handle->devices.size();
     const size_t es = elem_size(d.A.dtype);
     const bool f64 = d.A.dtype == HIP_R_64F || d.compute == CUTENSOR_COMPUTE_64F;
     const double b = f64 ? *static_cast<const double*>(beta) : (double)*static_cast<const float*>(beta);
     if (b != 0.0 && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (!ensure_runtime(handle, pl)) { (void)hipGetLastError(); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     const MgTensor* T[3] = {&d.A, &d.B, &d.C};
     const void* const* src[3] = {A, B, C};
 
-    auto staging = [&](int g, int k) -> char* {
+    auto staging = [&](int g, int k) -> char* {   // k = 3, 4: contraction workspace of compute stream 0, 1
         char* base = static_cast<char*>(workspaceDevice[g]);
-        for (int j = 0; j < k; ++j) base += plan->stagingBytes[j];
+        for (int j = 0; j < k && j < 3; ++j) base += pl->stagingBytes[j];
+        if (k > 3) base += (size_t)(k - 3) * pl->contractionWs;
         return base;
     };
+    auto ev = [&](int g, int i) { return pl->events[(size_t)(g * pl->evPerDevice + i)]; };   // 0 start, 1 localReady, 2 auxDone, 3.. commDone
+    auto compute_stream = [&](int g, int s) { return s == 0 ? streams[g] : handle->auxStreams[(size_t)g]; };
+#define MG_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return CUTENSOR_STATUS_EXECUTION_FAILED; } } while (0)
 
-    // ---- 1. gather ------------------------------------------------------------------------------
-    const bool useRccl = !handle->comms.empty();
-    bool grouped = false;
+    // ---- 0. fork: the helper streams of every device start behind the caller's stream ------------------------
     for (int g = 0; g < nDev; ++g) {
-        for (int k = 0; k < 3; ++k) {
-            if (k == 2 && b == 0.0) continue;
-            const MgTensor& t = *T[k];
-            const size_t cellBytes = (size_t)t.cellElems * es;
-            for (int c : plan->need[k][g]) {
-                char* dst = staging(g, k) + (size_t)c * cellBytes;
-                const int32_t owner = t.devices[c];
-                const int ownerRank = device_rank(handle, owner);
-                if (owner == handle->devices[g]) {
-                    (void)hipSetDevice(owner);
-                    if (hipMemcpyAsync(dst, src[k][c], cellBytes, hipMemcpyDeviceToDevice, streams[g]) != hipSuccess)
-                        return CUTENSOR_STATUS_EXECUTION_FAILED;
-                } else if (useRccl && ownerRank >= 0) {
-                    if (!grouped) { (void)ncclGroupStart(); grouped = true; }
-                    (void)hipSetDevice(owner);
-                    if (ncclSend(src[k][c], (size_t)t.cellElems, nccl_type(t.dtype), g, handle->comms[ownerRank], streams[ownerRank]) != ncclSuccess)
-                        return CUTENSOR_STATUS_EXECUTION_FAILED;
-                    (void)hipSetDevice(handle->devices[g]);
-                    if (ncclRecv(dst, (size_t)t.cellElems, nccl_type(t.dtype), ownerRank, handle->comms[g], streams[g]) != ncclSuccess)
-                        return CUTENSOR_STATUS_EXECUTION_FAILED;
-                } else {
-                    (void)hipSetDevice(handle->devices[g]);
-                    if (hipMemcpyPeerAsync(dst, handle->devices[g], src[k][c], owner, cellBytes, streams[g]) != hipSuccess)
-                        return CUTENSOR_STATUS_EXECUTION_FAILED;
-                }
-            }
+        MG_HIP(hipSetDevice(handle->devices[g]));
+        MG_HIP(hipEventRecord(ev(g, 0), streams[g]));
+    }
+    for (int g = 0; g < nDev; ++g) {
+        MG_HIP(hipSetDevice(handle->devices[g]));
+        MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 0), 0));
+        for (hipStream_t cs : handle->commStreams[(size_t)g]) {
+            // a communication stream reads the owners' cells: behind the caller's stream of every device
+            for (int o = 0; o < nDev; ++o) MG_HIP(hipStreamWaitEvent(cs, ev(o, 0), 0));
         }
     }
-    if (grouped && ncclGroupEnd() != ncclSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
 
-    // ---- 2. local contractions, 3. scatter -------------------------------------------------------
-    for (const Piece& p : plan->pieces) {
+    // ---- 1. gather ---------------------------------------------------------------------------------------------
+    // local cells (same physical device): device copies on the caller's stream
+    for (const Transfer& t : pl->transfers) {
+        if (!t.local || (t.tensor == 2 && b == 0.0)) continue;
+        MG_HIP(hipSetDevice(handle->devices[t.dst]));
+        MG_HIP(hipMemcpyAsync(staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes, src[t.tensor][t.cell], (size_t)t.bytes,
+                              hipMemcpyDeviceToDevice, streams[t.dst]));
+    }
+    for (int g = 0; g < nDev; ++g) {
+        MG_HIP(hipSetDevice(handle->devices[g]));
+        MG_HIP(hipEventRecord(ev(g, 1), streams[g]));
+        MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 1), 0));
+    }
+    // remote cells, wave by wave
+    for (int w = 0; w < pl->numWaves; ++w) {
+        bool grouped = false;
+        cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+        std::set<int> touched;   // events to record after this wave
+        for (const Transfer& t : pl->transfers) {
+            if (t.local || t.wave != w || (t.tensor == 2 && b == 0.0)) continue;
+            char* dst = staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes;
+            const int slot = (t.event - (t.dst * pl->evPerDevice + 3 + pl->commPerDevice)) % (pl->useRccl ? 1 : pl->commPerDevice);
+            if (pl->useRccl && t.src >= 0) {
+                if (!grouped) { (void)ncclGroupStart(); grouped = true; }
+                (void)hipSetDevice(t.ownerDevice);
+                if (ncclSend(src[t.tensor][t.cell], (size_t)T[t.tensor]->cellElems, nccl_type(T[t.tensor]->dtype), t.dst,
+                             handle->comms[(size_t)t.src], handle->commStreams[(size_t)t.src][0]) != ncclSuccess) { st = CUTENSOR_STATUS_EXECUTION_FAILED; break; }
+                (void)hipSetDevice(handle->devices[t.dst]);
+                if (ncclRecv(dst, (size_t)T[t.tensor]->cellElems, nccl_type(T[t.tensor]->dtype), t.src, handle->comms[(size_t)t.dst],
+                             handle->commStreams[(size_t)t.dst][0]) != ncclSuccess) { st = CUTENSOR_STATUS_EXECUTION_FAILED; break; }
+            } else {
+                (void)hipSetDevice(handle->devices[t.dst]);
+                if (hipMemcpyPeerAsync(dst, handle->devices[t.dst], src[t.tensor][t.cell], t.ownerDevice, (size_t)t.bytes,
+                                       handle->commStreams[(size_t)t.dst][(size_t)slot]) != hipSuccess) { st = CUTENSOR_STATUS_EXECUTION_FAILED; break; }
+            }
+            touched.insert(t.event);
+        }
+        if (grouped && ncclGroupEnd() != ncclSuccess) st = CUTENSOR_STATUS_EXECUTION_FAILED;   // also closes the group on the error path
+        if (st != CUTENSOR_STATUS_SUCCESS) { (void)hipGetLastError(); return st; }
+        for (int e : touched) {
+            const int g = e / pl->evPerDevice;
+            const int slot = (e - (g * pl->evPerDevice + 3 + pl->commPerDevice)) % (pl->useRccl ? 1 : pl->commPerDevice);
+            MG_HIP(hipSetDevice(handle->devices[g]));
+            MG_HIP(hipEventRecord(pl->events[(size_t)e], handle->commStreams[(size_t)g][(size_t)slot]));
+        }
+    }
+
+    // ---- 2. local contractions, 3. scatter ----------------------------------------------------------------------
+    std::set<std::pair<int, int>> waited;   // (device * 2 + stream, event): each stream waits for an event once
+    const float onef = 1.f;
+    const double oned = 1.0;
+    const void* one = f64 ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
+    for (const Piece& p : pl->pieces) {
         const int g = p.dev;
-        (void)hipSetDevice(handle->devices[g]);
-        char* sA = staging(g, 0);
-        char* sB = staging(g, 1);
-        char* sC = staging(g, 2);
-        char* ws = staging(g, 3);
-        cutensorStatus_t st = cutensorContract(handle->handles[g], p.plan, alpha, sA + p.offA * (int64_t)es, sB + p.offB * (int64_t)es,
-                                               beta, sC + p.offC * (int64_t)es, sC + p.offC * (int64_t)es, ws, plan->contractionWs, streams[g]);
+        MG_HIP(hipSetDevice(handle->devices[g]));
+        hipStream_t cs = compute_stream(g, p.stream);
+        for (int e : p.waitEvents) {
+            if (b == 0.0) {   // events of waves that carried only C cells were never recorded
+                bool live = false;
+                for (const Transfer& t : pl->transfers) if (!t.local && t.event == e && t.tensor != 2) { live = true; break; }
+                if (!live) continue;
+            }
+            if (waited.insert(std::make_pair(g * kComputeStreams + p.stream, e)).second) MG_HIP(hipStreamWaitEvent(cs, pl->events[(size_t)e], 0));
+        }
+        const char* pa = p.use[0].direct ? static_cast<const char*>(A[p.use[0].cell]) : staging(g, 0);
+        const char* pb = p.use[1].direct ? static_cast<const char*>(B[p.use[1].cell]) : staging(g, 1);
+        const char* pc;
+        char* pd;
+        if (p.use[2].direct) {
+            pc = (b != 0.0) ? static_cast<const char*>(C[p.use[2].cell]) : static_cast<const char*>(D[p.use[2].cell]);
+            pd = static_cast<char*>(D[p.use[2].cell]);
+        } else {
+            pc = staging(g, 2);
+            pd = staging(g, 2);
+        }
+        const int64_t oC = p.use[2].off * (int64_t)es;
+        cutensorStatus_t st = cutensorContract(handle->handles[(size_t)g], p.plan, alpha, pa + p.use[0].off * (int64_t)es,
+                                               pb + p.use[1].off * (int64_t)es, beta, pc + oC, pd + oC, staging(g, 3 + p.stream),
+                                               pl->contractionWs, cs);
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
-        const float onef = 1.f;
-        const double oned = 1.0;
-        const void* one = f64 ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
         const size_t cellBytes = (size_t)d.C.cellElems * es;
         for (const Piece::Scatter& s : p.scatter) {
-            const char* from = sC + (size_t)s.cell * cellBytes + s.off * (int64_t)es;
+            const char* from = staging(g, 2) + (size_t)s.cell * cellBytes + s.off * (int64_t)es;
             char* to = static_cast<char*>(D[s.cell]) + s.off * (int64_t)es;
-            st = cutensorPermute(handle->handles[g], s.plan, one, from, to, streams[g]);
+            st = cutensorPermute(handle->handles[(size_t)g], s.plan, one, from, to, cs);
             if (st != CUTENSOR_STATUS_SUCCESS) return st;
         }
     }
+
+    // ---- 4. join: the caller's stream of every device ends behind its helper streams -------------------------------
+    for (int g = 0; g < nDev; ++g) {
+        MG_HIP(hipSetDevice(handle->devices[g]));
+        MG_HIP(hipEventRecord(ev(g, 2), handle->auxStreams[(size_t)g]));
+        MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 2), 0));
+        for (size_t k = 0; k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k) {
+            MG_HIP(hipEventRecord(ev(g, 3 + (int)k), handle->commStreams[(size_t)g][k]));
+            MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 3 + (int)k), 0));
+        }
+    }
+#undef MG_HIP
     return CUTENSOR_STATUS_SUCCESS;
+}
+
+// ---- diagnostics (not part of the cuTENSORMg ABI; used by the tests and the bench) -------------------------------
+// One JSON object describing the plan: which mode is sharded, the pieces in execution order with the grid cells they
+// read in place / from the staging image and the events they wait for, and every cell transfer.
+int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_t len) {
+    if (plan == nullptr || buf == nullptr || len == 0) return -1;
+    std::string s;
+    char tmp[256];
+    auto add = [&](const char* fmt, auto... a) { std::snprintf(tmp, sizeof(tmp), fmt, a...); s += tmp; };
+    int64_t remote = 0, local = 0;
+    for (const Transfer& t : plan->transfers) (t.local ? local : remote) += t.bytes;
+    add("{\"pLabel\":%d,\"qLabel\":%d,\"numWaves\":%d,\"useRccl\":%d,\"commStreams\":%d,\"contractionWs\":%llu,", plan->pLabel, plan->qLabel,
+        plan->numWaves, (int)plan->useRccl, plan->commPerDevice, (unsigned long long)plan->contractionWs);
+    add("\"stagingBytes\":[%lld,%lld,%lld],\"remoteBytes\":%lld,\"localCopyBytes\":%lld,\"pieces\":[", (long long)plan->stagingBytes[0],
+        (long long)plan->stagingBytes[1], (long long)plan->stagingBytes[2], (long long)remote, (long long)local);
+    for (size_t i = 0; i < plan->pieces.size(); ++i) {
+        const Piece& p = plan->pieces[i];
+        add("%s{\"dev\":%d,\"lo\":%lld,\"hi\":%lld,\"q0\":%lld,\"q1\":%lld,\"stream\":%d,\"flops\":%.6g,\"use\":[", i ? "," : "", p.dev,
+            (long long)p.lo, (long long)p.hi, (long long)p.q0, (long long)p.q1, p.stream, p.flops);
+        for (int k = 0; k < 3; ++k) {
+            add("%s{\"direct\":%d,\"off\":%lld,\"cells\":[", k ? "," : "", (int)p.use[k].direct, (long long)p.use[k].off);
+            for (size_t c = 0; c < p.use[k].cells.size(); ++c) add("%s%d", c ? "," : "", p.use[k].cells[c]);
+            s += "]}";
+        }
+        s += "],\"wait\":[";
+        for (size_t e = 0; e < p.waitEvents.size(); ++e) add("%s%d", e ? "," : "", p.waitEvents[e]);
+        s += "],\"scatter\":[";
+        for (size_t c = 0; c < p.scatter.size(); ++c) add("%s%d", c ? "," : "", p.scatter[c].cell);
+        s += "]}";
+    }
+    s += "],\"transfers\":[";
+    for (size_t i = 0; i < plan->transfers.size(); ++i) {
+        const Transfer& t = plan->transfers[i];
+        add("%s{\"tensor\":%d,\"cell\":%d,\"dst\":%d,\"src\":%d,\"local\":%d,\"wave\":%d,\"bytes\":%lld,\"event\":%d}", i ? "," : "", t.tensor,
+            t.cell, t.dst, t.src, (int)t.local, t.wave, (long long)t.bytes, t.event);
+    }
+    s += "]}";
+    if (s.size() + 1 > len) return -(int)(s.size() + 1);
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 
 }  // extern "C"

@@ -37,8 +37,88 @@ for _name, _args in EXPORTS.items():
     _f.restype = ctypes.c_int
     globals()[_name] = _f
 
+lib.ctamdMgDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
+lib.ctamdMgDescribePlan.restype = ctypes.c_int
+
 check = ct.check
 i64, i32 = ct.i64, ct.i32
+
+
+def describe_plan(plan):
+    """ctamdMgDescribePlan -> dict: sharded / ordering mode labels, pieces in execution order, cell transfers."""
+    import json
+    n = 1 << 16
+    while True:
+        buf = ctypes.create_string_buffer(n)
+        r = lib.ctamdMgDescribePlan(plan, buf, n)
+        if r >= 0:
+            return json.loads(buf.value.decode())
+        if r == -1:
+            raise ValueError("ctamdMgDescribePlan: invalid arguments")
+        n = -r + 16
+
+
+class Contraction:
+    """RAII bundle of the cuTENSORMg call sequence of contraction_multi_gpu.cu:151-250 for C[mc] = A[ma] * B[mb]:
+    handle over `devices`, three block-cyclic descriptors (extent / blockSize / deviceCount per mode label, cells owned
+    by `cell_devices[k]`, default: handle devices repeated cyclically as the sample's fillUp() does), contraction
+    descriptor, find, workspace query and plan."""
+
+    def __init__(self, devices, modes, extent, block, dcount, cell_devices=None, dtype=0, compute=COMPUTE_32F):
+        self.devices = list(devices)
+        self.modes = modes
+        self.h = ctypes.c_void_p()
+        check(cutensorMgCreate(ctypes.byref(self.h), len(devices), i32(self.devices)))
+        self.descs, self.cells = [], []
+        for k, m in enumerate(modes):
+            ext = [extent[c] for c in m]
+            bs = [block[k].get(c, extent[c]) for c in m]
+            dc = [dcount[k].get(c, 1) for c in m]
+            ncell = 1
+            for x in dc:
+                ncell *= x
+            owners = list(cell_devices[k]) if cell_devices is not None else [self.devices[i % len(self.devices)] for i in range(ncell)]
+            d = ctypes.c_void_p()
+            check(cutensorMgCreateTensorDescriptor(self.h, ctypes.byref(d), len(m), i64(ext), None, i64(bs), None, i32(dc), ncell,
+                                                   i32(owners), dtype))
+            self.descs.append(d)
+            self.cells.append(dict(ext=ext, bs=bs, dc=dc, owners=owners, ncell=ncell))
+        lab = [i32([ord(c) for c in m]) for m in modes]
+        self.cd = ctypes.c_void_p()
+        check(cutensorMgCreateContractionDescriptor(self.h, ctypes.byref(self.cd), self.descs[0], lab[0], self.descs[1], lab[1],
+                                                    self.descs[2], lab[2], self.descs[2], lab[2], compute))
+        self.find = ctypes.c_void_p()
+        check(cutensorMgCreateContractionFind(self.h, ctypes.byref(self.find), ALGO_DEFAULT))
+        n = len(devices)
+        self.ws_sizes = (ctypes.c_int64 * n)()
+        self.host_size = ctypes.c_int64(0)
+        check(cutensorMgContractionGetWorkspace(self.h, self.cd, self.find, 2, self.ws_sizes, ctypes.byref(self.host_size)))
+        self.plan = ctypes.c_void_p()
+        check(cutensorMgCreateContractionPlan(self.h, ctypes.byref(self.plan), self.cd, self.find, self.ws_sizes, self.host_size.value))
+
+    def describe(self):
+        return describe_plan(self.plan)
+
+    def run(self, alpha, A, B, beta, C, D, workspaces, streams, scalar=ctypes.c_float):
+        a, b = scalar(alpha), scalar(beta)
+        return cutensorMgContraction(self.h, self.plan, ctypes.byref(a), ptr_array(A), ptr_array(B), ctypes.byref(b), ptr_array(C),
+                                     ptr_array(D), ptr_array(workspaces), None, ptr_array(streams))
+
+    def close(self):
+        if self.plan:
+            check(cutensorMgDestroyContractionPlan(self.plan))
+            check(cutensorMgDestroyContractionFind(self.find))
+            check(cutensorMgDestroyContractionDescriptor(self.cd))
+            for d in self.descs:
+                check(cutensorMgDestroyTensorDescriptor(d))
+            check(cutensorMgDestroy(self.h))
+            self.plan = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def ptr_array(values):

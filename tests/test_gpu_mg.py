@@ -117,3 +117,73 @@ def test_mg_contraction(mg, handle_devices, extent, block, beta):
                  (cm.cutensorMgDestroyTensorDescriptor, dB), (cm.cutensorMgDestroyTensorDescriptor, dC),
                  (cm.cutensorMgDestroy, h)):
         cm.check(f(o))
+
+
+def _cells_of(G, bs, dc):
+    """Global matrix -> packed per-cell buffers [w0, w1, lb0, lb1] (first index fastest), cell index first mode fastest."""
+    lb = [G.shape[i] // (bs[i] * dc[i]) for i in range(2)]
+    out = []
+    for c1 in range(dc[1]):
+        for c0 in range(dc[0]):
+            buf = np.zeros((bs[0], bs[1], lb[0], lb[1]), dtype=G.dtype, order="F")
+            for l1 in range(lb[1]):
+                for l0 in range(lb[0]):
+                    b0, b1 = l0 * dc[0] + c0, l1 * dc[1] + c1
+                    buf[:, :, l0, l1] = G[b0 * bs[0]:(b0 + 1) * bs[0], b1 * bs[1]:(b1 + 1) * bs[1]]
+            out.append(buf)
+    return out
+
+
+def _gather_cells(cells, shape, bs, dc, dtype):
+    lb = [shape[i] // (bs[i] * dc[i]) for i in range(2)]
+    G = np.zeros(shape, dtype=dtype)
+    for c1 in range(dc[1]):
+        for c0 in range(dc[0]):
+            buf = np.reshape(cells[c0 + dc[0] * c1], (bs[0], bs[1], lb[0], lb[1]), order="F")
+            for l1 in range(lb[1]):
+                for l0 in range(lb[0]):
+                    b0, b1 = l0 * dc[0] + c0, l1 * dc[1] + c1
+                    G[b0 * bs[0]:(b0 + 1) * bs[0], b1 * bs[1]:(b1 + 1) * bs[1]] = buf[:, :, l0, l1]
+    return G
+
+
+@pytest.mark.parametrize("n,E,beta,env", [
+    (4, 512, 0.0, {}),                                   # bench.py's layout: i cut n ways, B column slabs gathered
+    (2, 256, 0.75, {}),                                  # beta != 0: C read in place
+    (4, 512, 0.5, {"CUTENSORMG_AMD_WAVES": "3"}),        # gather in three waves, one event each
+    (4, 256, 0.5, {"CUTENSORMG_AMD_DIRECT": "0"}),       # everything through the staging images + scatter
+    (3, 384, 0.0, {"CUTENSORMG_AMD_QSPLIT": "0"}),       # no cut along j: one piece per device behind the whole gather
+])
+def test_mg_free_mode_shard_layout(mg, monkeypatch, n, E, beta, env):
+    """The cuTENSORMg case bench.py times (largest free mode sharded over the devices, B all-gathered) on n
+    virtual devices = device 0 listed n times: in-place operands, staged remote-coordinate runs, two compute streams,
+    differing device counts of j in B (n) and C (1)."""
+    cm, torch = mg
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(11)
+    A = rng.random((E, E), dtype=np.float32)
+    B = rng.random((E, E), dtype=np.float32)
+    C = rng.random((E, E), dtype=np.float32)
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=E // n), dict(j=E // n), dict(i=E // n, j=E // n)]
+    dcount = [dict(i=n), dict(j=n), dict(i=n)]
+    with cm.Contraction([0] * n, modes, dict(i=E, j=E, k=E), block, dcount) as con:
+        d = con.describe()
+        layouts = [((E // n, E), (n, 1)), ((E, E // n), (1, n)), ((E // n, E // n), (n, 1))]
+        dev = [[torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(G, bs, dc)]
+               for G, (bs, dc) in zip((A, B, C), layouts)]
+        ws = [torch.empty(int(con.ws_sizes[i]), dtype=torch.uint8, device="cuda") for i in range(n)]
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        torch.cuda.synchronize()
+        for rep in range(2):   # twice: the second call reuses the staging images and the events
+            for t, x in zip(dev[2], _cells_of(C, *layouts[2])):
+                t.copy_(torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))))
+            torch.cuda.synchronize()
+            cm.check(con.run(1.0, [t.data_ptr() for t in dev[0]], [t.data_ptr() for t in dev[1]], beta,
+                             [t.data_ptr() for t in dev[2]], [t.data_ptr() for t in dev[2]], [t.data_ptr() for t in ws],
+                             [s.cuda_stream for s in streams]))
+            torch.cuda.synchronize()
+            got = _gather_cells([t.cpu().numpy() for t in dev[2]], (E, E), *layouts[2], np.float32)
+            ref = A.astype(np.float64) @ B.astype(np.float64) + beta * C
+            np.testing.assert_allclose(got, ref, rtol=1e-4, err_msg=str(d)[:400])

@@ -1,0 +1,173 @@
+"""CPU coverage of the multi-device (N > 1) cuTENSORMg path: plans are built on plan-only handles (no GPU here; nothing is
+executed) for 2 / 4 / 8 *distinct* device ids and inspected through ctamdMgDescribePlan.  Checked: every grid cell a
+device needs and does not hold is gathered exactly once per consumer, nothing is gathered that is not needed, every
+element of C is produced exactly once, the first local contraction of every device depends on nothing remote (so the
+gather overlaps it), and the pieces of a device alternate between its two compute streams."""
+import itertools
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def cm(built):
+    from cudalibrarysamples_amd import cutensormg
+    return cutensormg
+
+
+def free_mode_layout(n, E):
+    """The layout bench.py uses for the cuTENSORMg case: C[i,j] = A[i,k] B[k,j] with the largest free mode i cut n ways
+    (A and C hold row slabs), B distributed along j (column slabs) — every device needs all of B: the all-gather."""
+    modes = ["ik", "kj", "ij"]
+    extent = dict(i=E, j=E, k=E)
+    block = [dict(i=E // n), dict(j=E // n), dict(i=E // n, j=E // n)]
+    dcount = [dict(i=n), dict(j=n), dict(i=n)]
+    return modes, extent, block, dcount
+
+
+def coverage(d, con, E):
+    """Number of times each C[i, j] is produced, from the pieces' p ranges and q coordinate ranges."""
+    assert d["pLabel"] == ord("i")
+    cov = np.zeros((E, E), dtype=np.int32)
+    bs_j = con.cells[2]["bs"][1]
+    qcount = con.cells[1]["dc"][1] if d["qLabel"] == ord("j") else 1
+    jblock = np.arange(E) // bs_j
+    for p in d["pieces"]:
+        cols = np.ones(E, dtype=bool) if p["q1"] == 0 else ((jblock % qcount >= p["q0"]) & (jblock % qcount < p["q1"]))
+        cov[p["lo"]:p["hi"], cols] += 1
+    return cov
+
+
+def check_transfers(d, con, ndev):
+    seen = set()
+    for t in d["transfers"]:
+        key = (t["dst"], t["tensor"], t["cell"])
+        assert key not in seen, "cell gathered twice: %r" % (key,)
+        seen.add(key)
+        owner = con.cells[t["tensor"]]["owners"][t["cell"]]
+        assert t["local"] == int(owner == con.devices[t["dst"]])
+        if not t["local"]:
+            assert con.devices[t["src"]] == owner and 0 <= t["wave"] < d["numWaves"] and t["event"] >= 0
+    # what the pieces read from the staging images is exactly what was transferred
+    needed = set()
+    for p in d["pieces"]:
+        for k, u in enumerate(p["use"]):
+            if not u["direct"]:
+                needed.update((p["dev"], k, c) for c in u["cells"])
+            else:
+                assert len(u["cells"]) == 1 and con.cells[k]["owners"][u["cells"][0]] == con.devices[p["dev"]]
+    assert needed == seen
+    return seen
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_free_mode_shard_with_all_gather(cm, n):
+    E = 128 * n
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, E)) as con:
+        d = con.describe()
+        assert d["qLabel"] == ord("j") and d["numWaves"] == 1
+        check_transfers(d, con, n)
+        assert (coverage(d, con, E) == 1).all()
+        cell_bytes = E * (E // n) * 4
+        # the all-gather of B: every device receives the n - 1 column slabs it does not hold; A and C never move
+        assert d["remoteBytes"] == n * (n - 1) * cell_bytes and d["localCopyBytes"] == 0
+        assert all(t["tensor"] == 1 and not t["local"] for t in d["transfers"])
+        assert d["stagingBytes"][0] == 0 and d["stagingBytes"][2] == 0 and d["stagingBytes"][1] >= n * cell_bytes
+        ev_wave = {t["event"]: t["wave"] for t in d["transfers"]}
+        for g in range(n):
+            mine = [p for p in d["pieces"] if p["dev"] == g]
+            # own column slab first: read in place, no event to wait for -> the gather overlaps this contraction
+            first = mine[0]
+            assert first["wait"] == [] and all(u["direct"] for u in first["use"]) and (first["q0"], first["q1"]) == (g, g + 1)
+            assert first["use"][1]["cells"] == [g]
+            # the rest: A and C still in place, B from the staging image, behind the gather's event of this device
+            for p in mine[1:]:
+                assert p["use"][0]["direct"] and p["use"][2]["direct"] and not p["use"][1]["direct"]
+                # one event per (wave, communication stream): one with RCCL, up to min(7, n - 1) with peer copies
+                assert 1 <= len(p["wait"]) <= d["commStreams"] and all(ev_wave[e] == 0 for e in p["wait"])
+                assert p["scatter"] == []
+            assert [p["stream"] for p in mine] == [i % 2 for i in range(len(mine))]
+            assert abs(sum(p["flops"] for p in mine) - 2.0 * E ** 3 / n) < 1e-3 * E ** 3
+        # every device receives from every other device exactly once (all xGMI links busy, none twice)
+        pairs = sorted((t["src"], t["dst"]) for t in d["transfers"])
+        assert pairs == sorted((s, r) for s in range(n) for r in range(n) if s != r)
+
+
+@pytest.mark.parametrize("n,waves", [(4, 3), (8, 7), (8, 2)])
+def test_gather_in_waves_orders_cells_by_first_use(cm, n, waves, monkeypatch):
+    """CUTENSORMG_AMD_WAVES=k: the remote cells arrive in k groups with one event each; a piece waits only for the
+    wave(s) that carry its cells and the waves are consumed in order."""
+    monkeypatch.setenv("CUTENSORMG_AMD_WAVES", str(waves))
+    E = 64 * n
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, E)) as con:
+        d = con.describe()
+        assert d["numWaves"] == waves
+        check_transfers(d, con, n)
+        assert (coverage(d, con, E) == 1).all()
+        ev_wave = {t["event"]: t["wave"] for t in d["transfers"]}
+        for g in range(n):
+            mine = [p for p in d["pieces"] if p["dev"] == g]
+            assert mine[0]["wait"] == []
+            last = -1
+            for p in mine[1:]:
+                ws = sorted(ev_wave[e] for e in p["wait"])
+                assert ws and ws[0] >= last
+                last = ws[0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+def test_sample_block_cyclic_layout(cm, n):
+    """contraction_multi_gpu.cu:154-217: 2 x 2 block-cyclic descriptors, cells owned by the handle devices cyclically."""
+    E, BS = 256, 64
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=BS, k=BS), dict(k=BS, j=BS), dict(i=BS, j=BS)]
+    dcount = [dict(i=2, k=2), dict(k=2, j=2), dict(i=2, j=2)]
+    with cm.Contraction(list(range(n)), modes, dict(i=E, j=E, k=E), block, dcount) as con:
+        d = con.describe()
+        seen = check_transfers(d, con, n)
+        assert (coverage(d, con, E) == 1).all()
+        # every staged piece of C goes back to the owners' cells: each (cell, region) exactly once
+        sc = [(p["lo"], p["hi"], p["q0"], p["q1"], c) for p in d["pieces"] for c in p["scatter"]]
+        assert len(sc) == len(set(sc))
+        for p in d["pieces"]:
+            if not p["use"][2]["direct"]:
+                assert sorted(p["scatter"]) == sorted(p["use"][2]["cells"])
+        if n == 1:
+            assert d["remoteBytes"] == 0
+        else:
+            assert d["remoteBytes"] > 0 and any(not t["local"] for t in d["transfers"])
+
+
+def test_device_counts_must_divide(cm):
+    """A mode shared by two tensors: same blocks, device counts that divide one another — anything else is refused."""
+    import ctypes
+    h = ctypes.c_void_p()
+    cm.check(cm.cutensorMgCreate(ctypes.byref(h), 6, cm.i32(list(range(6)))))
+
+    def desc(ext, bs, dc):
+        d = ctypes.c_void_p()
+        ncell = int(np.prod(dc))
+        cm.check(cm.cutensorMgCreateTensorDescriptor(h, ctypes.byref(d), 2, cm.i64(ext), None, cm.i64(bs), None, cm.i32(dc), ncell,
+                                                     cm.i32([i % 6 for i in range(ncell)]), 0))
+        return d
+
+    dA, dB, dC = desc([96, 96], [16, 96], [2, 1]), desc([96, 96], [96, 16], [1, 3]), desc([96, 96], [16, 16], [2, 2])
+    cd = ctypes.c_void_p()
+    st = cm.cutensorMgCreateContractionDescriptor(h, ctypes.byref(cd), dA, cm.i32("ik"), dB, cm.i32("kj"), dC, cm.i32("ij"), dC, cm.i32("ij"),
+                                                  cm.COMPUTE_32F)
+    assert st == 15   # NOT_SUPPORTED: j is cut over 3 devices in B and 2 in C
+    for d in (dA, dB, dC):
+        cm.check(cm.cutensorMgDestroyTensorDescriptor(d))
+    cm.check(cm.cutensorMgDestroy(h))
+
+
+def test_execution_on_a_plan_only_handle_is_refused(cm):
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the handle is a real one")
+    with cm.Contraction([0, 1], *free_mode_layout(2, 128)) as con:
+        buf = (ctypes.c_char * 64)()
+        addr = ctypes.addressof(buf)
+        st = con.run(1.0, [addr] * 2, [addr] * 2, 0.0, [addr] * 2, [addr] * 2, [addr] * 2, [0, 0])
+        assert st != 0
