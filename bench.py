@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X-native tensor-contraction engine.
+"""bench.py — benchmarks of the MI355X-native tensor-contraction engine behind the cuTENSOR C ABI.
 
-Workload (BASELINE.json configs[1]): einsum 'abcd,dcbe->ae', fp32, a=e=96, b=c=d=64 — the cuTENSOR
-call sequence of cuTENSOR/einsum.cu:248-339 (descriptors -> contraction -> plan -> cutensorContract)
-driven through the C ABI of lib/libcutensor.so.  A "step" is one cutensorContract call (GETT kernel +
-split-K fold) on tensors already resident in HBM; plan creation is outside the timed region, as in the
-reference samples (contraction.cu:218-222 vs :253-270).
+    python bench.py --gpus N --steps K --warmup W        (one JSON line on stdout)
 
-  N = 1 : the einsum above.
-  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL).  The contracted mode b is
-          sharded: every rank owns A[:, b_r, :, :] and B[:, :, b_r, :] of a b = 64*N problem
-          (weak scaling, per-GPU work fixed), computes its partial C and the partials are summed by
-          an RCCL all-reduce of the 96x96 result — the cheapest exchange for this shape, because
-          |C| (36 KB) << |B| (100 MB); sharding a free mode would all-gather B instead.
+N = 1 (BASELINE.json configs[1], the headline): einsum 'abcd,dcbe->ae', fp32, a=e=96, b=c=d=64 — the call
+    sequence of cuTENSOR/einsum.cu:248-339 (descriptors -> contraction -> plan -> cutensorContract) through
+    lib/libcutensor.so.  A "step" is one cutensorContract call (GETT kernel + split-K fold) on tensors resident in
+    HBM; plan creation is outside the timed region, as in the samples (contraction.cu:218-222 vs :253-270).
+    The same line carries `secondary`: the other BASELINE configs measured in the same process with the samples'
+    own formulas — contraction.cu default fp32 (configs[0] shape on the GPU), 2048^3 permute + reduce (configs[2]),
+    bf16 8192^3 (configs[3]), cuTENSORMg on one device (configs[4] at n = 1) — each with its roofline, and
+    `cold_operands_value`: the headline with four rotating (A, B) pairs (805 MB > the 256-MiB Infinity Cache).
 
-One JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+N > 1 (BASELINE.json configs[4], north_star's "cuTENSORMg sharded case"): cutensorMgContraction, fp32
+    C[i,j] = A[i,k] B[k,j], the largest free mode i cut over min(N, visible) DISTINCT devices, B distributed in
+    column slabs and all-gathered over xGMI by RCCL while the first local contraction runs (csrc/mg/mg.cpp) —
+    ONE process drives all devices, as cuTENSORMg/contraction_multi_gpu.cu:151,286-345 does.  `value` is the scaled
+    shape (16384^3, blog_post.cu:155-186 class), K calls back to back; the sample's default (4096^3, block 2048,
+    wall clock + per-device sync, min of 3: contraction_multi_gpu.cu:323-345) is in `secondary`.  Strong scaling:
+    the problem is fixed, `speedup_vs_1` is measured in the same run.
+    Launched plainly (`python bench.py --gpus 8`) this process opens the devices itself.  Launched by
+    torch.distributed.run with WORLD_SIZE = N (one rank per GPU), rank 0 runs the measurement in a child process
+    over the N devices while the other ranks wait on a CPU (gloo) barrier — their GPUs stay free for the
+    measurement — and all ranks then run the one-process-per-GPU variant of the headline einsum (contracted mode b
+    sharded, RCCL all-reduce of the 36-KB result) which is reported as a secondary line (and is the fallback
+    `value` if the multi-device measurement fails).  With fewer visible GPUs than requested the line says
+    `"n_gpus": <used>, "requested_gpus": N`.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,20 +44,285 @@ EXT = dict(a=96, b=64, c=64, d=64, e=96)
 FLOP = 2.0 * EXT["a"] * EXT["b"] * EXT["c"] * EXT["d"] * EXT["e"]          # contraction.cu:61 formula
 BYTES = 4.0 * (EXT["a"] * EXT["b"] * EXT["c"] * EXT["d"] + EXT["d"] * EXT["c"] * EXT["b"] * EXT["e"] + EXT["a"] * EXT["e"])
 PEAK_TFLOPS_F32_MFMA = 157.3      # 256 CU x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_TFLOPS_BF16_MFMA = 2516.6    # 256 CU x 4096 flop/clk x 2.4 GHz, dense
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s measured float4 copy)
+MG_SCALED_EXTENT = 16384
+MG_SAMPLE_EXTENT = 4096
+
+
+def openblas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        for lib in threadpool_info():
+            if lib.get("user_api") == "blas":
+                return int(lib["num_threads"])
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(a_np, b_np):
     """TTGT over OpenBLAS on the host cores (reported baseline, not the target)."""
     from oracle import ttgt
-    cores = len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
+    threads = openblas_threads() or min(affinity, 64)
     out, t_total, t_gemm = ttgt.time_ttgt(a_np, b_np, reps=3)
     return out, {
-        "value": FLOP / t_total / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-        "sample": "full workload (4.83 GFLOP), TTGT = transpose B + OpenBLAS sgemm via numpy, min of 3, "
-                  "transposes included (GEMM-only %.1f GFLOP/s)" % (FLOP / t_gemm / 1e9),
+        "value": FLOP / t_total / 1e9, "unit": "GFLOP/s", "cores": threads, "kind": "port",
+        "sample": "full workload (4.83 GFLOP), TTGT = transpose B + OpenBLAS sgemm via numpy, min of 3, transposes included "
+                  "(GEMM-only %.1f GFLOP/s); cores = threads OpenBLAS ran (its build caps at 64), host affinity mask %d"
+                  % (FLOP / t_gemm / 1e9, affinity),
     }
 
 
+# ---------------------------------------------------------------------------------------------------------
+# cuTENSORMg measurement (one process, n devices)
+# ---------------------------------------------------------------------------------------------------------
+def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True):
+    """C[i,j] = A[i,k] B[k,j] fp32 through libcutensorMg on devices 0..ndev-1: i cut ndev ways (A, C row slabs), B in
+    column slabs (all-gathered).  Returns a dict with the throughput of `steps` back-to-back calls and the sample's
+    protocol (wall clock + per-device sync, min of `sample_reps`)."""
+    import torch
+    from cudalibrarysamples_amd import cutensormg as cm
+    E, n = extent, ndev
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=E // n), dict(j=E // n), dict(i=E // n, j=E // n)]
+    dcount = [dict(i=n), dict(j=n), dict(i=n)]
+    flop = 2.0 * E * E * E
+    con = cm.Contraction(list(range(n)), modes, dict(i=E, j=E, k=E), block, dcount)
+    try:
+        d = con.describe()
+        cells = []
+        for k in range(3):
+            row = []
+            for g in range(n):
+                gen = torch.Generator(device="cuda:%d" % g)
+                gen.manual_seed(1234 + 17 * k + g)
+                row.append(torch.rand(E * (E // n), generator=gen, device="cuda:%d" % g, dtype=torch.float32))
+            cells.append(row)
+        ws = [torch.empty(int(con.ws_sizes[g]), dtype=torch.uint8, device="cuda:%d" % g) for g in range(n)]
+        streams = [torch.cuda.Stream(device=g) for g in range(n)]
+        ptr = [[t.data_ptr() for t in row] for row in cells]
+        wsp = [t.data_ptr() for t in ws]
+        sp = [s.cuda_stream for s in streams]
+
+        def sync_all():
+            for g in range(n):
+                torch.cuda.synchronize(g)
+
+        def call():
+            cm.check(con.run(1.0, ptr[0], ptr[1], 0.0, ptr[2], ptr[2], wsp, sp))
+
+        sync_all()
+        for _ in range(max(warmup, 1)):
+            call()
+        sync_all()
+        # the sample's protocol: contraction_multi_gpu.cu:323-345
+        best = 1e30
+        for _ in range(sample_reps):
+            t0 = time.perf_counter()
+            call()
+            sync_all()
+            best = min(best, time.perf_counter() - t0)
+        # throughput: K calls back to back, one sync of every device at the end
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        err = None
+        if check:
+            # sampled fp64 dot products: C[i, j] lives in row slab i // (E/n) as [j][i_local]; A[i, :] = slab[k][i_local];
+            # B[:, j] = column slab j // (E/n), local column j % (E/n), contiguous in k
+            rng = np.random.default_rng(5)
+            worst = 0.0
+            per = E // n
+            for _ in range(16):
+                i, j = int(rng.integers(0, E)), int(rng.integers(0, E))
+                a_row = cells[0][i // per].view(E, per)[:, i % per].double().cpu()
+                b_col = cells[1][j // per].view(per, E)[j % per, :].double().cpu()
+                ref = float((a_row * b_col).sum())
+                got = float(cells[2][i // per].view(E, per)[j, i % per].cpu())
+                worst = max(worst, abs(got - ref) / abs(ref))
+            err = worst
+            if worst > 1e-4:
+                raise RuntimeError("cuTENSORMg result check failed: max rel err %.3e" % worst)
+        return {"extent": E, "devices": n, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+                "gflops": flop / (elapsed / steps) / 1e9, "sample_protocol_min_ms": best * 1e3,
+                "sample_protocol_gflops": flop / best / 1e9, "flop": flop, "elapsed_s": elapsed,
+                "gather_bytes_per_call": d["remoteBytes"], "local_copy_bytes_per_call": d["localCopyBytes"],
+                "pieces": len(d["pieces"]), "gather_waves": d["numWaves"], "transport": "rccl" if d["useRccl"] else ("peer" if n > 1 else "none"),
+                "max_rel_err_sampled": err}
+    finally:
+        con.close()
+
+
+def mg_child_main(args):
+    """Child process: the multi-device cuTENSORMg measurement; one JSON line."""
+    import torch
+    ndev = min(args.mg_child, torch.cuda.device_count())
+    out = {"devices": ndev}
+    try:
+        out["scaled"] = mg_measure(ndev, MG_SCALED_EXTENT, args.steps, args.warmup)
+        out["sample"] = mg_measure(ndev, MG_SAMPLE_EXTENT, max(20, min(args.steps, 200)), 3)
+        if ndev > 1:   # the same problems on one device, same process: the base of the strong-scaling speedup
+            out["scaled_1"] = mg_measure(1, MG_SCALED_EXTENT, 3, 1, check=False)
+            out["sample_1"] = mg_measure(1, MG_SAMPLE_EXTENT, 20, 3, check=False)
+    except Exception as e:   # noqa: BLE001 — reported to the parent, which falls back
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    print("MGCHILD " + json.dumps(out), flush=True)
+
+
+def run_mg_child(ndev, steps, warmup, timeout_s):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--mg-child", str(ndev), "--steps", str(steps), "--warmup", str(warmup)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "multi-device measurement timed out after %d s" % timeout_s}
+    for line in r.stdout.splitlines():
+        if line.startswith("MGCHILD "):
+            res = json.loads(line[len("MGCHILD "):])
+            if r.returncode != 0 and "error" not in res:
+                res["error"] = "child exited with %d" % r.returncode
+            return res
+    return {"error": "child rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+
+
+def mg_lines(res, key, one_key):
+    """secondary entry of one cuTENSORMg measurement."""
+    m = res[key]
+    n = m["devices"]
+    peak = PEAK_TFLOPS_F32_MFMA * n
+    line = {"workload": "cuTENSORMg contraction_multi_gpu.cu C[i,j]=A[i,k]B[k,j] fp32 %d^3, free mode i cut over %d device(s), B all-gathered"
+                        % (m["extent"], n),
+            "dtype": "f32", "value": m["gflops"], "unit": "GFLOP/s", "n_gpus": n, "ms_per_call": m["ms_per_step"],
+            "sample_protocol": {"min_ms": m["sample_protocol_min_ms"], "gflops": m["sample_protocol_gflops"],
+                                "what": "wall clock + per-device sync, min of 3 (contraction_multi_gpu.cu:323-345)"},
+            "gather_bytes_per_call": m["gather_bytes_per_call"], "transport": m["transport"], "pieces": m["pieces"],
+            "max_rel_err_sampled": m["max_rel_err_sampled"],
+            "roofline": {"bound": "mfma", "achieved": m["gflops"] / 1e3, "peak": peak, "unit": "TFLOP/s", "frac": m["gflops"] / 1e3 / peak}}
+    if one_key in res:
+        line["speedup_vs_1"] = res[one_key]["ms_per_step"] / m["ms_per_step"]
+        line["one_device_gflops"] = res[one_key]["gflops"]
+    return line
+
+
+# ---------------------------------------------------------------------------------------------------------
+# secondary single-GPU configs (BASELINE configs 0 / 2 / 3), a few repetitions each
+# ---------------------------------------------------------------------------------------------------------
+def timed_batch(torch, fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary_single_gpu(torch, ct, ops, h, stream):
+    out = []
+    # ---- contraction.cu default: C[m,u,n,v] = 1.1 * A[m,h,k,n] B[u,k,v,h], fp32 (contraction.cu:46-59,184-185) ----
+    try:
+        e = dict(m=96, n=96, u=96, v=64, h=64, k=64)
+        mA, mB, mC = "mhkn", "ukvh", "munv"
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234)
+        A = torch.rand(int(np.prod([e[c] for c in mA])), generator=g, device="cuda")
+        B = torch.rand(int(np.prod([e[c] for c in mB])), generator=g, device="cuda")
+        C = torch.zeros(int(np.prod([e[c] for c in mC])), device="cuda")
+        p = ops.contraction_plan(h, [e[c] for c in mA], mA, [e[c] for c in mB], mB, [e[c] for c in mC], mC, workspace_limit=1 << 30)
+        ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+        ms = timed_batch(torch, lambda: p.contract(1.1, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(),
+                                                   p.required_workspace, stream), reps=10)
+        flop = 2.0 * np.prod([float(v) for v in e.values()])
+        byts = 4.0 * (A.numel() + B.numel() + C.numel())
+        tf = flop / (ms * 1e-3) / 1e12
+        d = p.describe()
+        out.append({"workload": "contraction.cu default C[m,u,n,v]=A[m,h,k,n]B[u,k,v,h] fp32 (BASELINE configs[0] shape, on the GPU)",
+                    "dtype": "f32", "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms, "GBps_sample_formula": byts / (ms * 1e-3) / 1e9,
+                    "kernel": "%s<%dx%dx%d>" % (d["kname"], d["bm"], d["bn"], d["bk"]),
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS_F32_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS_F32_MFMA,
+                                 "algorithmic_flop": flop, "algorithmic_bytes": byts}})
+        p.destroy()
+        del A, B, C, ws
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "contraction.cu default fp32", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- bf16 8192^3 (configs[3]) ---------------------------------------------------------------------------------
+    try:
+        n = 8192
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1)
+        A = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        B = (torch.rand((n, n), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        D = torch.empty((n, n), device="cuda", dtype=torch.bfloat16)
+        p = ops.contraction_plan(h, [n, n], "mk", [n, n], "kn", [n, n], "mn", dtype=ct.R_16BF)
+        fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), stream=stream)   # noqa: E731
+        for _ in range(40):   # clock ramp under this kernel's own load
+            fn()
+        ms = timed_batch(torch, fn, reps=30)
+        flop = 2.0 * n ** 3
+        tf = flop / (ms * 1e-3) / 1e12
+        d = p.describe()
+        out.append({"workload": "contraction bf16 C[m,n]=A[m,k]B[k,n] M=N=K=8192, U(-1,1) data, fp32 accumulate (BASELINE configs[3])",
+                    "dtype": "bf16", "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms, "kernel": d["kname"],
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS_BF16_MFMA,
+                                 "algorithmic_flop": flop, "algorithmic_bytes": 3.0 * 2 * n * n}})
+        p.destroy()
+        del A, B, D
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "contraction bf16 8192^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- 2048^3 fp32 permute abc->cab and reduce abc->ac (configs[2]); tensors generated on the device ----------------
+    try:
+        n = 2048
+        numel = n ** 3
+        free, _ = torch.cuda.mem_get_info()
+        if free < 2 * numel * 4 + (2 << 30):
+            raise RuntimeError("not enough free HBM for two 32-GiB tensors (%d bytes free)" % free)
+        A = torch.empty(numel, dtype=torch.float32, device="cuda")
+        chunk = 1 << 28
+        for s in range(0, numel, chunk):   # counter-based fill (fixed seed), in chunks
+            idx = torch.arange(s, min(numel, s + chunk), device="cuda", dtype=torch.int64)
+            A[s:s + idx.numel()] = ((idx * 2654435761 + 1234) % 16777216).to(torch.float32) / 16777216.0
+            del idx
+        D = torch.empty(numel, dtype=torch.float32, device="cuda")
+        p = ops.permutation_plan(h, [n, n, n], "abc", [n, n, n], "cab")
+        ms = timed_batch(torch, lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream), reps=3, warm=1)
+        gbs = 2.0 * numel * 4 / (ms * 1e-3) / 1e9          # elementwise_permute.cu:208
+        out.append({"workload": "elementwise_permute.cu A[a,b,c]->C[c,a,b] fp32 2048^3 (BASELINE configs[2])", "dtype": "f32", "value": gbs,
+                    "unit": "GB/s", "ms_per_call": ms,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
+                                 "algorithmic_bytes": 2.0 * numel * 4}})
+        p.destroy()
+        del D
+        R = torch.zeros(n * n, dtype=torch.float32, device="cuda")
+        p = ops.reduction_plan(h, [n, n, n], "abc", [n, n], "ac", workspace_limit=1 << 30)
+        ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+        ms = timed_batch(torch, lambda: p.reduce(1.1, A.data_ptr(), 0.0, R.data_ptr(), R.data_ptr(), ws.data_ptr(), p.required_workspace, stream),
+                         reps=3, warm=1)
+        gbs = (numel + n * n) * 4.0 / (ms * 1e-3) / 1e9    # reduction.cu:229-231
+        out.append({"workload": "reduction.cu C[a,c]=1.1*sum_b A[a,b,c] fp32 2048^3 (BASELINE configs[2])", "dtype": "f32", "value": gbs,
+                    "unit": "GB/s", "ms_per_call": ms,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
+                                 "algorithmic_bytes": (numel + n * n) * 4.0}})
+        p.destroy()
+        del A, R, ws
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "permute / reduce 2048^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,24 +333,43 @@ def main():
                          "before it settles into its steady clock state (profiles/r01e_long_run_timeline.txt)")
     ap.add_argument("--algo", type=str, default="default", help="default | patient | <candidate index>")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--mg-timeout", type=int, default=600)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.mg_child:
+        return mg_child_main(args)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    visible = torch.cuda.device_count()
+    requested = max(args.gpus, world)
+    torch.cuda.set_device(local_rank % visible)
+    cpu_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
         # device_id: bind the RCCL communicator to this rank's GPU now (eager init) instead of at the first collective
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank % visible))
+        cpu_group = dist.new_group(backend="gloo")   # waits that must not occupy a GPU
 
     from cudalibrarysamples_amd import cutensor as ct, ops, sharding
+
+    # ---- cuTENSORMg over the requested devices (N > 1): child process of rank 0 --------------------------------------
+    mg = None
+    mg_devices = min(requested, visible)
+    if requested > 1:
+        if rank == 0 and mg_devices > 1:
+            mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout)
+        if world > 1:
+            dist.barrier(group=cpu_group)   # CPU-side wait: the other ranks' GPUs stay idle during the measurement
 
     # ---- synthetic inputs: U(0,1) fp32, fixed seed per rank, generated on the device ---------------
     g = torch.Generator(device="cuda")
@@ -98,22 +394,21 @@ def main():
 
     pending = []
 
+    def contract(x, y, out):
+        plan.contract(1.0, x.data_ptr(), y.data_ptr(), 0.0, out.data_ptr(), out.data_ptr(), ws.data_ptr(), plan.required_workspace, stream)
+
     def step(i):
         out = outs[i % nbuf]
-        plan.contract(1.0, a.data_ptr(), b.data_ptr(), 0.0, out.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                      plan.required_workspace, stream)
+        contract(a, b, out)
         if world > 1:
             # fold the K-shards: RCCL all-reduce of the 36 KB result, overlapped with the next step
             if len(pending) >= nbuf - 1:
                 pending.pop(0).wait()
             pending.append(sharding.fold_partials(out, dist, async_op=True))
 
-    def drain():
+    def fence():
         while pending:
             pending.pop(0).wait()
-
-    def fence():
-        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -128,8 +423,7 @@ def main():
         t_end = time.perf_counter() + args.burn_in_ms * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(50):
-                plan.contract(1.0, a.data_ptr(), b.data_ptr(), 0.0, outs[0].data_ptr(), outs[0].data_ptr(), ws.data_ptr(),
-                              plan.required_workspace, stream)
+                contract(a, b, outs[0])
             torch.cuda.synchronize()
             burn_steps += 50
     for i in range(args.warmup):
@@ -144,50 +438,47 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * FLOP / (elapsed / args.steps) / 1e9
+    einsum_ms = elapsed / args.steps * 1e3
+    einsum_value = world * FLOP / (elapsed / args.steps) / 1e9
 
-    # ---- roofline of the dominant kernel: HIP events recorded by the library on the launch stream ---
-    roof = None
-    cpu = None
+    roof = cpu = None
+    secondary = []
+    cold = None
     if rank == 0:
-        # GETT kernel alone, in the same steady state as the timed loop: the fold is switched off (library
-        # diagnostic), `n` launches go out back to back (rocprofv3 shows < 0.05 us between them) and ONE HIP event
-        # pair on the launch stream brackets them.  Per-launch event pairs would put a ~6 us idle gap after every
-        # kernel, and the gapped stream runs at a different clock than the timed loop (42.6 vs 38.9 us).
+        # ---- roofline of the dominant kernel: one HIP event pair on the launch stream -----------------------------------
+        # GETT kernel alone, in the same steady state as the timed loop: the fold is switched off (per-handle diagnostic),
+        # `n` launches go out back to back (rocprofv3 shows < 0.05 us between them) and ONE HIP event pair on the launch
+        # stream brackets them.  Per-launch event pairs would put a ~6 us idle gap after every kernel, and the gapped
+        # stream runs at a different clock than the timed loop (42.6 vs 38.9 us).
         n = max(args.steps, 200)
-        ct.lib.ctamdSetSplitKFold(0)
+        ct.lib.ctamdSetSplitKFold(h.h, 0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(50):
-            plan.contract(1.0, a.data_ptr(), b.data_ptr(), 0.0, outs[0].data_ptr(), outs[0].data_ptr(), ws.data_ptr(),
-                          plan.required_workspace, stream)
+            contract(a, b, outs[0])
         e0.record()
         for i in range(n):
-            plan.contract(1.0, a.data_ptr(), b.data_ptr(), 0.0, outs[0].data_ptr(), outs[0].data_ptr(),
-                          ws.data_ptr(), plan.required_workspace, stream)
+            contract(a, b, outs[0])
         e1.record()
         torch.cuda.synchronize()
-        ct.lib.ctamdSetSplitKFold(1)
+        ct.lib.ctamdSetSplitKFold(h.h, 1)
         batch_ms = e0.elapsed_time(e1) / n
         # per-launch event pairs (the gapped stream), kept for reference
-        ct.lib.ctamdProfileBegin()
+        ct.lib.ctamdProfileBegin(h.h)
         for i in range(200):
-            plan.contract(1.0, a.data_ptr(), b.data_ptr(), 0.0, outs[0].data_ptr(), outs[0].data_ptr(),
-                          ws.data_ptr(), plan.required_workspace, stream)
+            contract(a, b, outs[0])
         torch.cuda.synchronize()
         mean_ms, min_ms = ctypes.c_float(0), ctypes.c_float(0)
-        ct.lib.ctamdProfileEnd(ctypes.byref(mean_ms), ctypes.byref(min_ms))
+        ct.lib.ctamdProfileEnd(h.h, ctypes.byref(mean_ms), ctypes.byref(min_ms))
         gapped_mean_us, gapped_min_us = mean_ms.value * 1e3, min_ms.value * 1e3
-        mean_ms = ctypes.c_float(batch_ms)
         prop = torch.cuda.get_device_properties(0)
         cus = prop.multi_processor_count
         clock_ghz = getattr(prop, "clock_rate", 2400000) / 1e6
         peak = cus * 256 * clock_ghz / 1e3      # TFLOP/s from the device's own CU count and max clock
-        achieved = FLOP / (mean_ms.value * 1e-3) / 1e12 if n else 0.0
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected by separate
-        # `rocprofv3 --pmc` runs of this same command, tools/gpu_profile.sh; corrected per
-        # MI355X_MICROARCH.md and committed under profiles/).  Counters cannot be read from inside the
-        # timed process, so the committed per-launch figure of the same kernel is reported, else null.
+        achieved = FLOP / (batch_ms * 1e-3) / 1e12
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected by separate `rocprofv3 --pmc` runs of
+        # this same command, tools/gpu_profile.sh; corrected per MI355X_MICROARCH.md and committed under profiles/).
+        # Counters cannot be read from inside the timed process, so the committed per-launch figure of the same kernel is
+        # reported, else null.
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_einsum.json")) as f:
@@ -199,30 +490,88 @@ def main():
                 "traffic_source": "profiles/pmc_traffic_einsum.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
                 "kernel": "%s<%dx%dx%d,w%dx%dx%d> (table index %d)" % (desc.get("kname", "gett_f32_kernel"), desc["bm"], desc["bn"], desc["bk"],
                                                                        desc["wm"], desc["wn"], desc["wk"], desc.get("kernel", -1)),
-                "launches": n, "mean_us": mean_ms.value * 1e3,
+                "launches": n, "mean_us": batch_ms * 1e3,
                 "timing": "one HIP event pair around %d back-to-back launches of the GETT kernel (fold off)" % n,
                 "gapped_mean_us": gapped_mean_us, "gapped_min_us": gapped_min_us,
                 "algorithmic_flop_per_launch": FLOP, "algorithmic_bytes_per_launch": BYTES,
-                "hbm_equiv_TBps": BYTES / (mean_ms.value * 1e-3) / 1e12 if n else None,
+                "hbm_equiv_TBps": BYTES / (batch_ms * 1e-3) / 1e12,
                 "cus": cus, "clock_ghz": clock_ghz, "nominal_peak": PEAK_TFLOPS_F32_MFMA}
+        # ---- HBM-cold variant of the headline: four rotating (A, B) pairs = 805 MB of operands, beyond the 256-MiB
+        #      Infinity Cache, so no step finds its inputs on-die ------------------------------------------------------------
+        try:
+            pairs = [(a, b)]
+            for k in range(3):
+                pairs.append((torch.rand(a.shape, generator=g, device="cuda"), torch.rand(b.shape, generator=g, device="cuda")))
+            for i in range(max(args.warmup, 20)):
+                contract(*pairs[i % 4], outs[i % nbuf])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                contract(*pairs[i % 4], outs[i % nbuf])
+            torch.cuda.synchronize()
+            cold_s = (time.perf_counter() - t1) / args.steps
+            cold = {"value": FLOP / cold_s / 1e9, "unit": "GFLOP/s", "ms_per_step": cold_s * 1e3, "operand_bytes_rotated": 4 * BYTES,
+                    "frac_of_nominal_f32_mfma_peak": FLOP / cold_s / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                    "hbm_TBps": BYTES / cold_s / 1e12,
+                    "what": "same %d steps, (A, B) rotate over 4 distinct pairs (805 MB > 256-MiB Infinity Cache): operands come from HBM" % args.steps}
+            del pairs
+        except Exception as ex:   # noqa: BLE001
+            cold = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if world == 1 and not args.no_cpu:
             a_np, b_np = a.cpu().numpy(), b.cpu().numpy()
             ref, cpu = cpu_baseline(a_np, b_np)
-            got = outs[(args.steps - 1) % nbuf].cpu().numpy()
-            err = float(np.max(np.abs(got - ref) / np.abs(ref)))
-            cpu["max_rel_diff_vs_gpu"] = err
+            contract(a, b, outs[0])
+            torch.cuda.synchronize()
+            got = outs[0].cpu().numpy()
+            cpu["max_rel_diff_vs_gpu"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
+        # ---- the other BASELINE configs, same process ---------------------------------------------------------------
+        if world == 1 and not args.no_secondary:
+            del a, b
+            torch.cuda.empty_cache()
+            secondary += secondary_single_gpu(torch, ct, ops, h, stream)
+            try:
+                one = {"sample": mg_measure(1, MG_SAMPLE_EXTENT, 20, 3), "scaled": mg_measure(1, MG_SCALED_EXTENT, 3, 1)}
+                secondary.append(mg_lines(one, "sample", "-"))
+                secondary.append(mg_lines(one, "scaled", "-"))
+            except Exception as ex:   # noqa: BLE001
+                secondary.append({"workload": "cuTENSORMg on one device", "error": "%s: %s" % (type(ex).__name__, ex)})
 
     if rank == 0:
+        einsum_line = {"workload": "einsum.cu 'abcd,dcbe->ae' a=e=96 b=c=d=64 fp32 (BASELINE configs[1])"
+                                   + ("" if world == 1 else ", b sharded x%d (b=%d), one process per GPU, RCCL all-reduce of C" % (world, 64 * world)),
+                       "dtype": "f32", "value": einsum_value, "unit": "GFLOP/s", "n_gpus": world, "ms_per_step": einsum_ms,
+                       "scaling": "weak", "frac_of_nominal_f32_mfma_peak": einsum_value / 1e3 / (PEAK_TFLOPS_F32_MFMA * world)}
+        use_mg = mg is not None and "error" not in mg and "scaled" in mg
+        if use_mg:
+            m = mg["scaled"]
+            value, ms_per_step, n_gpus, scaling = m["gflops"], m["ms_per_step"], m["devices"], "strong"
+            workload = ("cuTENSORMg contraction_multi_gpu.cu C[i,j]=A[i,k]B[k,j] fp32 %d^3 (BASELINE configs[4], scaled shape), largest free "
+                        "mode i cut over %d MI355X, B all-gathered over xGMI (%s), one process / %d devices" % (m["extent"], n_gpus, m["transport"], n_gpus))
+            secondary.append(mg_lines(mg, "sample", "sample_1"))
+            scaled_line = mg_lines(mg, "scaled", "scaled_1")
+            secondary.append(einsum_line)
+            config = {"workload": workload, "speedup_vs_1": scaled_line.get("speedup_vs_1"), "one_device_gflops": scaled_line.get("one_device_gflops"),
+                      "gather_bytes_per_call": m["gather_bytes_per_call"], "sample_protocol": scaled_line["sample_protocol"],
+                      "frac_of_nominal_f32_mfma_peak": value / 1e3 / (PEAK_TFLOPS_F32_MFMA * n_gpus), "max_rel_err_sampled": m["max_rel_err_sampled"]}
+            metric = "contraction GFLOP/s, fp32 cuTENSORMg C[i,j]=A[i,k]B[k,j] sharded over %d GPUs" % n_gpus
+            roof_out = scaled_line["roofline"]
+        else:
+            value, ms_per_step, n_gpus, scaling = einsum_value, einsum_ms, world, "weak"
+            config = {"workload": einsum_line["workload"], "plan": desc, "algo": args.algo,
+                      "frac_of_nominal_f32_mfma_peak": einsum_line["frac_of_nominal_f32_mfma_peak"]}
+            if requested > 1:
+                config["multi_device"] = (mg or {}).get("error") or ("only %d GPU visible: cuTENSORMg measured on one device (secondary)" % visible)
+            metric = "contraction GFLOP/s, fp32 einsum abcd,dcbe->ae"
+            roof_out = roof
         line = {
-            "metric": "contraction GFLOP/s, fp32 einsum abcd,dcbe->ae", "value": value, "unit": "GFLOP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "burn_in_ms": args.burn_in_ms, "burn_in_steps": burn_steps,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "einsum.cu 'abcd,dcbe->ae' a=e=96 b=c=d=64 fp32 (BASELINE configs[1])"
-                       + ("" if world == 1 else ", b sharded x%d (b=%d), RCCL all-reduce of C" % (world, 64 * world)),
-                       "plan": desc, "algo": args.algo,
-                       "frac_of_nominal_f32_mfma_peak": value / 1e3 / (PEAK_TFLOPS_F32_MFMA * world)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "metric": metric, "value": value, "unit": "GFLOP/s",
+            "n_gpus": n_gpus, "requested_gpus": requested, "steps": args.steps, "warmup": args.warmup, "burn_in_ms": args.burn_in_ms,
+            "burn_in_steps": burn_steps, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": config, "roofline": roof_out, "cpu_baseline": cpu,
+            "cold_operands_value": cold["value"] if cold and "value" in cold else None, "cold_operands": cold,
+            "headline_kernel_roofline": roof if use_mg else None,
+            "secondary": secondary,
         }
         print(json.dumps(line))
     if world > 1:

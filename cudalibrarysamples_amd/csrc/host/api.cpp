@@ -97,18 +97,33 @@ double scalar_imag(const void* s, hipDataType t) {
 
 bool misaligned(const void* p, uint32_t a) { return a > 1 && (reinterpret_cast<uintptr_t>(p) % a) != 0; }
 
-// Optional per-kernel timing of the dominant (GETT) kernel with HIP events recorded on the caller's
-// stream, for bench.py's roofline line.  Off by default; see ctamdProfileBegin/End below.
-unsigned long long* g_timingBuffer = nullptr;   // diagnostics: see ctamdSetTimingBuffer
-bool g_skipFold = false;                        // diagnostics: see ctamdSetSplitKFold
-
-struct KernelProfile {
-    bool enabled = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    std::mutex mtx;
-} g_prof;
-
 }  // namespace
+
+// Incremental autotuning (contraction_plan_cache.cu:215-237): cutensorContract on a trial plan brackets its launches with
+// an event pair; the pairs are read here — at the next plan creation, before the cache is written, at handle destruction —
+// never inside cutensorContract, which stays asynchronous.  The fastest candidate seen so far is what the cache holds.
+static void resolve_pending_measurements(cutensorHandle* handle) {
+    std::vector<cutensorHandle::PendingMeasurement> todo;
+    {
+        std::lock_guard<std::mutex> g(handle->mtx);
+        todo.swap(handle->pending);
+    }
+    for (auto& m : todo) {
+        float ms = 0.f;
+        const bool ok = hipEventSynchronize(m.e1) == hipSuccess && hipEventElapsedTime(&ms, m.e0, m.e1) == hipSuccess;
+        (void)hipEventDestroy(m.e0);
+        (void)hipEventDestroy(m.e1);
+        if (!ok) { (void)hipGetLastError(); continue; }
+        std::lock_guard<std::mutex> g(handle->mtx);
+        cutensorHandle::TuneState& t = handle->tuning[m.key];
+        CT_LOG("incremental autotune: kernel %d splitK %u -> %.3f us (best so far %.3f us)", m.kernel, m.splitK, ms * 1e3, t.bestMs * 1e3);
+        if (ms < t.bestMs) {
+            t.bestMs = ms; t.bestKernel = m.kernel; t.bestSplitK = m.splitK;
+            if (handle->planCache.count(m.key) || handle->planCache.size() < handle->planCacheCapacity)
+                handle->planCache[m.key] = PlanCacheEntry{m.key, m.kernel, m.splitK};
+        }
+    }
+}
 
 extern "C" {
 
@@ -135,6 +150,10 @@ cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
 }
 
 cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) {
+    if (handle != nullptr) {
+        for (auto& m : handle->pending) { (void)hipEventDestroy(m.e0); (void)hipEventDestroy(m.e1); }
+        for (auto& ev : handle->prof.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    }
     if (handle != nullptr && handle->syncPool != nullptr) (void)hipFree(handle->syncPool);
     delete handle;
     return CUTENSOR_STATUS_SUCCESS;
@@ -153,12 +172,17 @@ cutensorStatus_t cutensorHandleResizePlanCache(cutensorHandle_t handle, const ui
 cutensorStatus_t cutensorHandleWritePlanCacheToFile(const cutensorHandle_t handle, const char filename[]) {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    resolve_pending_measurements(handle);
     std::lock_guard<std::mutex> g(handle->mtx);
     FILE* f = std::fopen(filename, "w");
     if (f == nullptr) return CUTENSOR_STATUS_IO_ERROR;
     std::fprintf(f, "cutensor-amd-plancache 1\n");
-    for (const auto& kv : handle->planCache)
-        std::fprintf(f, "%s\t%d\t%u\n", kv.second.key.c_str(), kv.second.kernel, kv.second.splitK);
+    for (const auto& kv : handle->planCache) {   // key, kernel, splitK, candidates tried by incremental autotuning, best time [us]
+        auto t = handle->tuning.find(kv.first);
+        const int tried = t != handle->tuning.end() ? t->second.next : 0;
+        const double us = (t != handle->tuning.end() && t->second.bestMs < 1e29f) ? t->second.bestMs * 1e3 : 0.0;
+        std::fprintf(f, "%s\t%d\t%u\t%d\t%.3f\n", kv.second.key.c_str(), kv.second.kernel, kv.second.splitK, tried, us);
+    }
     std::fclose(f);
     return CUTENSOR_STATUS_SUCCESS;
 }
@@ -187,7 +211,9 @@ cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, co
         PlanCacheEntry e;
         e.key = line.data();
         unsigned sk = 1;
-        if (std::sscanf(t1 + 1, "%d\t%u", &e.kernel, &sk) != 2) continue;
+        int tried = 0;
+        double us = 0.0;
+        if (std::sscanf(t1 + 1, "%d\t%u\t%d\t%lf", &e.kernel, &sk, &tried, &us) < 2) continue;
         e.splitK = sk;
         if (handle->planCache.size() >= handle->planCacheCapacity && !handle->planCache.count(e.key)) {
             std::fclose(f);
@@ -195,6 +221,10 @@ cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, co
             return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;   // cache too small for the file
         }
         handle->planCache[e.key] = e;
+        if (tried > 0) {   // resume incremental autotuning where the writing process stopped
+            cutensorHandle::TuneState& t = handle->tuning[e.key];
+            t.next = tried; t.bestKernel = e.kernel; t.bestSplitK = e.splitK; t.bestMs = us > 0.0 ? (float)(us * 1e-3) : 1e30f;
+        }
         ++n;
     }
     std::fclose(f);
@@ -625,7 +655,8 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
 // outside every timed region of the samples (contraction.cu:218-222 vs :253-270).
 static int autotune_contraction(cutensorHandle_t handle, const cutensorOperationDescriptor& op,
                                 const ContractionView& v, const std::vector<ContractionChoice>& ch) {
-    const size_t es = 4;
+    const int family = ch.empty() ? 0 : ch[0].family;
+    const size_t es = dtype_size(op.A.desc.dtype);
     auto span = [&](const cutensorTensorDescriptor& d) {
         int64_t n = 1;
         for (uint32_t i = 0; i < d.numModes; ++i) n += (d.extent[i] - 1) * d.stride[i];
@@ -643,11 +674,11 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
         (void)hipGetLastError();
         goto done;
     }
-    (void)hipMemset(A, 0x3c, span(op.A.desc));   // 0x3c3c3c3c = 0.0115f: finite, non-trivial data
+    (void)hipMemset(A, 0x3c, span(op.A.desc));   // 0x3c3c3c3c = 0.0115f (0x3c3c: 0.0115 in bf16, 1.06 in fp16): finite, non-trivial data
     (void)hipMemset(B, 0x3c, span(op.B.desc));
     {
         int count = 0;
-        const GettKernelInfo* tab = gett_f32_kernels(&count);
+        const GettKernelInfo* tab = family == 1 ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
         float bestMs = 1e30f;
         for (size_t i = 0; i < nTry; ++i) {
             GettParams gp;
@@ -898,41 +929,56 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             return CUTENSOR_STATUS_SUCCESS;
         }
         const bool mfmaPath = pl->view.dtype == HIP_R_32F && !pl->accumulate64;
+        const bool h16Path = !mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F &&
+                             (pl->view.dtype == HIP_R_16BF || pl->view.dtype == HIP_R_16F);
         ContractionChoice pick;   // kernel = -1: simple kernel
-        if (mfmaPath) {
-            std::vector<ContractionChoice> ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs);
-            if (!ch.empty()) {
-                size_t idx = 0;
-                const std::string key = problem_key(*desc);
-                bool fromCache = false;
-                if (handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE) {
-                    std::lock_guard<std::mutex> g(handle->mtx);
-                    auto it = handle->planCache.find(key);
-                    if (it != handle->planCache.end()) {
-                        for (size_t i = 0; i < ch.size(); ++i)
-                            if (ch[i].kernel == it->second.kernel && ch[i].splitK == it->second.splitK) { idx = i; fromCache = true; break; }
-                    }
+        std::vector<ContractionChoice> ch;
+        if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+        else if (h16Path) ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+        if (!ch.empty()) {
+            size_t idx = 0;
+            const std::string key = problem_key(*desc);
+            const bool useCache = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE;
+            bool decided = false;
+            // incremental autotuning (contraction_plan_cache.cu:215-237): the first INCREMENTAL_COUNT plans of a problem
+            // are trials of candidates 0, 1, ... (timed by cutensorContract); after that — and for every plan without the
+            // autotune mode — the cache answers with the fastest candidate measured so far
+            if (useCache && pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL && (int)pr.algo < 0) {
+                resolve_pending_measurements(handle);
+                std::lock_guard<std::mutex> g(handle->mtx);
+                cutensorHandle::TuneState& t = handle->tuning[key];
+                const int limit = std::min<int>(std::max<int32_t>(pr.incrementalCount, 1), (int)ch.size());
+                if (t.next < limit) {
+                    idx = (size_t)t.next++;
+                    pl->tuneKey = key;
+                    decided = true;
                 }
-                if (!fromCache) {
-                    if ((int)pr.algo >= 0) idx = std::min<size_t>((size_t)pr.algo, ch.size() - 1);
-                    else if (pr.kernelRank > 0) idx = std::min<size_t>((size_t)pr.kernelRank, ch.size() - 1);
-                    else if (pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
-                    if (const char* f = std::getenv("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
-                        int fk = -1; unsigned fs = 1;
-                        if (std::sscanf(f, "%d:%u", &fk, &fs) >= 1)
-                            for (size_t i = 0; i < ch.size(); ++i)
-                                if (ch[i].kernel == fk && ch[i].splitK == fs) { idx = i; break; }
-                    }
-                    if (handle->planCacheCapacity > 0 && pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) {
-                        std::lock_guard<std::mutex> g(handle->mtx);
-                        if (handle->planCache.size() < handle->planCacheCapacity)
-                            handle->planCache[key] = PlanCacheEntry{key, ch[idx].kernel, ch[idx].splitK};
-                    }
-                }
-                pick = ch[idx];
             }
+            if (!decided && useCache) {
+                std::lock_guard<std::mutex> g(handle->mtx);
+                auto it = handle->planCache.find(key);
+                if (it != handle->planCache.end())
+                    for (size_t i = 0; i < ch.size(); ++i)
+                        if (ch[i].kernel == it->second.kernel && ch[i].splitK == it->second.splitK) { idx = i; decided = true; break; }
+            }
+            if (!decided) {
+                if ((int)pr.algo >= 0) idx = std::min<size_t>((size_t)pr.algo, ch.size() - 1);
+                else if (pr.kernelRank > 0) idx = std::min<size_t>((size_t)pr.kernelRank, ch.size() - 1);
+                else if (pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
+                if (const char* f = std::getenv("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
+                    int fk = -1; unsigned fs = 1;
+                    if (std::sscanf(f, "%d:%u", &fk, &fs) >= 1)
+                        for (size_t i = 0; i < ch.size(); ++i)
+                            if (ch[i].kernel == fk && ch[i].splitK == fs) { idx = i; break; }
+                }
+                if (useCache && pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) {
+                    std::lock_guard<std::mutex> g(handle->mtx);
+                    if (handle->planCache.size() < handle->planCacheCapacity)
+                        handle->planCache[key] = PlanCacheEntry{key, ch[idx].kernel, ch[idx].splitK};
+                }
+            }
+            pick = ch[idx];
         }
-        if (!mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F) (void)pick_h16_choice(pl->view, workspaceSizeLimit, handle->numCUs, pick);
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
         pl->requiredWorkspace = pick.workspace;
@@ -1084,7 +1130,18 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     p.D = D;
     p.alpha = (float)a; p.beta = (float)b;
     p.alpha64 = a; p.beta64 = b;
-    p.timing = g_timingBuffer;
+    p.timing = handle->timingBuffer.load(std::memory_order_relaxed);
+    // incremental-autotuning trial: one event pair around everything this call launches, read later (resolve_pending_measurements)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (!plan->tuneKey.empty()) {
+        if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {
+            (void)hipGetLastError();
+            if (t0) (void)hipEventDestroy(t0);
+            t0 = t1 = nullptr;
+        } else {
+            (void)hipEventRecord(t0, stream);
+        }
+    }
     hipError_t err;
     if (plan->choice.kernel == -2) {
         WideParams w = plan->wide;
@@ -1100,13 +1157,13 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         const GettKernelInfo* tab = gett_h16_kernels(&count);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        if (handle->prof.enabled.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
         err = tab[plan->choice.kernel].launch(p, stream);
         if (e0 && e1) {
             (void)hipEventRecord(e1, stream);
-            std::lock_guard<std::mutex> g(g_prof.mtx);
-            g_prof.events.emplace_back(e0, e1);
+            std::lock_guard<std::mutex> g(handle->prof.mtx);
+            handle->prof.events.emplace_back(e0, e1);
         }
         if (err == hipSuccess && plan->choice.splitK > 1) {
             SplitKReduceParams r = plan->skr;
@@ -1127,20 +1184,25 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             p.sync = handle->syncPool + (size_t)slot * 16;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_prof.enabled && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        if (handle->prof.enabled.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
         err = tab[plan->choice.kernel].launch(p, stream);
         if (e0 && e1) {
             (void)hipEventRecord(e1, stream);
-            std::lock_guard<std::mutex> g(g_prof.mtx);
-            g_prof.events.emplace_back(e0, e1);
+            std::lock_guard<std::mutex> g(handle->prof.mtx);
+            handle->prof.events.emplace_back(e0, e1);
         }
-        if (err == hipSuccess && plan->choice.splitK > 1 && !plan->fusedFold && !g_skipFold) {
+        if (err == hipSuccess && plan->choice.splitK > 1 && !plan->fusedFold && !handle->skipFold.load(std::memory_order_relaxed)) {
             SplitKReduceParams r = plan->skr;
             r.partial = static_cast<float*>(workspace);
             r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
             err = tab[plan->choice.kernel].fragPartials ? launch_splitk_reduce_frag(r, stream) : launch_splitk_reduce(r, stream);
         }
+    }
+    if (t0 != nullptr) {
+        (void)hipEventRecord(t1, stream);
+        std::lock_guard<std::mutex> g(handle->mtx);
+        handle->pending.push_back(cutensorHandle::PendingMeasurement{plan->tuneKey, plan->choice.kernel, plan->choice.splitK, t0, t1});
     }
     if (err != hipSuccess) { CT_LOG("cutensorContract: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
@@ -1364,29 +1426,35 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     return n;
 }
 
-// Diagnostics: device buffer of 8 x uint64 per workgroup that the GETT kernel fills with phase
+// Diagnostics, all per handle.  Device buffer of 8 x uint64 per workgroup that the GETT kernel fills with phase
 // timestamps (shader clock and wall clock); nullptr switches it off.
-void ctamdSetTimingBuffer(void* deviceBuffer) { g_timingBuffer = static_cast<unsigned long long*>(deviceBuffer); }
+void ctamdSetTimingBuffer(cutensorHandle_t handle, void* deviceBuffer) {
+    if (handle != nullptr) handle->timingBuffer.store(static_cast<unsigned long long*>(deviceBuffer), std::memory_order_relaxed);
+}
 
-// Diagnostics: enabled = 0 makes cutensorContract launch the GETT kernel only (the split-K partials stay unfolded, D is
+// enabled = 0 makes cutensorContract on this handle launch the GETT kernel only (the split-K partials stay unfolded, D is
 // not written) so that a stream of back-to-back GETT launches can be timed with one event pair — per-launch event
 // pairs put a ~6 us idle gap after every kernel and the chip leaves its steady clock state.  Never used by the samples.
-void ctamdSetSplitKFold(int enabled) { g_skipFold = (enabled == 0); }
-
-// Per-kernel timing of the GETT kernel inside cutensorContract: Begin() arms it, End() synchronises the
-// recorded event pairs and returns the number of launches and their mean / min duration in ms.
-void ctamdProfileBegin(void) {
-    std::lock_guard<std::mutex> g(g_prof.mtx);
-    g_prof.events.clear();
-    g_prof.enabled = true;
+void ctamdSetSplitKFold(cutensorHandle_t handle, int enabled) {
+    if (handle != nullptr) handle->skipFold.store(enabled == 0, std::memory_order_relaxed);
 }
-int ctamdProfileEnd(float* meanMs, float* minMs) {
-    std::lock_guard<std::mutex> g(g_prof.mtx);
-    g_prof.enabled = false;
+
+// Per-kernel timing of the GETT kernel inside cutensorContract on this handle: Begin() arms it, End() synchronises the
+// recorded event pairs and returns the number of launches and their mean / min duration in ms.
+void ctamdProfileBegin(cutensorHandle_t handle) {
+    if (handle == nullptr) return;
+    std::lock_guard<std::mutex> g(handle->prof.mtx);
+    handle->prof.events.clear();
+    handle->prof.enabled.store(true, std::memory_order_relaxed);
+}
+int ctamdProfileEnd(cutensorHandle_t handle, float* meanMs, float* minMs) {
+    if (handle == nullptr) return 0;
+    std::lock_guard<std::mutex> g(handle->prof.mtx);
+    handle->prof.enabled.store(false, std::memory_order_relaxed);
     double sum = 0.0;
     float mn = 1e30f;
     int n = 0;
-    for (auto& ev : g_prof.events) {
+    for (auto& ev : handle->prof.events) {
         float t = 0.f;
         if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) {
             sum += t;
@@ -1396,7 +1464,7 @@ int ctamdProfileEnd(float* meanMs, float* minMs) {
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
     }
-    g_prof.events.clear();
+    handle->prof.events.clear();
     if (meanMs) *meanMs = n ? (float)(sum / n) : 0.f;
     if (minMs) *minMs = n ? mn : 0.f;
     return n;

@@ -1,5 +1,6 @@
 // internal.hpp — objects behind the opaque cuTENSOR handles and the planner interfaces.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -105,6 +106,9 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
                                                         int numCUs);
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
+// 16-bit family: the default kernel variant first, then the other variants of the same tile / split (the candidates
+// CUTENSOR_ALGO_DEFAULT_PATIENT and incremental autotuning measure)
+std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64_t wsLimit, int numCUs);
 void fill_gett_params(const ContractionView& v, const ContractionChoice& c, GettParams& p,
                       SplitKReduceParams& r);
 
@@ -166,6 +170,7 @@ struct cutensorPlan {
     ctamd::SplitKReduceParams  skr{};
     bool                       accumulate64 = false;
     bool                       fusedFold = false;     // split-K partials are folded inside the GETT launch
+    std::string                tuneKey;               // non-empty: an incremental-autotuning trial, timed by cutensorContract
     // element-wise / reduction
     ctamd::EwPlan     ew;
     ctamd::EwTrinaryPlan ew3;
@@ -189,7 +194,7 @@ struct cutensorHandle {
     int numCUs = 256;
     int clockKHz = 2400000;
     std::mutex mtx;
-    uint32_t planCacheCapacity = 0;
+    uint32_t planCacheCapacity = 64;    // a fresh handle can read a plan-cache file before any resize (contraction_plan_cache.cu:132-152)
     std::map<std::string, PlanCacheEntry> planCache;   // problem signature -> tuned choice
     int logLevel = 0;
     // {arrivals, departures} counter pairs for in-launch split-K folds, 64 B apart, zeroed once; a launch
@@ -200,4 +205,24 @@ struct cutensorHandle {
     uint32_t* syncPool = nullptr;
     uint32_t  syncNext = 0;
     static constexpr uint32_t kSyncSlots = 256;
+    // diagnostics, per handle (ctamdSetSplitKFold / ctamdSetTimingBuffer / ctamdProfileBegin): a second handle — another
+    // framework thread's — never sees them
+    std::atomic<bool> skipFold{false};
+    std::atomic<unsigned long long*> timingBuffer{nullptr};
+    struct KernelProfile {
+        std::atomic<bool> enabled{false};
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+        std::mutex mtx;
+    } prof;
+    // incremental autotuning (CUTENSOR_AUTOTUNE_MODE_INCREMENTAL, contraction_plan_cache.cu:215-237): per problem, the
+    // candidates tried so far with their measured time; the best one is what the plan cache holds
+    struct TuneState {
+        int      next = 0;                 // next candidate rank to try
+        int      bestKernel = -1;
+        uint32_t bestSplitK = 1;
+        float    bestMs = 1e30f;
+    };
+    std::map<std::string, TuneState> tuning;
+    struct PendingMeasurement { std::string key; int kernel; uint32_t splitK; hipEvent_t e0, e1; };
+    std::vector<PendingMeasurement> pending;   // cutensorContract calls of tuning plans whose events were not read yet
 };

@@ -417,6 +417,23 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     return true;
 }
 
+std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64_t wsLimit, int numCUs) {
+    std::vector<ContractionChoice> out;
+    ContractionChoice base;
+    if (!pick_h16_choice(v, wsLimit, numCUs, base)) return out;
+    out.push_back(base);
+    int count = 0;
+    (void)gett_h16_kernels(&count);
+    const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
+    for (int other : {0, 16, 8}) {      // ping-pong rows, free-running eight waves, four waves
+        if (other == variant || layoutIdx + other >= count) continue;
+        ContractionChoice c = base;
+        c.kernel = layoutIdx + other;
+        out.push_back(c);
+    }
+    return out;
+}
+
 static void fill_group(ModeGroup& g, const std::vector<CanonMode>& modes) {
     std::memset(&g, 0, sizeof(g));
     g.n = (int32_t)modes.size();

@@ -31,7 +31,10 @@ WORKSPACE_MIN, WORKSPACE_DEFAULT, WORKSPACE_MAX = 1, 2, 3
 JIT_MODE_NONE = 0
 OPERATION_DESCRIPTOR_TAG, OPERATION_DESCRIPTOR_SCALAR_TYPE, OPERATION_DESCRIPTOR_FLOPS, OPERATION_DESCRIPTOR_MOVED_BYTES = 0, 1, 2, 3
 PLAN_REQUIRED_WORKSPACE = 0
+PLAN_PREFERENCE_AUTOTUNE_MODE, PLAN_PREFERENCE_CACHE_MODE, PLAN_PREFERENCE_INCREMENTAL_COUNT = 0, 1, 2
 PLAN_PREFERENCE_ALGO, PLAN_PREFERENCE_KERNEL_RANK = 3, 4
+AUTOTUNE_MODE_NONE, AUTOTUNE_MODE_INCREMENTAL = 0, 1
+CACHE_MODE_NONE, CACHE_MODE_PEDANTIC = 0, 1
 
 _vp = ctypes.c_void_p
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -96,12 +99,13 @@ lib.cutensorGetErrorString.restype = ctypes.c_char_p
 lib.cutensorGetVersion.restype = ctypes.c_size_t
 lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
-lib.ctamdSetTimingBuffer.argtypes = [_vp]
+lib.ctamdSetTimingBuffer.argtypes = [_vp, _vp]
 lib.ctamdSetTimingBuffer.restype = None
-lib.ctamdSetSplitKFold.argtypes = [ctypes.c_int]
+lib.ctamdSetSplitKFold.argtypes = [_vp, ctypes.c_int]
 lib.ctamdSetSplitKFold.restype = None
+lib.ctamdProfileBegin.argtypes = [_vp]
 lib.ctamdProfileBegin.restype = None
-lib.ctamdProfileEnd.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+lib.ctamdProfileEnd.argtypes = [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 lib.ctamdEinsumCreate.argtypes = [ctypes.c_char_p, _i64p, ctypes.c_int, _i64p, ctypes.c_int, ctypes.c_int]
 lib.ctamdEinsumCreate.restype = _vp
 lib.ctamdEinsumSetConjugate.argtypes = [_vp, ctypes.c_int, ctypes.c_int]

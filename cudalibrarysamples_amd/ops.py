@@ -42,15 +42,16 @@ class Plan:
     """An operation descriptor + plan pair with its scalar type and workspace requirement."""
 
     def __init__(self, handle, op, kind, dtype, algo=ct.ALGO_DEFAULT, kernel_rank=0, workspace_limit=None,
-                 workspace_pref=ct.WORKSPACE_DEFAULT):
+                 workspace_pref=ct.WORKSPACE_DEFAULT, autotune=None, cache_mode=None, incremental_count=None):
         self.handle, self.kind, self.dtype = handle, kind, dtype
         self.op = op
         pref = ctypes.c_void_p()
         ct.check(ct.cutensorCreatePlanPreference(handle.h, ctypes.byref(pref), algo, ct.JIT_MODE_NONE))
-        if kernel_rank:
-            v = ctypes.c_int32(kernel_rank)
-            ct.check(ct.cutensorPlanPreferenceSetAttribute(handle.h, pref, ct.PLAN_PREFERENCE_KERNEL_RANK,
-                                                           ctypes.byref(v), 4))
+        for attr, val in ((ct.PLAN_PREFERENCE_KERNEL_RANK, kernel_rank or None), (ct.PLAN_PREFERENCE_AUTOTUNE_MODE, autotune),
+                          (ct.PLAN_PREFERENCE_CACHE_MODE, cache_mode), (ct.PLAN_PREFERENCE_INCREMENTAL_COUNT, incremental_count)):
+            if val is not None:   # contraction_plan_cache.cu:215-237
+                v = ctypes.c_int32(val)
+                ct.check(ct.cutensorPlanPreferenceSetAttribute(handle.h, pref, attr, ctypes.byref(v), 4))
         est = ctypes.c_uint64(0)
         ct.check(ct.cutensorEstimateWorkspaceSize(handle.h, op, pref, workspace_pref, ctypes.byref(est)))
         self.workspace_estimate = est.value

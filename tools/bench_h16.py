@@ -49,12 +49,12 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
-    ct.lib.ctamdProfileBegin()
+    ct.lib.ctamdProfileBegin(h.h)
     for _ in range(args.reps):
         plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), stream=stream)
     torch.cuda.synchronize()
     mean_ms, min_ms = ctypes.c_float(0), ctypes.c_float(0)
-    ct.lib.ctamdProfileEnd(ctypes.byref(mean_ms), ctypes.byref(min_ms))
+    ct.lib.ctamdProfileEnd(h.h, ctypes.byref(mean_ms), ctypes.byref(min_ms))
     flop = 2.0 * n * n * n
     peak = 256 * 4096 * 2.4e9
     # spot check against torch (rocBLAS is used here only as a checker of the bench's own output)

@@ -24,10 +24,10 @@ def main():
     for _ in range(3):
         plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
     torch.cuda.synchronize()
-    ct.lib.ctamdSetTimingBuffer(tbuf.data_ptr())
+    ct.lib.ctamdSetTimingBuffer(h.h, tbuf.data_ptr())
     plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
     torch.cuda.synchronize()
-    ct.lib.ctamdSetTimingBuffer(None)
+    ct.lib.ctamdSetTimingBuffer(h.h, None)
     t = tbuf.cpu().numpy().reshape(2, 32)[:, :28].reshape(2, 4, 7).astype(np.int64)
     names = ["reads+dma", "vmcnt", "barrier1", "lgkm", "mfma", "barrier2"]
     out = {}

@@ -37,10 +37,10 @@ def main():
     for _ in range(5 if args.cold else 1500):   # steady clock state by default; --cold: 5 warm-up calls
         p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
     torch.cuda.synchronize()
-    ct.lib.ctamdSetTimingBuffer(tbuf.data_ptr())
+    ct.lib.ctamdSetTimingBuffer(h.h, tbuf.data_ptr())
     p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, 0)
     torch.cuda.synchronize()
-    ct.lib.ctamdSetTimingBuffer(None)
+    ct.lib.ctamdSetTimingBuffer(h.h, None)
     t = tbuf.cpu().numpy().reshape(-1, 16).astype(np.float64)
     if args.dump:
         np.save(args.dump, tbuf.cpu().numpy().reshape(-1, 16))

@@ -67,12 +67,12 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / args.reps
         # GETT kernel alone (HIP events recorded by the library around the kernel launch)
         import ctypes
-        ct.lib.ctamdProfileBegin()
+        ct.lib.ctamdProfileBegin(h.h)
         for _ in range(args.reps):
             p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 30, stream)
         torch.cuda.synchronize()
         mean_ms, min_ms = ctypes.c_float(0), ctypes.c_float(0)
-        ct.lib.ctamdProfileEnd(ctypes.byref(mean_ms), ctypes.byref(min_ms))
+        ct.lib.ctamdProfileEnd(h.h, ctypes.byref(mean_ms), ctypes.byref(min_ms))
         d = p.describe()
         print(json.dumps({"rank": r, "us": us, "kernel_us": mean_ms.value * 1e3, "kernel_min_us": min_ms.value * 1e3, "tflops": flop / us / 1e6, "kernel": d["kernel"],
                           "tile": [d["bm"], d["bn"], d["bk"]], "waves": [d["wm"], d["wn"], d["wk"]],

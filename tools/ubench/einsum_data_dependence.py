@@ -15,12 +15,12 @@ for name, fill in (("random", None), ("zeros", 0.0), ("ones", 1.0)):
     for _ in range(20):
         plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), plan.required_workspace, s)
     torch.cuda.synchronize()
-    ct.lib.ctamdProfileBegin()
+    ct.lib.ctamdProfileBegin(h.h)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(200):
         plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), plan.required_workspace, s)
     e1.record(); torch.cuda.synchronize()
     m, mn = ctypes.c_float(0), ctypes.c_float(0)
-    ct.lib.ctamdProfileEnd(ctypes.byref(m), ctypes.byref(mn))
+    ct.lib.ctamdProfileEnd(h.h, ctypes.byref(m), ctypes.byref(mn))
     print(name, "step %.2f us  kernel %.2f us (min %.2f)" % (e0.elapsed_time(e1) * 5, m.value * 1e3, mn.value * 1e3))
