@@ -177,17 +177,27 @@ public:
 
     uint64_t requiredWorkspace() const { return requiredWorkspace_; }
 
+    // Drops the plan and builds it again under a different workspace limit — the CUTENSOR_WORKSPACE_MIN retry of
+    // python/cutensor/torch/einsum.cc:104-123 when the workspace of the first plan cannot be allocated.
+    bool replan(const cutensorHandle_t handle, uint64_t workspaceLimit) {
+        if (plan_) { cutensorDestroyPlan(plan_); plan_ = nullptr; }
+        requiredWorkspace_ = 0;
+        return plan(handle, workspaceLimit);
+    }
+
     // C = einsum(A, B) on `stream`; work_raw must hold getWorksize() bytes (or requiredWorkspace()
     // after an explicit plan()).
     bool execute(const cutensorHandle_t handle, const void* A_raw, const void* B_raw, void* C_raw,
                  void* work_raw, cudaStream_t stream) {
+        const bool plannedByCaller = plan_ != nullptr;    // plan()/replan() called explicitly: the buffer holds requiredWorkspace()
         if (!plan(handle, kWorksize_)) return false;
+        const uint64_t workSize = plannedByCaller ? requiredWorkspace_ : (uint64_t)kWorksize_;
         typename EinsumTypeTraits<ComputeType>::ScalarType alpha = 1, beta = 0;
         cutensorStatus_t st;
         if (hasB_)
-            st = cutensorContract(handle, plan_, &alpha, A_raw, B_raw, &beta, C_raw, C_raw, work_raw, kWorksize_, stream);
+            st = cutensorContract(handle, plan_, &alpha, A_raw, B_raw, &beta, C_raw, C_raw, work_raw, workSize, stream);
         else
-            st = cutensorReduce(handle, plan_, &alpha, A_raw, &beta, C_raw, C_raw, work_raw, kWorksize_, stream);
+            st = cutensorReduce(handle, plan_, &alpha, A_raw, &beta, C_raw, C_raw, work_raw, workSize, stream);
         return st == CUTENSOR_STATUS_SUCCESS;
     }
 

@@ -14,6 +14,7 @@ struct Base {
     virtual bool init() const = 0;
     virtual std::vector<int64_t> shape() const = 0;
     virtual bool plan(cutensorHandle_t h, uint64_t limit) = 0;
+    virtual bool replan(cutensorHandle_t h, uint64_t limit) = 0;
     virtual uint64_t required() const = 0;
     virtual bool exec(cutensorHandle_t h, const void* A, const void* B, void* C, void* w, hipStream_t s) = 0;
     virtual cutensorPlan_t raw() const = 0;
@@ -26,6 +27,7 @@ struct Impl : Base {
     bool init() const override { return e.isInitialized(); }
     std::vector<int64_t> shape() const override { return e.getOutputShape(); }
     bool plan(cutensorHandle_t h, uint64_t limit) override { return e.plan(h, limit); }
+    bool replan(cutensorHandle_t h, uint64_t limit) override { return e.replan(h, limit); }
     uint64_t required() const override { return e.requiredWorkspace(); }
     bool exec(cutensorHandle_t h, const void* A, const void* B, void* C, void* w, hipStream_t s) override {
         return e.execute(h, A, B, C, w, s);
@@ -61,6 +63,12 @@ int ctamdEinsumOutputShape(void* e, int64_t* out, int cap) {
 }
 int ctamdEinsumPlan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) {
     if (!e || !static_cast<Base*>(e)->plan(h, limit)) return 0;
+    if (required) *required = static_cast<Base*>(e)->required();
+    return 1;
+}
+// einsum.cc:104-123: plan again under a smaller workspace limit (0 = CUTENSOR_WORKSPACE_MIN) after an allocation failure
+int ctamdEinsumReplan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) {
+    if (!e || !static_cast<Base*>(e)->replan(h, limit)) return 0;
     if (required) *required = static_cast<Base*>(e)->required();
     return 1;
 }

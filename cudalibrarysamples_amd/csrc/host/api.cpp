@@ -1329,11 +1329,12 @@ cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cu
     const uint64_t tOff = (plan->tBytes + 255) & ~255ull;
     void* T = workspace;
     void* ws = static_cast<char*>(workspace) + tOff;
-    const double one64 = 1.0, zero64 = 0.0;
-    const float one32 = 1.f, zero32 = 0.f;
-    const bool f64 = plan->scalarType == HIP_R_64F;
-    const void* one = f64 ? static_cast<const void*>(&one64) : static_cast<const void*>(&one32);
-    const void* zero = f64 ? static_cast<const void*>(&zero64) : static_cast<const void*>(&zero32);
+    // one / zero in the plan's scalar type; {re, im} pairs so that a complex scalar type reads a well-defined imaginary part
+    const double one64[2] = {1.0, 0.0}, zero64[2] = {0.0, 0.0};
+    const float one32[2] = {1.f, 0.f}, zero32[2] = {0.f, 0.f};
+    const bool f64 = plan->scalarType == HIP_R_64F || plan->scalarType == HIP_C_64F;
+    const void* one = f64 ? static_cast<const void*>(one64) : static_cast<const void*>(one32);
+    const void* zero = f64 ? static_cast<const void*>(zero64) : static_cast<const void*>(zero32);
     cutensorStatus_t st = cutensorContract(handle, plan->sub1, one, X, Y, zero, T, T, ws, workspaceSize - tOff, stream);
     if (st != CUTENSOR_STATUS_SUCCESS) return st;
     return cutensorContract(handle, plan->sub2, alpha, T, Z, beta, D, E, ws, workspaceSize - tOff, stream);

@@ -272,6 +272,8 @@ cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t han
     op->kind = OpKind::BlockSparseContraction;
     op->compute = descCompute;
     op->bs = bs;
+    // real data only: the per-block scalars below are real (complex block-sparse contractions are not on the path)
+    if (descA->dtype == HIP_C_32F || descA->dtype == HIP_C_64F) { delete op; return CUTENSOR_STATUS_NOT_SUPPORTED; }
     op->scalarType = (descA->dtype == HIP_R_64F || descCompute->id == 5) ? HIP_R_64F : HIP_R_32F;
     uint64_t ws = 0;
     const cutensorStatus_t st = build_blocksparse(handle, *bs, ~0ull, false, nullptr, &ws);   // validates shapes / modes

@@ -203,7 +203,8 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
     };
     auto ok_op = [](cutensorOperator_t o) { return o == CUTENSOR_OP_ADD || o == CUTENSOR_OP_MUL || o == CUTENSOR_OP_MAX || o == CUTENSOR_OP_MIN; };
     if (!ok_op(op.opAB) || !ok_op(op.opReduce)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "binary operator");
-    if (op.B.op != CUTENSOR_OP_IDENTITY) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    if (op.A.op != CUTENSOR_OP_IDENTITY || op.B.op != CUTENSOR_OP_IDENTITY || op.C.op != CUTENSOR_OP_IDENTITY)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
     auto same_layout = [&](const TensorUse& X) {
         if (X.modes.size() != op.D.modes.size() || X.desc.dtype != op.D.desc.dtype) return false;
         for (size_t i = 0; i < op.D.modes.size(); ++i) {

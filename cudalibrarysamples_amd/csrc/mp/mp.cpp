@@ -669,7 +669,10 @@ cutensorStatus_t run_reduce(cutensorMpHandle* handle, const cutensorMpPlan* plan
     const int64_t es = (int64_t)elem_size(dt);
     const size_t perElem = is_complex(dt) ? 2 : 1;
     const double zero[2] = {0.0, 0.0};                  // a zero scalar of every scalar type
-    const bool haveBeta = !scalar_is_zero(beta, dt);
+    // alpha / beta are of the operation's SCALAR type, which is not always the data type: fp32 data with
+    // CUTENSOR_COMPUTE_DESC_64F takes double scalars (the single-GPU layer's rule, api.cpp scalar_type_for)
+    const hipDataType scalarType = is_complex(dt) ? dt : ((dt == HIP_R_64F || d.compute == CUTENSOR_COMPUTE_DESC_64F) ? HIP_R_64F : HIP_R_32F);
+    const bool haveBeta = !scalar_is_zero(beta, scalarType);
     char* ctrWs = ws + plan->stageBytes;
     int64_t cElems = 1;
     for (int64_t e : d.C.extent) cElems *= e;

@@ -49,6 +49,14 @@ class EinsumPlan:
     def describe(self):
         return ct.describe_plan(ct.lib.ctamdEinsumRawPlan(self.e))
 
+    def replan_min_workspace(self):
+        """The reference binding's fallback (cutensor/torch/einsum.cc:104-123): when the workspace of the first plan
+        cannot be allocated, plan again with CUTENSOR_WORKSPACE_MIN (here: limit 0) and use what that plan needs."""
+        req = ctypes.c_uint64(0)
+        if not ct.lib.ctamdEinsumReplan(self.e, get_handle(), 0, ctypes.byref(req)):
+            raise RuntimeError("cutensor: plan with less workspace failed.")
+        self.required_workspace = req.value
+
     def execute(self, a, b, out, workspace):
         stream = torch.cuda.current_stream().cuda_stream
         ok = ct.lib.ctamdEinsumExecute(self.e, get_handle(), a.data_ptr(), b.data_ptr() if b is not None else None,
@@ -80,14 +88,33 @@ def einsum(equation, a, b=None, conj_a=False, conj_b=False):
     if plan is None:
         plan = _plans[key] = EinsumPlan(equation, a.shape, b.shape if b is not None else (), a.dtype, conj_a, conj_b)
     out = torch.empty(plan.output_shape, dtype=a.dtype, device=a.device)
-    ws = None
-    if plan.required_workspace:
-        # the helper passes its fixed 1 GiB worksize to the ABI (einsum.cu:380); provide that much once
-        ws = _workspace.get(a.device)
-        if ws is None:
-            ws = _workspace[a.device] = torch.empty(1 << 30, dtype=torch.uint8, device=a.device)
+    try:
+        ws = _get_workspace(a.device, plan.required_workspace)
+    except torch.cuda.OutOfMemoryError:
+        # einsum.cc:104-123: the workspace the plan asked for cannot be allocated -> plan again with the minimum
+        plan.replan_min_workspace()
+        try:
+            ws = _get_workspace(a.device, plan.required_workspace)
+        except torch.cuda.OutOfMemoryError:
+            raise RuntimeError("cutensor: error allocating workspace")
     plan.execute(a, b, out, ws)
     return out
+
+
+def _alloc_workspace(nbytes, device):
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _get_workspace(device, nbytes):
+    """One growing workspace buffer per device, exactly as large as the largest plan so far asked for (the plan reports
+    CUTENSOR_PLAN_REQUIRED_WORKSPACE; python/einsum.h:365-392)."""
+    if not nbytes:
+        return None
+    ws = _workspace.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _workspace.pop(device, None)
+        ws = _workspace[device] = _alloc_workspace(nbytes, device)
+    return ws
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 def build(force=False):
     src = os.path.join(_HERE, "oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", _SO, src])
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", _SO, src, "-lm"])
     return _SO
 
 
@@ -57,12 +57,36 @@ def _ptr(arr):
     return ctypes.c_void_p(arr.ctypes.data)
 
 
-def contract(A, modesA, B, modesB, D, modesD, alpha=1.0, beta=0.0, C=None, acc64=True):
-    """D[modesD] = alpha * sum A[modesA]*B[modesB] + beta*C[modesD]; D is written in place."""
+def contract(A, modesA, B, modesB, D, modesD, alpha=1.0, beta=0.0, C=None, acc64=True, conjA=False, conjB=False, h16=None):
+    """D[modesD] = alpha * sum A[modesA]*B[modesB] + beta*C[modesD]; D is written in place.
+    float32 / float64 / complex64 / complex128 arrays; h16 = "bf16" | "f16" with uint16 arrays of bit patterns (16-bit
+    data, fp64 accumulation, one rounding of the result); conjA / conjB for complex data (CUTENSOR_OP_CONJ)."""
     if C is None:
         C = D
     if A.dtype != B.dtype or A.dtype != D.dtype or C.dtype != D.dtype:
         raise ValueError("dtype mismatch")
+    if h16 is not None or np.iscomplexobj(A):
+        if h16 is not None:
+            if A.dtype != np.uint16:
+                raise ValueError("16-bit tensors are passed as uint16 bit patterns")
+            fn = {"bf16": lib().oracle_contract_bf16, "f16": lib().oracle_contract_f16}[h16]
+        else:
+            fn = lib().oracle_contract_c32 if A.dtype == np.complex64 else lib().oracle_contract_c64
+        nA, mA, eA, sA = _desc(A, modesA)
+        nB, mB, eB, sB = _desc(B, modesB)
+        nC, mC, eC, sC = _desc(C, modesD)
+        _, _, _, sD = _desc(D, modesD)
+        fn.restype = ctypes.c_int
+        if h16 is not None:
+            rc = fn(nA, mA, eA, sA, _ptr(A), nB, mB, eB, sB, _ptr(B), nC, mC, eC, sC, _ptr(C), sD, _ptr(D),
+                    ctypes.c_double(alpha), ctypes.c_double(beta))
+        else:
+            al, be = complex(alpha), complex(beta)
+            rc = fn(nA, mA, eA, sA, _ptr(A), int(conjA), nB, mB, eB, sB, _ptr(B), int(conjB), nC, mC, eC, sC, _ptr(C), sD, _ptr(D),
+                    ctypes.c_double(al.real), ctypes.c_double(al.imag), ctypes.c_double(be.real), ctypes.c_double(be.imag))
+        if rc != 0:
+            raise RuntimeError("oracle_contract failed: %d" % rc)
+        return D
     if A.dtype == np.float32:
         fn = lib().oracle_contract_f32 if acc64 else lib().oracle_contract_f32_naive
     elif A.dtype == np.float64:
@@ -142,16 +166,35 @@ def einsum_parse(equation, shapeA, shapeB=(), max_modes=40):
     }
 
 
-def einsum(equation, a, b=None):
-    """Framework-level einsum through the oracle (row-major numpy arrays in, row-major out)."""
-    p = einsum_parse(equation, a.shape, b.shape if b is not None else ())
+def einsum(equation, a, b=None, h16=None, max_modes=40):
+    """Framework-level einsum through the oracle (row-major numpy arrays in, row-major out).  float32 / float64 /
+    complex64 / complex128 arrays, or uint16 bit patterns with h16 = "bf16" | "f16" (two-operand equations)."""
+    p = einsum_parse(equation, a.shape, b.shape if b is not None else (), max_modes=max_modes)
     if p is None:
         raise ValueError("not supported: %s" % equation)
     out = np.zeros(p["output_shape"], dtype=a.dtype)
     # numpy axis i of a row-major array carries mode modes[::-1][i]
     ma, mc = p["modesA"][::-1], p["modesC"][::-1]
     if b is not None:
-        contract(a, ma, b, p["modesB"][::-1], out, mc)
+        contract(a, ma, b, p["modesB"][::-1], out, mc, h16=h16)
     else:
         reduce(a, ma, out, mc)
     return out
+
+
+def to_bits(x, kind):
+    """float array -> uint16 bit patterns of the 16-bit type (round to nearest even), through the oracle's own conversion."""
+    f = lib().oracle_double_to_bf16 if kind == "bf16" else lib().oracle_double_to_f16
+    f.restype = ctypes.c_uint16
+    f.argtypes = [ctypes.c_double]
+    flat = np.asarray(x, dtype=np.float64).ravel(order="K")
+    out = np.fromiter((f(float(v)) for v in flat), dtype=np.uint16, count=flat.size)
+    return out.reshape(np.shape(x), order="F" if np.isfortran(np.asarray(x)) else "C")
+
+
+def from_bits(u, kind):
+    """uint16 bit patterns -> float64 values (exact)."""
+    u = np.asarray(u, dtype=np.uint16)
+    if kind == "f16":
+        return u.view(np.float16).astype(np.float64)
+    return (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64)

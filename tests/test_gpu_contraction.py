@@ -54,6 +54,28 @@ def test_contraction_sample_modes_shrunk(env):
     run_contraction(env, ext, "mhkn", "ukvh", "munv", alpha=1.1, beta=0.7, seed=10)
 
 
+def test_against_the_naive_fp32_host_loop(env):
+    """BASELINE.json's wording: "results match a naive host triple-loop on the same random tensors".  The oracle's literal
+    fp32 loop nest (oracle_contract_f32_naive: fp32 accumulation in loop order) on the contraction.cu modes, shrunk, and on
+    the headline equation, shrunk: the GPU's blocked fp32 accumulation and the sequential host loop both sit within fp32
+    round-off of the fp64 value, so they agree with each other to 2e-5 of the result magnitude."""
+    ct, ops, h, torch = env
+    for ext, mA, mB, mC in [(dict(m=24, n=12, u=16, v=8, h=8, k=12), "mhkn", "ukvh", "munv"),
+                            (dict(a=24, b=8, c=8, d=16, e=24), "dcba", "ebcd", "ea")]:
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        A, B, C = make_tensor(eA, 31), make_tensor(eB, 32), make_tensor(eC, 33)
+        p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, workspace_limit=1 << 28)
+        dA, dB, dC = to_device(A), to_device(B), to_device(C)
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        p.contract(1.1, dA.data_ptr(), dB.data_ptr(), 0.5, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), p.required_workspace)
+        torch.cuda.synchronize()
+        naive = np.zeros_like(C)
+        oracle.contract(A, mA, B, mB, naive, mC, alpha=1.1, beta=0.5, C=C, acc64=False)
+        got = from_device(dC, C)
+        assert_close(got, naive, rtol=2e-5, atol=2e-5 * float(np.abs(naive).max()), what="naive fp32 loop %s,%s->%s" % (mA, mB, mC))
+        p.destroy()
+
+
 @pytest.mark.parametrize("case", [
     # (extents, modesA, modesB, modesC): every operand-layout combination of the GETT kernels
     (dict(m=64, n=48, k=40), "mk", "kn", "mn"),      # A free-contig (after swap), B K-contig
@@ -291,6 +313,9 @@ def test_complex_contraction_with_conjugation(built, dtype):
     got = dC.cpu().numpy().reshape(C.shape, order="F")
     ref = alpha * np.einsum("mkl,knl->mnl", np.conj(A).astype(np.complex128), B.astype(np.complex128)) + beta * C
     np.testing.assert_allclose(got, ref, rtol=2e-5 if dtype == "complex64" else 1e-13, atol=2e-6 if dtype == "complex64" else 1e-13)
+    want = np.zeros_like(C)
+    oracle.contract(A, "mkl", B, "knl", want, "mnl", alpha=alpha, beta=beta, C=C, conjA=True)      # the oracle's complex entry point
+    np.testing.assert_allclose(got, want, rtol=2e-5 if dtype == "complex64" else 1e-13, atol=2e-6 if dtype == "complex64" else 1e-13)
 
 
 def test_patient_algo_measures_candidates_and_stays_correct(env):

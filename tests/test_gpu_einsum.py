@@ -1,6 +1,7 @@
 """GPU parity of the einsum front end against the golden fixtures of the reference's own test cases
-(tests/golden, generated from cuTENSOR/python/cutensor/torch/einsum_test.py:47-124) at the
-reference's tolerance (rtol 5e-3, atol 6e-3; :35-42) — and tighter for fp32/fp64."""
+(tests/golden: the parameter list parsed out of cuTENSOR/python/cutensor/torch/einsum_test.py:45-125 by
+tests/golden/make_golden.py, every dtype of it — fp32, fp64, fp16, complex64, complex128 and the commented-out bf16
+case) at the reference's tolerance (rtol 5e-3, atol 6e-3; :35-42) — and tighter for fp32/fp64/complex."""
 import json
 import os
 
@@ -29,6 +30,14 @@ def test_golden_cases(te, name):
     b = torch.from_numpy(z["b"]).to(dtype).cuda()
     out = torch_einsum.einsum(meta["equation"], a, b)
     torch.cuda.synchronize()
+    assert out.dtype == dtype
+    if dtype.is_complex:
+        got, ref = out.to(torch.complex128).cpu().numpy(), z["out"].astype(np.complex128)
+        assert list(got.shape) == list(ref.shape)
+        for part in (np.real, np.imag):     # einsum_test.py:38-40
+            np.testing.assert_allclose(part(got), part(ref), rtol=5e-3, atol=6e-3)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+        return
     got = out.double().cpu().numpy()
     ref = z["out"].astype(np.float64)
     assert list(got.shape) == list(ref.shape)

@@ -206,3 +206,49 @@ def test_reduce_tensor_larger_than_4_gib(env):
         ref = A.sum(dim=dim, dtype=torch.float64)
         rel = float(((D.double() - ref).abs() / ref).max())
         assert rel < 2e-5, (kept, rel, p.describe())
+
+
+def test_bandwidth_config_at_true_size_2048_cubed(env):
+    """BASELINE configs[2] at its true size: 2048^3 fp32 (32 GiB per tensor, generated on the device — SURVEY 8d: never
+    mirror the samples' pinned-host copies), cutensorPermute abc->cab and cutensorReduce abc->ac (alpha 1.1, as
+    reduction.cu:45).  Size-independent checks: 2^18 sampled elements of the permutation must be bit-exact gathers of
+    the source, and the reduction must match fp64 sums over b at rtol 2e-4 (sums of 2048 terms ... 4M terms)."""
+    ct, ops, h, torch = env
+    n = 2048
+    numel = n ** 3
+    free, _ = torch.cuda.mem_get_info()
+    if free < 2 * numel * 4 + (6 << 30):
+        pytest.skip("needs two 32-GiB tensors in HBM (%d bytes free)" % free)
+    A = torch.empty(numel, dtype=torch.float32, device="cuda")
+    chunk = 1 << 28
+    for s in range(0, numel, chunk):          # counter-based fill (fixed seed), in chunks
+        idx = torch.arange(s, min(numel, s + chunk), device="cuda", dtype=torch.int64)
+        A[s:s + idx.numel()] = ((idx * 2654435761 + 1234) % 16777216).to(torch.float32) / 16777216.0
+        del idx
+    D = torch.empty(numel, dtype=torch.float32, device="cuda")
+    p = ops.permutation_plan(h, [n, n, n], "abc", [n, n, n], "cab")
+    p.permute(1.0, A.data_ptr(), D.data_ptr())
+    torch.cuda.synchronize()
+    At = A.view(n, n, n)                      # At[c][b][a]: row-major view of the column-major tensor with modes a, b, c
+    Dt = D.view(n, n, n)                      # Dt[b][a][c]: modes c, a, b
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    ia, ib, ic = (torch.randint(0, n, (1 << 18,), generator=g, device="cuda") for _ in range(3))
+    assert int((Dt[ib, ia, ic] != At[ic, ib, ia]).sum().item()) == 0
+    # corners and the last element (64-bit offsets)
+    for a_, b_, c_ in ((0, 0, 0), (n - 1, n - 1, n - 1), (n - 1, 0, n - 1), (0, n - 1, 1)):
+        assert float(Dt[b_, a_, c_]) == float(At[c_, b_, a_])
+    p.destroy()
+    del D, Dt
+    R = torch.zeros(n * n, dtype=torch.float32, device="cuda")
+    p = ops.reduction_plan(h, [n, n, n], "abc", [n, n], "ac", workspace_limit=1 << 30)
+    ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+    p.reduce(1.1, A.data_ptr(), 0.0, R.data_ptr(), R.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    ref = At.sum(dim=1, dtype=torch.float64) * 1.1           # [c][a]
+    got = R.view(n, n).double()                               # modes a, c -> row-major [c][a]
+    rel = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+    assert rel < 2e-4, (rel, p.describe())
+    p.destroy()
+    del A, At, R, ref, got
+    torch.cuda.empty_cache()

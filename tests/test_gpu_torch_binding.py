@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-BINARY = [  # einsum_test.py:49-118
+BINARY = [  # einsum_test.py:47-124: every case, plus the bf16 one the reference keeps commented out (:115-123)
     ("test0", (48, 37), (37, 74), "ik,kj->ij", "float32"),
     ("test0_complex", (50, 50), (50, 50), "ik,kj->ij", "complex64"),
     ("test1_complex", (50, 50, 50), (50, 50, 50), "lik,lkj->lij", "complex128"),
@@ -15,6 +15,7 @@ BINARY = [  # einsum_test.py:49-118
     ("test3", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "float32"),
     ("test4", (50, 50), (50, 50), "ik,kj->ij", "float16"),
     ("test5", (50, 50, 50), (50, 50, 50), "lik,lkj->lij", "float16"),
+    ("test6", (50, 50, 50, 20), (50, 50, 50, 20), "likm,lkjm->lij", "float16"),
     ("test7", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "float16"),
     ("test8", (2, 5, 50, 2), (5, 2, 50, 2), "mlik,lkjm", "float64"),
     ("test8_bf16", (20, 50, 50, 50), (50, 50, 50, 20), "mlik,lkjm->lij", "bfloat16"),
@@ -56,9 +57,9 @@ def test_einsum_function_forward_and_gradients(te, name, a_size, b_size, equatio
     torch, tein = te
     torch.manual_seed(0)
     dt = getattr(torch, dtype)
-    scale = 0.25 if dtype in ("float16", "bfloat16") else 1.0   # keep 16-bit sums of 50*20 terms inside the reference's atol
-    A = (torch.randn(*a_size, dtype=dt if dt.is_complex else torch.float32) * scale).to(dt).cuda().requires_grad_(True)
-    B = (torch.randn(*b_size, dtype=dt if dt.is_complex else torch.float32) * scale).to(dt).cuda().requires_grad_(True)
+    # inputs exactly as the reference draws them (einsum_test.py:141-147): unscaled randn, also for the 16-bit types
+    A = torch.randn(*a_size, dtype=dt if dt.is_complex else torch.float32).to(dt).cuda().requires_grad_(True)
+    B = torch.randn(*b_size, dtype=dt if dt.is_complex else torch.float32).to(dt).cuda().requires_grad_(True)
     out = tein.EinsumFunction.apply(equation, A, B)
     out.backward(torch.ones_like(out))
     rA = A.detach().to(_wide(torch, dtype)).cpu().requires_grad_(True)
@@ -127,3 +128,39 @@ def test_scalar_output_gradients_use_a_scalar_second_operand(te):
         torch.einsum(eq, rA, rB).backward(torch.tensor(1.5, device="cuda", dtype=torch.float64))
         _close(torch, A.grad, rA.grad.cpu(), "float32")
         _close(torch, B.grad, rB.grad.cpu(), "float32")
+
+
+def test_workspace_min_replan_when_the_workspace_cannot_be_allocated(te, monkeypatch):
+    """cutensor/torch/einsum.cc:104-123: if allocating the plan's workspace fails, the binding plans again with
+    CUTENSOR_WORKSPACE_MIN and runs with what that plan needs.  The headline equation (shrunk) wants split-K partials;
+    the first allocation is made to fail."""
+    torch, tein = te
+    torch.manual_seed(4)
+    A = torch.rand(96, 16, 16, 64, device="cuda")
+    B = torch.rand(64, 16, 16, 96, device="cuda")
+    eq = "abcd,dcbe->ae"
+    tein._plans.clear()
+    tein._workspace.clear()
+    want = tein.einsum(eq, A, B)
+    plan = next(iter(tein._plans.values()))
+    assert plan.required_workspace > 0 and plan.describe()["splitK"] > 1
+    tein._plans.clear()
+    tein._workspace.clear()
+    calls = []
+    real = tein._alloc_workspace
+
+    def failing(nbytes, device):
+        calls.append(nbytes)
+        if len(calls) == 1:
+            raise torch.cuda.OutOfMemoryError("simulated: no room for %d bytes" % nbytes)
+        return real(nbytes, device)
+
+    monkeypatch.setattr(tein, "_alloc_workspace", failing)
+    got = tein.einsum(eq, A, B)
+    plan = next(iter(tein._plans.values()))
+    assert len(calls) == 1 and plan.required_workspace == 0 and plan.describe()["splitK"] == 1     # the minimum: no partials
+    ref = torch.einsum(eq, A.double().cpu(), B.double().cpu())
+    torch.testing.assert_close(got.double().cpu(), ref, rtol=2e-4, atol=2e-3)
+    torch.testing.assert_close(want.double().cpu(), ref, rtol=2e-4, atol=2e-3)
+    tein._plans.clear()
+    tein._workspace.clear()

@@ -85,14 +85,81 @@ def test_headline_einsum_view():
 
 @pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz")))
 def test_against_reference_golden(name):
-    """torch.einsum outputs for the reference's own test cases (einsum_test.py:47-124) — the only
-    numerical pins the reference has for this path; tolerance is the reference's (:35-42)."""
+    """torch.einsum outputs for the reference's own test cases (einsum_test.py:45-125, the list parsed out of that file
+    by tests/golden/make_golden.py) — the only numerical pins the reference has for this path; tolerance is the
+    reference's (:35-42).  Every dtype of the list goes through the oracle's own entry point for it: fp32 / fp64,
+    complex64 / complex128, and the 16-bit types as bit patterns (fp64 accumulation, one rounding to the 16-bit type)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
-    a = z["a"].astype(np.float64 if meta["dtype"] == "float64" else np.float32)
-    b = z["b"].astype(a.dtype)
+    dt = meta["dtype"]
+    ref = z["out"]
+    if dt in ("float16", "bfloat16"):
+        kind = "f16" if dt == "float16" else "bf16"
+        a, b = oracle.to_bits(z["a"], kind), oracle.to_bits(z["b"], kind)
+        np.testing.assert_array_equal(oracle.from_bits(a, kind), z["a"].astype(np.float64))   # fixtures hold rounded inputs
+        out = oracle.from_bits(oracle.einsum(meta["equation"], a, b, h16=kind), kind)
+        np.testing.assert_allclose(out, ref.astype(np.float64), rtol=5e-3, atol=6e-3)
+        # one rounding of the exact sum: half an ulp of the 16-bit type
+        ulp = 2.0 ** -11 if kind == "f16" else 2.0 ** -8
+        np.testing.assert_allclose(out, ref.astype(np.float64), rtol=ulp, atol=1e-6)
+        return
+    a, b = z["a"], z["b"]
     out = oracle.einsum(meta["equation"], a, b)
-    np.testing.assert_allclose(out, z["out"].astype(np.float64), rtol=5e-3, atol=6e-3)
+    if np.iscomplexobj(ref):
+        for part in (np.real, np.imag):       # einsum_test.py:38-40 compares real and imaginary parts separately
+            np.testing.assert_allclose(part(out), part(ref), rtol=5e-3, atol=6e-3)
+        np.testing.assert_allclose(out, ref, rtol=2e-4 if dt == "complex64" else 1e-12, atol=1e-4 if dt == "complex64" else 1e-12)
+        return
+    np.testing.assert_allclose(out, ref.astype(np.float64), rtol=5e-3, atol=6e-3)
     # and much tighter than the reference's bound for the fp32/fp64 cases
-    if meta["dtype"] in ("float32", "float64"):
-        np.testing.assert_allclose(out, z["out"].astype(np.float64), rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(out, ref.astype(np.float64), rtol=2e-4, atol=1e-4)
+
+
+def test_golden_case_list_is_the_reference_list():
+    """The fixtures cover every parameter set of einsum_test.py:45-125 (ten live cases + the bf16 one the reference keeps
+    commented out) and carry the source line they were parsed from."""
+    metas = [json.loads(str(np.load(os.path.join(GOLDEN, f))["meta"])) for f in sorted(os.listdir(GOLDEN)) if f.endswith(".npz")]
+    names = sorted(m["reference_case"] + "/" + m["dtype"] for m in metas)
+    assert names == sorted(["test 0/float32", "test 0 (complex)/complex64", "test 1/complex128", "test 2/float32", "test 3/float32",
+                            "test 4/float16", "test 5/float16", "test 6/float16", "test 7/float16", "test 8/float64", "test 8/bfloat16"])
+    assert all(m["source"].startswith("cuTENSOR/python/cutensor/torch/einsum_test.py:") for m in metas)
+    assert [m["dtype"] for m in metas if m["commented_out_in_reference"]] == ["bfloat16"]
+
+
+def test_sixteen_bit_conversions_match_numpy_and_torch():
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(500) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 6e4)] +
+                       [np.array([0.0, -0.0, 65504, 65519.9, 65520, 1e9, 6e-8, 3e-8, 2.98e-8, 5.96e-8, np.inf, -np.inf])])
+    with np.errstate(over="ignore"):
+        np.testing.assert_array_equal(oracle.to_bits(x, "f16"), x.astype(np.float16).view(np.uint16))
+    np.testing.assert_array_equal(oracle.to_bits(x, "bf16"), torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16))
+
+
+def test_complex_contraction_with_conjugation():
+    # python/einsum.h:82-83,321-322: opA / opB in {IDENTITY, CONJ}, complex alpha / beta (contraction_jit.cu:205)
+    rng = np.random.default_rng(2)
+    A = (rng.standard_normal((4, 5, 3)) + 1j * rng.standard_normal((4, 5, 3))).astype(np.complex64)
+    B = (rng.standard_normal((5, 6, 3)) + 1j * rng.standard_normal((5, 6, 3))).astype(np.complex64)
+    C = (rng.standard_normal((4, 6, 3)) + 1j * rng.standard_normal((4, 6, 3))).astype(np.complex64)
+    D = np.zeros_like(C)
+    oracle.contract(A, "mkl", B, "knl", D, "mnl", alpha=1.5 - 0.5j, beta=0.25j, C=C, conjA=True)
+    ref = (1.5 - 0.5j) * np.einsum("mkl,knl->mnl", np.conj(A).astype(np.complex128), B.astype(np.complex128)) + 0.25j * C
+    np.testing.assert_allclose(D, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_naive_fp32_loop_is_the_literal_triple_loop():
+    """oracle_contract_f32_naive is the loop BASELINE.json names (fp32 accumulation in loop order): identical to a Python
+    restatement of that loop on a tiny case, and within fp32 round-off of the fp64-accumulating oracle."""
+    A = make_tensor([3, 4], 11)
+    B = make_tensor([4, 5], 12)
+    D = np.zeros((3, 5), dtype=np.float32, order="F")
+    oracle.contract(A, "mk", B, "kn", D, "mn", acc64=False)
+    ref = np.zeros((3, 5), dtype=np.float32)
+    for m in range(3):
+        for n in range(5):
+            acc = np.float32(0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(A[m, k] * B[k, n]))
+            ref[m, n] = acc
+    np.testing.assert_array_equal(D, ref)
