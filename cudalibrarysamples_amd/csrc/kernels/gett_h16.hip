@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "params.h"
 #include "launch.h"
@@ -942,6 +943,95 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Measurement only: the rate at which THIS device sustains nothing but independent v_mfma_f32_32x32x16_{bf16,f16} on a
+// given kind of operand data (one wave per SIMD, eight operand register pairs, no memory traffic at all).  On zeros it
+// is the nominal peak; on U(-1,1) data the power limit pulls the clock down and the rate differs from box to box by up to
+// 30 % — bench.py quotes the GETT kernel against both.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ void __launch_bounds__(256, 1) mfma_ceiling_kernel(const s16x8* __restrict__ data, float* out, int iters) {
+    s16x8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = data[(i * 2 + 0) * 256 + threadIdx.x];
+        b[i] = data[(i * 2 + 1) * 256 + threadIdx.x];
+    }
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i & 7] = h_mfma<BF>(a[i & 7], b[(i >> 1) & 7], acc[i & 7]);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][7];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+}  // namespace ctamd
+
+// dataKind 0: zeros, 1: U(-1,1) (fixed seed).  Returns 0 and the sustained TFLOP/s (after ~40 ms of burn-in), or -1.
+extern "C" int ctamdMeasureMfmaCeiling(int bf16, int dataKind, float* tflops) {
+    using namespace ctamd;
+    if (tflops == nullptr) return -1;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    const int cus = prop.multiProcessorCount;
+    const size_t n = 16 * 256 * 8;     // 8 operand pairs x 256 lanes x 8 elements
+    uint16_t* h = static_cast<uint16_t*>(malloc(n * 2));
+    if (h == nullptr) return -1;
+    uint32_t lcg = 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        lcg = lcg * 1664525u + 1013904223u;
+        const float x = dataKind == 0 ? 0.f : 2.f * (float)(lcg >> 8) / 16777216.f - 1.f;
+        if (bf16) {
+            uint32_t u;
+            memcpy(&u, &x, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            h[i] = (uint16_t)(u >> 16);
+        } else {
+            const _Float16 hf = (_Float16)x;
+            memcpy(&h[i], &hf, 2);
+        }
+    }
+    s16x8* d = nullptr;
+    float* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    if (hipMalloc((void**)&d, n * 2) == hipSuccess && hipMalloc((void**)&out, (size_t)cus * 256 * 4) == hipSuccess &&
+        hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        const int iters = 20000;       // ~12-25 ms per launch
+        auto launch = [&]() {
+            if (bf16) hipLaunchKernelGGL((mfma_ceiling_kernel<true>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+            else      hipLaunchKernelGGL((mfma_ceiling_kernel<false>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+        };
+        for (int w = 0; w < 3; ++w) launch();
+        (void)hipEventRecord(e0, nullptr);
+        for (int w = 0; w < 3; ++w) launch();
+        (void)hipEventRecord(e1, nullptr);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
+            const double flops = 3.0 * (double)cus * 4 * iters * 16 * 2.0 * 32 * 32 * 16;
+            *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+            rc = 0;
+        }
+    }
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (out) (void)hipFree(out);
+    free(h);
+    return rc;
+}
+
+namespace ctamd {
 
 // bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F)
 #define CTAMD_H16_ENTRY(bf, la, lb) \

@@ -117,6 +117,8 @@ lib.ctamdEinsumOutputShape.argtypes = [_vp, _i64p, ctypes.c_int]
 lib.ctamdEinsumPlan.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
 lib.ctamdEinsumReplan.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
 lib.ctamdEinsumReplan.restype = ctypes.c_int
+lib.ctamdMeasureMfmaCeiling.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+lib.ctamdMeasureMfmaCeiling.restype = ctypes.c_int
 lib.ctamdEinsumExecute.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.ctamdEinsumRawPlan.argtypes = [_vp]
 lib.ctamdEinsumRawPlan.restype = _vp
