@@ -390,11 +390,11 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c.family = 1;
     c.kernel = (v.dtype == HIP_R_16BF ? 0 : 4) + (v.layA == LAY_F ? 2 : 0) + (v.layB == LAY_F ? 1 : 0);
     // entries 0..7: eight waves, two rows alternated by barriers (ping-pong); 8..15: four waves per workgroup (one per
-    // SIMD); 16..23: eight free-running waves, one barrier per K-tile
+    // SIMD); 16..23: eight free-running waves, K-tile of 32, deep LDS ring, one barrier per K-tile
     static const int variant = [] {
         const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
         if (e && e[0] == '4') return 8;
-        if (e && e[0] == 'f') return 16;
+        if (e && e[0] == 's') return 16;
         return 0;
     }();
     c.kernel += variant;
@@ -425,7 +425,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 16, 8}) {      // ping-pong rows, free-running eight waves, four waves
+    for (int other : {0, 16, 8}) {      // ping-pong rows, streamed (free-running waves, deep ring), four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

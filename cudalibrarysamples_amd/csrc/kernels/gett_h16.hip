@@ -255,7 +255,10 @@ struct HOdometer {
 
 // TIMED (measurement-only instantiation, selected with CUTENSOR_AMD_H16_TIMED=1): waves 0 and 4 of workgroup 0
 // record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
-template <bool BF, int LA, int LB, bool TIMED = false>
+// ABL (measurement only, wrong results; CUTENSOR_AMD_H16_ABL with the default kernel): 1 = no LDS-DMA in the main loop,
+// 2 = no A-fragment reads in the main loop, 3 = neither fragment reads nor LDS-DMA (MFMAs + barriers only),
+// 4 = no B-fragment reads — what each kind of data movement costs under the power limit on random data.
+template <bool BF, int LA, int LB, bool TIMED = false, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     prefetch_kernarg<(int)sizeof(GettParams)>();
@@ -353,11 +356,16 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
                                             "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
 #define CTAMD_H_FENCE_B(BREG) asm volatile("" : "+v"(BREG[0]), "+v"(BREG[1]), "+v"(BREG[2]), "+v"(BREG[3]));
 #define CTAMD_H_FENCE_ACC(AH, BH) asm volatile("" : "+v"(acc[AH][0][BH]), "+v"(acc[AH][1][BH]));
-#define CTAMD_H_MFMA(AH, BH, BREG)                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+#define CTAMD_H_MFMA_RANGE(AH, BH, BREG, S0, S1)                                                   \
+    _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                          \
         acc[AH][0][BH] = h_mfma<BF>(a[0][s], BREG[s], acc[AH][0][BH]);                             \
         acc[AH][1][BH] = h_mfma<BF>(a[1][s], BREG[s], acc[AH][1][BH]);                             \
     }
+#define CTAMD_H_MFMA_Q(Q, S0, S1)                                                                  \
+        if constexpr ((Q) == 0) { CTAMD_H_MFMA_RANGE(0, 0, b0, S0, S1) CTAMD_H_FENCE_ACC(0, 0) }   \
+        if constexpr ((Q) == 1) { CTAMD_H_MFMA_RANGE(0, 1, b1, S0, S1) CTAMD_H_FENCE_ACC(0, 1) }   \
+        if constexpr ((Q) == 2) { CTAMD_H_MFMA_RANGE(1, 1, b1, S0, S1) CTAMD_H_FENCE_ACC(1, 1) }   \
+        if constexpr ((Q) == 3) { CTAMD_H_MFMA_RANGE(1, 0, b0, S0, S1) CTAMD_H_FENCE_ACC(1, 0) }
 
     // One phase.  P = LDS buffer of the current K-tile (compile time), Q = phase inside the tile.
     //   load segment : fragment reads of the operand half that changes, one half-tile of LDS-DMA, counted
@@ -374,14 +382,15 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     {                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         CTAMD_H_STAMP(Q, 0)                                                                        \
-        if constexpr ((Q) == 0) { CTAMD_H_READ_A((P) * 4 + 0) CTAMD_H_READ_B((P) * 4 + 2, b0) }   \
-        if constexpr ((Q) == 1) { CTAMD_H_READ_B((P) * 4 + 3, b1) }                                \
-        if constexpr ((Q) == 2) { CTAMD_H_READ_A((P) * 4 + 1) }                                    \
-        if constexpr ((Q) == 0) ob.template issue<false>(h_make_rsrc(bB + offB1), 1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
-        if constexpr ((Q) == 1) oa.template issue<false>(h_make_rsrc(bA + offA1), 1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
-        if constexpr ((Q) == 2) oa.template issue<false>(h_make_rsrc(bA + offA2), 0, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
+        if constexpr ((Q) == 0 && ABL != 2 && ABL != 3) { CTAMD_H_READ_A((P) * 4 + 0) }             \
+        if constexpr ((Q) == 0 && ABL != 4 && ABL != 3) { CTAMD_H_READ_B((P) * 4 + 2, b0) }         \
+        if constexpr ((Q) == 1 && ABL != 4 && ABL != 3) { CTAMD_H_READ_B((P) * 4 + 3, b1) }         \
+        if constexpr ((Q) == 2 && ABL != 2 && ABL != 3) { CTAMD_H_READ_A((P) * 4 + 1) }             \
+        if constexpr ((Q) == 0 && ABL != 1 && ABL != 3) ob.template issue<false>(h_make_rsrc(bB + offB1), 1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 1 && ABL != 1 && ABL != 3) oa.template issue<false>(h_make_rsrc(bA + offA1), 1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 2 && ABL != 1 && ABL != 3) oa.template issue<false>(h_make_rsrc(bA + offA2), 0, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
         if constexpr ((Q) == 3) {                                                                  \
-            ob.template issue<false>(h_make_rsrc(bB + offB2), 0, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
+            if constexpr (ABL != 1 && ABL != 3) ob.template issue<false>(h_make_rsrc(bB + offB2), 0, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
             offA1 = offA2; offB1 = offB2;                                                          \
             ++tNext;                                                                               \
             if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
@@ -398,10 +407,7 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         CTAMD_H_FENCE_A()                                                                          \
         if constexpr ((Q) == 0 || (Q) == 3) { CTAMD_H_FENCE_B(b0) } else { CTAMD_H_FENCE_B(b1) }   \
         __builtin_amdgcn_s_setprio(1);                                                             \
-        if constexpr ((Q) == 0) { CTAMD_H_MFMA(0, 0, b0) CTAMD_H_FENCE_ACC(0, 0) }                 \
-        if constexpr ((Q) == 1) { CTAMD_H_MFMA(0, 1, b1) CTAMD_H_FENCE_ACC(0, 1) }                 \
-        if constexpr ((Q) == 2) { CTAMD_H_MFMA(1, 1, b1) CTAMD_H_FENCE_ACC(1, 1) }                 \
-        if constexpr ((Q) == 3) { CTAMD_H_MFMA(1, 0, b0) CTAMD_H_FENCE_ACC(1, 0) }                 \
+        CTAMD_H_MFMA_Q(Q, 0, 4)                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         CTAMD_H_STAMP(Q, 5)                                                                        \
@@ -410,6 +416,9 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     }
 #define CTAMD_H_TILE(P) CTAMD_H_PHASE(P, 0) CTAMD_H_PHASE(P, 1) CTAMD_H_PHASE(P, 2) CTAMD_H_PHASE(P, 3)
 
+    if constexpr (ABL >= 2) {   // the fragments the ablated loop never refreshes
+        CTAMD_H_READ_A(0) CTAMD_H_READ_B(2, b0) CTAMD_H_READ_B(3, b1)
+    }
     unsigned long long* tstamp = nullptr;
     int t8 = 0;
     if constexpr (TIMED) {
@@ -700,148 +709,11 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
 }
 
 
-// =====================================================================================================
-// Free-running eight-wave variant (CUTENSOR_AMD_H16_WAVES=f): the tile, LDS images and source-side swizzles of the
-// kernels above, 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 4 x 2 accumulator fragments (128 registers) and
-// stages 8 KiB per K-tile.  Unlike gett_h16_kernel the two waves of a SIMD are NOT alternated by barriers: every wave
-// runs the four-wave kernel's software pipeline (fragment reads of k-step s + 1 and its share of the LDS-DMA pieces
-// interleaved with the 8 MFMAs of k-step s, two register sets), the SIMD's arbiter fills one wave's read / DMA-issue
-// slots with the other wave's MFMAs, and the workgroup meets ONCE per K-tile — in front of k-step 3, whose 8 MFMAs
-// (operands already in registers) are issued after the barrier and cover the first fragment reads of the next tile.
-// NP3 = LDS-DMA pieces (of the wave's 8 per K-tile) issued in k-step 3 right after the barrier frees the buffer; the
-// rest go out in k-step 0 of the next tile.
-// =====================================================================================================
-template <bool BF, int LA, int LB, int NP3 = 4>
-__global__ void __launch_bounds__(512, 2) gett_h16fr_kernel(const GettParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
-    prefetch_kernarg<(int)sizeof(GettParams)>();
-    const int tid  = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
-    const uint32_t tilesMN = p.tilesM * p.tilesN;
-    const uint32_t tilesAll = tilesMN * p.gL.total;
-    const uint32_t slice = id / tilesAll;
-    id -= slice * tilesAll;
-    const uint32_t l = id / tilesMN;
-    id -= l * tilesMN;
-    const uint32_t perGroup = 8u * p.tilesN;
-    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
-    const uint32_t first = grp * 8u;
-    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
-    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
-    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
-    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
-    const uint32_t tile0 = slice * tilesPerSlice;
-    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
-
-    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
-    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
-    HOperand<LA, 8> oa;
-    HOperand<LB, 8> ob;
-    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
-    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
-    bA += oa.base;
-    bB += ob.base;
-
-    uint32_t offK[4], offFa[4], offFb[2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { offK[s] = h_offK(lane, s); offFa[s] = h_offF(lane, s); }
-    offFb[0] = h_offF(lane, 2 * (wc & 1));
-    offFb[1] = h_offF(lane, 2 * (wc & 1) + 1);
-
-    HOdometer odo;
-    odo.init(p.gK, tile0 * kHBK);
-    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-
-    // piece n = 0..7 of a K-tile for this wave: operand half q = n >> 1 (A0, A1, B0, B1), piece i = n & 1
-#define CTAMD_FR_DMA(P, N, PAD)                                                                                     \
-    {                                                                                                              \
-        constexpr int q_ = (N) >> 1, i_ = (N) & 1;                                                                 \
-        if constexpr (q_ < 2) oa.template issue_piece<PAD>(h_make_rsrc(bA + odo.offA), q_, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave); \
-        else ob.template issue_piece<PAD>(h_make_rsrc(bB + odo.offB), q_ - 2, i_, ldsBase + ((P) * 4 + q_) * kHalfBytes, wave);   \
-    }
-#define CTAMD_FR_DMA_IF(P, N, PAD) if constexpr ((N) >= 0 && (N) < 8) CTAMD_FR_DMA(P, ((N) >= 0 && (N) < 8 ? (N) : 0), PAD)
-
-    // ---- prologue: K-tile 0 and the first NP3 pieces of K-tile 1 -----------------------------------------------
-    CTAMD_FR_DMA(0, 0, true) CTAMD_FR_DMA(0, 1, true) CTAMD_FR_DMA(0, 2, true) CTAMD_FR_DMA(0, 3, true)
-    CTAMD_FR_DMA(0, 4, true) CTAMD_FR_DMA(0, 5, true) CTAMD_FR_DMA(0, 6, true) CTAMD_FR_DMA(0, 7, true)
-    if (1 < nTiles) odo.advance(p.gK);           // past the end the last tile is re-staged (never read)
-    CTAMD_FR_DMA_IF(1, NP3 > 0 ? 0 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 1 ? 1 : -1, true)
-    CTAMD_FR_DMA_IF(1, NP3 > 2 ? 2 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 3 ? 3 : -1, true)
-    CTAMD_FR_DMA_IF(1, NP3 > 4 ? 4 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 5 ? 5 : -1, true)
-    CTAMD_FR_DMA_IF(1, NP3 > 6 ? 6 : -1, true) CTAMD_FR_DMA_IF(1, NP3 > 7 ? 7 : -1, true)
-    int tNext = 1;                                // K-tile the odometer describes
-    CTAMD_H_VMCNT(NP3);                           // this wave's pieces of tile 0
-    __builtin_amdgcn_s_barrier();
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    s16x8 a[2][4], b[2][2];                       // two register sets: k-step s uses set s & 1
-
-    const char* const aSlot0 = lds + wr * kHalfBytes;                 // A-half wr of buffer 0 (buffer 1: + 4 slots)
-    const char* const bSlot0 = lds + (2 + (wc >> 1)) * kHalfBytes;    // B-half wc >> 1 of buffer 0
-    const int bRow = 64 * (wc & 1);                                   // this wave's columns inside the B half
-    // fragment f = 0..5 of k-step S from buffer P into register set SET: f < 2 -> B columns bRow + 32 f, else A rows 32 (f - 2)
-#define CTAMD_FR_READ(P, S, SET, F)                                                                                 \
-    {                                                                                                              \
-        if constexpr ((F) < 2) b[SET][F] = h_read_frag<LB>(bSlot0 + (P) * 4 * kHalfBytes, bRow + 32 * (F), S, offK, offFb[F]);          \
-        else a[SET][(F) - 2] = h_read_frag<LA>(aSlot0 + (P) * 4 * kHalfBytes, 32 * ((F) - 2), S, offK, offFa[(F) - 2]);        \
-    }
-#define CTAMD_FR_MFMA(SET, M) acc[(M) >> 1][(M) & 1] = h_mfma<BF>(a[SET][(M) >> 1], b[SET][(M) & 1], acc[(M) >> 1][(M) & 1]);
-    // group G = 0..3 of k-step S < 3: reads of step S + 1 (G = 0: both B fragments, G = 1: A rows 0-63, G = 2, 3: one A
-    // fragment each), two MFMAs of step S, and in k-step 0 one of the pieces NP3.. of the tile going into the other buffer
-#define CTAMD_FR_GROUP(P, S, G)                                                                                     \
-    if constexpr ((G) == 0) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 0) CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 1) } \
-    if constexpr ((G) == 1) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 2) CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 3) } \
-    if constexpr ((G) == 2) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 4) }                                         \
-    if constexpr ((G) == 3) { CTAMD_FR_READ(P, (S) + 1, ((S) + 1) & 1, 5) }                                         \
-    CTAMD_FR_MFMA((S) & 1, 2 * (G))                                                                                \
-    if constexpr ((S) == 0) { CTAMD_FR_DMA_IF((P) ^ 1, NP3 + (G), false) }                                          \
-    CTAMD_FR_MFMA((S) & 1, 2 * (G) + 1)                                                                            \
-    if constexpr ((S) == 0) { CTAMD_FR_DMA_IF((P) ^ 1, NP3 + 4 + (G), false) }                                      \
-    __builtin_amdgcn_sched_barrier(0);
-#define CTAMD_FR_STEP(P, S) CTAMD_FR_GROUP(P, S, 0) CTAMD_FR_GROUP(P, S, 1) CTAMD_FR_GROUP(P, S, 2) CTAMD_FR_GROUP(P, S, 3)
-    // k-step 3 (after the barrier): reads of the next tile's step 0 from the other buffer, pieces 0 .. NP3 - 1 of tile t + 2
-    // into this buffer, MFMAs of step 3
-#define CTAMD_FR_LAST(P, G)                                                                                         \
-    if constexpr ((G) == 0) { CTAMD_FR_READ((P) ^ 1, 0, 0, 0) CTAMD_FR_READ((P) ^ 1, 0, 0, 1) }                     \
-    if constexpr ((G) == 1) { CTAMD_FR_READ((P) ^ 1, 0, 0, 2) CTAMD_FR_READ((P) ^ 1, 0, 0, 3) }                     \
-    if constexpr ((G) == 2) { CTAMD_FR_READ((P) ^ 1, 0, 0, 4) }                                                     \
-    if constexpr ((G) == 3) { CTAMD_FR_READ((P) ^ 1, 0, 0, 5) }                                                     \
-    CTAMD_FR_MFMA(1, 2 * (G))                                                                                      \
-    if constexpr (NP3 <= 4) { CTAMD_FR_DMA_IF(P, (G) < NP3 ? (G) : -1, false) }                                     \
-    else { CTAMD_FR_DMA_IF(P, 2 * (G) < NP3 ? 2 * (G) : -1, false) }                                               \
-    CTAMD_FR_MFMA(1, 2 * (G) + 1)                                                                                  \
-    if constexpr (NP3 > 4) { CTAMD_FR_DMA_IF(P, 2 * (G) + 1 < NP3 ? 2 * (G) + 1 : -1, false) }                      \
-    __builtin_amdgcn_sched_barrier(0);
-#define CTAMD_FR_TILE(P)                                                                                            \
-    CTAMD_FR_STEP(P, 0)                                                                                            \
-    ++tNext;                                                                                                       \
-    if (tNext < nTiles) odo.advance(p.gK);                                                                         \
-    CTAMD_FR_STEP(P, 1) CTAMD_FR_STEP(P, 2)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    CTAMD_H_LGKM0();                                                                                               \
-    CTAMD_H_VMCNT(0);                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
-    CTAMD_FR_LAST(P, 0) CTAMD_FR_LAST(P, 1) CTAMD_FR_LAST(P, 2) CTAMD_FR_LAST(P, 3)
-
-    // first fragments of tile 0
-    CTAMD_FR_READ(0, 0, 0, 0) CTAMD_FR_READ(0, 0, 0, 1) CTAMD_FR_READ(0, 0, 0, 2)
-    CTAMD_FR_READ(0, 0, 0, 3) CTAMD_FR_READ(0, 0, 0, 4) CTAMD_FR_READ(0, 0, 0, 5)
-    int t = 0;
-    for (; t + 1 < nTiles; t += 2) { CTAMD_FR_TILE(0) CTAMD_FR_TILE(1) }
-    if (t < nTiles) { CTAMD_FR_TILE(0) }
-    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
-
+// Epilogue of the 2 (M) x 4 (N) wave grid with 128 x 64 per wave (gett_h16s_kernel): split-K partial
+// tile or D = alpha * acc + beta * C with one rounding to the 16-bit type.
+template <bool BF>
+__device__ __forceinline__ void h_epilogue_128x64(const GettParams& p, const f32x16 (&acc)[4][2], uint32_t m0, uint32_t n0, int wr, int wc,
+                                                  uint32_t slice, uint32_t l, int lane) {
     const uint32_t mW = m0 + 128 * wr, nW = n0 + 64 * wc;     // this wave's 128 x 64 block
     if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
         const uint32_t Mt = p.gM.total, Nt = p.gN.total;
@@ -906,14 +778,266 @@ __global__ void __launch_bounds__(512, 2) gett_h16fr_kernel(const GettParams p) 
     store_row(acc[3][0], acc[3][1], mW + 96);
 }
 
+// =====================================================================================================
+// Streamed eight-wave variant (CUTENSOR_AMD_H16_WAVES=s; a measured alternative and an autotuning candidate, not the
+// default): the tile and source-side swizzles of the kernels above, 8 waves as 2 (M) x 4 (N), a wave owns 128 x 64 = 4 x 2
+// accumulator fragments.  Unlike gett_h16_kernel the two waves of a SIMD are NOT alternated by barriers: every wave
+// runs a software pipeline of its own (fragment reads of k-step s + 1 and its LDS-DMA pieces interleaved with the 8
+// MFMAs of k-step s, two register sets) and the SIMD's arbiter fills one wave's read / DMA-issue slots with the other
+// wave's MFMAs.  K-tile of 32 and an NS-deep LDS ring (NS x 32 KiB): NS - 2 ... NS - 1 K-tiles (64-96 KiB per CU for
+// NS = 4, 5) are in flight behind a counted vmcnt.  Per K-tile a wave issues 16 MFMAs (two k-steps), 12 fragment
+// reads, 4 LDS-DMA pieces and meets the workgroup ONCE — in front of k-step 1, whose 8 MFMAs are already in registers
+// and cover the first fragment reads of the next tile; the tile's buffer is refilled (tile t + NS) behind that barrier.
+// Measured: within 0-7 % of gett_h16_kernel on U(-1,1) data depending on the operand layout, 21 %
+// behind it on zero-filled operands — the fine interleave of one wave's reads with its own MFMAs stalls on the matrix
+// pipe its partner occupies; a burst-ordered form (loads | MFMAs in opposite order on the two wave rows) measured slower still.
+//   LDS images per half-tile (8 KiB): LAY_K [128 rows][32 k] (64-byte rows), 16-byte unit u of row r at slot
+//   u ^ ((r >> 3) & 3): the four 16-lane groups of a ds_read_b128 fragment read (32 rows x one unit) each touch all 64
+//   banks once; LAY_F [32 k][128 rows] — the 256-byte k-rows and rotation of the 64-deep kernels, half as many rows.
+// =====================================================================================================
+constexpr int kSBK = 32;
+constexpr int kSHalfBytes = 8192;
+
+template <int LAY>
+struct HOperandS {        // one 1-KiB piece per half-tile and wave (8 waves)
+    uint32_t src[2];
+    uint64_t base;
+    __device__ __forceinline__ void init(const ModeGroup& gFree, int64_t strideK0, uint32_t row0, int wave, int lane) {
+        int64_t off[2];
+        int64_t mn = INT64_MAX;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (LAY == LAY_K) {
+                const int r = 16 * wave + (lane >> 2), p = lane & 3;
+                const int u = p ^ ((r >> 3) & 3);
+                uint32_t row = row0 + 128 * h + r;
+                if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
+                off[h] = (group_offset<0>(gFree, row) + 8 * u) * 2;
+            } else {
+                const int kk = 4 * wave + (lane >> 4), p = lane & 15;
+                const int u = p ^ (4 * ((lane >> 4) & 3));
+                uint32_t row = row0 + 128 * h + 8 * u;
+                if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
+                off[h] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
+            }
+            mn = off[h] < mn ? off[h] : mn;
+        }
+        const int64_t mnW = (int64_t)h_uniform64((uint64_t)h_wave_min(mn));
+        base = (uint64_t)mnW;
+        src[0] = (uint32_t)(off[0] - mnW);
+        src[1] = (uint32_t)(off[1] - mnW);
+    }
+    template <bool PAD>
+    __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t slotByte, int wave) const {
+        h_dma16<PAD>(X, src[h], slotByte + (uint32_t)wave * 1024u);
+    }
+};
+
+__device__ __forceinline__ uint32_t h_offK32(int lane, int s) {     // fragment read of k-step s (0, 1) in the 64-byte-row image
+    const int u = (lane >> 5) + 2 * s;
+    return (uint32_t)((lane & 31) * 64 + ((u ^ ((lane >> 3) & 3)) << 4));
+}
+template <int LAY>
+__device__ __forceinline__ s16x8 h_read_frag32(const char* slot, int rb, int s, const uint32_t (&offK)[2], uint32_t offF) {
+    if constexpr (LAY == LAY_K) {
+        return *reinterpret_cast<const s16x8*>(slot + rb * 64 + offK[s]);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef s16x4 __attribute__((address_space(3))) * lptr;
+        const char* p = slot + s * 4096 + offF;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 1024));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#else
+        (void)slot; (void)rb; (void)s; (void)offK; (void)offF; return s16x8{};
+#endif
+    }
+}
+
+// K-tile walk in steps of 32 (HOdometer with the tile length as a member)
+struct HOdometerS {
+    uint32_t j0, n0, j1, e1, hi;
+    uint64_t offA, offB, stepA, stepB, wrapA, wrapB;
+    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
+        const uint32_t E0 = gK.div[0].d;
+        n0 = HOdometer::sgpr(E0 / kSBK);
+        e1 = HOdometer::sgpr(gK.div[1].d);
+        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
+        j0 = HOdometer::sgpr((k0 - q0 * E0) / kSBK);
+        hi = HOdometer::sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
+        j1 = HOdometer::sgpr(q0 - hi * e1);
+        offA = h_uniform64((uint64_t)(group_offset<0>(gK, k0) * 2));
+        offB = h_uniform64((uint64_t)(group_offset<1>(gK, k0) * 2));
+        stepA = h_uniform64((uint64_t)((int64_t)kSBK * gK.stride[0][0] * 2));
+        stepB = h_uniform64((uint64_t)((int64_t)kSBK * gK.stride[1][0] * 2));
+        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
+        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
+    }
+    __device__ __forceinline__ void advance(const ModeGroup& gK) {
+        const bool c0 = (j0 + 1 == n0);
+        j0 = c0 ? 0u : j0 + 1;
+        offA += c0 ? wrapA : stepA;
+        offB += c0 ? wrapB : stepB;
+        j1 += c0 ? 1u : 0u;
+        if (j1 == e1) {
+            j1 = 0;
+            hi += 1;
+            const uint32_t k = hi * e1 * gK.div[0].d;
+            if (k < gK.total) {
+                offA = h_uniform64((uint64_t)(group_offset<0>(gK, k) * 2));
+                offB = h_uniform64((uint64_t)(group_offset<1>(gK, k) * 2));
+            }
+        }
+    }
+};
+
+template <bool BF, int LA, int LB, int NS>
+__global__ void __launch_bounds__(512, 2) gett_h16s_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[NS * 4 * kSHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kSBK, tilesPerSlice = p.kPerSlice / kSBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
+    HOperandS<LA> oa;
+    HOperandS<LB> ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    bA += oa.base;
+    bB += ob.base;
+
+    uint32_t offK[2], offFa[4], offFb[2];
+    offK[0] = h_offK32(lane, 0);
+    offK[1] = h_offK32(lane, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offFa[i] = h_offF(lane, i);
+    offFb[0] = h_offF(lane, 2 * (wc & 1));
+    offFb[1] = h_offF(lane, 2 * (wc & 1) + 1);
+
+    HOdometerS odo;
+    odo.init(p.gK, tile0 * kSBK);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // the wave's four pieces of the K-tile the odometer describes, into ring buffer P: A-half 0, A-half 1, B-half 0, B-half 1
+#define CTAMD_S_DMA(P, Q, PAD)                                                                                      \
+    {                                                                                                              \
+        if constexpr ((Q) < 2) oa.template issue<PAD>(h_make_rsrc(bA + odo.offA), (Q), ldsBase + ((P) * 4 + (Q)) * kSHalfBytes, wave);      \
+        else ob.template issue<PAD>(h_make_rsrc(bB + odo.offB), (Q) - 2, ldsBase + ((P) * 4 + (Q)) * kSHalfBytes, wave);                 \
+    }
+    // ---- prologue: fill the whole ring (tiles 0 .. NS - 1; past the end the last tile is re-staged, never read) ----
+    int tNext = 0;                                // K-tile the odometer describes
+#define CTAMD_S_FILL(P)                                                                                             \
+    if constexpr ((P) < NS) {                                                                                      \
+        CTAMD_S_DMA((P) < NS ? (P) : 0, 0, true) CTAMD_S_DMA((P) < NS ? (P) : 0, 1, true)                          \
+        CTAMD_S_DMA((P) < NS ? (P) : 0, 2, true) CTAMD_S_DMA((P) < NS ? (P) : 0, 3, true)                          \
+        ++tNext;                                                                                                   \
+        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+    }
+    CTAMD_S_FILL(0) CTAMD_S_FILL(1) CTAMD_S_FILL(2) CTAMD_S_FILL(3) CTAMD_S_FILL(4) CTAMD_S_FILL(5)
+    CTAMD_H_VMCNT(4 * (NS - 1));                  // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][2];                       // two register sets: k-step s uses set s
+
+    const char* const aSlot0 = lds + wr * kSHalfBytes;                 // A-half wr of buffer 0 (buffer P: + 4 P slots)
+    const char* const bSlot0 = lds + (2 + (wc >> 1)) * kSHalfBytes;    // B-half wc >> 1 of buffer 0
+    const int bRow = 64 * (wc & 1);
+#define CTAMD_S_READ(P, S, SET, F)                                                                                  \
+    {                                                                                                              \
+        if constexpr ((F) < 2) b[SET][F] = h_read_frag32<LB>(bSlot0 + (P) * 4 * kSHalfBytes, bRow + 32 * (F), S, offK, offFb[F]);       \
+        else a[SET][(F) - 2] = h_read_frag32<LA>(aSlot0 + (P) * 4 * kSHalfBytes, 32 * ((F) - 2), S, offK, offFa[(F) - 2]);     \
+    }
+#define CTAMD_S_MFMA(SET, M) acc[(M) >> 1][(M) & 1] = h_mfma<BF>(a[SET][(M) >> 1], b[SET][(M) & 1], acc[(M) >> 1][(M) & 1]);
+    // k-step 0 of the tile in buffer P: reads of k-step 1 beside the MFMAs of k-step 0
+#define CTAMD_S_G0(P, G)                                                                                            \
+    if constexpr ((G) == 0) { CTAMD_S_READ(P, 1, 1, 0) CTAMD_S_READ(P, 1, 1, 1) }                                   \
+    if constexpr ((G) == 1) { CTAMD_S_READ(P, 1, 1, 2) CTAMD_S_READ(P, 1, 1, 3) }                                   \
+    if constexpr ((G) == 2) { CTAMD_S_READ(P, 1, 1, 4) }                                                            \
+    if constexpr ((G) == 3) { CTAMD_S_READ(P, 1, 1, 5) }                                                            \
+    CTAMD_S_MFMA(0, 2 * (G)) CTAMD_S_MFMA(0, 2 * (G) + 1)                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (after the barrier): reads of the next tile's k-step 0 from buffer PN, one piece of tile t + NS into buffer P
+#define CTAMD_S_G1(P, PN, G)                                                                                        \
+    if constexpr ((G) == 0) { CTAMD_S_READ(PN, 0, 0, 0) CTAMD_S_READ(PN, 0, 0, 1) }                                 \
+    if constexpr ((G) == 1) { CTAMD_S_READ(PN, 0, 0, 2) CTAMD_S_READ(PN, 0, 0, 3) }                                 \
+    if constexpr ((G) == 2) { CTAMD_S_READ(PN, 0, 0, 4) }                                                           \
+    if constexpr ((G) == 3) { CTAMD_S_READ(PN, 0, 0, 5) }                                                           \
+    CTAMD_S_MFMA(1, 2 * (G))                                                                                       \
+    CTAMD_S_DMA(P, G, false)                                                                                       \
+    CTAMD_S_MFMA(1, 2 * (G) + 1)                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_S_SYNC()                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        CTAMD_H_LGKM0();                                                                                           \
+        CTAMD_H_VMCNT(4 * (NS - 2));              /* tile t + 1 has landed (this wave's pieces) */                 \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_S_TILE(P, W)                                                                                          \
+    {                                                                                                              \
+        constexpr int PN_ = ((P) + 1) % NS;                                                                        \
+        CTAMD_S_G0(P, 0) CTAMD_S_G0(P, 1) CTAMD_S_G0(P, 2) CTAMD_S_G0(P, 3)                                        \
+        CTAMD_S_SYNC()                                                                                             \
+        CTAMD_S_G1(P, PN_, 0) CTAMD_S_G1(P, PN_, 1) CTAMD_S_G1(P, PN_, 2) CTAMD_S_G1(P, PN_, 3)                    \
+        ++tNext;                                                                                                   \
+        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+    }
+#define CTAMD_S_LOOP(W)                                                                                             \
+    {                                                                                                              \
+        int t = 0;                                                                                                 \
+        if constexpr (NS == 4) {                                                                                   \
+            for (; t + 3 < nTiles; t += 4) { CTAMD_S_TILE(0, W) CTAMD_S_TILE(1, W) CTAMD_S_TILE(2, W) CTAMD_S_TILE(3, W) }   \
+            if (t < nTiles) { CTAMD_S_TILE(0, W) }                                                                 \
+            if (t + 1 < nTiles) { CTAMD_S_TILE(1, W) }                                                             \
+            if (t + 2 < nTiles) { CTAMD_S_TILE(2, W) }                                                             \
+        } else {                                                                                                   \
+            for (; t + 4 < nTiles; t += 5) { CTAMD_S_TILE(0, W) CTAMD_S_TILE(1, W) CTAMD_S_TILE(2, W) CTAMD_S_TILE(3, W) CTAMD_S_TILE(4, W) } \
+            if (t < nTiles) { CTAMD_S_TILE(0, W) }                                                                 \
+            if (t + 1 < nTiles) { CTAMD_S_TILE(1, W) }                                                             \
+            if (t + 2 < nTiles) { CTAMD_S_TILE(2, W) }                                                             \
+            if (t + 3 < nTiles) { CTAMD_S_TILE(3, W) }                                                             \
+        }                                                                                                          \
+    }
+
+    // first fragments of tile 0
+    CTAMD_S_READ(0, 0, 0, 0) CTAMD_S_READ(0, 0, 0, 1) CTAMD_S_READ(0, 0, 0, 2)
+    CTAMD_S_READ(0, 0, 0, 3) CTAMD_S_READ(0, 0, 0, 4) CTAMD_S_READ(0, 0, 0, 5)
+    CTAMD_S_LOOP(2)
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+    h_epilogue_128x64<BF>(p, acc, m0, n0, wr, wc, slice, l, lane);
+}
+
 template <bool BF, int LA, int LB>
-static hipError_t launch_h16fr(const GettParams& p, hipStream_t stream) {
-    static const int np3 = [] { const char* e = getenv("CUTENSOR_AMD_H16_NP3"); return e ? atoi(e) : 4; }();
-    if (np3 == 8) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 8>), dim3(p.nBlocks), dim3(512), 0, stream, p);
-    else if (np3 == 0) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 0>), dim3(p.nBlocks), dim3(512), 0, stream, p);
-    else if (np3 == 1) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 1>), dim3(p.nBlocks), dim3(512), 0, stream, p);
-    else if (np3 == 2) hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 2>), dim3(p.nBlocks), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((gett_h16fr_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+static hipError_t launch_h16s(const GettParams& p, hipStream_t stream) {
+    static const int ns = [] { const char* e = getenv("CUTENSOR_AMD_H16_STAGES"); return e ? atoi(e) : 5; }();
+    if (ns == 4) hipLaunchKernelGGL((gett_h16s_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gett_h16s_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -939,6 +1063,13 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
             hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(512), 0, stream, p);
             return hipGetLastError();
         }
+    }
+    if constexpr (BF && LA == LAY_K && LB == LAY_K) {   // ablations: one instantiation ('km,kn' bf16)
+        static const int abl = [] { const char* e = getenv("CUTENSOR_AMD_H16_ABL"); return e ? atoi(e) : 0; }();
+        if (abl == 1) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 1>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 2) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 2>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 3) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 3>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 4) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
@@ -1038,8 +1169,8 @@ namespace ctamd {
     {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 0, &launch_h16<bf, la, lb>, 0},
 #define CTAMD_H16W4_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 2, 1, 0, &launch_h16w4<bf, la, lb>, 0},
-#define CTAMD_H16FR_ENTRY(bf, la, lb) \
-    {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 2, 1, 0, &launch_h16fr<bf, la, lb>, 0},
+#define CTAMD_H16S_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kSBK, 2, 4, 1, la, lb, 512, 4, 1, 0, &launch_h16s<bf, la, lb>, 0},
 static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)
@@ -1050,11 +1181,11 @@ static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16W4_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_K, LAY_F)
     CTAMD_H16W4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4_ENTRY(false, LAY_F, LAY_F)
-    // entries 16..23: the free-running eight-wave variant, same order
-    CTAMD_H16FR_ENTRY(true, LAY_K, LAY_K) CTAMD_H16FR_ENTRY(true, LAY_K, LAY_F)
-    CTAMD_H16FR_ENTRY(true, LAY_F, LAY_K) CTAMD_H16FR_ENTRY(true, LAY_F, LAY_F)
-    CTAMD_H16FR_ENTRY(false, LAY_K, LAY_K) CTAMD_H16FR_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16FR_ENTRY(false, LAY_F, LAY_K) CTAMD_H16FR_ENTRY(false, LAY_F, LAY_F)};
+    // entries 16..23: the streamed eight-wave variant (free-running waves, K-tile 32, deep LDS ring), same order
+    CTAMD_H16S_ENTRY(true, LAY_K, LAY_K) CTAMD_H16S_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16S_ENTRY(true, LAY_F, LAY_K) CTAMD_H16S_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16S_ENTRY(false, LAY_K, LAY_K) CTAMD_H16S_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16S_ENTRY(false, LAY_F, LAY_K) CTAMD_H16S_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16_kernels(int* count) {
     *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));

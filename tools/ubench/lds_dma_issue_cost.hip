@@ -18,6 +18,17 @@ __device__ __forceinline__ void dma_piece(rsrc_t r, uint32_t laneBytes, uint32_t
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsByte), "v"(laneBytes), "s"(r) : "memory");
 }
 
+// the same 1 KiB as four dword pieces (buffer_load_dword ... lds: 256 B per wave-instruction)
+__device__ __forceinline__ void dma_piece_b32x4(rsrc_t r, uint32_t laneBytes, uint32_t ldsByte) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(ldsByte + 256u * q), "v"(laneBytes / 4u + 256u * q), "s"(r) : "memory");
+}
+// one dword piece (a quarter of the bytes), for modes that spread the four quarters over the MFMA stream
+__device__ __forceinline__ void dma_piece_b32(rsrc_t r, uint32_t laneBytes, uint32_t ldsByte) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(ldsByte), "v"(laneBytes), "s"(r) : "memory");
+}
+
 template <int MODE, int PERIOD>
 __global__ void __launch_bounds__(512, 1) k(const char* src, float* out, int iters) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
@@ -46,8 +57,17 @@ __global__ void __launch_bounds__(512, 1) k(const char* src, float* out, int ite
                     dma_piece(r, (uint32_t)lane * 16u + (piece & 63u) * 1024u, ldsBase + (piece & 63u) * 1024u);
                     ++piece;
                 }
+                if (MODE == 3 && (i % PERIOD) == PERIOD - 1) {
+                    dma_piece_b32x4(r, (uint32_t)lane * 16u + (piece & 63u) * 1024u, ldsBase + (piece & 63u) * 1024u);
+                    ++piece;
+                }
+                if (MODE == 4 && PERIOD >= 4 && (i % (PERIOD / 4)) == (PERIOD / 4) - 1) {   // same bytes per MFMA, spread out
+                    dma_piece_b32(r, (uint32_t)lane * 4u + (piece & 255u) * 256u, ldsBase + (piece & 255u) * 256u);
+                    ++piece;
+                }
             }
             if (MODE == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (MODE == 3 || MODE == 4) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         }
         for (int i = 0; i < 8; ++i) res += acc[i][0] + acc[i][9];
     } else if (MODE == 2) {
@@ -90,6 +110,11 @@ int main() {
     run<1, 4>("self-issued pieces", src, out, cus);
     run<1, 2>("self-issued pieces", src, out, cus);
     run<1, 1>("self-issued pieces", src, out, cus);
+    run<3, 4>("self-issued, 4 dword pieces back to back per KiB", src, out, cus);
+    run<3, 2>("self-issued, 4 dword pieces back to back per KiB", src, out, cus);
+    run<4, 4>("self-issued, one dword piece per MFMA (1 KiB per 4 MFMAs)", src, out, cus);
+    run<4, 8>("self-issued, one dword piece per 2 MFMAs (1 KiB per 8 MFMAs)", src, out, cus);
+    run<1, 8>("self-issued pieces", src, out, cus);
     run<2, 4>("dedicated issuer waves", src, out, cus);
     run<2, 2>("dedicated issuer waves", src, out, cus);
     run<2, 1>("dedicated issuer waves", src, out, cus);
