@@ -1,0 +1,40 @@
+#!/bin/bash
+# The round's rocprofv3 evidence in one GPU call.  Kernel-trace runs and --pmc runs are separate invocations (never combined).
+# usage: tools/gpu_profile_all.sh <tag>      -> gpurun_out/<tag>/*.summary.txt (+ pmc_traffic_*.json, bench logs)
+set -u
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+summ() {   # summ <dir> <name>
+  f=$(find $OUT/$1 -name '*.db' | head -1)
+  [ -n "$f" ] && (cd $ROOT && python tools/rocprof_summary.py $f > $OUT/$2.summary.txt 2>&1)
+}
+# ---- 1. headline einsum (bench.py): trace + three PMC passes ----------------------------------------------------------
+cd $ROOT && bash tools/gpu_profile.sh $TAG/einsum > $OUT/einsum_profile.log 2>&1
+for d in trace pmc_sq pmc_fetch pmc_write; do cp $OUT/einsum/$d.summary.txt $OUT/einsum_$d.summary.txt 2>/dev/null; done
+cp $OUT/einsum/pmc_traffic_einsum.json $OUT/pmc_traffic_einsum.json 2>/dev/null
+# ---- 2. bf16 8192^3, default kernel, two layouts: trace, SQ, FETCH, WRITE ---------------------------------------------
+cd /tmp
+for L in mk,kn km,kn; do
+  N=$(echo $L | tr , _)
+  H16="python $ROOT/tools/bench_h16.py --layout $L --reps 30"
+  rocprofv3 --kernel-trace --stats -d $OUT/h16_${N}_trace -o r -- $H16 > $OUT/h16_${N}_trace.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/h16_${N}_sq -o r -- $H16 > $OUT/h16_${N}_sq.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $OUT/h16_${N}_fetch -o r -- $H16 > $OUT/h16_${N}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/h16_${N}_write -o r -- $H16 > $OUT/h16_${N}_write.log 2>&1
+  for p in trace sq fetch write; do summ h16_${N}_$p h16_${N}_$p; done
+done
+# ---- 3. the whole default bench line (secondary configs included): kernel trace only ------------------------------------
+rocprofv3 --kernel-trace --stats -d $OUT/bench_all_trace -o r -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu > $OUT/bench_all_trace.log 2>&1
+summ bench_all_trace bench_all_trace
+# ---- 4. un-profiled reference lines ------------------------------------------------------------------------------------
+cd $ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.log 2>&1
+python bench.py > $OUT/bench_default.log 2>&1
+find $OUT -name '*.csv' -size +1M -delete
+find $OUT -name '*.db' -delete
+rm -rf $OUT/einsum/trace $OUT/einsum/pmc_sq $OUT/einsum/pmc_fetch $OUT/einsum/pmc_write
+du -sh $OUT
+ls $OUT
