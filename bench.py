@@ -78,7 +78,7 @@ def cpu_baseline(a_np, b_np):
 # ---------------------------------------------------------------------------------------------------------
 # cuTENSORMg measurement (one process, n devices)
 # ---------------------------------------------------------------------------------------------------------
-def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True):
+def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True, virtual=False):
     """C[i,j] = A[i,k] B[k,j] fp32 through libcutensorMg on devices 0..ndev-1: i cut ndev ways (A, C row slabs), B in
     column slabs (all-gathered).  Returns a dict with the throughput of `steps` back-to-back calls and the sample's
     protocol (wall clock + per-device sync, min of `sample_reps`)."""
@@ -89,25 +89,26 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True):
     block = [dict(i=E // n), dict(j=E // n), dict(i=E // n, j=E // n)]
     dcount = [dict(i=n), dict(j=n), dict(i=n)]
     flop = 2.0 * E * E * E
-    con = cm.Contraction(list(range(n)), modes, dict(i=E, j=E, k=E), block, dcount)
+    devs = [0] * n if virtual else list(range(n))      # virtual: n logical devices on GPU 0 (exercises the machinery, not xGMI)
+    con = cm.Contraction(devs, modes, dict(i=E, j=E, k=E), block, dcount)
     try:
         d = con.describe()
         cells = []
         for k in range(3):
             row = []
             for g in range(n):
-                gen = torch.Generator(device="cuda:%d" % g)
+                gen = torch.Generator(device="cuda:%d" % devs[g])
                 gen.manual_seed(1234 + 17 * k + g)
-                row.append(torch.rand(E * (E // n), generator=gen, device="cuda:%d" % g, dtype=torch.float32))
+                row.append(torch.rand(E * (E // n), generator=gen, device="cuda:%d" % devs[g], dtype=torch.float32))
             cells.append(row)
-        ws = [torch.empty(int(con.ws_sizes[g]), dtype=torch.uint8, device="cuda:%d" % g) for g in range(n)]
-        streams = [torch.cuda.Stream(device=g) for g in range(n)]
+        ws = [torch.empty(int(con.ws_sizes[g]), dtype=torch.uint8, device="cuda:%d" % devs[g]) for g in range(n)]
+        streams = [torch.cuda.Stream(device=devs[g]) for g in range(n)]
         ptr = [[t.data_ptr() for t in row] for row in cells]
         wsp = [t.data_ptr() for t in ws]
         sp = [s.cuda_stream for s in streams]
 
         def sync_all():
-            for g in range(n):
+            for g in set(devs):
                 torch.cuda.synchronize(g)
 
         def call():
@@ -148,7 +149,7 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True):
             err = worst
             if worst > 1e-4:
                 raise RuntimeError("cuTENSORMg result check failed: max rel err %.3e" % worst)
-        return {"extent": E, "devices": n, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        return {"extent": E, "devices": n, "distinct_devices": len(set(devs)), "steps": steps, "ms_per_step": elapsed / steps * 1e3,
                 "gflops": flop / (elapsed / steps) / 1e9, "sample_protocol_min_ms": best * 1e3,
                 "sample_protocol_gflops": flop / best / 1e9, "flop": flop, "elapsed_s": elapsed,
                 "gather_bytes_per_call": d["remoteBytes"], "local_copy_bytes_per_call": d["localCopyBytes"],
@@ -161,11 +162,12 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True):
 def mg_child_main(args):
     """Child process: the multi-device cuTENSORMg measurement; one JSON line."""
     import torch
-    ndev = min(args.mg_child, torch.cuda.device_count())
-    out = {"devices": ndev}
+    virtual = args.mg_virtual
+    ndev = args.mg_child if virtual else min(args.mg_child, torch.cuda.device_count())
+    out = {"devices": ndev, "virtual": virtual}
     try:
-        out["scaled"] = mg_measure(ndev, MG_SCALED_EXTENT, args.steps, args.warmup)
-        out["sample"] = mg_measure(ndev, MG_SAMPLE_EXTENT, max(20, min(args.steps, 200)), 3)
+        out["scaled"] = mg_measure(ndev, MG_SCALED_EXTENT if not virtual else 4096, args.steps, args.warmup, virtual=virtual)
+        out["sample"] = mg_measure(ndev, MG_SAMPLE_EXTENT if not virtual else 2048, max(20, min(args.steps, 200)), 3, virtual=virtual)
         if ndev > 1:   # the same problems on one device, same process: the base of the strong-scaling speedup
             out["scaled_1"] = mg_measure(1, MG_SCALED_EXTENT, 3, 1, check=False)
             out["sample_1"] = mg_measure(1, MG_SAMPLE_EXTENT, 20, 3, check=False)
@@ -174,13 +176,15 @@ def mg_child_main(args):
     print("MGCHILD " + json.dumps(out), flush=True)
 
 
-def run_mg_child(ndev, steps, warmup, timeout_s):
+def run_mg_child(ndev, steps, warmup, timeout_s, virtual=False):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.abspath(__file__), "--mg-child", str(ndev), "--steps", str(steps), "--warmup", str(warmup)]
+    if virtual:
+        cmd.append("--mg-virtual")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
     except subprocess.TimeoutExpired:
@@ -348,6 +352,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--mg-timeout", type=int, default=600)
+    ap.add_argument("--mg-virtual", action="store_true",
+                    help="self-test of the N > 1 path on a box with fewer GPUs: the N devices are N logical devices on GPU 0 and the "
+                         "shapes are shrunk; the line then says n_gpus = 1 and the numbers are not scaling results")
     args = ap.parse_args()
 
     import torch
@@ -376,10 +383,10 @@ def main():
 
     # ---- cuTENSORMg over the requested devices (N > 1): child process of rank 0 --------------------------------------
     mg = None
-    mg_devices = min(requested, visible)
+    mg_devices = requested if args.mg_virtual else min(requested, visible)
     if requested > 1:
         if rank == 0 and mg_devices > 1:
-            mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout)
+            mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout, virtual=args.mg_virtual)
         if world > 1:
             dist.barrier(group=cpu_group)   # CPU-side wait: the other ranks' GPUs stay idle during the measurement
 
@@ -556,9 +563,11 @@ def main():
         use_mg = mg is not None and "error" not in mg and "scaled" in mg
         if use_mg:
             m = mg["scaled"]
-            value, ms_per_step, n_gpus, scaling = m["gflops"], m["ms_per_step"], m["devices"], "strong"
+            value, ms_per_step, n_gpus, scaling = m["gflops"], m["ms_per_step"], m.get("distinct_devices", m["devices"]), "strong"
             workload = ("cuTENSORMg contraction_multi_gpu.cu C[i,j]=A[i,k]B[k,j] fp32 %d^3 (BASELINE configs[4], scaled shape), largest free "
-                        "mode i cut over %d MI355X, B all-gathered over xGMI (%s), one process / %d devices" % (m["extent"], n_gpus, m["transport"], n_gpus))
+                        "mode i cut over %d MI355X, B all-gathered over xGMI (%s), one process / %d devices" % (m["extent"], n_gpus, m["transport"], m["devices"]))
+            if mg.get("virtual"):
+                workload += " — SELF-TEST: %d logical devices on one GPU, shrunk shape, not a scaling result" % m["devices"]
             secondary.append(mg_lines(mg, "sample", "sample_1"))
             scaled_line = mg_lines(mg, "scaled", "scaled_1")
             secondary.append(einsum_line)

@@ -141,6 +141,7 @@ struct cutensorMgContractionPlan {
     std::vector<hipEvent_t> events;
     int evPerDevice = 0;
     int commPerDevice = 1;
+    std::vector<char> usesAux, usesComm;       // per handle device: does any piece run on the auxiliary stream / any cell arrive from afar
     const cutensorMgHandle* owner = nullptr;
 };
 
@@ -737,6 +738,11 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     }
     for (int k = 0; k < 3; ++k)
         if (!staged[k]) pl->stagingBytes[k] = 0;
+    pl->usesAux.assign((size_t)nDev, 0);
+    pl->usesComm.assign((size_t)nDev, 0);
+    for (const Piece& p : pieces) if (p.stream != 0) pl->usesAux[(size_t)p.dev] = 1;
+    for (const Transfer& t : pl->transfers)
+        if (!t.local) { pl->usesComm[(size_t)t.dst] = 1; if (t.src >= 0) pl->usesComm[(size_t)t.src] = 1; }
 
     // ---- local plans ----------------------------------------------------------------------------
     const cutensorComputeDescriptor_t cd = compute_desc(d.compute);
@@ -868,13 +874,17 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
 #define MG_HIP(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return CUTENSOR_STATUS_EXECUTION_FAILED; } } while (0)
 
     // ---- 0. fork: the helper streams of every device start behind the caller's stream ------------------------
+    bool anyComm = false;
+    for (int g = 0; g < nDev; ++g) anyComm = anyComm || pl->usesComm[(size_t)g];
     for (int g = 0; g < nDev; ++g) {
+        if (!anyComm && !pl->usesAux[(size_t)g]) continue;
         MG_HIP(hipSetDevice(handle->devices[g]));
         MG_HIP(hipEventRecord(ev(g, 0), streams[g]));
     }
-    for (int g = 0; g < nDev; ++g) {
+    for (int g = 0; g < nDev; ++g) {      // helper streams a plan never uses are left alone (one device, no transfers: no fork at all)
         MG_HIP(hipSetDevice(handle->devices[g]));
-        MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 0), 0));
+        if (pl->usesAux[(size_t)g]) MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 0), 0));
+        if (!pl->usesComm[(size_t)g]) continue;
         for (hipStream_t cs : handle->commStreams[(size_t)g]) {
             // a communication stream reads the owners' cells: behind the caller's stream of every device
             for (int o = 0; o < nDev; ++o) MG_HIP(hipStreamWaitEvent(cs, ev(o, 0), 0));
@@ -890,6 +900,7 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
                               hipMemcpyDeviceToDevice, streams[t.dst]));
     }
     for (int g = 0; g < nDev; ++g) {
+        if (!pl->usesAux[(size_t)g]) continue;
         MG_HIP(hipSetDevice(handle->devices[g]));
         MG_HIP(hipEventRecord(ev(g, 1), streams[g]));
         MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 1), 0));
@@ -973,9 +984,11 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
     // ---- 4. join: the caller's stream of every device ends behind its helper streams -------------------------------
     for (int g = 0; g < nDev; ++g) {
         MG_HIP(hipSetDevice(handle->devices[g]));
-        MG_HIP(hipEventRecord(ev(g, 2), handle->auxStreams[(size_t)g]));
-        MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 2), 0));
-        for (size_t k = 0; k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k) {
+        if (pl->usesAux[(size_t)g]) {
+            MG_HIP(hipEventRecord(ev(g, 2), handle->auxStreams[(size_t)g]));
+            MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 2), 0));
+        }
+        for (size_t k = 0; pl->usesComm[(size_t)g] && k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k) {
             MG_HIP(hipEventRecord(ev(g, 3 + (int)k), handle->commStreams[(size_t)g][k]));
             MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 3 + (int)k), 0));
         }

@@ -187,3 +187,31 @@ def test_mg_free_mode_shard_layout(mg, monkeypatch, n, E, beta, env):
             got = _gather_cells([t.cpu().numpy() for t in dev[2]], (E, E), *layouts[2], np.float32)
             ref = A.astype(np.float64) @ B.astype(np.float64) + beta * C
             np.testing.assert_allclose(got, ref, rtol=1e-4, err_msg=str(d)[:400])
+
+
+def test_bench_multi_device_path_self_test(built):
+    """bench.py --gpus N on a box with fewer GPUs than N: `--mg-virtual` drives the whole N > 1 path of the benchmark — child
+    process, cuTENSORMg over N (logical) devices, result check, speedup bookkeeping, JSON assembly — on GPU 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--mg-virtual", "--steps", "3", "--warmup", "1", "--no-cpu",
+                        "--no-secondary", "--burn-in-ms", "0"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["requested_gpus"] == 4 and line["n_gpus"] == 1 and line["scaling"] == "strong", line
+    assert "cuTENSORMg" in line["metric"] and "SELF-TEST" in line["config"]["workload"], line
+    assert line["config"]["max_rel_err_sampled"] < 1e-4 and line["config"]["gather_bytes_per_call"] == 0      # logical devices: nothing crosses xGMI
+    assert line["value"] > 0 and line["config"]["speedup_vs_1"] > 0
+    kinds = [s["workload"] for s in line["secondary"]]
+    assert any("4096^3" in k or "2048^3" in k for k in kinds) and any("einsum.cu" in k for k in kinds), kinds
+    # and with one visible GPU and no self-test switch the line says so instead of pretending
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-secondary",
+                        "--burn-in-ms", "0"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    import torch
+    if torch.cuda.device_count() == 1:
+        assert line["n_gpus"] == 1 and line["requested_gpus"] == 8 and "einsum" in line["metric"] and "multi_device" in line["config"], line
