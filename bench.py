@@ -166,11 +166,12 @@ def mg_child_main(args):
     ndev = args.mg_child if virtual else min(args.mg_child, torch.cuda.device_count())
     out = {"devices": ndev, "virtual": virtual}
     try:
-        out["scaled"] = mg_measure(ndev, MG_SCALED_EXTENT if not virtual else 4096, args.steps, args.warmup, virtual=virtual)
-        out["sample"] = mg_measure(ndev, MG_SAMPLE_EXTENT if not virtual else 2048, max(20, min(args.steps, 200)), 3, virtual=virtual)
+        scaled, sample = (MG_SCALED_EXTENT, MG_SAMPLE_EXTENT) if not virtual else (4096, 2048)
+        out["scaled"] = mg_measure(ndev, scaled, args.steps, args.warmup, virtual=virtual)
+        out["sample"] = mg_measure(ndev, sample, max(20, min(args.steps, 200)), 3, virtual=virtual)
         if ndev > 1:   # the same problems on one device, same process: the base of the strong-scaling speedup
-            out["scaled_1"] = mg_measure(1, MG_SCALED_EXTENT, 3, 1, check=False)
-            out["sample_1"] = mg_measure(1, MG_SAMPLE_EXTENT, 20, 3, check=False)
+            out["scaled_1"] = mg_measure(1, scaled, 3, 1, check=False)
+            out["sample_1"] = mg_measure(1, sample, 20, 3, check=False)
     except Exception as e:   # noqa: BLE001 — reported to the parent, which falls back
         out["error"] = "%s: %s" % (type(e).__name__, e)
     print("MGCHILD " + json.dumps(out), flush=True)
@@ -371,13 +372,29 @@ def main():
     visible = torch.cuda.device_count()
     requested = max(args.gpus, world)
     torch.cuda.set_device(local_rank % visible)
-    cpu_group = None
+    cpu_group = gpu_group = None
+    rccl_error = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
-        # device_id: bind the RCCL communicator to this rank's GPU now (eager init) instead of at the first collective
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank % visible))
-        cpu_group = dist.new_group(backend="gloo")   # waits that must not occupy a GPU
+        # coordination (barriers, the max over ranks) runs on gloo: waits that must not occupy a GPU, and a line is printed
+        # even if the RCCL communicator of the secondary one-process-per-GPU measurement cannot be built
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cpu_group = dist.group.WORLD
+        try:
+            gpu_group = dist.new_group(backend="nccl")
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe, group=gpu_group)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("RCCL all-reduce probe returned %r" % probe.item())
+        except Exception as ex:   # noqa: BLE001
+            rccl_error = "%s: %s" % (type(ex).__name__, ex)
+            gpu_group = None
+        ok = torch.tensor([0 if gpu_group is None else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=cpu_group)      # all ranks or none
+        if int(ok.item()) == 0:
+            gpu_group = None
 
     from cudalibrarysamples_amd import cutensor as ct, ops, sharding
 
@@ -419,18 +436,18 @@ def main():
     def step(i):
         out = outs[i % nbuf]
         contract(a, b, out)
-        if world > 1:
+        if gpu_group is not None:
             # fold the K-shards: RCCL all-reduce of the 36 KB result, overlapped with the next step
             if len(pending) >= nbuf - 1:
                 pending.pop(0).wait()
-            pending.append(sharding.fold_partials(out, dist, async_op=True))
+            pending.append(sharding.fold_partials(out, dist, async_op=True, group=gpu_group))
 
     def fence():
         while pending:
             pending.pop(0).wait()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=cpu_group)
         torch.cuda.synchronize()
 
     # ---- device clock ramp (untimed, not a step count: wall-clock bounded) -----------------------------
@@ -454,8 +471,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cpu_group)
         elapsed = float(t.item())
     einsum_ms = elapsed / args.steps * 1e3
     einsum_value = world * FLOP / (elapsed / args.steps) / 1e9
@@ -557,7 +574,9 @@ def main():
 
     if rank == 0:
         einsum_line = {"workload": "einsum.cu 'abcd,dcbe->ae' a=e=96 b=c=d=64 fp32 (BASELINE configs[1])"
-                                   + ("" if world == 1 else ", b sharded x%d (b=%d), one process per GPU, RCCL all-reduce of C" % (world, 64 * world)),
+                                   + ("" if world == 1 else ", b sharded x%d (b=%d), one process per GPU, %s" % (
+                                       world, 64 * world, "RCCL all-reduce of C" if gpu_group is not None else
+                                       "NO all-reduce (RCCL communicator unavailable: %s)" % rccl_error)),
                        "dtype": "f32", "value": einsum_value, "unit": "GFLOP/s", "n_gpus": world, "ms_per_step": einsum_ms,
                        "scaling": "weak", "frac_of_nominal_f32_mfma_peak": einsum_value / 1e3 / (PEAK_TFLOPS_F32_MFMA * world)}
         use_mg = mg is not None and "error" not in mg and "scaled" in mg

@@ -1,4 +1,5 @@
-"""Multi-process (one process per GPU) sharding of the headline einsum, used by bench.py --gpus N.
+"""Multi-process (one process per GPU) sharding of the headline einsum — the secondary N > 1 measurement of bench.py under
+torch.distributed.run (the primary one is cuTENSORMg over N devices).
 
 'abcd,dcbe->ae' has a 96 x 96 result and a contracted volume b*c*d of 262,144 per 64 b's, so the
 cheapest partition is along a *contracted* mode: rank r owns A[:, b_r, :, :] and B[:, :, b_r, :] for a
@@ -24,8 +25,8 @@ def shard_operands(a, b, world, rank):
     return a[:, lo:hi], b[:, :, lo:hi]
 
 
-def fold_partials(partial, dist=None, async_op=False):
-    """Sum the per-rank partial results in place (all-reduce); no-op for a single process."""
+def fold_partials(partial, dist=None, async_op=False, group=None):
+    """Sum the per-rank partial results in place (all-reduce on `group`, default: the world); no-op for a single process."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return None
-    return dist.all_reduce(partial, async_op=async_op)
+    return dist.all_reduce(partial, async_op=async_op, group=group)
