@@ -371,10 +371,11 @@ cutensorStatus_t cutensorMgCreateTensorDescriptor(const cutensorMgHandle_t handl
         t.blockSize[i] = blockSize ? blockSize[i] : extent[i];
         t.deviceCount[i] = deviceCount ? deviceCount[i] : 1;
         if (t.blockSize[i] <= 0 || t.deviceCount[i] <= 0) { delete d; return CUTENSOR_STATUS_INVALID_VALUE; }
-        // uniform block-cyclic layouts only: extent divisible by blockSize * deviceCount (the sample
-        // pads to that, contraction_multi_gpu.cu:256)
-        if (extent[i] % (t.blockSize[i] * t.deviceCount[i]) != 0) { delete d; return CUTENSOR_STATUS_NOT_SUPPORTED; }
-        t.localBlocks[i] = extent[i] / (t.blockSize[i] * t.deviceCount[i]);
+        // every cell stores whole blocks: ceil(ceil(extent / blockSize) / deviceCount) of them per mode, exactly what the
+        // samples allocate (contraction_multi_gpu.cu:256 discretize(); blog_post.cu:107-113).  A ragged extent leaves
+        // padding at the end of the index space; the contraction descriptor decides whether that is acceptable.
+        const int64_t blocks = (extent[i] + t.blockSize[i] - 1) / t.blockSize[i];
+        t.localBlocks[i] = (blocks + t.deviceCount[i] - 1) / t.deviceCount[i];
         t.cellStride[i] = cells;
         cells *= t.deviceCount[i];
         t.elemStride[i] = elementStride ? elementStride[i] : run;
@@ -435,12 +436,21 @@ cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t 
             if (x.blockSize[i] != y.blockSize[j]) return CUTENSOR_STATUS_NOT_SUPPORTED;
             const int64_t a = x.deviceCount[i], b = y.deviceCount[j];
             if (a % b != 0 && b % a != 0) return CUTENSOR_STATUS_NOT_SUPPORTED;
+            if (x.localBlocks[i] * a != y.localBlocks[j] * b) return CUTENSOR_STATUS_NOT_SUPPORTED;   // same padded block count
         }
         return CUTENSOR_STATUS_SUCCESS;
     };
     cutensorStatus_t st = check(d->A, d->mA, d->B, d->mB);
     if (st == CUTENSOR_STATUS_SUCCESS) st = check(d->A, d->mA, d->C, d->mC);
     if (st == CUTENSOR_STATUS_SUCCESS) st = check(d->B, d->mB, d->C, d->mC);
+    // Ragged extents (not a multiple of blockSize * deviceCount): the local contractions run over the padded index space.
+    // For a mode of C that only produces results in the padding of D's cells (never read by the caller; blog_post.cu's
+    // ceil()-derived block sizes do this) — for a contracted mode the padding would enter every sum: refused.
+    auto ragged = [](const MgTensor& t, uint32_t i) { return t.extent[i] != t.localBlocks[i] * t.deviceCount[i] * t.blockSize[i]; };
+    for (uint32_t i = 0; i < d->A.n && st == CUTENSOR_STATUS_SUCCESS; ++i)
+        if (find_label(d->mC, d->mA[i]) < 0 && ragged(d->A, i)) st = CUTENSOR_STATUS_NOT_SUPPORTED;
+    for (uint32_t i = 0; i < d->B.n && st == CUTENSOR_STATUS_SUCCESS; ++i)
+        if (find_label(d->mC, d->mB[i]) < 0 && ragged(d->B, i)) st = CUTENSOR_STATUS_NOT_SUPPORTED;
     if (st != CUTENSOR_STATUS_SUCCESS) { delete d; return st; }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
@@ -535,7 +545,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             const int i = find_label(*M[k], universe[li]);
             if (i < 0) continue;
             r.blockSize = T[k]->blockSize[i];
-            r.numBlocks = T[k]->extent[i] / T[k]->blockSize[i];
+            r.numBlocks = T[k]->localBlocks[i] * T[k]->deviceCount[i];      // padded: whole blocks per cell
             dcs.insert(T[k]->deviceCount[i]);
         }
         int64_t prev = 1;

@@ -34,7 +34,7 @@ struct Dist {                       // a block-cyclic tensor: host mirror + devi
         int64_t run = 1;
         cells = 1;
         for (size_t i = 0; i < n; ++i) {
-            nlb[i] = extent[i] / (block[i] * dcount[i]);
+            nlb[i] = ((extent[i] + block[i] - 1) / block[i] + dcount[i] - 1) / dcount[i];   // whole blocks per cell (blog_post.cu:107-113)
             cellStride[i] = cells; cells *= dcount[i];
             elemStride[i] = run; run *= block[i];
         }

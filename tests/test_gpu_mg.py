@@ -215,3 +215,44 @@ def test_bench_multi_device_path_self_test(built):
     import torch
     if torch.cuda.device_count() == 1:
         assert line["n_gpus"] == 1 and line["requested_gpus"] == 8 and "einsum" in line["metric"] and "multi_device" in line["config"], line
+
+
+@pytest.mark.parametrize("handle_devices", [[0], [0, 0, 0]])
+def test_mg_ragged_free_modes(mg, handle_devices):
+    """Extents that are not a multiple of blockSize x deviceCount in the FREE modes (blog_post.cu derives its block sizes
+    with ceil(), :168-175; cells then hold whole blocks with padding at the end, :107-113): the result inside the extents is
+    exact, the padding of D's cells is unspecified.  A ragged CONTRACTED mode is refused."""
+    cm, torch = mg
+    rng = np.random.default_rng(21)
+    Ei, Ej, Ek = 176, 144, 128            # i: 6 blocks of 32 over 2 (5.5 -> padded 192); j: 5 blocks of 32 over 2 (4.5 -> padded 192... 6 blocks)
+    bs, dc = 32, 2
+    A = rng.random((Ei, Ek), dtype=np.float32)
+    B = rng.random((Ek, Ej), dtype=np.float32)
+    pad = lambda e: -(-(-(-e // bs)) // dc) * dc * bs          # noqa: E731  whole blocks per cell
+    Pi, Pj = pad(Ei), pad(Ej)
+
+    def padded(G, shape):
+        out = np.full(shape, np.nan, dtype=np.float32)      # NaN padding: it must never leak into the valid region
+        out[:G.shape[0], :G.shape[1]] = G
+        return out
+
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=bs, k=bs), dict(k=bs, j=bs), dict(i=bs, j=bs)]
+    dcount = [dict(i=dc, k=dc), dict(k=dc, j=dc), dict(i=dc, j=dc)]
+    with cm.Contraction(handle_devices, modes, dict(i=Ei, j=Ej, k=Ek), block, dcount) as con:
+        cellsA = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(padded(A, (Pi, Ek)), (bs, bs), (dc, dc))]
+        cellsB = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(padded(B, (Ek, Pj)), (bs, bs), (dc, dc))]
+        cellsC = [torch.zeros((Pi // dc) * (Pj // dc), device="cuda") for _ in range(dc * dc)]
+        n = len(handle_devices)
+        ws = [torch.empty(int(con.ws_sizes[i]), dtype=torch.uint8, device="cuda") for i in range(n)]
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        torch.cuda.synchronize()
+        cm.check(con.run(1.0, [t.data_ptr() for t in cellsA], [t.data_ptr() for t in cellsB], 0.0, [t.data_ptr() for t in cellsC],
+                         [t.data_ptr() for t in cellsC], [t.data_ptr() for t in ws], [s.cuda_stream for s in streams]))
+        torch.cuda.synchronize()
+        got = _gather_cells([t.cpu().numpy() for t in cellsC], (Pi, Pj), (bs, bs), (dc, dc), np.float32)[:Ei, :Ej]
+        np.testing.assert_allclose(got, A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4)
+    # contracted mode ragged -> NOT_SUPPORTED at the contraction descriptor
+    with pytest.raises(Exception) as ei:
+        cm.Contraction([0], modes, dict(i=128, j=128, k=176), block, dcount)
+    assert "NOT_SUPPORTED" in str(ei.value)
