@@ -260,6 +260,10 @@ cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t han
         return CUTENSOR_STATUS_INVALID_VALUE;
     if (opA != CUTENSOR_OP_IDENTITY || opB != CUTENSOR_OP_IDENTITY || opC != CUTENSOR_OP_IDENTITY) return CUTENSOR_STATUS_NOT_SUPPORTED;
     if (descA->dtype != descB->dtype || descA->dtype != descC->dtype || descA->dtype != descD->dtype) return CUTENSOR_STATUS_NOT_SUPPORTED;
+    // C is read through D's block descriptors and untouched output blocks are cleared as packed blocks: C must be laid out
+    // exactly like D (the sample passes one descriptor for both, blocksparse.cu:177-182) and D's blocks must be packed
+    if (descC->sections != descD->sections || descC->strides != descD->strides || descC->coords != descD->coords || !descD->strides.empty())
+        return CUTENSOR_STATUS_NOT_SUPPORTED;
     auto bs = std::make_shared<BlockSparseOp>();
     bs->A = *descA; bs->B = *descB; bs->C = *descC; bs->D = *descD;
     bs->mA.assign(modeA, modeA + descA->numModes);

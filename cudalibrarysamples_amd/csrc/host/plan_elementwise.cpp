@@ -223,6 +223,9 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
         plan.twoPass = false;
         plan.swapAB = !aSame;                    // E = B, permuted operand = A
         last.A = plan.swapAB ? op.A : op.B;
+        // E rides along with D's strides and is read with D's lane width: its pointer alignment bounds the vector variants too
+        const TensorUse& eop = plan.swapAB ? op.B : op.A;
+        if (eop.desc.alignment % 16 != 0) last.D.desc.alignment = std::min<uint32_t>(last.D.desc.alignment, eop.desc.alignment);
     } else {
         // both permuted: one pass if the tile decomposition of (B -> D) also reads A with 16-byte lanes (the sample's
         // A_{c,b,a}, B_{c,a,b} -> D_{a,b,c} share the partner mode c), 4 |D| bytes instead of 6
