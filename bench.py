@@ -84,7 +84,8 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True, virtual=F
     protocol (wall clock + per-device sync, min of `sample_reps`)."""
     import torch
     from cudalibrarysamples_amd import cutensormg as cm
-    E, n = extent, ndev
+    n = ndev
+    E = extent - extent % (16 * n)        # every device count cuts the extents evenly (N = 1, 2, 4, 8 leave them as they are)
     modes = ["ik", "kj", "ij"]
     block = [dict(i=E // n), dict(j=E // n), dict(i=E // n, j=E // n)]
     dcount = [dict(i=n), dict(j=n), dict(i=n)]
@@ -165,15 +166,24 @@ def mg_child_main(args):
     virtual = args.mg_virtual
     ndev = args.mg_child if virtual else min(args.mg_child, torch.cuda.device_count())
     out = {"devices": ndev, "virtual": virtual}
-    try:
-        scaled, sample = (MG_SCALED_EXTENT, MG_SAMPLE_EXTENT) if not virtual else (4096, 2048)
-        out["scaled"] = mg_measure(ndev, scaled, args.steps, args.warmup, virtual=virtual)
-        out["sample"] = mg_measure(ndev, sample, max(20, min(args.steps, 200)), 3, virtual=virtual)
-        if ndev > 1:   # the same problems on one device, same process: the base of the strong-scaling speedup
-            out["scaled_1"] = mg_measure(1, scaled, 3, 1, check=False)
-            out["sample_1"] = mg_measure(1, sample, 20, 3, check=False)
-    except Exception as e:   # noqa: BLE001 — reported to the parent, which falls back
-        out["error"] = "%s: %s" % (type(e).__name__, e)
+    scaled, sample = (MG_SCALED_EXTENT, MG_SAMPLE_EXTENT) if not virtual else (4096, 2048)
+    for attempt in range(2):
+        try:
+            out["scaled"] = mg_measure(ndev, scaled, args.steps, args.warmup, virtual=virtual)
+            out["sample"] = mg_measure(ndev, sample, max(20, min(args.steps, 200)), 3, virtual=virtual)
+            if ndev > 1:   # the same problems on one device, same process: the base of the strong-scaling speedup
+                out["scaled_1"] = mg_measure(1, scaled, 3, 1, check=False)
+                out["sample_1"] = mg_measure(1, sample, 20, 3, check=False)
+            out.pop("error", None)
+            break
+        except Exception as e:   # noqa: BLE001 — reported to the parent, which falls back
+            out["error"] = "%s: %s" % (type(e).__name__, e)
+            if attempt == 0 and ndev > 1 and os.environ.get("CUTENSORMG_AMD_TRANSPORT") != "peer":
+                # the RCCL send/recv gather failed (status or wrong values): once more with peer copies over xGMI
+                out["first_attempt_error"] = out["error"]
+                os.environ["CUTENSORMG_AMD_TRANSPORT"] = "peer"
+                continue
+            break
     print("MGCHILD " + json.dumps(out), flush=True)
 
 
@@ -352,7 +362,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--mg-timeout", type=int, default=600)
+    ap.add_argument("--mg-timeout", type=int, default=300, help="seconds per attempt of the multi-device child process")
     ap.add_argument("--mg-virtual", action="store_true",
                     help="self-test of the N > 1 path on a box with fewer GPUs: the N devices are N logical devices on GPU 0 and the "
                          "shapes are shrunk; the line then says n_gpus = 1 and the numbers are not scaling results")
@@ -404,6 +414,12 @@ def main():
     if requested > 1:
         if rank == 0 and mg_devices > 1:
             mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout, virtual=args.mg_virtual)
+            if "timed out" in str(mg.get("error", "")) and os.environ.get("CUTENSORMG_AMD_TRANSPORT") != "peer":
+                # a hang (killed by the timeout) in the RCCL path: one more child with peer copies instead
+                first = mg["error"]
+                os.environ["CUTENSORMG_AMD_TRANSPORT"] = "peer"
+                mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout, virtual=args.mg_virtual)
+                mg["first_attempt_error"] = first
         if world > 1:
             dist.barrier(group=cpu_group)   # CPU-side wait: the other ranks' GPUs stay idle during the measurement
 
@@ -592,7 +608,8 @@ def main():
             secondary.append(einsum_line)
             config = {"workload": workload, "speedup_vs_1": scaled_line.get("speedup_vs_1"), "one_device_gflops": scaled_line.get("one_device_gflops"),
                       "gather_bytes_per_call": m["gather_bytes_per_call"], "sample_protocol": scaled_line["sample_protocol"],
-                      "frac_of_nominal_f32_mfma_peak": value / 1e3 / (PEAK_TFLOPS_F32_MFMA * n_gpus), "max_rel_err_sampled": m["max_rel_err_sampled"]}
+                      "frac_of_nominal_f32_mfma_peak": value / 1e3 / (PEAK_TFLOPS_F32_MFMA * n_gpus), "max_rel_err_sampled": m["max_rel_err_sampled"],
+                      "first_attempt_error": mg.get("first_attempt_error")}
             metric = "contraction GFLOP/s, fp32 cuTENSORMg C[i,j]=A[i,k]B[k,j] sharded over %d GPUs" % n_gpus
             roof_out = scaled_line["roofline"]
         else:
