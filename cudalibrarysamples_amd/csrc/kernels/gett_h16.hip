@@ -128,6 +128,140 @@ __device__ __forceinline__ uint16_t h_from_float(float f, bool bf) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of the 16-bit kernels: D = alpha * acc + beta * C, one rounding to the 16-bit type.
+// An MFMA accumulator fragment holds one output column per lane (32 consecutive n in lanes 0-31, 16 rows in the 16
+// registers).  Storing it from the registers means 16 two-byte stores per lane and fragment (two-byte stores cost ~12x the
+// time per byte of 16-byte ones), and — worse — fully unrolled address arithmetic and conversions for every one of them:
+// the first form of this epilogue was 100+ KB of straight-line code that every workgroup streamed through once, and the
+// instruction fetch alone cost 30 us of a workgroup's 150 us on 8192^3 (K-sweep: 37 us fixed cost per workgroup, 7 us
+// without the epilogue).  Now a wave parks four fragments at a time in 16 KiB of LDS of its own (the operand ring is dead by
+// then: 64 ds_write_b32 in accumulator order, the only unrolled part) and a ROLLED loop of eight iterations turns them into
+// 16-byte row pieces: every lane reads 8 consecutive n of one row, adds beta * C, converts (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+// and issues one 16-byte global store (rows of 64 contiguous bytes, 4 lanes each).  The vector form needs 8 consecutive n
+// contiguous and 16-byte aligned in D (and in C when beta != 0): checked once per workgroup (wave-uniform); otherwise a rolled
+// element-wise loop stores from the same LDS image with any strides.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BF>
+__device__ __forceinline__ uint16_t h_round16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BF) return __builtin_bit_cast(uint16_t, (__bf16)f);      // round to nearest even, NaN stays NaN
+    else              return __builtin_bit_cast(uint16_t, (_Float16)f);
+#else
+    (void)f; return 0;
+#endif
+}
+
+struct HEpilogue {
+    const uint16_t* C;
+    uint16_t*       D;
+    float alpha, beta;
+    uint32_t Mtot, Ntot;
+    bool vecD, vecC;
+    bool flat;           // M and N are single modes: offsets are one multiplication, no digit decomposition
+    float* scratch;      // this wave's 16 KiB of LDS: four fragments [32 rows][32 n] fp32
+
+    __device__ __forceinline__ void init(const GettParams& p, uint32_t l, char* lds, int wave) {
+        C = static_cast<const uint16_t*>(p.C);
+        D = static_cast<uint16_t*>(p.D);
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+        alpha = p.alpha; beta = p.beta;
+        Mtot = p.gM.total; Ntot = p.gN.total;
+        scratch = reinterpret_cast<float*>(lds + wave * 16384);
+        // 8 consecutive n stay inside the fastest N mode and are contiguous; every other stride keeps 16-byte alignment
+        bool d = (p.gN.div[0].d % 8u == 0u) && p.gN.stride[1][0] == 1 && (reinterpret_cast<uintptr_t>(D) % 16u == 0u);
+        bool c = d && p.cStrideN[0] == 1 && (reinterpret_cast<uintptr_t>(C) % 16u == 0u);
+#pragma unroll
+        for (int i = 0; i < kMaxGroupModes; ++i) {
+            d = d && (p.gM.stride[1][i] % 8 == 0) && (i == 0 || p.gN.stride[1][i] % 8 == 0);
+            c = c && (p.cStrideM[i] % 8 == 0) && (i == 0 || p.cStrideN[i] % 8 == 0);
+        }
+        vecD = d; vecC = c;
+        flat = p.gM.n <= 1 && p.gN.n <= 1;
+    }
+    __device__ __forceinline__ void offsets(const GettParams& p, uint32_t m, uint32_t n, int64_t& offD, int64_t& offC) const {
+        if (flat) {
+            offD = (int64_t)m * p.gM.stride[1][0] + (int64_t)n * p.gN.stride[1][0];
+            offC = (int64_t)m * p.cStrideM[0] + (int64_t)n * p.cStrideN[0];
+        } else {
+            int64_t dm, cm, dn, cn;
+            group_offset2<1>(p.gM, p.cStrideM, m, dm, cm);
+            group_offset2<1>(p.gN, p.cStrideN, n, dn, cn);
+            offD = dm + dn; offC = cm + cn;
+        }
+    }
+
+    // park fragment F (0..3) of the current pass: element (row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31) = acc[r]
+    __device__ __forceinline__ void park(int F, const f32x16& acc, int lane) const {
+        float* st = scratch + F * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = alpha * acc[r];
+    }
+
+    // store the four parked fragments; fragment f covers rows mB + mHi (f >> 1) + mLo (f & 1) + [0, 32), columns alike
+    // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a kernel that uses all 160 KiB of
+    // LDS and touches scratch memory faults on gfx950)
+    template <bool BF>
+    __device__ __forceinline__ void flush(const GettParams& p, uint32_t mB0, uint32_t mHi, uint32_t mLo, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane) const {
+        if (vecD) {
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {              // fragment it >> 1, chunks (it & 1) * 64 + lane of its 128
+                const int f = it >> 1;
+                const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
+                const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
+                const int cidx = lane + 64 * (it & 1), row = cidx >> 2, piece = cidx & 3;
+                const float* src = scratch + f * 1024 + row * 32 + piece * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+                const uint32_t m = mB + row, n = nB + 8 * piece;
+                if (m < Mtot && n < Ntot) {
+                    int64_t offD, offC;
+                    offsets(p, m, n, offD, offC);
+                    f32x4 v0 = lo, v1 = hi;              // explicit elements below: nothing here may become a stack array
+                    if (beta != 0.f) {
+                        if (vecC) {
+                            const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
+#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
+                            CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
+                            CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
+#undef CTAMD_EP_C
+                        } else {
+#define CTAMD_EP_CS(E, V, I) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(C[oC_], BF); }
+                            CTAMD_EP_CS(0, v0, 0) CTAMD_EP_CS(1, v0, 1) CTAMD_EP_CS(2, v0, 2) CTAMD_EP_CS(3, v0, 3)
+                            CTAMD_EP_CS(4, v1, 0) CTAMD_EP_CS(5, v1, 1) CTAMD_EP_CS(6, v1, 2) CTAMD_EP_CS(7, v1, 3)
+#undef CTAMD_EP_CS
+                        }
+                    }
+                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
+                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+                    __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // the result is not read again by this kernel
+                }
+            }
+            return;
+        }
+        // element-wise form (any strides): lane = column, one row per iteration
+#pragma unroll 1
+        for (int it = 0; it < 4 * 32; ++it) {
+            const int f = it >> 5, row = it & 31;
+            const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
+            const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
+            if (lane < 32) {
+                const uint32_t m = mB + row, n = nB + lane;
+                if (m < Mtot && n < Ntot) {
+                    int64_t offD, offC;
+                    offsets(p, m, n, offD, offC);
+                    float val = scratch[f * 1024 + row * 32 + lane];
+                    if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
+                    D[offD] = h_round16<BF>(val);
+                }
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // One operand (A rows or B columns) of the streamed K-tile.
 // ---------------------------------------------------------------------------------------------
@@ -257,10 +391,13 @@ struct HOdometer {
 // record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
 // ABL (measurement only, wrong results; CUTENSOR_AMD_H16_ABL with the default kernel): 1 = no LDS-DMA in the main loop,
 // 2 = no A-fragment reads in the main loop, 3 = neither fragment reads nor LDS-DMA (MFMAs + barriers only),
-// 4 = no B-fragment reads — what each kind of data movement costs under the power limit on random data.
+// 4 = no B-fragment reads, 5 = complete main loop but no epilogue — what each kind of data movement costs under the power
+// limit on random data, and what the epilogue costs.
 template <bool BF, int LA, int LB, bool TIMED = false, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    unsigned long long wgStamp[6] = {0, 0, 0, 0, 0, 0};   // TIMED: cycles at entry / loop start / loop end / exit, wall clock at entry / exit
+    if constexpr (TIMED) { wgStamp[0] = __builtin_readcyclecounter(); wgStamp[4] = wall_clock64(); }
     prefetch_kernarg<(int)sizeof(GettParams)>();
     // slot index: buffer * 4 + {0: A-half 0, 1: A-half 1, 2: B-half 0, 3: B-half 1}
 
@@ -424,9 +561,11 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     if constexpr (TIMED) {
         if (p.timing != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4)) tstamp = p.timing + (wave >> 2) * 32;
     }
+    if constexpr (TIMED) wgStamp[1] = __builtin_readcyclecounter();
     int t = 0;
     for (; t + 1 < nTiles; t += 2) { t8 = t; CTAMD_H_TILE(0) t8 = t + 1; CTAMD_H_TILE(1) }
     if (t < nTiles) { t8 = t; CTAMD_H_TILE(0) }
+    if constexpr (TIMED) wgStamp[2] = __builtin_readcyclecounter();
     if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
     CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive the workgroup
 
@@ -452,50 +591,33 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         store_partial(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
         return;
     }
-    // ---- epilogue: D = alpha * acc + beta * C, 16-bit stores (32 lanes x 2 B contiguous along n) -------
-    const uint16_t* C = static_cast<const uint16_t*>(p.C);
-    uint16_t*       D = static_cast<uint16_t*>(p.D);
-    {
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-    }
-    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
-    const float alpha = p.alpha, beta = p.beta;
-    int64_t offDn[2], offCn[2];
-    bool    okN[2];
+    // ---- epilogue: D = alpha * acc + beta * C through the per-wave LDS turn (HEpilogue) --------------------------------
+    if constexpr (ABL == 5) {                     // measurement only: no epilogue (one word per lane keeps the accumulators alive)
+        float keep = 0.f;
 #pragma unroll
-    for (int bh = 0; bh < 2; ++bh) {
-        const uint32_t n = n0 + 128 * bh + 32 * wc + (lane & 31);
-        okN[bh] = n < Ntot;
-        offDn[bh] = 0; offCn[bh] = 0;
-        if (okN[bh]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[bh], offCn[bh]);
+        for (int r = 0; r < 16; ++r) keep += acc[0][0][0][r] + acc[0][0][1][r] + acc[0][1][0][r] + acc[0][1][1][r] + acc[1][0][0][r] + acc[1][0][1][r] + acc[1][1][0][r] + acc[1][1][1][r];
+        if (keep == 12345.678f) static_cast<uint16_t*>(p.D)[tid] = 1;
+        return;
     }
-    auto store_frag = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < Mtot) {
-                int64_t offDm, offCm;
-                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
-                if (okN[0]) {
-                    float val = alpha * c0[r];
-                    if (beta != 0.f) val += beta * h_to_float(C[offCm + offCn[0]], BF);
-                    D[offDm + offDn[0]] = h_from_float(val, BF);
-                }
-                if (okN[1]) {
-                    float val = alpha * c1[r];
-                    if (beta != 0.f) val += beta * h_to_float(C[offCm + offCn[1]], BF);
-                    D[offDm + offDn[1]] = h_from_float(val, BF);
-                }
-            }
+    for (int ah = 0; ah < 2; ++ah) {              // two passes of four fragments: (fr, bh) = (0,0) (0,1) (1,0) (1,1)
+        ep.park(0, acc[ah][0][0], lane); ep.park(1, acc[ah][0][1], lane); ep.park(2, acc[ah][1][0], lane); ep.park(3, acc[ah][1][1], lane);
+        const uint32_t mB = m0 + 128 * ah + 64 * wr, nB = n0 + 32 * wc;
+        ep.template flush<BF>(p, mB, 32u, 0u, nB, 0u, 128u, lane);
+    }
+    if constexpr (TIMED) {
+        if (p.timing != nullptr && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of this wave have left
+            wgStamp[3] = __builtin_readcyclecounter();
+            wgStamp[5] = wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
+            p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
         }
-    };
-    store_frag(acc[0][0][0], acc[0][0][1], m0 + 64 * wr);
-    store_frag(acc[0][1][0], acc[0][1][1], m0 + 64 * wr + 32);
-    store_frag(acc[1][0][0], acc[1][0][1], m0 + 128 + 64 * wr);
-    store_frag(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
+    }
 }
 
 
@@ -664,48 +786,15 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
         store_partial(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
         return;
     }
-    const uint16_t* C = static_cast<const uint16_t*>(p.C);
-    uint16_t*       D = static_cast<uint16_t*>(p.D);
-    {
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-    }
-    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
-    const float alpha = p.alpha, beta = p.beta;
-    int64_t offDn[4], offCn[4];
-    bool    okN[4];
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t n = nW + 32 * j + (lane & 31);
-        okN[j] = n < Ntot;
-        offDn[j] = 0; offCn[j] = 0;
-        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    for (int i = 0; i < 4; ++i) {                 // four passes: the four fragments of accumulator row i
+        ep.park(0, acc[i][0], lane); ep.park(1, acc[i][1], lane); ep.park(2, acc[i][2], lane); ep.park(3, acc[i][3], lane);
+        const uint32_t mB = mW + 32 * i;
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
     }
-    auto store_one = [&](float v, int64_t offD, int64_t offC) {
-        float val = alpha * v;
-        if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-        D[offD] = h_from_float(val, BF);
-    };
-    auto store_row = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < Mtot) {
-                int64_t offDm, offCm;
-                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
-                if (okN[0]) store_one(c0[r], offDm + offDn[0], offCm + offCn[0]);
-                if (okN[1]) store_one(c1[r], offDm + offDn[1], offCm + offCn[1]);
-                if (okN[2]) store_one(c2[r], offDm + offDn[2], offCm + offCn[2]);
-                if (okN[3]) store_one(c3[r], offDm + offDn[3], offCm + offCn[3]);
-            }
-        }
-    };
-    store_row(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
-    store_row(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
-    store_row(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
-    store_row(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
 }
 
 
@@ -713,7 +802,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
 // tile or D = alpha * acc + beta * C with one rounding to the 16-bit type.
 template <bool BF>
 __device__ __forceinline__ void h_epilogue_128x64(const GettParams& p, const f32x16 (&acc)[4][2], uint32_t m0, uint32_t n0, int wr, int wc,
-                                                  uint32_t slice, uint32_t l, int lane) {
+                                                  uint32_t slice, uint32_t l, int lane, char* lds, int wave) {
     const uint32_t mW = m0 + 128 * wr, nW = n0 + 64 * wc;     // this wave's 128 x 64 block
     if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
         const uint32_t Mt = p.gM.total, Nt = p.gN.total;
@@ -736,46 +825,15 @@ __device__ __forceinline__ void h_epilogue_128x64(const GettParams& p, const f32
         store_partial(acc[3][0], acc[3][1], mW + 96);
         return;
     }
-    const uint16_t* C = static_cast<const uint16_t*>(p.C);
-    uint16_t*       D = static_cast<uint16_t*>(p.D);
-    {
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-    }
-    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
-    const float alpha = p.alpha, beta = p.beta;
-    int64_t offDn[2], offCn[2];
-    bool    okN[2];
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t n = nW + 32 * j + (lane & 31);
-        okN[j] = n < Ntot;
-        offDn[j] = 0; offCn[j] = 0;
-        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    for (int h = 0; h < 2; ++h) {                 // two passes: accumulator rows 2 h and 2 h + 1, both column fragments
+        ep.park(0, acc[2 * h][0], lane); ep.park(1, acc[2 * h][1], lane); ep.park(2, acc[2 * h + 1][0], lane); ep.park(3, acc[2 * h + 1][1], lane);
+        const uint32_t mB = mW + 64 * h;
+        ep.template flush<BF>(p, mB, 32u, 0u, nW, 0u, 32u, lane);
     }
-    auto store_one = [&](float v, int64_t offD, int64_t offC) {
-        float val = alpha * v;
-        if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-        D[offD] = h_from_float(val, BF);
-    };
-    auto store_row = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m < Mtot) {
-                int64_t offDm, offCm;
-                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
-                if (okN[0]) store_one(c0[r], offDm + offDn[0], offCm + offCn[0]);
-                if (okN[1]) store_one(c1[r], offDm + offDn[1], offCm + offCn[1]);
-            }
-        }
-    };
-    store_row(acc[0][0], acc[0][1], mW);
-    store_row(acc[1][0], acc[1][1], mW + 32);
-    store_row(acc[2][0], acc[2][1], mW + 64);
-    store_row(acc[3][0], acc[3][1], mW + 96);
 }
 
 // =====================================================================================================
@@ -1030,7 +1088,7 @@ __global__ void __launch_bounds__(512, 2) gett_h16s_kernel(const GettParams p) {
     CTAMD_S_READ(0, 0, 0, 3) CTAMD_S_READ(0, 0, 0, 4) CTAMD_S_READ(0, 0, 0, 5)
     CTAMD_S_LOOP(2)
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
-    h_epilogue_128x64<BF>(p, acc, m0, n0, wr, wc, slice, l, lane);
+    h_epilogue_128x64<BF>(p, acc, m0, n0, wr, wc, slice, l, lane, lds, wave);
 }
 
 template <bool BF, int LA, int LB>
@@ -1070,6 +1128,7 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
         if (abl == 2) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 2>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
         if (abl == 3) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 3>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
         if (abl == 4) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 5) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 5>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
