@@ -161,7 +161,7 @@ struct HEpilogue {
     bool flat;           // M and N are single modes: offsets are one multiplication, no digit decomposition
     float* scratch;      // this wave's 16 KiB of LDS: four fragments [32 rows][32 n] fp32
 
-    __device__ __forceinline__ void init(const GettParams& p, uint32_t l, char* lds, int wave) {
+    __device__ __forceinline__ void init(const GettParams& p, uint32_t l, char* lds, int wave, int bytesPerWave = 16384) {
         C = static_cast<const uint16_t*>(p.C);
         D = static_cast<uint16_t*>(p.D);
         int64_t oD, oC;
@@ -170,7 +170,7 @@ struct HEpilogue {
         C += oC;
         alpha = p.alpha; beta = p.beta;
         Mtot = p.gM.total; Ntot = p.gN.total;
-        scratch = reinterpret_cast<float*>(lds + wave * 16384);
+        scratch = reinterpret_cast<float*>(lds + wave * bytesPerWave);
         // 8 consecutive n stay inside the fastest N mode and are contiguous; every other stride keeps 16-byte alignment
         bool d = (p.gN.div[0].d % 8u == 0u) && p.gN.stride[1][0] == 1 && (reinterpret_cast<uintptr_t>(D) % 16u == 0u);
         bool c = d && p.cStrideN[0] == 1 && (reinterpret_cast<uintptr_t>(C) % 16u == 0u);
@@ -201,10 +201,69 @@ struct HEpilogue {
         for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = alpha * acc[r];
     }
 
+    // ---- 64-column form (the default kernel: a wave's two B-side fragments are adjacent columns) --------------------------
+    // Staging image [16 rows][64 columns] fp32 = 4 KiB per wave at `scratch`: half HALF (rows 16 HALF + [0,16)) of the fragment
+    // pair (c0: columns 0-31, c1: columns 32-63).  One store instruction then writes 8 rows x 128 contiguous bytes (whole cache
+    // lines; tools/ubench/store_pattern.hip: 128 MiB of such stores drain in 25.8 us against 34.2 us for 64-byte row pieces).
+    template <int HALF>
+    __device__ __forceinline__ void park_pair(const f32x16& c0, const f32x16& c1, int lane) const {
+        float* st = scratch + ((lane >> 5) * 4) * 64 + (lane & 31);
+#pragma unroll
+        for (int r = 8 * HALF; r < 8 * HALF + 8; ++r) {
+            const int row = (r & 3) + 8 * ((r >> 2) & 1);
+            st[row * 64]      = alpha * c0[r];
+            st[row * 64 + 32] = alpha * c1[r];
+        }
+    }
+    // rows mB + [0,16), columns nB + [0,64)
+    template <bool BF, int ST = 0>
+    __device__ __forceinline__ void flush_pair(const GettParams& p, uint32_t mB, uint32_t nB, int lane) const {
+        if (vecD && (beta == 0.f || vecC)) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int cidx = lane + 64 * it, row = cidx >> 3, piece = cidx & 7;
+                const float* src = scratch + row * 64 + piece * 8;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                const uint32_t m = mB + row, n = nB + 8 * piece;
+                if (m < Mtot && n < Ntot) {
+                    int64_t offD, offC;
+                    offsets(p, m, n, offD, offC);
+                    if (beta != 0.f) {
+                        const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
+#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
+                        CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
+                        CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
+#undef CTAMD_EP_C
+                    }
+                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
+                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // not read again by this kernel; keeps the operand panels in L2
+                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
+                    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
+                }
+            }
+            return;
+        }
+#pragma unroll 1
+        for (int row = 0; row < 16; ++row) {           // element-wise form (any strides): lane = column
+            const uint32_t m = mB + row, n = nB + lane;
+            if (m < Mtot && n < Ntot) {
+                int64_t offD, offC;
+                offsets(p, m, n, offD, offC);
+                float val = scratch[row * 64 + lane];
+                if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
+                D[offD] = h_round16<BF>(val);
+            }
+        }
+    }
+
+    // ---- four-fragment form (four-wave and streamed kernels) ------------------------------------------------------------
     // store the four parked fragments; fragment f covers rows mB + mHi (f >> 1) + mLo (f & 1) + [0, 32), columns alike
     // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a kernel that uses all 160 KiB of
     // LDS and touches scratch memory faults on gfx950)
-    template <bool BF>
+    // ST (measurement): 0 = nontemporal stores, 1 = plain, 2 = write-through (sc1)
+    template <bool BF, int ST = 0>
     __device__ __forceinline__ void flush(const GettParams& p, uint32_t mB0, uint32_t mHi, uint32_t mLo, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane) const {
         if (vecD) {
 #pragma unroll 2
@@ -237,7 +296,9 @@ struct HEpilogue {
                     }
                     const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                        (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // the result is not read again by this kernel
+                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // the result is not read again by this kernel
+                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
+                    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
                 }
             }
             return;
@@ -265,7 +326,10 @@ struct HEpilogue {
 // ---------------------------------------------------------------------------------------------
 // One operand (A rows or B columns) of the streamed K-tile.
 // ---------------------------------------------------------------------------------------------
-template <int LAY, int NW = 8>
+// IL (the default kernel's B operand): half-tile h holds the 32-row stripes {64 j + 32 h + [0,32)}, j = 0..3, of the 256 rows
+// instead of rows 128 h + [0,128) — the two fragments a wave owns (stripe j = wc of either half) are then ADJACENT columns of
+// the output tile, and the epilogue stores whole 128-byte lines.
+template <int LAY, int NW = 8, bool IL = false>
 struct HOperand {
     static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
     // Byte offset of this lane's 16-byte unit, [half-tile][piece i of this wave], for the K-tile at k = 0 — relative to
@@ -285,13 +349,13 @@ struct HOperand {
                 if constexpr (LAY == LAY_K) {
                     const int r = 8 * c + (lane >> 3), p = lane & 7;
                     const int u = p ^ ((r >> 1) & 7);
-                    uint32_t row = row0 + 128 * h + r;
+                    uint32_t row = row0 + (IL ? 64 * (r >> 5) + 32 * h + (r & 31) : 128 * h + r);
                     if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
                     off[h][i] = (group_offset<0>(gFree, row) + 8 * u) * 2;
                 } else {
                     const int kk = 4 * c + (lane >> 4), p = lane & 15;
                     const int u = p ^ (4 * ((lane >> 4) & 3));
-                    uint32_t row = row0 + 128 * h + 8 * u;
+                    uint32_t row = row0 + (IL ? 64 * (u >> 2) + 32 * h + 8 * (u & 3) : 128 * h + 8 * u);
                     if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
                     off[h][i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
                 }
@@ -348,6 +412,22 @@ __device__ __forceinline__ s16x8 h_read_frag(const char* slot, int rb, int s, co
     }
 }
 
+// A fresh copy of the kernel's argument block (the kernel's only parameter, at offset 0 of the kernarg segment), read
+// through a laundered pointer so that the loads cannot be merged with earlier ones: only the fields used are loaded.
+__device__ __forceinline__ void h_reload_params(GettParams& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    typedef const __attribute__((address_space(4))) uint32_t* wptr;
+    wptr w = (wptr)kp;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(GettParams) / 4); ++i) d[i] = w[i];
+#else
+    (void)q;
+#endif
+}
+
 // Wave-uniform walk over the K-tiles of the contraction: byte offsets of tile t in A and B.  Fast-K: the
 // fastest contracted digit's extent is a multiple of kHBK, so a tile never straddles a digit boundary.
 struct HOdometer {
@@ -369,20 +449,23 @@ struct HOdometer {
         wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
         wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
     }
+    __device__ __forceinline__ void carry(const ModeGroup& gK) {
+        const uint32_t k = hi * e1 * gK.div[0].d;
+        if (k < gK.total) {
+            offA = h_uniform64((uint64_t)(group_offset<0>(gK, k) * 2));
+            offB = h_uniform64((uint64_t)(group_offset<1>(gK, k) * 2));
+        }
+    }
     __device__ __forceinline__ void advance(const ModeGroup& gK) {
         const bool c0 = (j0 + 1 == n0);
         j0 = c0 ? 0u : j0 + 1;
         offA += c0 ? wrapA : stepA;
         offB += c0 ? wrapB : stepB;
         j1 += c0 ? 1u : 0u;
-        if (j1 == e1) {   // carry beyond the second digit
+        if (j1 == e1) {   // carry beyond the second digit (rare)
             j1 = 0;
             hi += 1;
-            const uint32_t k = hi * e1 * gK.div[0].d;
-            if (k < gK.total) {
-                offA = h_uniform64((uint64_t)(group_offset<0>(gK, k) * 2));
-                offB = h_uniform64((uint64_t)(group_offset<1>(gK, k) * 2));
-            }
+            carry(gK);
         }
     }
 };
@@ -395,55 +478,65 @@ struct HOdometer {
 // limit on random data, and what the epilogue costs.
 template <bool BF, int LA, int LB, bool TIMED = false, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
+    // operand ring: 8 half-tile slots (slot index: buffer * 4 + {0: A-half 0, 1: A-half 1, 2: B-half 0, 3: B-half 1});
+    // the epilogue turns the result through the first 4 KiB per wave of it
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     unsigned long long wgStamp[6] = {0, 0, 0, 0, 0, 0};   // TIMED: cycles at entry / loop start / loop end / exit, wall clock at entry / exit
-    if constexpr (TIMED) { wgStamp[0] = __builtin_readcyclecounter(); wgStamp[4] = wall_clock64(); }
     prefetch_kernarg<(int)sizeof(GettParams)>();
-    // slot index: buffer * 4 + {0: A-half 0, 1: A-half 1, 2: B-half 0, 3: B-half 1}
 
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    // ---- tile mapping: XCD-contiguous ids, then groups of 8 tile rows so that the 32 tiles an XCD runs
-    //      at a time form an 8 x 4 block (12 operand panels for 32 tiles) ---------------------------------
-    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
-    const uint32_t tilesMN = p.tilesM * p.tilesN;
-    const uint32_t tilesAll = tilesMN * p.gL.total;
-    const uint32_t slice = id / tilesAll;          // split-K: slice-major ids (splitK == 1: slice = 0)
-    id -= slice * tilesAll;
-    const uint32_t l = id / tilesMN;
-    id -= l * tilesMN;
-    const uint32_t perGroup = 8u * p.tilesN;
-    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
-    const uint32_t first = grp * 8u;
-    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
-    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
-    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
-    // K range of this slice in K-tiles (fast-K: every tile is full)
-    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
-    const uint32_t tile0 = slice * tilesPerSlice;
-    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
-
-    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
-    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
-    HOperand<LA> oa;
-    HOperand<LB> ob;
-    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
-    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
-    bA += oa.base;                                 // descriptor base = operand + batch offset + this wave's smallest piece offset
-    bB += ob.base;
-
     uint32_t offK[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) offK[s] = h_offK(lane, s);
     const uint32_t offFa0 = h_offF(lane, 2 * wr), offFa1 = h_offF(lane, 2 * wr + 1), offFb = h_offF(lane, wc);
-
-    HOdometer odo;
-    odo.init(p.gK, tile0 * kHBK);
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;   // LDS byte address of the ring
+    // The argument block is re-read (scalar loads through a laundered kernarg pointer) wherever a tile boundary needs it:
+    // kept in SGPRs across the main loop, the mode tables alone would spill a few hundred scalars into VGPR lanes.
 
+    // ---- state of the tile being staged / computed -------------------------------------------------------------------
+    uint32_t m0 = 0, n0 = 0, l = 0, slice = 0;
+    int nTiles = 0;
+    uint64_t bA = 0, bB = 0;
+    HOperand<LA> oa;
+    HOperand<LB, 8, true> ob;                      // B halves = interleaved 32-column stripes (see HOperand)
+    HOdometer odo;
+    uint64_t offA1 = 0, offB1 = 0, offA2 = 0, offB2 = 0;
+    int tNext = 0;
+
+    // Tile mapping: XCD-contiguous ids, then groups of 8 tile rows so that the 32 tiles an XCD runs at a time form an 8 x 4
+    // block (12 operand panels for 32 tiles).
+    auto setup = [&](uint32_t vb, const GettParams& p) {
+        const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+        const uint32_t tilesMN = p.tilesM * p.tilesN;
+        const uint32_t tilesAll = tilesMN * p.gL.total;
+        uint32_t id = xcd_remap(vb, p.nBlocks);
+        slice = id / tilesAll;                     // split-K: slice-major ids (splitK == 1: slice = 0)
+        id -= slice * tilesAll;
+        l = id / tilesMN;
+        id -= l * tilesMN;
+        const uint32_t perGroup = 8u * p.tilesN;
+        const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+        const uint32_t first = grp * 8u;
+        const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+        const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+        m0 = mt * kHTile; n0 = nt * kHTile;
+        // K range of this slice in K-tiles (fast-K: every tile is full)
+        const uint32_t tile0 = slice * tilesPerSlice;
+        nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+        bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+        bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
+        int laneT = lane;                          // opaque: nothing derived from it may be hoisted out of the tile loop and kept
+        asm volatile("" : "+v"(laneT));            // (spilled) across the main loop
+        oa.init(p.gM, p.gK.stride[0][0], m0, wave, laneT);
+        ob.init(p.gN, p.gK.stride[1][0], n0, wave, laneT);
+        bA += oa.base;                             // descriptor base = operand + batch offset + this wave's smallest piece offset
+        bB += ob.base;
+        odo.init(p.gK, tile0 * kHBK);
+    };
     // ---- prologue: K-tile 0 and the first halves of K-tile 1, in consumption order ---------------------
     // Staging schedule (global phase P = 4 t + q; one half-tile per phase, restaged two or more phases
     // after the slot's last read, so a slot is never rewritten while the other wave row may still have
@@ -452,30 +545,21 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     //   q = 2: A-half 0 of tile t + 2     q = 3: B-half 0 of tile t + 2
     // A half-tile is first read at least five phases after it was issued and the wait in front of each
     // phase's first barrier leaves four half-tiles (8 LDS-DMA instructions of this wave) in flight.
-    oa.issue(h_make_rsrc(bA + odo.offA), 0, ldsBase + 0 * kHalfBytes, wave);
-    ob.issue(h_make_rsrc(bB + odo.offB), 0, ldsBase + 2 * kHalfBytes, wave);
-    ob.issue(h_make_rsrc(bB + odo.offB), 1, ldsBase + 3 * kHalfBytes, wave);
-    oa.issue(h_make_rsrc(bA + odo.offA), 1, ldsBase + 1 * kHalfBytes, wave);
-    if (1 < nTiles) odo.advance(p.gK);
-    uint64_t offA1 = odo.offA, offB1 = odo.offB;  // offsets of tile t + 1 (t = current tile)
-    oa.issue(h_make_rsrc(bA + offA1), 0, ldsBase + 4 * kHalfBytes, wave);
-    ob.issue(h_make_rsrc(bB + offB1), 0, ldsBase + 6 * kHalfBytes, wave);
-    int tNext = 2;                                // K-tile the odometer is about to describe
-    if (tNext < nTiles) odo.advance(p.gK);
-    uint64_t offA2 = odo.offA, offB2 = odo.offB;  // offsets of tile t + 2
-    CTAMD_H_VMCNT(8);                             // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
+    auto prologue = [&]() {
+        oa.issue(h_make_rsrc(bA + odo.offA), 0, ldsBase + 0 * kHalfBytes, wave);
+        ob.issue(h_make_rsrc(bB + odo.offB), 0, ldsBase + 2 * kHalfBytes, wave);
+        ob.issue(h_make_rsrc(bB + odo.offB), 1, ldsBase + 3 * kHalfBytes, wave);
+        oa.issue(h_make_rsrc(bA + odo.offA), 1, ldsBase + 1 * kHalfBytes, wave);
+        if (1 < nTiles) odo.advance(p.gK);
+        offA1 = odo.offA; offB1 = odo.offB;        // offsets of tile t + 1 (t = current tile)
+        oa.issue(h_make_rsrc(bA + offA1), 0, ldsBase + 4 * kHalfBytes, wave);
+        ob.issue(h_make_rsrc(bB + offB1), 0, ldsBase + 6 * kHalfBytes, wave);
+        tNext = 2;                                 // K-tile the odometer is about to describe
+        if (tNext < nTiles) odo.advance(p.gK);
+        offA2 = odo.offA; offB2 = odo.offB;        // offsets of tile t + 2
+    };
 
     f32x16 acc[2][2][2];                          // [A half][32-row fragment][B half]
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int z = 0; z < 2; ++z)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[x][y][z][r] = 0.f;
     s16x8 a[2][4], b0[4], b1[4];
 
     // rows of this wave inside an A half-tile: 64 wr + 32 fa; columns inside a B half-tile: 32 wc
@@ -553,69 +637,110 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
     }
 #define CTAMD_H_TILE(P) CTAMD_H_PHASE(P, 0) CTAMD_H_PHASE(P, 1) CTAMD_H_PHASE(P, 2) CTAMD_H_PHASE(P, 3)
 
-    if constexpr (ABL >= 2) {   // the fragments the ablated loop never refreshes
-        CTAMD_H_READ_A(0) CTAMD_H_READ_B(2, b0) CTAMD_H_READ_B(3, b1)
-    }
     unsigned long long* tstamp = nullptr;
     int t8 = 0;
     if constexpr (TIMED) {
         if (p.timing != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4)) tstamp = p.timing + (wave >> 2) * 32;
     }
-    if constexpr (TIMED) wgStamp[1] = __builtin_readcyclecounter();
-    int t = 0;
-    for (; t + 1 < nTiles; t += 2) { t8 = t; CTAMD_H_TILE(0) t8 = t + 1; CTAMD_H_TILE(1) }
-    if (t < nTiles) { t8 = t; CTAMD_H_TILE(0) }
-    if constexpr (TIMED) wgStamp[2] = __builtin_readcyclecounter();
-    if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
-    CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive the workgroup
 
-    // ---- split-K: fp32 partial tile, row-major [slice][l][m][n] (32 lanes x 4 B contiguous along n); the fold
-    //      (splitk_reduce_kernel, 16-bit output) applies alpha / beta -------------------------------------------
-    if (p.partial != nullptr) {
-        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
-        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
-        auto store_partial = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+    // One output tile per workgroup.  (A persistent form — one workgroup per CU walking over its tiles, the next tile's first
+    // half-tiles streaming in while the result goes out — measured SLOWER, 529 vs 505 us on 8192^3 zeros: vmcnt counts loads and
+    // stores in order, so the next tile's main loop waits for the stores anyway, whereas a workgroup that ends leaves its stores
+    // to drain behind the next workgroup's start.)
+    setup(blockIdx.x, p);
+    prologue();
+    {
+        if constexpr (TIMED) { wgStamp[0] = __builtin_readcyclecounter(); wgStamp[4] = wall_clock64(); }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < Mt) {
-                    const uint32_t na = n0 + 32 * wc + (lane & 31), nb = na + 128;
-                    if (na < Nt) P[(size_t)m * Nt + na] = c0[r];
-                    if (nb < Nt) P[(size_t)m * Nt + nb] = c1[r];
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[x][y][z][r] = 0.f;
+        CTAMD_H_VMCNT(8);                             // A-half 0 and B-half 0 of tile 0 have landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
+
+        if constexpr (ABL >= 2 && ABL <= 5) {   // the fragments the ablated loop never refreshes
+            CTAMD_H_READ_A(0) CTAMD_H_READ_B(2, b0) CTAMD_H_READ_B(3, b1)
+        }
+        if constexpr (TIMED) wgStamp[1] = __builtin_readcyclecounter();
+        int t = 0;
+        for (; t + 1 < nTiles; t += 2) { t8 = t; CTAMD_H_TILE(0) t8 = t + 1; CTAMD_H_TILE(1) }
+        if (t < nTiles) { t8 = t; CTAMD_H_TILE(0) }
+        if constexpr (TIMED) wgStamp[2] = __builtin_readcyclecounter();
+        if (wr == 0) __builtin_amdgcn_s_barrier();    // pairs with the last barrier of the second wave row
+        CTAMD_H_VMCNT(0);                             // the re-staged tail tiles: no LDS-DMA may outlive its tile
+        __syncthreads();                              // every wave has finished reading the ring, every piece has landed
+
+        const uint32_t em0 = m0, en0 = n0, el = l, eslice = slice, evb = blockIdx.x;
+        GettParams q;                                 // a fresh copy of the arguments for the epilogue (only the fields used are loaded)
+        h_reload_params(q);
+
+        if (q.partial != nullptr) {
+            // ---- split-K: fp32 partial tile, row-major [slice][l][m][n] (32 lanes x 4 B contiguous along n); the fold
+            //      (splitk_reduce_kernel, 16-bit output) applies alpha / beta ---------------------------------------
+            int laneE = lane;
+            asm volatile("" : "+v"(laneE));
+            const uint32_t Mt = q.gM.total, Nt = q.gN.total;
+            float* P = q.partial + ((size_t)eslice * q.gL.total + el) * (size_t)Mt * Nt;
+            auto store_partial = [&](const f32x16& c0, const f32x16& c1, uint32_t mBase) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (laneE >> 5);
+                    if (m < Mt) {
+                        const uint32_t na = en0 + 64 * wc + (laneE & 31), nb = na + 32;
+                        if (na < Nt) P[(size_t)m * Nt + na] = c0[r];
+                        if (nb < Nt) P[(size_t)m * Nt + nb] = c1[r];
+                    }
                 }
+            };
+            store_partial(acc[0][0][0], acc[0][0][1], em0 + 64 * wr);
+            store_partial(acc[0][1][0], acc[0][1][1], em0 + 64 * wr + 32);
+            store_partial(acc[1][0][0], acc[1][0][1], em0 + 128 + 64 * wr);
+            store_partial(acc[1][1][0], acc[1][1][1], em0 + 128 + 64 * wr + 32);
+        } else if constexpr (ABL == 5) {              // measurement only: no epilogue (one word per lane keeps the accumulators alive)
+            float keep = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[0][0][0][r] + acc[0][0][1][r] + acc[0][1][0][r] + acc[0][1][1][r] + acc[1][0][0][r] + acc[1][0][1][r] + acc[1][1][0][r] + acc[1][1][1][r];
+            if (keep == 12345.678f) static_cast<uint16_t*>(q.D)[tid] = 1;
+        } else {
+            // ---- epilogue: D = alpha * acc + beta * C, 16 rows x 64 columns at a time through 4 KiB of LDS per wave --------
+            HEpilogue ep;
+            ep.init(q, el, lds, wave, 4096);
+            int laneE = lane;                         // opaque (see setup): lane-derived addresses are recomputed here, not kept
+            asm volatile("" : "+v"(laneE));
+            constexpr int ST = (ABL == 6 ? 1 : ABL == 7 ? 2 : 0);
+            const uint32_t nB = en0 + 64 * wc;
+            // ONE copy of the store code: a rolled loop over the eight (fragment pair, half) passes; only the parking of the
+            // accumulators (registers cannot be indexed at run time) is selected by a wave-uniform switch
+#pragma unroll 1
+            for (int pass = 0; pass < 8; ++pass) {
+                switch (pass) {
+                    case 0: ep.template park_pair<0>(acc[0][0][0], acc[0][0][1], laneE); break;
+                    case 1: ep.template park_pair<1>(acc[0][0][0], acc[0][0][1], laneE); break;
+                    case 2: ep.template park_pair<0>(acc[0][1][0], acc[0][1][1], laneE); break;
+                    case 3: ep.template park_pair<1>(acc[0][1][0], acc[0][1][1], laneE); break;
+                    case 4: ep.template park_pair<0>(acc[1][0][0], acc[1][0][1], laneE); break;
+                    case 5: ep.template park_pair<1>(acc[1][0][0], acc[1][0][1], laneE); break;
+                    case 6: ep.template park_pair<0>(acc[1][1][0], acc[1][1][1], laneE); break;
+                    default: ep.template park_pair<1>(acc[1][1][0], acc[1][1][1], laneE); break;
+                }
+                const uint32_t mB = em0 + 128u * (uint32_t)(pass >> 2) + 64u * (uint32_t)wr + 16u * (uint32_t)(pass & 3);
+                ep.template flush_pair<BF, ST>(q, mB, nB, laneE);
             }
-        };
-        store_partial(acc[0][0][0], acc[0][0][1], m0 + 64 * wr);
-        store_partial(acc[0][1][0], acc[0][1][1], m0 + 64 * wr + 32);
-        store_partial(acc[1][0][0], acc[1][0][1], m0 + 128 + 64 * wr);
-        store_partial(acc[1][1][0], acc[1][1][1], m0 + 128 + 64 * wr + 32);
-        return;
-    }
-    // ---- epilogue: D = alpha * acc + beta * C through the per-wave LDS turn (HEpilogue) --------------------------------
-    if constexpr (ABL == 5) {                     // measurement only: no epilogue (one word per lane keeps the accumulators alive)
-        float keep = 0.f;
+        }
+        if constexpr (TIMED) {
+            if (p.timing != nullptr && tid == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of this wave have left
+                wgStamp[3] = __builtin_readcyclecounter();
+                wgStamp[5] = wall_clock64();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) keep += acc[0][0][0][r] + acc[0][0][1][r] + acc[0][1][0][r] + acc[0][1][1][r] + acc[1][0][0][r] + acc[1][0][1][r] + acc[1][1][0][r] + acc[1][1][1][r];
-        if (keep == 12345.678f) static_cast<uint16_t*>(p.D)[tid] = 1;
-        return;
-    }
-    __syncthreads();                              // every wave has finished reading the operand ring
-    HEpilogue ep;
-    ep.init(p, l, lds, wave);
-#pragma unroll
-    for (int ah = 0; ah < 2; ++ah) {              // two passes of four fragments: (fr, bh) = (0,0) (0,1) (1,0) (1,1)
-        ep.park(0, acc[ah][0][0], lane); ep.park(1, acc[ah][0][1], lane); ep.park(2, acc[ah][1][0], lane); ep.park(3, acc[ah][1][1], lane);
-        const uint32_t mB = m0 + 128 * ah + 64 * wr, nB = n0 + 32 * wc;
-        ep.template flush<BF>(p, mB, 32u, 0u, nB, 0u, 128u, lane);
-    }
-    if constexpr (TIMED) {
-        if (p.timing != nullptr && tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores of this wave have left
-            wgStamp[3] = __builtin_readcyclecounter();
-            wgStamp[5] = wall_clock64();
-#pragma unroll
-            for (int i = 0; i < 6; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
-            p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+                for (int i = 0; i < 6; ++i) p.timing[64 + 8 * (size_t)evb + i] = wgStamp[i];
+                p.timing[64 + 8 * (size_t)evb + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+            }
         }
     }
 }
@@ -1116,21 +1241,24 @@ static hipError_t launch_h16w4(const GettParams& p, hipStream_t stream) {
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
+    const dim3 grid(p.nBlocks);
     if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps
         if (timed) {
-            hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+            hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, true>), grid, dim3(512), 0, stream, p);
             return hipGetLastError();
         }
     }
     if constexpr (BF && LA == LAY_K && LB == LAY_K) {   // ablations: one instantiation ('km,kn' bf16)
         static const int abl = [] { const char* e = getenv("CUTENSOR_AMD_H16_ABL"); return e ? atoi(e) : 0; }();
-        if (abl == 1) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 1>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
-        if (abl == 2) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 2>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
-        if (abl == 3) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 3>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
-        if (abl == 4) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
-        if (abl == 5) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 5>), dim3(p.nBlocks), dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 1) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 1>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 2) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 2>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 3) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 3>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 4) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 4>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 5) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 5>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 6) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 6>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 7) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 7>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
     }
-    hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@
 # limit (measurement only; wrong results).  usage: tools/h16_pp_abl.sh <outfile>
 OUT=${1:-gpurun_out/h16_pp_abl.jsonl}
 for z in "" "--zeros"; do
-for a in 0 1 2 4 3; do
+for a in 0 1 2 4 3 5; do
     CUTENSOR_AMD_H16_ABL=$a timeout 120 python tools/bench_h16.py --layout km,kn $z 2>&1 | grep workload | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print(json.dumps({'abl': $a, 'zeros': '$z' != '', 'tflops': d['tflops'], 'ms': d['ms_per_call']}))" >> $OUT
