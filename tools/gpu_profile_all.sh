@@ -26,6 +26,29 @@ for L in mk,kn km,kn; do
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/h16_${N}_write -o r -- $H16 > $OUT/h16_${N}_write.log 2>&1
   for p in trace sq fetch write; do summ h16_${N}_$p h16_${N}_$p; done
 done
+# ---- 2b. all four layouts beside the vendor GEMM and the MFMA-only rate of this box, same call (no profiler) ----------------
+cd $ROOT
+: > $OUT/h16_vs_vendor.jsonl
+for L in mk,kn km,kn mk,nk km,nk; do
+  python tools/bench_h16.py --layout $L 2>/dev/null | grep workload >> $OUT/h16_vs_vendor.jsonl
+  python tools/bench_h16.py --layout $L --zeros 2>/dev/null | grep workload >> $OUT/h16_vs_vendor.jsonl
+done
+python tools/ubench/vendor_gemm_bf16.py 2>/dev/null | grep vendor >> $OUT/h16_vs_vendor.jsonl
+python tools/ubench/vendor_gemm_bf16.py --zeros 2>/dev/null | grep vendor >> $OUT/h16_vs_vendor.jsonl
+python - >> $OUT/h16_vs_vendor.jsonl 2>/dev/null <<PY
+import ctypes, json, sys
+sys.path.insert(0, '.')
+from cudalibrarysamples_amd import cutensor as ct
+import torch
+torch.cuda.init()
+out = {}
+for name, kind in (('zeros', 0), ('uniform', 1)):
+    v = ctypes.c_float(0); ct.lib.ctamdMeasureMfmaCeiling(1, kind, ctypes.byref(v)); out[name] = v.value
+print(json.dumps({'mfma_only_tflops': out}))
+PY
+python tools/h16_ksweep.py --zeros 2>/dev/null | tail -1 > $OUT/h16_ksweep.jsonl
+python tools/h16_ksweep.py 2>/dev/null | tail -1 >> $OUT/h16_ksweep.jsonl
+cd /tmp
 # ---- 3. the whole default bench line (secondary configs included): kernel trace only ------------------------------------
 rocprofv3 --kernel-trace --stats -d $OUT/bench_all_trace -o r -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu > $OUT/bench_all_trace.log 2>&1
 summ bench_all_trace bench_all_trace
