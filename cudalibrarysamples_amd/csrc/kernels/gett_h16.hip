@@ -12,8 +12,9 @@
 //   * one 512-thread workgroup per CU owns a 256 x 256 output tile; K advances in tiles of 64.
 //   * HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, issued from
 //     inline asm so that the compiler's wait-count pass does not drain it in front of every ds_read).
-//     A K-tile is four 16-KiB half-tiles (A rows 0-127 / 128-255, B columns 0-127 / 128-255) and the LDS
-//     holds two K-tiles = eight half-tile slots (128 KiB).  Which 16-byte unit of the half-tile a lane
+//     A K-tile is four 16-KiB half-tiles (A rows 0-127 / 128-255; B half h = the 32-column stripes
+//     64 j + 32 h + [0,32), j = 0..3, in the default kernel, columns 128 h + [0,128) in the variants) and the
+//     LDS holds two K-tiles = eight half-tile slots (128 KiB).  Which 16-byte unit of the half-tile a lane
 //     fetches is free, so the LDS image is shaped by permuting the *source* units:
 //       - K-contiguous operand (LAY_K): image [128 rows][64 k] (128-byte rows); unit p of row r holds
 //         k-unit p ^ ((r >> 1) & 7): the ds_read_b128 fragment reads (32 rows x 2 k-units) are
@@ -22,8 +23,9 @@
 //         holds row-unit p ^ (4 * (k & 3)); fragments are read with the transposing ds_read_b64_tr_b16
 //         (4 k x 16 rows per 16-lane group), the four k-rows of a half-wave fall into the four 64-byte
 //         quarters of the bank row: conflict-free.
-//   * 8 waves as 2 (M) x 4 (N); a wave owns rows {64 wr + [0,64)} of both A halves and columns
-//     {32 wc + [0,32)} of both B halves: 2 x 2 x 2 accumulator fragments of 32 x 32 (128 registers).
+//   * 8 waves as 2 (M) x 4 (N); a wave owns rows {64 wr + [0,64)} of both A halves and stripe wc of
+//     both B halves (output columns 64 wc + [0,64)): 2 x 2 x 2 accumulator fragments of 32 x 32 (128
+//     registers).
 //     A K-tile is four phases, one accumulator quadrant (64 x 32, eight MFMAs) each, in the order
 //     (a0,b0) (a0,b1) (a1,b1) (a1,b0): a phase reads only the operand half that changes, so A-half 0 and
 //     B-half 0 are dead after phase 0, B-half 1 after phase 1, A-half 1 after phase 2 — each slot is
