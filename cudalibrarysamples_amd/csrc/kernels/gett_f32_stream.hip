@@ -239,8 +239,17 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     const int wave = wave8 & 3;
     const bool loader = wave8 >= 4;
     unsigned long long* tlog = p.timing ? p.timing + (size_t)blockIdx.x * 16 : nullptr;
+    // lane id from the exec-mask bit count, not from threadIdx: nothing derived from the launch registers has to stay alive
+    // through the main loop for the sake of the epilogue or of a diagnostic stamp
+    auto lane_now = []() -> int {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#else
+        return 0;
+#endif
+    };
     auto stamp = [&](int slot) {
-        if (tlog != nullptr && tid == 0) tlog[slot] = (slot >= 5 && slot != 7) ? wall_clock64() : __builtin_readcyclecounter();
+        if (tlog != nullptr && wave8 == 0 && lane_now() == 0) tlog[slot] = (slot >= 5 && slot != 7) ? wall_clock64() : __builtin_readcyclecounter();
     };
     stamp(0);
     stamp(5);
@@ -392,10 +401,12 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     // One K-tile in ring slot U (compile-time, so every LDS address is base + immediate).  The fragments
     // of the odd 16-step are fetched under the MFMAs of the even step; the barrier sits a third into the
     // odd step and the first fragments of the next tile are fetched under the remaining two thirds.
-#define CTAMD_TILE_BODY(U, LASTTILE)                                                                       \
+#define CTAMD_TILE_BODY(U, LASTTILE) CTAMD_TILE_BODY_AT(lds + (U) * STAGE, lds + (((U) + 1) % S) * STAGE, LASTTILE)
+#define CTAMD_TILE_BODY_AT(CUR, NXT, LASTTILE) CTAMD_TILE_BODY_AT2(CUR, NXT, LASTTILE, load0, load1)
+#define CTAMD_TILE_BODY_AT2(CUR, NXT, LASTTILE, load0, load1)                                              \
     {                                                                                                      \
-        const float* cur = lds + (U) * STAGE;                                                              \
-        const float* nxt = lds + (((U) + 1) % S) * STAGE;                                                  \
+        const float* cur = (CUR);                                                                          \
+        const float* nxt = (NXT);                                                                          \
         load1(cur);                                                                                        \
         CTAMD_MFMA_RANGE(a0, b0, 0, NMFMA)                                                                 \
         CTAMD_INTERLEAVE_DS(TM + 4 * TN)                                                                   \
@@ -429,20 +440,42 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     stamp(2);
     const int r = nTiles - t;
 #define CTAMD_BODY_END(U) CTAMD_TILE_BODY(U, (U) == S - 1)
-#define CTAMD_BODY_TAIL(U)                                                     \
-    if (r == (U) + 1) CTAMD_TILE_BODY(U, true)                                 \
-    else if (r > (U) + 1) CTAMD_TILE_BODY(U, false)
     if (r == S) {          // the common case (whole ring turns): straight-line code, no per-tile branch
         CTAMD_FOR_SLOTS(CTAMD_BODY_END)
     } else {
-        CTAMD_FOR_SLOTS(CTAMD_BODY_TAIL)
+        // 1 .. S - 1 tiles left (slots 0 .. r - 1): ONE rolled copy of the tile body with run-time slot addresses.  (Unrolled
+        // per slot with a branch on r in front of every copy, this tail alone spilled 90-180 VGPRs to scratch memory in the
+        // 128 x 128 instantiations — and a kernel that spills is one the next unrelated edit can break.)
+        // The fragment bases go through an opaque copy per use, so that derived addresses (base ^ 16, base + slot) are formed
+        // where they are needed instead of being carried through the loop in registers it does not have.
+        auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+        auto load0t = [&](const float* st) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a0[i] = OpA::template fragment<0>(st, opaque(baseA[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b0[j] = OpB::template fragment<0>(st + OpA::FLOATS, opaque(baseB[j]));
+        };
+        auto load1t = [&](const float* st) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a1[i] = OpA::template fragment<1>(st, opaque(baseA[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b1[j] = OpB::template fragment<1>(st + OpA::FLOATS, opaque(baseB[j]));
+        };
+        int u = 0;
+#pragma unroll 1
+        for (; u + 1 < r; ++u) CTAMD_TILE_BODY_AT2(lds + u * STAGE, lds + (u + 1) * STAGE, false, load0t, load1t)
+        CTAMD_TILE_BODY_AT2(lds + u * STAGE, lds, true, load0t, load1t)     // u == r - 1
     }
     stamp(3);
     if constexpr (Cfg::ABL == 3) {
-        if (tlog != nullptr && tid == 0) tlog[8] = waitC;
+        if (tlog != nullptr && wave8 == 0 && lane_now() == 0) tlog[8] = waitC;
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
+    // Everything the epilogue derives from the lane number is derived HERE (opaque copy): hoisted to kernel entry it would
+    // occupy registers across the main loop, and the 128 x 128 instantiations have none to spare.
+    const int laneE = lane_now();
+    const int tidE = wave8 * 64 + laneE;           // multiplying waves: wave8 = 0..3
     const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
     if (p.partial != nullptr) {
         // accumulator-order partials: [slice][l][nt][mt][wave][i][j][lane] x 16 B
@@ -454,7 +487,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) store_wt_16(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + lane) * 16));
+            for (int j = 0; j < TN; ++j) store_wt_16(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + laneE) * 16));
         stamp(4);
         if (p.sync == nullptr) {   // the fold runs as its own kernel
             stamp(6);
@@ -470,7 +503,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         uint32_t* cnt = p.sync;
-        if (tid == 0) {
+        if (tidE == 0) {
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.nBlocks && ++spins < (1u << 22))
@@ -487,7 +520,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         // share: 128-byte lines (8 accumulator quads) of the tile image, line i -> workgroup i mod nBlocks
         const uint32_t quadsTotal = p.tilesM * p.tilesN * 4u * TM * TN * 64u;
         const uint32_t lines = quadsTotal / 8u;
-        const int q = tid & 7, g = tid >> 3;                // 8 quads x 32 slice groups (256 multiplying threads)
+        const int q = tidE & 7, g = tidE >> 3;                // 8 quads x 32 slice groups (256 multiplying threads)
         f32x4* red = reinterpret_cast<f32x4*>(lds);         // the ring is idle now
         for (uint32_t line = blockIdx.x; line < lines; line += p.nBlocks) {
             const uint32_t e = line * 8u + q;
@@ -506,9 +539,9 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
             for (int m = 8; m < 64; m <<= 1)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) sum[c] += __shfl_xor(sum[c], m, 64);
-            if (lane < 8) red[wave * 8 + q] = sum;
+            if (laneE < 8) red[wave * 8 + q] = sum;
             __builtin_amdgcn_s_barrier();
-            if (tid < 8) {
+            if (tidE < 8) {
                 sum = (red[q] + red[8 + q]) + (red[16 + q] + red[24 + q]);
                 uint32_t rem = e;
                 const uint32_t ln = rem % 64; rem /= 64;
@@ -547,18 +580,64 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     bool    okN[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const uint32_t n = n0 + wn * (BN / 2) + 16 * j + (lane & 15);
+        const uint32_t n = n0 + wn * (BN / 2) + 16 * j + (laneE & 15);
         okN[j] = n < Ntot;
         offDn[j] = 0;
         offCn[j] = 0;
         if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
     }
     const float alpha = p.alpha, beta = p.beta;
+    // A lane's four accumulator registers of a fragment are four consecutive m at one n.  When the fastest M mode of D is
+    // contiguous, a multiple of 4 long and everything else keeps 16-byte alignment (wave-uniform test), they leave as ONE
+    // 16-byte store (64-byte row pieces per instruction) instead of four 4-byte stores — 4-byte pieces cost ~6x the time per
+    // byte (tools/f32_ksweep.py: fixed cost per workgroup).  Nontemporal: the result is not read again, the operand panels
+    // stay in L2.
+    bool vecD = p.gM.stride[1][0] == 1 && (p.gM.div[0].d & 3u) == 0u && (reinterpret_cast<uintptr_t>(D) & 15u) == 0u;
+    bool vecC = vecD && p.cStrideM[0] == 1 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0u;
+#pragma unroll
+    for (int q = 0; q < kMaxGroupModes; ++q) {
+        vecD = vecD && (q == 0 || (p.gM.stride[1][q] & 3) == 0) && (p.gN.stride[1][q] & 3) == 0;
+        vecC = vecC && (q == 0 || (p.cStrideM[q] & 3) == 0) && (p.cStrideN[q] & 3) == 0;
+    }
+    if (vecD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = m0 + wm * (BM / 2) + 16 * i + 4 * (laneE >> 4);
+            if (m >= Mtot) continue;               // Mtot is a multiple of 4 here: the four rows are all in or all out
+            int64_t offDm, offCm;
+            group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!okN[j]) continue;
+                f32x4 val = {alpha * acc[i][j][0], alpha * acc[i][j][1], alpha * acc[i][j][2], alpha * acc[i][j][3]};
+                if (beta != 0.f) {
+                    const float* c = C + offCm + offCn[j];
+                    if (vecC) {
+                        const f32x4 cv = *reinterpret_cast<const f32x4*>(c);
+                        val[0] += beta * cv[0]; val[1] += beta * cv[1]; val[2] += beta * cv[2]; val[3] += beta * cv[3];
+                    } else {
+                        int64_t dD, dC1, dC2, dC3;
+                        group_offset2<1>(p.gM, p.cStrideM, m + 1, dD, dC1);
+                        group_offset2<1>(p.gM, p.cStrideM, m + 2, dD, dC2);
+                        group_offset2<1>(p.gM, p.cStrideM, m + 3, dD, dC3);
+                        val[0] += beta * c[0];
+                        val[1] += beta * C[dC1 + offCn[j]];
+                        val[2] += beta * C[dC2 + offCn[j]];
+                        val[3] += beta * C[dC3 + offCn[j]];
+                    }
+                }
+                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(D + offDm + offDn[j]));
+            }
+        }
+        stamp(4);
+        stamp(6);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t m = m0 + wm * (BM / 2) + 16 * i + 4 * (lane >> 4) + r;
+            const uint32_t m = m0 + wm * (BM / 2) + 16 * i + 4 * (laneE >> 4) + r;
             if (m >= Mtot) continue;
             int64_t offDm, offCm;
             group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
