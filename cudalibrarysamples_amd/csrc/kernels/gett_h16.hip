@@ -262,8 +262,8 @@ struct HEpilogue {
 
     // ---- four-fragment form (four-wave and streamed kernels) ------------------------------------------------------------
     // store the four parked fragments; fragment f covers rows mB + mHi (f >> 1) + mLo (f & 1) + [0, 32), columns alike
-    // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a kernel that uses all 160 KiB of
-    // LDS and touches scratch memory faults on gfx950)
+    // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a scratch allocation is paid for at
+    // every dispatch)
     // ST (measurement): 0 = nontemporal stores, 1 = plain, 2 = write-through (sc1)
     template <bool BF, int ST = 0>
     __device__ __forceinline__ void flush(const GettParams& p, uint32_t mB0, uint32_t mHi, uint32_t mLo, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane) const {
