@@ -1,0 +1,75 @@
+"""Properties of the compiled gfx950 kernels that no numerical test sees, read from the code objects inside build/obj/*.o
+(no GPU needed): the hot kernels must not touch scratch memory, and the kernel-argument prefetch must give every touched
+word a scalar register of its own ("the kernel-argument prefetch": one shared destination register let a
+late scalar load overwrite a live value — a fault that came and went with register allocation and timing)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _code_object(tmp_path, name):
+    obj = os.path.join(ROOT, "build", "obj", name + ".o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no %s or no llvm-objdump in this environment" % obj)
+    local = os.path.join(str(tmp_path), name + ".o")
+    shutil.copy(obj, local)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=str(tmp_path))
+    co = [f for f in os.listdir(str(tmp_path)) if f.startswith(name + ".o.") and "gfx950" in f]
+    assert co, "no gfx950 code object inside %s" % obj
+    return os.path.join(str(tmp_path), co[0])
+
+
+def _kernel_notes(co):
+    """{kernel symbol: {field: int}} from the code object's metadata note."""
+    out = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels, cur = {}, None
+    for line in out.splitlines():
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m and m.group(1).startswith("_Z"):
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s*\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|group_segment_fixed_size):\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return kernels
+
+
+def test_default_16_bit_kernels_use_no_scratch(built, tmp_path):
+    k = _kernel_notes(_code_object(tmp_path, "gett_h16"))
+    hot = {n: v for n, v in k.items() if "gett_h16_kernel" in n or "gett_h16s_kernel" in n}
+    assert len(hot) >= 16, sorted(k)
+    bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+
+
+def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
+    k = _kernel_notes(_code_object(tmp_path, "gett_f32_stream"))
+    hot = {n: v for n, v in k.items() if "gett_f32_stream_kernel" in n}
+    assert len(hot) >= 19, sorted(k)
+    bad = {n: v for n, v in hot.items() if v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+    # the headline einsum's kernel and the contraction.cu default's: no private segment at all
+    for cfg in ("Li96ELi96ELi1ELi0ELi3ELi0", "Li96ELi96ELi0ELi0ELi3ELi0", "Li128ELi128ELi1ELi0ELi3ELi0"):
+        (name,) = [n for n in hot if cfg in n]
+        assert hot[name].get("private_segment_fixed_size", 0) == 0, (name, hot[name])
+
+
+@pytest.mark.parametrize("obj,symbol", [
+    ("gett_f32_stream", "_ZN5ctamd22gett_f32_stream_kernelINS_9StreamCfgILi96ELi96ELi1ELi0ELi3ELi0EEEEEvNS_10GettParamsE"),
+    ("gett_h16", "_ZN5ctamd15gett_h16_kernelILb1ELi1ELi0ELb0ELi0EEEvNS_10GettParamsE"),
+])
+def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, obj, symbol):
+    co = _code_object(tmp_path, obj)
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + symbol, co], check=True,
+                         capture_output=True, text=True).stdout
+    # the burst: s_load_dword sN, s[a:b], 0x40 * i — one per 64-byte line of the 816-byte argument block
+    loads = re.findall(r"s_load_dword (s\d+), s\[\d+:\d+\], (0x[0-9a-f]+)", dis)
+    burst = {int(off, 16): reg for reg, off in loads if int(off, 16) % 64 == 0 and int(off, 16) < 832}
+    assert sorted(burst) == [64 * i for i in range(13)], loads[:20]
+    assert len(set(burst.values())) == 13, burst          # thirteen lines, thirteen different destination registers
