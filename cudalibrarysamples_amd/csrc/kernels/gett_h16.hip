@@ -476,7 +476,8 @@ struct HOdometer {
 // record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
 // ABL (measurement only, wrong results; CUTENSOR_AMD_H16_ABL with the default kernel): 1 = no LDS-DMA in the main loop,
 // 2 = no A-fragment reads in the main loop, 3 = neither fragment reads nor LDS-DMA (MFMAs + barriers only),
-// 4 = no B-fragment reads, 5 = complete main loop but no epilogue — what each kind of data movement costs under the power
+// 4 = no B-fragment reads, 8 = no B traffic through LDS at all (neither LDS-DMA nor fragment reads), 5 = complete main loop
+// but no epilogue — what each kind of data movement costs under the power
 // limit on random data, and what the epilogue costs.
 template <bool BF, int LA, int LB, bool TIMED = false, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
@@ -606,14 +607,14 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         __builtin_amdgcn_sched_barrier(0);                                                         \
         CTAMD_H_STAMP(Q, 0)                                                                        \
         if constexpr ((Q) == 0 && ABL != 2 && ABL != 3) { CTAMD_H_READ_A((P) * 4 + 0) }             \
-        if constexpr ((Q) == 0 && ABL != 4 && ABL != 3) { CTAMD_H_READ_B((P) * 4 + 2, b0) }         \
-        if constexpr ((Q) == 1 && ABL != 4 && ABL != 3) { CTAMD_H_READ_B((P) * 4 + 3, b1) }         \
+        if constexpr ((Q) == 0 && ABL != 4 && ABL != 3 && ABL != 8) { CTAMD_H_READ_B((P) * 4 + 2, b0) }         \
+        if constexpr ((Q) == 1 && ABL != 4 && ABL != 3 && ABL != 8) { CTAMD_H_READ_B((P) * 4 + 3, b1) }         \
         if constexpr ((Q) == 2 && ABL != 2 && ABL != 3) { CTAMD_H_READ_A((P) * 4 + 1) }             \
-        if constexpr ((Q) == 0 && ABL != 1 && ABL != 3) ob.template issue<false>(h_make_rsrc(bB + offB1), 1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
+        if constexpr ((Q) == 0 && ABL != 1 && ABL != 3 && ABL != 8) ob.template issue<false>(h_make_rsrc(bB + offB1), 1, ldsBase + (((P) ^ 1) * 4 + 3) * kHalfBytes, wave);  \
         if constexpr ((Q) == 1 && ABL != 1 && ABL != 3) oa.template issue<false>(h_make_rsrc(bA + offA1), 1, ldsBase + (((P) ^ 1) * 4 + 1) * kHalfBytes, wave);  \
         if constexpr ((Q) == 2 && ABL != 1 && ABL != 3) oa.template issue<false>(h_make_rsrc(bA + offA2), 0, ldsBase + ((P) * 4 + 0) * kHalfBytes, wave);        \
         if constexpr ((Q) == 3) {                                                                  \
-            if constexpr (ABL != 1 && ABL != 3) ob.template issue<false>(h_make_rsrc(bB + offB2), 0, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
+            if constexpr (ABL != 1 && ABL != 3 && ABL != 8) ob.template issue<false>(h_make_rsrc(bB + offB2), 0, ldsBase + ((P) * 4 + 2) * kHalfBytes, wave);    \
             offA1 = offA2; offB1 = offB2;                                                          \
             ++tNext;                                                                               \
             if (tNext < nTiles) odo.advance(p.gK);   /* past the end: re-stage the last tile (never read) */ \
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(512, 2) gett_h16_kernel(const GettParams p) {
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();    // second wave row runs half a phase behind
 
-        if constexpr (ABL >= 2 && ABL <= 5) {   // the fragments the ablated loop never refreshes
+        if constexpr ((ABL >= 2 && ABL <= 5) || ABL == 8) {   // the fragments the ablated loop never refreshes
             CTAMD_H_READ_A(0) CTAMD_H_READ_B(2, b0) CTAMD_H_READ_B(3, b1)
         }
         if constexpr (TIMED) wgStamp[1] = __builtin_readcyclecounter();
@@ -1259,6 +1260,7 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
         if (abl == 5) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 5>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
         if (abl == 6) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 6>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
         if (abl == 7) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 7>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
+        if (abl == 8) { hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB, false, 8>), grid, dim3(512), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16_kernel<BF, LA, LB>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
