@@ -62,6 +62,93 @@ __device__ __forceinline__ void group_offset2(const ModeGroup& g, const int64_t*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// D = alpha * acc + beta * C for the TM x TN accumulator fragments (16 x 16, v_mfma_f32_16x16x4_f32 map: acc[i][j][r] is row
+// 4 * (lane >> 4) + r, column lane & 15 of fragment (i, j)) of one wave, rows from mBase, columns from nBase.  A lane's four
+// registers of a fragment are four consecutive m: when D's fastest M mode is contiguous, a multiple of 4 long and everything
+// else keeps 16-byte alignment (wave-uniform test) they leave as ONE nontemporal 16-byte store instead of four 4-byte stores
+// (4-byte pieces cost ~6x the time per byte; DESIGN.md section 6, fixed cost per workgroup).
+// ---------------------------------------------------------------------------------------------
+template <int TM, int TN>
+__device__ __forceinline__ void gett_store_tile_f32(const GettParams& p, const f32x4 (&acc)[TM][TN], uint32_t mBase, uint32_t nBase,
+                                                    uint32_t l, int lane) {
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    const float* C = static_cast<const float*>(p.C);
+    float*       D = static_cast<float*>(p.D);
+    {
+        int64_t oD, oC;
+        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
+        D += oD;
+        C += oC;
+    }
+    int64_t offDn[TN], offCn[TN];
+    bool    okN[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const uint32_t n = nBase + 16 * j + (lane & 15);
+        okN[j] = n < Ntot;
+        offDn[j] = 0;
+        offCn[j] = 0;
+        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
+    }
+    const float alpha = p.alpha, beta = p.beta;
+    bool vecD = p.gM.stride[1][0] == 1 && (p.gM.div[0].d & 3u) == 0u && (reinterpret_cast<uintptr_t>(D) & 15u) == 0u;
+    bool vecC = vecD && p.cStrideM[0] == 1 && (reinterpret_cast<uintptr_t>(C) & 15u) == 0u;
+#pragma unroll
+    for (int q = 0; q < kMaxGroupModes; ++q) {
+        vecD = vecD && (q == 0 || (p.gM.stride[1][q] & 3) == 0) && (p.gN.stride[1][q] & 3) == 0;
+        vecC = vecC && (q == 0 || (p.cStrideM[q] & 3) == 0) && (p.cStrideN[q] & 3) == 0;
+    }
+    if (vecD) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint32_t m = mBase + 16 * i + 4 * (lane >> 4);
+            if (m >= Mtot) continue;               // Mtot is a multiple of 4 here: the four rows are all in or all out
+            int64_t offDm, offCm;
+            group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!okN[j]) continue;
+                f32x4 val = {alpha * acc[i][j][0], alpha * acc[i][j][1], alpha * acc[i][j][2], alpha * acc[i][j][3]};
+                if (beta != 0.f) {
+                    const float* c = C + offCm + offCn[j];
+                    if (vecC) {
+                        const f32x4 cv = *reinterpret_cast<const f32x4*>(c);
+                        val[0] += beta * cv[0]; val[1] += beta * cv[1]; val[2] += beta * cv[2]; val[3] += beta * cv[3];
+                    } else {
+                        int64_t dD, dC1, dC2, dC3;
+                        group_offset2<1>(p.gM, p.cStrideM, m + 1, dD, dC1);
+                        group_offset2<1>(p.gM, p.cStrideM, m + 2, dD, dC2);
+                        group_offset2<1>(p.gM, p.cStrideM, m + 3, dD, dC3);
+                        val[0] += beta * c[0];
+                        val[1] += beta * C[dC1 + offCn[j]];
+                        val[2] += beta * C[dC2 + offCn[j]];
+                        val[3] += beta * C[dC3 + offCn[j]];
+                    }
+                }
+                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(D + offDm + offDn[j]));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t m = mBase + 16 * i + 4 * (lane >> 4) + r;
+            if (m >= Mtot) continue;
+            int64_t offDm, offCm;
+            group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!okN[j]) continue;
+                float val = alpha * acc[i][j][r];
+                if (beta != 0.f) val += beta * C[offCm + offCn[j]];
+                D[offDm + offDn[j]] = val;
+            }
+        }
+}
+
 // Touch every 64-byte line of the kernel-argument segment with one burst of scalar loads and wait once.
 // hipcc fetches arguments lazily, in as many dependent rounds as the control flow has stages (8 for the
 // streaming GETT kernel), and a round that misses the scalar cache costs ~900 cycles at kernel start; after

@@ -479,41 +479,7 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         return;
     }
 
-    const float* C = static_cast<const float*>(p.C);
-    float*       D = static_cast<float*>(p.D);
-    {
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-    }
-    int64_t offDn[TN], offCn[TN];
-    bool    okN[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const uint32_t n = n0 + wn * (BN / WN) + 16 * j + (lane & 15);
-        okN[j] = n < Ntot;
-        offDn[j] = 0;
-        offCn[j] = 0;
-        if (okN[j]) group_offset2<1>(p.gN, p.cStrideN, n, offDn[j], offCn[j]);
-    }
-    const float alpha = p.alpha, beta = p.beta;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t m = m0 + wm * (BM / WM) + 16 * i + 4 * (lane >> 4) + r;
-            if (m >= Mtot) continue;
-            int64_t offDm, offCm;
-            group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (!okN[j]) continue;
-                float val = alpha * acc[i][j][r];
-                if (beta != 0.f) val += beta * C[offCm + offCn[j]];
-                D[offDm + offDn[j]] = val;
-            }
-        }
+    gett_store_tile_f32<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -713,34 +679,7 @@ __global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(
         stamp(6);
         return;
     }
-    const float* C = static_cast<const float*>(p.C);
-    float*       D = static_cast<float*>(p.D);
-    {
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-    }
-    const float alpha = p.alpha, beta = p.beta;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const uint32_t n = n0 + wn * (BN / WN) + 16 * j + (lane & 15);
-        if (n >= Ntot) continue;
-        int64_t offDn, offCn;
-        group_offset2<1>(p.gN, p.cStrideN, n, offDn, offCn);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t m = m0 + wm * (BM / WM) + 16 * i + 4 * (lane >> 4) + r;
-                if (m >= Mtot) continue;
-                int64_t offDm, offCm;
-                group_offset2<1>(p.gM, p.cStrideM, m, offDm, offCm);
-                float val = alpha * acc[i][j][r];
-                if (beta != 0.f) val += beta * C[offCm + offCn];
-                D[offDm + offDn] = val;
-            }
-    }
+    gett_store_tile_f32<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
