@@ -171,3 +171,53 @@ def test_execution_on_a_plan_only_handle_is_refused(cm):
         addr = ctypes.addressof(buf)
         st = con.run(1.0, [addr] * 2, [addr] * 2, 0.0, [addr] * 2, [addr] * 2, [addr] * 2, [0, 0])
         assert st != 0
+
+
+def _blocks_of(E, bs, dc, coord):
+    """Index set of a mode that lives in grid coordinate `coord`: blocks coord, coord + dc, ... of size bs (ragged last block)."""
+    nblk = -(-E // bs)
+    idx = []
+    for b in range(coord, nblk, dc):
+        idx.extend(range(b * bs, min(E, (b + 1) * bs)))
+    return idx
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ragged_and_mixed_layouts_cover_c_once_and_gather_what_they_read(cm, seed):
+    """Random block-cyclic layouts of C[i,j] = A[i,k] B[k,j] over 2-4 devices with extents that do not divide the block size
+    (the blog_post harness's ceil()-derived blocks): whatever p / q cut the planner takes, every element of C is produced exactly
+    once (the p index ranges times the q-coordinate classes tile the padded index space), a cell is gathered at most once per
+    consumer, and every cell a piece reads from a staging image was gathered to that device."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([2, 3, 4]))
+    Ei, Ej, Ek = (int(rng.integers(40, 200)) for _ in range(3))
+    bi, bj = int(rng.integers(8, 48)), int(rng.integers(8, 48))
+    di = n
+    dj = int(rng.choice([1, 2])) if n % 2 == 0 else 1
+    modes = ["ik", "kj", "ij"]
+    extent = dict(i=Ei, j=Ej, k=Ek)
+    block = [dict(i=bi), dict(j=bj), dict(i=bi, j=bj)]
+    dcount = [dict(i=di), dict(j=dj), dict(i=di, j=dj)]
+    with cm.Contraction(list(range(n)), modes, extent, block, dcount) as con:
+        d = con.describe()
+        check_transfers(d, con, n)
+        cov = np.zeros((Ei, Ej), dtype=np.int32)
+        # which j indices belong to q coordinate c (q is a mode of B / C cut dj ways), or all of j when q is not j
+        for p in d["pieces"]:
+            assert 0 <= p["lo"] < p["hi"]
+            if d["pLabel"] == ord("i"):
+                rows = np.arange(p["lo"], min(p["hi"], Ei))
+                if d["qLabel"] == ord("j") and p["q1"] > 0:
+                    cols = np.array(sorted(sum((_blocks_of(Ej, bj, dj, c) for c in range(p["q0"], p["q1"])), [])), dtype=np.int64)
+                else:
+                    cols = np.arange(Ej)
+            else:
+                assert d["pLabel"] == ord("j")
+                cols = np.arange(p["lo"], min(p["hi"], Ej))
+                if d["qLabel"] == ord("i") and p["q1"] > 0:
+                    rows = np.array(sorted(sum((_blocks_of(Ei, bi, di, c) for c in range(p["q0"], p["q1"])), [])), dtype=np.int64)
+                else:
+                    rows = np.arange(Ei)
+            if len(rows) and len(cols):
+                cov[np.ix_(rows, cols)] += 1
+        assert (cov == 1).all(), (seed, n, extent, block, dcount, int(cov.min()), int(cov.max()))
