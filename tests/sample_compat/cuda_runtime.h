@@ -27,6 +27,7 @@ struct cudaDeviceProp : public hipDeviceProp_t {};   /* the Mg sample writes `st
 #define cudaFreeHost                hipHostFree
 #define cudaMemcpy                  hipMemcpy
 #define cudaMemset                  hipMemset
+#define cudaMemGetInfo              hipMemGetInfo            /* torch/einsum.cc:70 */
 #define cudaMemcpyAsync             hipMemcpyAsync
 #define cudaMemcpy2DAsync           hipMemcpy2DAsync
 #define cudaMemcpyHostToDevice      hipMemcpyHostToDevice

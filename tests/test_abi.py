@@ -271,3 +271,30 @@ def test_padding_attributes(ct, ops):
     ct.check(ct.cutensorCreateReduction(h.h, ctypes.byref(red), dA, ct.i32("whc"), ct.OP_IDENTITY, dR, ct.i32("w"), ct.OP_IDENTITY, dR, ct.i32("w"),
                                         ct.OP_ADD, ct.compute_desc("32F")))
     assert ct.cutensorOperationDescriptorSetAttribute(h.h, red, 4, pad, 12) == 15
+
+
+def test_reference_torch_binding_loads_without_gpu(built):
+    """oracle/_ref/pyref (the reference's einsum.cc compiled unmodified against include/ + libcutensor.so, see
+    oracle/build_ref_torch_binding.sh) imports on a CPU-only host and exposes the three entry points the reference's
+    einsum.py binds (einsum.py:22); its undefined cutensor* symbols all resolve in OUR library."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pyref = os.path.join(root, "oracle", "_ref", "pyref")
+    sos = glob.glob(os.path.join(pyref, "cutensor", "torch", "binding*.so"))
+    if not sos:
+        pytest.skip("oracle/_ref/pyref was not built (reference tree absent at build time)")
+    code = ("import sys; sys.path[:0]=[%r,%r]; import cutensor.torch as c, cutensor.torch.binding as b; "
+            "print(sorted(n for n in dir(b) if not n.startswith('_')))") % (pyref, os.path.join(root, "tests", "sample_compat", "pyshim"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "'einsum', 'execute', 'plan'" in r.stdout, r.stdout
+    und = subprocess.run(["nm", "-D", "--undefined-only", sos[0]], capture_output=True, text=True).stdout
+    wanted = sorted({ln.split()[-1] for ln in und.splitlines() if " cutensor" in ln or ln.split()[-1].startswith("CUTENSOR_")})
+    assert "cutensorContract" in wanted and "cutensorCreatePlan" in wanted, wanted
+    lib = subprocess.run(["nm", "-D", "--defined-only", os.path.join(root, "cudalibrarysamples_amd", "lib", "libcutensor.so")],
+                         capture_output=True, text=True).stdout
+    have = {ln.split()[-1] for ln in lib.splitlines()}
+    assert not [s for s in wanted if s not in have], [s for s in wanted if s not in have]

@@ -1,0 +1,122 @@
+"""The reference's OWN numerical test on this path, run against OUR library on the GPU.
+
+oracle/build_ref_torch_binding.sh compiles the reference's pybind11 module (cuTENSOR/python/cutensor/torch/einsum.cc over
+cuTENSOR/python/einsum.h) UNMODIFIED against include/cutensor.h + lib/libcutensor.so and stages the reference's python
+package (cutensor/common.py, cutensor/torch/einsum.py, cutensor/torch/einsum_test.py) around it under oracle/_ref/pyref/.
+The staged tree travels to the GPU box with the snapshot; /root/reference is not read at run time.
+
+What is pinned here is the reference's own assertion (einsum_test.py:35-42: rtol 5e-3 / atol 6e-3 against torch.einsum,
+forward AND both gradients, seed 0) for its 10 binary cases (:47-124) and its 5 EinsumGeneral cases (:155-187), through
+the reference's C++: Einsum<>::plan (einsum.h:277-399), ::execute (:411-442), the CUTENSOR_R_* spellings (:39-67), the
+handle singleton (:455-502), cutensorPlanGetAttribute(REQUIRED_WORKSPACE) and the torch caching allocator for the
+workspace (einsum.cc:96-123).  Nothing under cudalibrarysamples_amd/ imports the staged package: it is the checker."""
+import os
+import subprocess
+import sys
+import unittest
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PYREF = os.path.join(ROOT, "oracle", "_ref", "pyref")
+PYSHIM = os.path.join(ROOT, "tests", "sample_compat", "pyshim")   # `parameterized` (not installed here): param + expand
+
+# the names parameterized.expand generates for einsum_test.py's two lists, in file order
+BINARY = ["0_test_0", "1_test_0_complex_", "2_test_1", "3_test_2", "4_test_3", "5_test_4", "6_test_5", "7_test_6", "8_test_7",
+          "9_test_8"]
+GENERAL = ["0_test_0", "1_test_1", "2_test_2", "3_test_3", "4_test_4"]
+
+
+def _have():
+    import glob
+    return bool(glob.glob(os.path.join(PYREF, "cutensor", "torch", "binding*.so")))
+
+
+@pytest.fixture(scope="module")
+def ref_test_module(built):
+    if not _have():
+        pytest.skip("oracle/_ref/pyref was not built (reference tree absent at build time)")
+    for p in (PYREF, PYSHIM):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cutensor.torch.einsum_test as mod   # the reference's file, staged verbatim
+    import cutensor.torch.binding as binding   # the reference's einsum.cc, compiled verbatim
+    assert os.path.realpath(binding.__file__).startswith(os.path.realpath(PYREF))
+    return mod
+
+
+def _run(mod, name):
+    suite = unittest.defaultTestLoader.loadTestsFromName(name, mod.EinsumTest)
+    assert suite.countTestCases() == 1, name
+    res = unittest.TestResult()
+    suite.run(res)
+    problems = res.errors + res.failures
+    assert not problems, problems[0][1]
+    assert res.testsRun == 1 and not res.skipped
+
+
+@pytest.mark.parametrize("case", BINARY)
+def test_reference_einsum_equivalent_results(ref_test_module, case):
+    """einsum_test.py:127-151 — EinsumFunction.apply forward + backward vs torch.einsum."""
+    _run(ref_test_module, "test_einsum_equivalent_results_" + case)
+
+
+@pytest.mark.parametrize("case", GENERAL)
+def test_reference_einsum_general_equivalent_results(ref_test_module, case):
+    """einsum_test.py:200-230 — EinsumGeneral (numpy einsum_path, pairwise contractions, unary reduction) fwd + bwd."""
+    _run(ref_test_module, "test_einsum_general_equivalent_results_" + case)
+
+
+def test_reference_case_list_is_complete(ref_test_module):
+    """Every test the reference's file defines is named above — a case added upstream cannot be silently skipped."""
+    names = sorted(n for n in dir(ref_test_module.EinsumTest)
+                   if n.startswith("test_") and callable(getattr(ref_test_module.EinsumTest, n)))
+    want = sorted(["test_einsum_equivalent_results_" + c for c in BINARY]
+                  + ["test_einsum_general_equivalent_results_" + c for c in GENERAL])
+    assert names == want
+
+
+def test_reference_test_file_as_the_reference_runs_it(built):
+    """`python einsum_test.py`-style: the file's own unittest.main() in a fresh interpreter (einsum_test.py:234-235)."""
+    if not _have():
+        pytest.skip("oracle/_ref/pyref was not built (reference tree absent at build time)")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PYREF, PYSHIM, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-m", "unittest", "-v", "cutensor.torch.einsum_test"], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=PYREF)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "Ran 15 tests" in tail and "OK" in tail, tail
+
+
+def test_reference_plan_execute_split(ref_test_module):
+    """The binding's plan()/execute() pair (einsum.cc:148-233, einsum.py:69-90, module API :105-109): plan once, execute
+    twice on refreshed inputs; not covered by the reference's test file, checked at its tolerance."""
+    import torch
+    import cutensor.torch as ct
+    torch.manual_seed(0)
+    a = torch.randn(20, 50, 50, 50, device="cuda")
+    b = torch.randn(50, 50, 50, 20, device="cuda")
+    m = ct.Einsum("mlik,lkjm->lij")
+    p = m.plan(a, b)
+    assert p.worksize >= 0 and p.workspace.numel() == p.worksize
+    for _ in range(2):
+        out = m.execute(p)
+        torch.testing.assert_close(out, torch.einsum("mlik,lkjm->lij", a, b), rtol=5e-3, atol=6e-3)
+        a.normal_()
+        b.normal_()
+
+
+def test_reference_binding_bf16(ref_test_module):
+    """einsum_test.py:116-123 keeps the bf16 case commented out ("Activate when cuTENSOR supports it"); the binding carries
+    the trait (einsum.cc:35-40, CUTENSOR_R_16BF + COMPUTE_DESC_16BF), so it is run here through the binding directly."""
+    import torch
+    import cutensor.torch as ct
+    torch.manual_seed(0)
+    a = torch.randn(20, 50, 50, 50, device="cuda", dtype=torch.bfloat16)
+    b = torch.randn(50, 50, 50, 20, device="cuda", dtype=torch.bfloat16)
+    got = ct.EinsumFunction.apply("mlik,lkjm->lij", a, b)
+    ref = torch.einsum("mlik,lkjm->lij", a.double(), b.double())
+    # K = 20*50 terms of N(0,1) products: |ref| ~ 32; bf16 output rounding 2^-8 relative
+    torch.testing.assert_close(got.double(), ref, rtol=1e-2, atol=0.25)
