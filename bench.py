@@ -209,6 +209,35 @@ def run_mg_child(ndev, steps, warmup, timeout_s, virtual=False):
     return {"error": "child rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
 
 
+def einsum_flow_line(calls=2000):
+    """secondary entry: Einsum::execute as cuTENSOR/einsum.cu:264-339 runs it (descriptors + plan preference + contraction
+    descriptor + plan created and destroyed inside every call, plan cache at 1024 entries :443-445), timed from C by the native
+    driver samples/einsum.hip --flow next to the plan-once loop on the same buffers."""
+    exe = os.path.join(ROOT, "samples", "bin", "einsum")
+    r = subprocess.run([exe, "--flow", "--calls", str(calls), "--cache", "1024"], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"workload": "einsum.cu flow (plan per call)", "error": "rc %d: %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+    d = json.loads(line[-1])
+    return {"workload": "einsum.cu flow 'abcd,dcbe->ae': descriptors + plan + contract + destroy per call, plan cache 1024 (einsum.cu:264-339,:445), "
+                        "timed from C (samples/einsum.hip --flow)",
+            "dtype": "f32", "value": d["flow_gflops"], "unit": "GFLOP/s", "ms_per_call": d["flow_us_per_call"] * 1e-3,
+            "plan_once_value": d["plan_once_gflops"], "flow_over_plan_once": d["flow_over_plan_once"],
+            "host_issue_us_per_call": d["flow_host_issue_us_per_call"], "plan_once_host_issue_us_per_call": d["plan_once_host_issue_us_per_call"],
+            "plan_create_us": {"hit": d["plan_create_us_hit"], "miss": d["plan_create_us_miss"]}, "calls": d["calls"],
+            "max_rel_diff_flow_vs_plan_once": d["max_rel_diff_flow_vs_plan_once"]}
+
+
+def newest_traffic_file():
+    """profiles/*pmc_traffic_einsum.json of the latest round (names sort by round prefix; the un-prefixed round-1 file last)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*pmc_traffic_einsum.json")))
+    if files:
+        return files[-1]
+    f = os.path.join(ROOT, "profiles", "pmc_traffic_einsum.json")
+    return f if os.path.exists(f) else None
+
+
 def mg_lines(res, key, one_key):
     """secondary entry of one cuTENSORMg measurement."""
     m = res[key]
@@ -532,14 +561,15 @@ def main():
         # Counters cannot be read from inside the timed process, so the committed per-launch figure of the same kernel is
         # reported, else null.
         traffic = None
+        traffic_file = newest_traffic_file()
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic_einsum.json")) as f:
+            with open(traffic_file) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
+        except (OSError, ValueError, TypeError):
             traffic = None
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak if peak else None, "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic_einsum.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
+                "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, bytes per launch)" % os.path.relpath(traffic_file, ROOT)) if traffic else None,
                 "kernel": "%s<%dx%dx%d,w%dx%dx%d> (table index %d)" % (desc.get("kname", "gett_f32_kernel"), desc["bm"], desc["bn"], desc["bk"],
                                                                        desc["wm"], desc["wn"], desc["wk"], desc.get("kernel", -1)),
                 "launches": n, "mean_us": batch_ms * 1e3,
@@ -581,6 +611,10 @@ def main():
             del a, b
             torch.cuda.empty_cache()
             secondary += secondary_single_gpu(torch, ct, ops, h, stream)
+            try:
+                secondary.append(einsum_flow_line())
+            except Exception as ex:   # noqa: BLE001
+                secondary.append({"workload": "einsum.cu flow (plan per call)", "error": "%s: %s" % (type(ex).__name__, ex)})
             try:
                 one = {"sample": mg_measure(1, MG_SAMPLE_EXTENT, 20, 3), "scaled": mg_measure(1, MG_SCALED_EXTENT, 3, 1)}
                 secondary.append(mg_lines(one, "sample", "-"))

@@ -84,6 +84,62 @@ std::string problem_key(const cutensorOperationDescriptor& op) {
     return ss.str();
 }
 
+// POD memo key (internal.hpp): false when the problem is outside what the memo holds
+bool build_memo_key(const cutensorOperationDescriptor& op, const cutensorPlanPreference& pr, uint64_t wsLimit, PlanMemoKey& k) {
+    if (op.kind != OpKind::Contraction && op.kind != OpKind::Reduction && op.kind != OpKind::Permutation &&
+        op.kind != OpKind::ElementwiseBinary) return false;
+    if (!op.padLeft.empty() || !op.padRight.empty()) return false;
+    const TensorUse* u[4] = {&op.A, &op.B, &op.C, &op.D};
+    size_t total = 0;
+    for (const TensorUse* t : u) if (t->present) total += t->modes.size();
+    if (total > (size_t)PlanMemoKey::kMaxModes) return false;
+    k.wsLimit = wsLimit;
+    k.algo = (int32_t)pr.algo; k.kernelRank = pr.kernelRank; k.autotune = (int32_t)pr.autotune;
+    k.incrementalCount = pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL ? pr.incrementalCount : 0;
+    k.kind = (uint8_t)op.kind; k.dtype = (uint8_t)op.A.desc.dtype; k.compute = (uint8_t)(op.compute ? op.compute->id : 255);
+    k.scalarType = (uint8_t)op.scalarType;
+    k.op[0] = (uint8_t)op.A.op; k.op[1] = (uint8_t)op.B.op; k.op[2] = (uint8_t)op.C.op; k.op[3] = (uint8_t)op.opReduce;
+    k.present = 0;
+    uint32_t w = 0;
+    for (int i = 0; i < 4; ++i) {
+        const TensorUse& t = *u[i];
+        k.n[i] = 0; k.alignment[i] = 0;
+        if (!t.present) continue;
+        k.present |= (uint8_t)(1u << i);
+        const size_t n = t.modes.size();
+        k.n[i] = (uint8_t)n; k.alignment[i] = t.desc.alignment;
+        for (size_t j = 0; j < n; ++j) k.data[w++] = t.modes[j];
+        std::memcpy(&k.data[w], t.desc.extent.data(), n * sizeof(int64_t)); w += (uint32_t)n;
+        std::memcpy(&k.data[w], t.desc.stride.data(), n * sizeof(int64_t)); w += (uint32_t)n;
+    }
+    k.used = w;
+    return true;
+}
+
+}  // namespace
+
+uint64_t PlanMemoKey::hash() const {
+    // the fixed head (everything before data[]) and the used words, 8 bytes at a time through a multiply-xorshift mix
+    auto mix = [](uint64_t h, uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); };
+    uint64_t h = 0xCBF29CE484222325ull;
+    const size_t headWords = offsetof(PlanMemoKey, data) / 8;
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(this);
+    for (size_t i = 0; i < headWords; ++i) h = mix(h, p[i]);
+    for (uint32_t i = 0; i < used; ++i) h = mix(h, (uint64_t)data[i]);
+    return h;
+}
+bool PlanMemoKey::operator==(const PlanMemoKey& o) const {
+    return used == o.used && std::memcmp(this, &o, offsetof(PlanMemoKey, data)) == 0 &&
+           std::memcmp(data, o.data, (size_t)used * sizeof(int64_t)) == 0;
+}
+
+namespace {
+
+// any experiment knob that changes what cutensorCreatePlan decides: the memo stands aside while one is set
+bool plan_env_override() {
+    return std::getenv("CUTENSOR_AMD_FORCE") || std::getenv("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD");
+}
+
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
     if (s == nullptr) return 0.0;
     return (t == HIP_R_64F || t == HIP_C_64F) ? *static_cast<const double*>(s) : (double)*static_cast<const float*>(s);
@@ -107,6 +163,7 @@ static void resolve_pending_measurements(cutensorHandle* handle) {
     {
         std::lock_guard<std::mutex> g(handle->mtx);
         todo.swap(handle->pending);
+        handle->pendingCount.store(0, std::memory_order_relaxed);
     }
     for (auto& m : todo) {
         float ms = 0.f;
@@ -119,10 +176,30 @@ static void resolve_pending_measurements(cutensorHandle* handle) {
         CT_LOG("incremental autotune: kernel %d splitK %u -> %.3f us (best so far %.3f us)", m.kernel, m.splitK, ms * 1e3, t.bestMs * 1e3);
         if (ms < t.bestMs) {
             t.bestMs = ms; t.bestKernel = m.kernel; t.bestSplitK = m.splitK;
-            if (handle->planCache.count(m.key) || handle->planCache.size() < handle->planCacheCapacity)
+            if (handle->planCache.count(m.key) || handle->planCache.size() < handle->planCacheCapacity) {
                 handle->planCache[m.key] = PlanCacheEntry{m.key, m.kernel, m.splitK};
+                handle->planMemo.clear();   // prototypes built from the previous best are stale
+            }
         }
     }
+}
+
+// A finished plan that owns nothing becomes the prototype later plans of the same problem are cloned from; the least
+// recently used prototype makes room when the cache is full (capacity = cutensorHandleResizePlanCache's numEntries).
+static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash, const cutensorPlan& pl) {
+    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || pl.bsp) return;
+    std::shared_ptr<const cutensorPlan> proto(new (std::nothrow) cutensorPlan(pl));
+    if (!proto) return;
+    std::lock_guard<std::mutex> g(h->mtx);
+    if (h->planCacheCapacity == 0) return;
+    if (h->planMemo.size() >= h->planCacheCapacity && h->planMemo.find(hash) == h->planMemo.end()) {
+        auto victim = h->planMemo.begin();
+        for (auto it = h->planMemo.begin(); it != h->planMemo.end(); ++it)
+            if (it->second.stamp < victim->second.stamp) victim = it;
+        h->planMemo.erase(victim);
+    }
+    PlanMemoEntry& e = h->planMemo[hash];
+    e.key = key; e.proto = std::move(proto); e.stamp = ++h->memoClock;
 }
 
 extern "C" {
@@ -165,6 +242,7 @@ cutensorStatus_t cutensorHandleResizePlanCache(cutensorHandle_t handle, const ui
     std::lock_guard<std::mutex> g(handle->mtx);
     handle->planCacheCapacity = numEntries;
     while (handle->planCache.size() > numEntries) handle->planCache.erase(handle->planCache.begin());
+    if (handle->planMemo.size() > numEntries) handle->planMemo.clear();
     return CUTENSOR_STATUS_SUCCESS;
 }
 
@@ -202,6 +280,7 @@ cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, co
         return CUTENSOR_STATUS_IO_ERROR;
     }
     std::lock_guard<std::mutex> g(handle->mtx);
+    handle->planMemo.clear();   // the file may bring a different tuned choice for a memoised problem
     std::vector<char> line(1 << 16);
     uint32_t n = 0;
     while (std::fgets(line.data(), (int)line.size(), f)) {
@@ -851,6 +930,33 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     if (plan == nullptr || desc == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorPlanPreference defaults;
     const cutensorPlanPreference& pr = pref ? *pref : defaults;
+    // Plan memo first (einsum.cu:264-329 plans inside every call with the cache on, :443-445): a repeated problem is one
+    // hash + one lookup + one clone; ranking candidates, string keys and tile arithmetic happen on a miss only.
+    PlanMemoKey mkey;
+    uint64_t mhash = 0;
+    const bool memoable = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE && !plan_env_override() &&
+                          build_memo_key(*desc, pr, workspaceSizeLimit, mkey);
+    if (memoable) {
+        mhash = mkey.hash();
+        if (handle->pendingCount.load(std::memory_order_relaxed) > 0) resolve_pending_measurements(handle);
+        std::shared_ptr<const cutensorPlan> proto;
+        {
+            std::lock_guard<std::mutex> g(handle->mtx);
+            auto it = handle->planMemo.find(mhash);
+            if (it != handle->planMemo.end() && it->second.key == mkey) {
+                proto = it->second.proto;
+                it->second.stamp = ++handle->memoClock;
+            }
+        }
+        if (proto) {
+            cutensorPlan* clone = new (std::nothrow) cutensorPlan(*proto);
+            if (clone == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
+            handle->memoHits.fetch_add(1, std::memory_order_relaxed);
+            *plan = clone;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
+        handle->memoMisses.fetch_add(1, std::memory_order_relaxed);
+    }
     cutensorPlan* pl = new (std::nothrow) cutensorPlan();
     if (pl == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
     pl->kind = desc->kind;
@@ -937,26 +1043,40 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         else if (h16Path) ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
         if (!ch.empty()) {
             size_t idx = 0;
-            const std::string key = problem_key(*desc);
             const bool useCache = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE;
+            const bool explicitPick = (int)pr.algo >= 0 || pr.kernelRank > 0;   // the caller names a candidate: the cache has no say
+            const bool incremental = useCache && !explicitPick && pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL;
+            const bool patient = pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT;
+            bool needKey = incremental || (useCache && patient);
+            if (useCache && !explicitPick && !needKey) {
+                std::lock_guard<std::mutex> g(handle->mtx);
+                needKey = !handle->planCache.empty();
+            }
+            const std::string key = needKey ? problem_key(*desc) : std::string();   // the string form is what the cache FILE holds
             bool decided = false;
             // incremental autotuning (contraction_plan_cache.cu:215-237): the first INCREMENTAL_COUNT plans of a problem
-            // are trials of candidates 0, 1, ... (timed by cutensorContract); after that — and for every plan without the
-            // autotune mode — the cache answers with the fastest candidate measured so far
-            if (useCache && pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL && (int)pr.algo < 0) {
+            // are trials of candidates 0, 1, ... (timed by cutensorContract: the best of a trial plan's first few executions);
+            // after that — and for every plan without the autotune mode — the cache answers with the fastest candidate
+            // measured so far.  (The sample's loop is count + 1 rounds of which the last must hit the cache, :262.)
+            if (incremental) {
                 resolve_pending_measurements(handle);
                 std::lock_guard<std::mutex> g(handle->mtx);
-                cutensorHandle::TuneState& t = handle->tuning[key];
-                const int limit = std::min<int>(std::max<int32_t>(pr.incrementalCount, 1), (int)ch.size());
-                if (t.next < limit) {
-                    idx = (size_t)t.next++;
-                    pl->tuneKey = key;
-                    decided = true;
+                auto tit = handle->tuning.find(key);
+                if (tit == handle->tuning.end() && handle->tuning.size() < std::max<size_t>(handle->planCacheCapacity, 1))
+                    tit = handle->tuning.emplace(key, cutensorHandle::TuneState{}).first;   // bounded like the cache itself
+                if (tit != handle->tuning.end()) {
+                    cutensorHandle::TuneState& t = tit->second;
+                    const int limit = std::min<int>(std::max<int32_t>(pr.incrementalCount, 1), (int)ch.size());
+                    if (t.next < limit) {
+                        idx = (size_t)t.next++;
+                        pl->tuneKey = key;
+                        decided = true;
+                    }
                 }
             }
-            if (!decided && useCache) {
+            if (!decided && useCache && !explicitPick) {
                 std::lock_guard<std::mutex> g(handle->mtx);
-                auto it = handle->planCache.find(key);
+                auto it = needKey ? handle->planCache.find(key) : handle->planCache.end();
                 if (it != handle->planCache.end())
                     for (size_t i = 0; i < ch.size(); ++i)
                         if (ch[i].kernel == it->second.kernel && ch[i].splitK == it->second.splitK) { idx = i; decided = true; break; }
@@ -964,14 +1084,14 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             if (!decided) {
                 if ((int)pr.algo >= 0) idx = std::min<size_t>((size_t)pr.algo, ch.size() - 1);
                 else if (pr.kernelRank > 0) idx = std::min<size_t>((size_t)pr.kernelRank, ch.size() - 1);
-                else if (pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
+                else if (patient) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
                 if (const char* f = std::getenv("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
                     int fk = -1; unsigned fs = 1;
                     if (std::sscanf(f, "%d:%u", &fk, &fs) >= 1)
                         for (size_t i = 0; i < ch.size(); ++i)
                             if (ch[i].kernel == fk && ch[i].splitK == fs) { idx = i; break; }
                 }
-                if (useCache && pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT) {
+                if (useCache && patient) {
                     std::lock_guard<std::mutex> g(handle->mtx);
                     if (handle->planCache.size() < handle->planCacheCapacity)
                         handle->planCache[key] = PlanCacheEntry{key, ch[idx].kernel, ch[idx].splitK};
@@ -1078,6 +1198,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         CT_LOG("plan: elementwise variant=%d E0=%u E1=%u rest=%u blocks=%u", pl->ew.variant, pl->ew.p.E0, pl->ew.p.E1,
                pl->ew.p.rest.total, pl->ew.p.nBlocks);
     }
+    if (memoable) memo_insert(handle, mkey, mhash, *pl);
     *plan = pl;
     return CUTENSOR_STATUS_SUCCESS;
 }
@@ -1133,7 +1254,10 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     p.timing = handle->timingBuffer.load(std::memory_order_relaxed);
     // incremental-autotuning trial: one event pair around everything this call launches, read later (resolve_pending_measurements)
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (!plan->tuneKey.empty()) {
+    // only the first kTrialTimedRuns executions of a trial plan are timed: a plan created once and run in a loop neither
+    // grows the pending list nor pays event creation per launch
+    if (!plan->tuneKey.empty() && plan->trial.timed.load(std::memory_order_relaxed) < cutensorPlan::kTrialTimedRuns &&
+        plan->trial.timed.fetch_add(1, std::memory_order_relaxed) < cutensorPlan::kTrialTimedRuns) {
         if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) {
             (void)hipGetLastError();
             if (t0) (void)hipEventDestroy(t0);
@@ -1200,9 +1324,14 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         }
     }
     if (t0 != nullptr) {
-        (void)hipEventRecord(t1, stream);
-        std::lock_guard<std::mutex> g(handle->mtx);
-        handle->pending.push_back(cutensorHandle::PendingMeasurement{plan->tuneKey, plan->choice.kernel, plan->choice.splitK, t0, t1});
+        if (err == hipSuccess && hipEventRecord(t1, stream) == hipSuccess) {
+            std::lock_guard<std::mutex> g(handle->mtx);
+            handle->pending.push_back(cutensorHandle::PendingMeasurement{plan->tuneKey, plan->choice.kernel, plan->choice.splitK, t0, t1});
+            handle->pendingCount.store((int)handle->pending.size(), std::memory_order_relaxed);
+        } else {   // a failed launch is not a measurement
+            (void)hipEventDestroy(t0);
+            (void)hipEventDestroy(t1);
+        }
     }
     if (err != hipSuccess) { CT_LOG("cutensorContract: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
@@ -1388,6 +1517,13 @@ const char* cutensorGetErrorString(const cutensorStatus_t error) {
 size_t cutensorGetVersion(void) { return CUTENSOR_VERSION; }
 
 // ---- diagnostics (not part of the cuTENSOR ABI; used by the tests and the bench) ----------------
+// Plan-memo counters of this handle: plans answered by cloning a prototype / plans that went through the planner.
+void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) {
+    if (handle == nullptr) return;
+    if (hits) *hits = handle->memoHits.load(std::memory_order_relaxed);
+    if (misses) *misses = handle->memoMisses.load(std::memory_order_relaxed);
+    if (entries) { std::lock_guard<std::mutex> g(handle->mtx); *entries = (uint32_t)handle->planMemo.size(); }
+}
 // Writes a one-line JSON description of the plan's kernel choice into buf.
 int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     if (plan == nullptr || buf == nullptr || len == 0) return -1;

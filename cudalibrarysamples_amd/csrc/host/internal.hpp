@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <cutensor.h>
@@ -149,7 +150,18 @@ size_t  dtype_size(hipDataType t);
 
 }  // namespace ctamd
 
+// Incremental-autotuning trial plans are timed by cutensorContract for their first few executions only; the counter lives in
+// the (otherwise immutable) plan, copyable so that plans stay copy-constructible (the plan memo clones prototypes).
+struct TrialCounter {
+    mutable std::atomic<int> timed{0};
+    TrialCounter() = default;
+    TrialCounter(const TrialCounter& o) : timed(o.timed.load(std::memory_order_relaxed)) {}
+    TrialCounter& operator=(const TrialCounter& o) { timed.store(o.timed.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
+};
+
 struct cutensorPlan {
+    cutensorPlan() = default;
+    cutensorPlan(const cutensorPlan&) = default;   // valid only for plans that own nothing (sub1/sub2/wide.modes null): the memo's clones
     ~cutensorPlan();
     ctamd::WideParams wide{};        // mode-table contraction (view.wide): .modes is device memory owned by this plan
     // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
@@ -171,6 +183,8 @@ struct cutensorPlan {
     bool                       accumulate64 = false;
     bool                       fusedFold = false;     // split-K partials are folded inside the GETT launch
     std::string                tuneKey;               // non-empty: an incremental-autotuning trial, timed by cutensorContract
+    TrialCounter               trial;                 // executions of this trial plan timed so far (at most kTrialTimedRuns)
+    static constexpr int       kTrialTimedRuns = 3;
     // element-wise / reduction
     ctamd::EwPlan     ew;
     ctamd::EwTrinaryPlan ew3;
@@ -189,13 +203,42 @@ struct PlanCacheEntry {
     uint32_t    splitK;
 };
 
+// Plan memo: the einsum.cu flow creates descriptors and a plan inside every call (einsum.cu:264-329) with the plan cache on
+// (:443-445), so a repeated problem must cost a lookup, not a planning pass.  The key is a fixed-size POD built straight from
+// the operation descriptor + preference + workspace limit (no strings, no allocation); the value is a finished prototype plan
+// that a hit clones.  Problems with more than kMaxModes mode slots in total are simply not memoised.
+struct PlanMemoKey {
+    static constexpr int kMaxModes = 40;          // sum of the mode counts of A, B, C, D
+    uint64_t wsLimit = 0;
+    int32_t  algo = 0, kernelRank = 0, autotune = 0, incrementalCount = 0;
+    uint32_t alignment[4] = {0, 0, 0, 0};
+    uint8_t  kind = 0, dtype = 0, compute = 0, scalarType = 0;
+    uint8_t  n[4] = {0, 0, 0, 0};
+    uint8_t  op[4] = {0, 0, 0, 0};                 // opA, opB, opC, opReduce
+    uint8_t  present = 0, pad_[3] = {0, 0, 0};
+    uint32_t used = 0;                             // int64 words of data[] in use
+    uint32_t pad2_ = 0;                            // (no implicit padding anywhere in the head: it is hashed and compared bytewise)
+    int64_t  data[3 * kMaxModes];                  // per tensor: modes, extents, strides
+    uint64_t hash() const;
+    bool operator==(const PlanMemoKey& o) const;
+};
+struct PlanMemoEntry {
+    PlanMemoKey key;
+    std::shared_ptr<const cutensorPlan> proto;
+    uint64_t stamp = 0;                            // last use, for LRU eviction
+};
+
 struct cutensorHandle {
     int device = 0;
     int numCUs = 256;
     int clockKHz = 2400000;
     std::mutex mtx;
     uint32_t planCacheCapacity = 64;    // a fresh handle can read a plan-cache file before any resize (contraction_plan_cache.cu:132-152)
-    std::map<std::string, PlanCacheEntry> planCache;   // problem signature -> tuned choice
+    std::map<std::string, PlanCacheEntry> planCache;   // problem signature -> tuned choice (what the cache FILE holds)
+    std::unordered_map<uint64_t, PlanMemoEntry> planMemo;   // hashed POD key -> finished prototype plan (at most planCacheCapacity)
+    uint64_t memoClock = 0;
+    std::atomic<uint64_t> memoHits{0}, memoMisses{0};
+    std::atomic<int> pendingCount{0};                  // == pending.size(), readable without the lock
     int logLevel = 0;
     // {arrivals, departures} counter pairs for in-launch split-K folds, 64 B apart, zeroed once; a launch
     // draws the next slot round-robin and its last workgroup re-arms it (gett_f32_stream.hip)

@@ -99,6 +99,8 @@ lib.cutensorGetErrorString.restype = ctypes.c_char_p
 lib.cutensorGetVersion.restype = ctypes.c_size_t
 lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
+lib.ctamdPlanMemoStats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+lib.ctamdPlanMemoStats.restype = None
 lib.ctamdSetTimingBuffer.argtypes = [_vp, _vp]
 lib.ctamdSetTimingBuffer.restype = None
 lib.ctamdSetSplitKFold.argtypes = [_vp, ctypes.c_int]
@@ -122,6 +124,13 @@ lib.ctamdMeasureMfmaCeiling.restype = ctypes.c_int
 lib.ctamdEinsumExecute.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.ctamdEinsumRawPlan.argtypes = [_vp]
 lib.ctamdEinsumRawPlan.restype = _vp
+
+
+def plan_memo_stats(handle):
+    """(hits, misses, entries) of the handle's plan memo (cutensorCreatePlan answered by cloning a prototype / by planning)."""
+    h, m, e = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
+    lib.ctamdPlanMemoStats(handle, ctypes.byref(h), ctypes.byref(m), ctypes.byref(e))
+    return h.value, m.value, e.value
 
 
 def compute_desc(name):

@@ -24,10 +24,14 @@ mkdir -p "$OUT/cutensor/torch"
 for f in __init__.py common.py package_info.py torch/__init__.py torch/einsum.py torch/einsum_test.py; do
     install -m 644 "$REF/cutensor/$f" "$OUT/cutensor/$f"
 done
+SUFFIX=$($PY -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')
+SO="$OUT/cutensor/torch/binding$SUFFIX"
+if [ -f "$SO" ] && [ -z "$(find "$REF/cutensor/torch/einsum.cc" "$REF/einsum.h" "$ROOT/include" "$ROOT/tests/sample_compat" "${BASH_SOURCE[0]}" -newer "$SO" -type f -print -quit)" ]; then
+    exit 0   # up to date (the module links libcutensor.so dynamically: a rebuilt library needs no relink)
+fi
 TORCH_DIR=$($PY -c 'import torch, os; print(os.path.dirname(torch.__file__))')
 PYINC=$($PY -c 'import sysconfig; print(sysconfig.get_paths()["include"])')
 PB11=$($PY -c 'import pybind11; print(pybind11.get_include())' 2>/dev/null || echo "$TORCH_DIR/include")
-SUFFIX=$($PY -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')
 ABI=$($PY -c 'import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))')
 # same macros the reference's CustomExtension.Torch passes (c_extensions_utils.py:58-64)
 hipcc -x c++ -std=c++17 -O2 -w -fPIC -shared -fopenmp \
