@@ -1557,8 +1557,8 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           (unsigned long long)plan->requiredWorkspace);
     } else {
         const EwPlan& e = (plan->kind == OpKind::Reduction) ? plan->red.perm : plan->ew;
-        n = std::snprintf(buf, len, "{\"op\":\"elementwise\",\"variant\":%d,\"E0\":%u,\"E1\":%u,\"rest\":%u,\"blocks\":%u}",
-                          e.variant, e.p.E0, e.p.E1, e.p.rest.total, e.p.nBlocks);
+        n = std::snprintf(buf, len, "{\"op\":\"elementwise\",\"variant\":%d,\"E0\":%u,\"E1\":%u,\"rest\":%u,\"blocks\":%u,\"tile0\":%u,\"order\":%u}",
+                          e.variant, e.p.E0, e.p.E1, e.p.rest.total, e.p.nBlocks, e.p.tile0, e.p.order);
     }
     return n;
 }

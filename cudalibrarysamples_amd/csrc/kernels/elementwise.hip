@@ -93,15 +93,23 @@ __device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
 // EW_TRANSPOSE (fp32): requires sD0 == 1, sA1 == 1, E0 % 4 == 0, E1 % 4 == 0, every other stride
 // a multiple of 4 elements and 16-byte aligned bases.
 // ---------------------------------------------------------------------------------------------
-constexpr int TT = 64;          // tile edge
-constexpr int TT_LD = TT + 4;   // LDS row stride (floats), keeps rows 16-byte aligned
+constexpr int TT = 64;          // tile extent along dim1 (A's contiguous mode: 256-B read segments); also the h16 kernels' edge
 
+// T0 = tile extent along dim0 (D's contiguous mode): 64, 128 or 256 floats = 256-B / 512-B / 1-KiB written row segments.
+// The width of the WRITTEN segment is what moves the 2048^3 permutation (profiles/r03_transpose_sweep*.jsonl: 64 -> 6.14,
+// 128 -> 6.45, 256 -> 6.56 TB/s with one workgroup per tile; the read width and the tile order do not matter), so the
+// planner takes the widest T0 the extent fills (Ew2DParams::tile0).
 // HASX: second permuted operand through a second LDS tile (a separate instantiation, so that the plain permutation
-// keeps its 17-KiB footprint and 8 workgroups per CU)
-template <bool HASX>
+// keeps its smaller footprint)
+template <bool HASX, int T0>
 __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams p) {
-    __shared__ __attribute__((aligned(16))) float tile[TT * TT_LD];   // [dim1][dim0]
-    __shared__ __attribute__((aligned(16))) float tileX[HASX ? TT * TT_LD : 4];
+    constexpr int LD = T0 + 4;                      // LDS row stride (floats)
+    constexpr int RD_PASSES = T0 / 64;              // a read pass covers 64 dim0 rows (16 lane groups x 4 rows) x 64 dim1 floats
+    constexpr int LPW = T0 / 4;                     // write: lanes per dim1 row
+    constexpr int RPW = 256 / LPW;                  //        dim1 rows per pass
+    constexpr int WR_PASSES = TT / RPW;
+    __shared__ __attribute__((aligned(16))) float tile[TT * LD];   // [dim1][dim0]
+    __shared__ __attribute__((aligned(16))) float tileX[HASX ? TT * LD : 4];
     const float* X = HASX ? static_cast<const float*>(p.X) : nullptr;
     const float* A = static_cast<const float*>(p.A);
     const float* C = static_cast<const float*>(p.C);
@@ -109,72 +117,130 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
     float*       D = static_cast<float*>(p.D);
     const int tid = threadIdx.x;
 
-    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
-        const TileId t = decode_tile(p, b);
+    // order 1 (planner: both the rows A is read by and the rows D is written by lie a large pitch apart, e.g. the full
+    // reversal A[a,b,c] -> C[c,b,a] at 2048^3, 16 MiB on both sides): ids walk rest, then dim1, then dim0, and XCD x =
+    // workgroup id % 8 takes the x-th eighth of that sequence, so that at any time one XCD works inside a few dim0 / dim1
+    // tiles — a few hundred distinct pages per XCD instead of every page of both tensors (5.79 -> 6.31 TB/s,
+    // profiles/r03_transpose_sweep3_rev.jsonl; the same order WITHOUT the per-XCD split is the worst: 4.14)
+    const uint32_t nIds = p.order ? 8u * p.idsPerXcd : p.nBlocks;
+    for (uint32_t b = blockIdx.x; b < nIds; b += gridDim.x) {
+        TileId t;
+        if (p.order) {
+            const uint32_t id = (b & 7u) * p.idsPerXcd + (b >> 3);
+            if (id >= p.nBlocks) continue;
+            const uint32_t q = ew_fast_div(id, p.divRest);
+            t.rest = id - q * p.rest.total;
+            const uint32_t q2 = ew_fast_div(q, p.divTiles1);
+            t.t1 = q - q2 * p.tiles1;
+            t.t0 = q2;
+        } else {
+            t = decode_tile(p, b);
+        }
         int64_t oA, oD, oC;
         rest_offsets(p.rest, t.rest, oA, oD, oC);
-        const uint32_t i0 = t.t0 * TT, i1 = t.t1 * TT;   // tile origin (dim0, dim1)
+        const uint32_t i0 = t.t0 * T0, i1 = t.t1 * TT;   // tile origin (dim0, dim1)
 
-        // ---- read: lane -> (dim1 float4 c1 = tid%16, dim0 block r0 = tid/16), 4 dim0 rows each
+        // interior tiles (all of them when the extents divide) take the unguarded path: every load of the tile is issued
+        // before the first one is used, every store is a plain scaled copy
+        const bool full = (i0 + T0 <= p.E0) && (i1 + TT <= p.E1);
+        // ---- read: lane -> (dim1 float4 c1 = tid%16, dim0 block r0 = tid/16 [+ 64 per pass]), 4 dim0 rows each
         {
             const uint32_t c1 = i1 + 4 * (tid & 15);
-            const uint32_t r0 = i0 + 4 * (tid >> 4);
-            f32x4 in[4];
+            if (full) {
+                const float* src = A + oA + (int64_t)(i0 + 4 * (tid >> 4)) * p.sA0 + c1;
+                f32x4 in[RD_PASSES][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (c1 < p.E1 && (r0 + r) < p.E0)
-                    in[r] = __builtin_nontemporal_load(
-                        reinterpret_cast<const f32x4*>(A + oA + (int64_t)(r0 + r) * p.sA0 + c1));
-            }
-            // 4x4 register transpose: out[j] = (in[0][j], in[1][j], in[2][j], in[3][j])
+                for (int ps = 0; ps < RD_PASSES; ++ps)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
-                *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * TT_LD + 4 * (tid >> 4)]) = o;
+                    for (int r = 0; r < 4; ++r)
+                        in[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)(64 * ps + r) * p.sA0));
+#pragma unroll
+                for (int ps = 0; ps < RD_PASSES; ++ps)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 o = {in[ps][0][j], in[ps][1][j], in[ps][2][j], in[ps][3][j]};
+                        *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * LD + 4 * (tid >> 4) + 64 * ps]) = o;
+                    }
+            } else {
+#pragma unroll 1
+                for (int ps = 0; ps < RD_PASSES; ++ps) {
+                    const int      l0 = 4 * (tid >> 4) + 64 * ps;
+                    const uint32_t r0 = i0 + l0;
+                    f32x4 in[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (c1 < p.E1 && (r0 + r) < p.E0)
+                            in[r] = __builtin_nontemporal_load(
+                                reinterpret_cast<const f32x4*>(A + oA + (int64_t)(r0 + r) * p.sA0 + c1));
+                    }
+                    // 4x4 register transpose: out[j] = (in[0][j], in[1][j], in[2][j], in[3][j])
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
+                        *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * LD + l0]) = o;
+                    }
+                }
             }
             if constexpr (HASX) {
                 const int64_t oX = rest_offset_x(p.rest, p.restX, t.rest);
+#pragma unroll 1
+                for (int ps = 0; ps < RD_PASSES; ++ps) {
+                    const int      l0 = 4 * (tid >> 4) + 64 * ps;
+                    const uint32_t r0 = i0 + l0;
+                    f32x4 in[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (c1 < p.E1 && (r0 + r) < p.E0)
-                        in[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + oX + (int64_t)(r0 + r) * p.sX0 + c1));
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        in[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (c1 < p.E1 && (r0 + r) < p.E0)
+                            in[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + oX + (int64_t)(r0 + r) * p.sX0 + c1));
+                    }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
-                    *reinterpret_cast<f32x4*>(&tileX[(4 * (tid & 15) + j) * TT_LD + 4 * (tid >> 4)]) = o;
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 o = {in[0][j], in[1][j], in[2][j], in[3][j]};
+                        *reinterpret_cast<f32x4*>(&tileX[(4 * (tid & 15) + j) * LD + l0]) = o;
+                    }
                 }
             }
         }
         __syncthreads();
-        // ---- write: lane -> (dim0 float4 c0 = tid%16, dim1 row = tid/16 + 16*pass)
+        // ---- write: lane -> (dim0 float4 c0 = tid % LPW, dim1 row = tid / LPW + RPW * pass)
         {
-            const uint32_t c0 = i0 + 4 * (tid & 15);
+            const int      l0 = 4 * (tid % LPW);
+            const uint32_t c0 = i0 + l0;
+            if (!HASX && full && E == nullptr && C == nullptr) {
+                float* dst = D + oD + (int64_t)(i1 + tid / LPW) * p.sD1 + c0;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int      lr = (tid >> 4) + 16 * pass;
-                const uint32_t r1 = i1 + lr;
-                if (c0 < p.E0 && r1 < p.E1) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * TT_LD + 4 * (tid & 15)]);
+                for (int pass = 0; pass < WR_PASSES; ++pass) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[(tid / LPW + RPW * pass) * LD + l0]);
                     v *= p.alpha;
-                    if constexpr (HASX)
-                        v = ew_comb4(p.opAB, p.xi * *reinterpret_cast<const f32x4*>(&tileX[lr * TT_LD + 4 * (tid & 15)]), v);
-                    if (E != nullptr)
-                        v = ew_comb4(p.opAB, p.delta * *reinterpret_cast<const f32x4*>(E + oD + (int64_t)r1 * p.sD1 + c0), v);
-                    if (C != nullptr) {
-                        const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
-                        f32x4 c;
-                        if (p.sC0 == 1) {
-                            c = *reinterpret_cast<const f32x4*>(cp);
-                        } else {
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (int64_t)(RPW * pass) * p.sD1));
+                }
+            } else {
+#pragma unroll 1
+                for (int pass = 0; pass < WR_PASSES; ++pass) {
+                    const int      lr = tid / LPW + RPW * pass;
+                    const uint32_t r1 = i1 + lr;
+                    if (c0 < p.E0 && r1 < p.E1) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * LD + l0]);
+                        v *= p.alpha;
+                        if constexpr (HASX)
+                            v = ew_comb4(p.opAB, p.xi * *reinterpret_cast<const f32x4*>(&tileX[lr * LD + l0]), v);
+                        if (E != nullptr)
+                            v = ew_comb4(p.opAB, p.delta * *reinterpret_cast<const f32x4*>(E + oD + (int64_t)r1 * p.sD1 + c0), v);
+                        if (C != nullptr) {
+                            const float* cp = C + oC + (int64_t)r1 * p.sC1 + (int64_t)c0 * p.sC0;
+                            f32x4 c;
+                            if (p.sC0 == 1) {
+                                c = *reinterpret_cast<const f32x4*>(cp);
+                            } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) c[e] = cp[(int64_t)e * p.sC0];
+                                for (int e = 0; e < 4; ++e) c[e] = cp[(int64_t)e * p.sC0];
+                            }
+                            v = ew_comb4(p.opAC, v, p.gamma * c);
                         }
-                        v = ew_comb4(p.opAC, v, p.gamma * c);
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
                     }
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
                 }
             }
         }
@@ -450,14 +516,23 @@ hipError_t launch_fill(void* D, uint64_t n, int dtype, double value, hipStream_t
 
 hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream) {
     if (p.nBlocks == 0) return hipSuccess;
-    // a grid-stride loop over tiles; cap the grid so that very large tensors do not pay for
-    // millions of workgroup launches (256 CUs x 8 resident 256-thread workgroups x 4 rounds)
+    // One workgroup per tile: a workgroup that loops over tiles serialises its own read -> barrier -> write phases, fresh
+    // workgroups overlap them across the CU (2048^3 permutation, 64 x 64 tiles: 5.37 TB/s with the grid capped at 32 Ki
+    // workgroups, 6.09-6.14 with one workgroup per tile; profiles/r03_transpose_sweep*.jsonl).  The grid-stride loop stays
+    // for tensors beyond 2^22 tiles.
     unsigned grid = p.nBlocks;
-    const unsigned cap = 256u * 8u * 16u;
+    const unsigned cap = 1u << 22;
+    if (variant == EW_TRANSPOSE && dtype == HIP_R_32F && p.order) grid = 8u * p.idsPerXcd;
     if (grid > cap) grid = cap;
     if (variant == EW_TRANSPOSE && dtype == HIP_R_32F) {
-        if (p.X != nullptr) hipLaunchKernelGGL(ew_transpose_f32_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
-        else                hipLaunchKernelGGL(ew_transpose_f32_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+        if (p.X != nullptr) {
+            if (p.tile0 == 128) hipLaunchKernelGGL((ew_transpose_f32_kernel<true, 128>), dim3(grid), dim3(256), 0, stream, p);
+            else                hipLaunchKernelGGL((ew_transpose_f32_kernel<true, 64>), dim3(grid), dim3(256), 0, stream, p);
+        } else {
+            if (p.tile0 == 256)      hipLaunchKernelGGL((ew_transpose_f32_kernel<false, 256>), dim3(grid), dim3(256), 0, stream, p);
+            else if (p.tile0 == 128) hipLaunchKernelGGL((ew_transpose_f32_kernel<false, 128>), dim3(grid), dim3(256), 0, stream, p);
+            else                     hipLaunchKernelGGL((ew_transpose_f32_kernel<false, 64>), dim3(grid), dim3(256), 0, stream, p);
+        }
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_32F) {
         hipLaunchKernelGGL(ew_rowcopy_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_TRANSPOSE && dtype == HIP_R_16BF) {
