@@ -187,7 +187,7 @@ static void resolve_pending_measurements(cutensorHandle* handle) {
 // A finished plan that owns nothing becomes the prototype later plans of the same problem are cloned from; the least
 // recently used prototype makes room when the cache is full (capacity = cutensorHandleResizePlanCache's numEntries).
 static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash, const cutensorPlan& pl) {
-    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || pl.bsp) return;
+    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || !pl.wideTab.empty() || pl.bsp) return;
     std::shared_ptr<const cutensorPlan> proto(new (std::nothrow) cutensorPlan(pl));
     if (!proto) return;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -1018,15 +1018,10 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             pl->wide.conjA = v.swapped ? cB : cA;
             pl->wide.conjB = v.swapped ? cA : cB;
             pl->wide.conjC = desc->C.op == CUTENSOR_OP_CONJ;
-            void* dev = nullptr;
-            if (hipMalloc(&dev, std::max<size_t>(tab.size(), 1) * sizeof(WideMode)) != hipSuccess ||
-                (!tab.empty() && hipMemcpy(dev, tab.data(), tab.size() * sizeof(WideMode), hipMemcpyHostToDevice) != hipSuccess)) {
-                (void)hipGetLastError();
-                if (dev) (void)hipFree(dev);
-                delete pl;
-                return CUTENSOR_STATUS_ALLOC_FAILED;
-            }
-            pl->wide.modes = static_cast<const WideMode*>(dev);
+            // the table goes to device memory with the first cutensorContract: planning needs no GPU (and a plan that is never
+            // executed allocates nothing)
+            pl->wideTab = tab;
+            if (pl->wideTab.empty()) pl->wideTab.push_back(WideMode{make_fastdiv(1), 0, 0, 0, 0});
             pl->choice = ContractionChoice{};
             pl->choice.kernel = -2;
             pl->requiredWorkspace = 0;
@@ -1268,6 +1263,19 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     }
     hipError_t err;
     if (plan->choice.kernel == -2) {
+        if (plan->wide.modes == nullptr) {   // first execution: the mode table moves to the device (kept until the plan dies)
+            std::lock_guard<std::mutex> g(handle->mtx);
+            if (plan->wide.modes == nullptr) {
+                void* dev = nullptr;
+                const size_t bytes = plan->wideTab.size() * sizeof(WideMode);
+                if (hipMalloc(&dev, bytes) != hipSuccess || hipMemcpy(dev, plan->wideTab.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (dev) (void)hipFree(dev);
+                    return CUTENSOR_STATUS_ALLOC_FAILED;
+                }
+                plan->wide.modes = static_cast<const WideMode*>(dev);
+            }
+        }
         WideParams w = plan->wide;
         w.A = p.A; w.B = p.B; w.C = p.C; w.D = D;
         w.alpha = p.alpha; w.beta = p.beta; w.alpha64 = a; w.beta64 = b;

@@ -163,7 +163,8 @@ struct cutensorPlan {
     cutensorPlan() = default;
     cutensorPlan(const cutensorPlan&) = default;   // valid only for plans that own nothing (sub1/sub2/wide.modes null): the memo's clones
     ~cutensorPlan();
-    ctamd::WideParams wide{};        // mode-table contraction (view.wide): .modes is device memory owned by this plan
+    ctamd::WideParams wide{};        // mode-table contraction (view.wide): .modes is device memory owned by this plan,
+    std::vector<ctamd::WideMode> wideTab;   // uploaded from this host copy by the first cutensorContract
     // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
     std::shared_ptr<ctamd::BlockSparsePlan> bsp;     // block-sparse contraction: dense plans + block-pair task list
     cutensorPlan* sub1 = nullptr;

@@ -89,8 +89,11 @@ struct Piece {
     int64_t lo = 0, hi = 0;       // range of the sharded mode p
     int64_t q0 = 0, q1 = 0;       // range of q's grid coordinate (q1 == 0: q is not cut)
     int stream = 0;               // 0 = caller's stream, 1 = auxiliary stream
-    cutensorPlan_t plan = nullptr;
-    uint64_t planWs = 0;
+    // One local contraction per box of the contracted index space: a single box unless a contracted mode is ragged
+    // (extent not a multiple of blockSize * deviceCount, blog_post.cu:168-175 derives every block size with ceil()) —
+    // then the valid part of the padded index space is a union of boxes (kbox_list) and the boxes accumulate into D.
+    struct Sub { cutensorPlan_t plan = nullptr; uint64_t ws = 0; int64_t off[3] = {0, 0, 0}; };
+    std::vector<Sub> subs;
     OperandUse use[3];
     struct Scatter { int cell; int64_t off; cutensorPlan_t plan; };
     std::vector<Scatter> scatter; // staged C -> owner cells
@@ -136,12 +139,29 @@ struct cutensorMgContractionPlan {
     int64_t stagingBytes[3] = {0, 0, 0};
     uint64_t contractionWs = 0;                // per compute stream
     int pLabel = -1, qLabel = -1;
+    int numBoxes = 1;                          // local contractions per piece (> 1: a contracted mode is ragged)
     bool useRccl = false;
     // events (created on first execution): per device {start, localReady, auxDone, commDone[k]...}, then one per (device, wave)
     std::vector<hipEvent_t> events;
     int evPerDevice = 0;
     int commPerDevice = 1;
     std::vector<char> usesAux, usesComm;       // per handle device: does any piece run on the auxiliary stream / any cell arrive from afar
+    // ---- cross-device ordering the caller's streams owe each other (filled by the plan) ----
+    // scatterOwners[g * kComputeStreams + s]: handle devices whose cells of D the pieces on (g, s) store into from afar: their
+    // caller streams end behind that compute stream.  readOwners[g]: handle devices whose cells device g's communication
+    // streams read by peer copies: their caller streams end behind those reads (the owner may overwrite its operand next).
+    std::vector<std::vector<int>> scatterOwners, readOwners;
+    int evScatter = 0;                         // first of the kComputeStreams "scatter done" events inside a device's event block
+    // ---- all-gather transport (contraction_multi_gpu.cu:328-332 sits on one all-gather of the operand that does not carry the
+    // sharded mode): tensor k qualifies when it has one cell per handle device, cell c owned by handle device c, and every
+    // device gathers every cell in wave 0 — then its staging image [cell][cell buffer] IS ncclAllGather's receive layout.
+    bool allGatherEligible[3] = {false, false, false};
+    int transport = 0;                         // 0 = auto (all-gather where eligible, timed against send/recv on the first two calls),
+                                               // 1 = all-gather where eligible, 2 = send/recv pairs only   (CUTENSORMG_AMD_TRANSPORT)
+    int calls = 0;                             // executions so far (auto: call 0 all-gather, call 1 send/recv, then the faster)
+    hipEvent_t trialEv[4] = {nullptr, nullptr, nullptr, nullptr};   // {start, end} of the gather on device 0's communication stream, per trial
+    int chosen = 0;                            // auto, after the trials: 1 = all-gather, 2 = send/recv, 0 = not decided yet
+    float trialMs[2] = {0.f, 0.f};
     const cutensorMgHandle* owner = nullptr;
 };
 
@@ -175,10 +195,62 @@ struct View {
 
 // Restriction of a label inside a view: the sharded mode p is pinned to [lo, hi) inside block `block`; q's digit
 // `digit` is cut to [c0, c1).
+// Clip of a (contracted, ragged) label to one box of its valid index space: w in [0, wHi), digit j in [lo_j, hi_j).
+struct Clip {
+    int label = -1;
+    int64_t wHi = 0;
+    std::vector<std::pair<int64_t, int64_t>> digit;
+};
 struct Restrict {
     int pLabel = -1; int64_t lo = 0, hi = 0;
     int qLabel = -1; int qDigit = -1; int64_t c0 = 0, c1 = 0;
+    std::vector<Clip> clips;
+    const Clip* clip_of(int li) const {
+        for (const Clip& c : clips) if (c.label == li) return &c;
+        return nullptr;
+    }
 };
+
+// Boxes that tile the valid part [0, extent) of a label's padded index space idx = w + blockSize * b,
+// b = sum_j digit_j * prod_{i<j} f_i: the full blocks b < extent / blockSize as a mixed-radix prefix (one box per non-zero
+// digit of the bound, most significant first), then the partial last block.  At most digits + 1 boxes; one box (everything)
+// when the extent fills the padded space.
+std::vector<Clip> kbox_list(int li, const Radix& r, int64_t extent) {
+    std::vector<Clip> out;
+    const int n = (int)r.f.size();
+    const int64_t full = extent / r.blockSize, rem = extent % r.blockSize;
+    auto all_digits = [&]() { std::vector<std::pair<int64_t, int64_t>> d((size_t)n); for (int j = 0; j < n; ++j) d[(size_t)j] = {0, r.f[(size_t)j]}; return d; };
+    if (rem == 0 && full >= r.numBlocks) {
+        Clip c; c.label = li; c.wHi = r.blockSize; c.digit = all_digits();
+        out.push_back(c);
+        return out;
+    }
+    std::vector<int64_t> below((size_t)n + 1, 1);
+    for (int j = 0; j < n; ++j) below[(size_t)j + 1] = below[(size_t)j] * r.f[(size_t)j];
+    // full blocks: b in [0, full)
+    if (n == 0) {
+        if (full >= 1) { Clip c; c.label = li; c.wHi = r.blockSize; out.push_back(c); }
+    } else {
+        std::vector<std::pair<int64_t, int64_t>> pinned = all_digits();
+        for (int j = n - 1; j >= 0; --j) {
+            const int64_t t = (full / below[(size_t)j]) % r.f[(size_t)j];
+            const bool topOverflow = (j == n - 1) && full >= below[(size_t)n];   // bound beyond the padded space: cannot happen (full < numBlocks here)
+            if (t > 0 && !topOverflow) {
+                Clip c; c.label = li; c.wHi = r.blockSize; c.digit = pinned;
+                c.digit[(size_t)j] = {0, t};
+                for (int i = 0; i < j; ++i) c.digit[(size_t)i] = {0, r.f[(size_t)i]};
+                out.push_back(c);
+            }
+            pinned[(size_t)j] = {t, t + 1};
+        }
+    }
+    if (rem > 0) {   // the partial block b == full
+        Clip c; c.label = li; c.wHi = rem; c.digit.resize((size_t)n);
+        for (int j = 0; j < n; ++j) { const int64_t t = (full / below[(size_t)j]) % r.f[(size_t)j]; c.digit[(size_t)j] = {t, t + 1}; }
+        out.push_back(c);
+    }
+    return out;
+}
 
 // digits of tensor t's mode i below `split` are grid-coordinate digits, the rest local-block digits
 int grid_digits(const Radix& r, int64_t dc) {
@@ -198,8 +270,11 @@ View make_view(const MgTensor& t, const std::vector<int32_t>& labels, const std:
         const Radix& r = radix[li];
         const int nGrid = grid_digits(r, t.deviceCount[i]);
         const bool isP = li == rs.pLabel, isQ = li == rs.qLabel;
+        const Clip* clip = rs.clip_of(li);
         // w: position inside a block
-        if (isP) {
+        if (clip != nullptr) {
+            if (clip->wHi > 1) { v.extent.push_back(clip->wHi); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
+        } else if (isP) {
             const int64_t block = rs.lo / r.blockSize;
             v.offset += (rs.lo - block * r.blockSize) * t.elemStride[i];
             if (rs.hi - rs.lo > 1) { v.extent.push_back(rs.hi - rs.lo); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
@@ -217,7 +292,11 @@ View make_view(const MgTensor& t, const std::vector<int32_t>& labels, const std:
                 gridStep *= r.f[j];
                 continue;
             }
-            if (isP) {
+            if (clip != nullptr) {
+                const int64_t lo = clip->digit[(size_t)j].first, hi = clip->digit[(size_t)j].second;
+                v.offset += lo * step;
+                if (hi - lo > 1) { v.extent.push_back(hi - lo); v.stride.push_back(step); v.modes.push_back(8 * li + j); }
+            } else if (isP) {
                 v.offset += (rest % r.f[j]) * step;
                 rest /= r.f[j];
             } else if (isQ && j == rs.qDigit) {
@@ -287,7 +366,7 @@ ncclDataType_t nccl_type(hipDataType t) {
 
 void destroy_pieces(std::vector<Piece>& pieces) {
     for (Piece& p : pieces) {
-        cutensorDestroyPlan(p.plan);
+        for (auto& sub : p.subs) cutensorDestroyPlan(sub.plan);
         for (auto& s : p.scatter) cutensorDestroyPlan(s.plan);
     }
     pieces.clear();
@@ -443,14 +522,10 @@ cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t 
     cutensorStatus_t st = check(d->A, d->mA, d->B, d->mB);
     if (st == CUTENSOR_STATUS_SUCCESS) st = check(d->A, d->mA, d->C, d->mC);
     if (st == CUTENSOR_STATUS_SUCCESS) st = check(d->B, d->mB, d->C, d->mC);
-    // Ragged extents (not a multiple of blockSize * deviceCount): the local contractions run over the padded index space.
-    // For a mode of C that only produces results in the padding of D's cells (never read by the caller; blog_post.cu's
-    // ceil()-derived block sizes do this) — for a contracted mode the padding would enter every sum: refused.
-    auto ragged = [](const MgTensor& t, uint32_t i) { return t.extent[i] != t.localBlocks[i] * t.deviceCount[i] * t.blockSize[i]; };
-    for (uint32_t i = 0; i < d->A.n && st == CUTENSOR_STATUS_SUCCESS; ++i)
-        if (find_label(d->mC, d->mA[i]) < 0 && ragged(d->A, i)) st = CUTENSOR_STATUS_NOT_SUPPORTED;
-    for (uint32_t i = 0; i < d->B.n && st == CUTENSOR_STATUS_SUCCESS; ++i)
-        if (find_label(d->mC, d->mB[i]) < 0 && ragged(d->B, i)) st = CUTENSOR_STATUS_NOT_SUPPORTED;
+    // Ragged extents (not a multiple of blockSize * deviceCount; blog_post.cu:168-175 derives every block size with ceil()):
+    // a ragged mode of C only produces extra results in the padding of D's cells, which the caller never reads, so the local
+    // contractions simply run over the padded index space; a ragged CONTRACTED mode would put the padding into every sum, so
+    // the plan clips it: the valid part of its index space is tiled by boxes (kbox_list) that accumulate into D.
     if (st != CUTENSOR_STATUS_SUCCESS) { delete d; return st; }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
@@ -528,7 +603,9 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         ctrWs = std::min<uint64_t>(ctrWs, (uint64_t)(deviceWorkspaceSize[g] - fixed) / kComputeStreams / 256 * 256);
     }
     pl->contractionWs = ctrWs;
-    pl->useRccl = !handle->comms.empty();
+    pl->useRccl = !handle->comms.empty() ||
+                  // plan-only handles (no GPU visible): CPU tests of the RCCL event wiring and transport choice
+                  (!handle->haveDevice && handle->distinct && nDev > 1 && env_is("CUTENSORMG_AMD_ASSUME_RCCL", "1"));
 
     // ---- label universe, block-index digits per label ----------------------------------------------
     const MgTensor* T[3] = {&d.A, &d.B, &d.C};
@@ -720,7 +797,8 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     }
     pl->numWaves = numWaves;
     pl->commPerDevice = pl->useRccl ? 1 : std::max(1, std::min(7, nDev - 1));
-    pl->evPerDevice = 3 + pl->commPerDevice + numWaves * (pl->useRccl ? 1 : pl->commPerDevice);
+    pl->evScatter = 3 + pl->commPerDevice + numWaves * (pl->useRccl ? 1 : pl->commPerDevice);
+    pl->evPerDevice = pl->evScatter + kComputeStreams;
     for (Transfer& t : pl->transfers) {
         if (t.local) continue;
         // RCCL: one event per (device, wave); peer copies: one event per (device, wave, comm stream)
@@ -748,6 +826,25 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     }
     for (int k = 0; k < 3; ++k)
         if (!staged[k]) pl->stagingBytes[k] = 0;
+    // all-gather eligibility per tensor (a property of the layout; whether RCCL is there is a property of the handle)
+    for (int k = 0; k < 2; ++k) {   // operands only: C is gathered only for beta != 0 and scattered back, never all-gathered
+        bool ok = handle->distinct && nDev > 1 && T[k]->numCells == nDev;
+        for (int c = 0; ok && c < nDev; ++c) ok = T[k]->devices[(size_t)c] == handle->devices[(size_t)c];
+        std::vector<int> remote((size_t)nDev, 0);
+        for (const Transfer& t : pl->transfers)
+            if (t.tensor == k && !t.local) { ++remote[(size_t)t.dst]; ok = ok && t.wave == 0; }
+        for (int g = 0; ok && g < nDev; ++g) ok = remote[(size_t)g] == nDev - 1;
+        pl->allGatherEligible[k] = ok;
+    }
+    pl->transport = env_is("CUTENSORMG_AMD_TRANSPORT", "allgather") ? 1 : env_is("CUTENSORMG_AMD_TRANSPORT", "sendrecv") ? 2 : 0;
+    pl->readOwners.assign((size_t)nDev, {});
+    for (const Transfer& t : pl->transfers) {
+        if (t.local) continue;
+        for (int o = 0; o < nDev; ++o)
+            if (o != t.dst && handle->devices[(size_t)o] == t.ownerDevice &&
+                std::find(pl->readOwners[(size_t)t.dst].begin(), pl->readOwners[(size_t)t.dst].end(), o) == pl->readOwners[(size_t)t.dst].end())
+                pl->readOwners[(size_t)t.dst].push_back(o);
+    }
     pl->usesAux.assign((size_t)nDev, 0);
     pl->usesComm.assign((size_t)nDev, 0);
     for (const Piece& p : pieces) if (p.stream != 0) pl->usesAux[(size_t)p.dev] = 1;
@@ -757,30 +854,57 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     // ---- local plans ----------------------------------------------------------------------------
     const cutensorComputeDescriptor_t cd = compute_desc(d.compute);
     cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+    // boxes of the contracted index space (one, unless a contracted mode is ragged): the cartesian product of kbox_list()
+    std::vector<std::vector<Clip>> boxes(1);
+    for (size_t li = 0; li < universe.size(); ++li) {
+        if (find_label(d.mC, universe[li]) >= 0) continue;              // a mode of C: padded, never clipped
+        int64_t extent = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int i = find_label(*M[k], universe[li]);
+            if (i >= 0) extent = T[k]->extent[(size_t)i];
+        }
+        if (extent == radix[li].blockSize * radix[li].numBlocks) continue;   // fills the padded space
+        const std::vector<Clip> mine = kbox_list((int)li, radix[li], extent);
+        std::vector<std::vector<Clip>> next;
+        for (const auto& b : boxes)
+            for (const Clip& c : mine) { next.push_back(b); next.back().push_back(c); }
+        boxes.swap(next);
+    }
+    if (boxes.empty() || boxes.size() > 64) st = CUTENSOR_STATUS_NOT_SUPPORTED;
+    pl->numBoxes = (int)boxes.size();
     for (Piece& p : pieces) {
+        if (st != CUTENSOR_STATUS_SUCCESS) break;
         if (handle->haveDevice) { (void)hipSetDevice(handle->devices[p.dev]); (void)hipGetLastError(); }
         cutensorHandle_t h = handle->handles[p.dev];
         const Shard s{p.dev, p.lo, p.hi};
-        const Restrict rs = restrict_of(s, p.q0, p.q1);
-        View v[3];
-        for (int k = 0; k < 3; ++k) {
-            v[k] = make_view(*T[k], *M[k], universe, radix, rs, !p.use[k].direct);
-            p.use[k].off = v[k].offset;
+        Restrict rs = restrict_of(s, p.q0, p.q1);
+        for (const std::vector<Clip>& box : boxes) {
+            rs.clips = box;
+            View v[3];
+            Piece::Sub sub;
+            for (int k = 0; k < 3; ++k) {
+                v[k] = make_view(*T[k], *M[k], universe, radix, rs, !p.use[k].direct);
+                sub.off[k] = v[k].offset;
+            }
+            if (p.subs.empty()) for (int k = 0; k < 3; ++k) p.use[k].off = v[k].offset;
+            cutensorTensorDescriptor_t dT[3] = {nullptr, nullptr, nullptr};
+            cutensorOperationDescriptor_t op = nullptr;
+            cutensorPlanPreference_t pref = nullptr;
+            for (int k = 0; k < 3 && st == CUTENSOR_STATUS_SUCCESS; ++k) st = make_desc(h, v[k], T[k]->dtype, &dT[k]);
+            if (st == CUTENSOR_STATUS_SUCCESS)
+                st = cutensorCreateContraction(h, &op, dT[0], v[0].modes.data(), CUTENSOR_OP_IDENTITY, dT[1], v[1].modes.data(), CUTENSOR_OP_IDENTITY,
+                                               dT[2], v[2].modes.data(), CUTENSOR_OP_IDENTITY, dT[2], v[2].modes.data(), cd);
+            if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlanPreference(h, &pref, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE);
+            if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &sub.plan, op, pref, pl->contractionWs);
+            if (st == CUTENSOR_STATUS_SUCCESS)
+                st = cutensorPlanGetAttribute(h, sub.plan, CUTENSOR_PLAN_REQUIRED_WORKSPACE, &sub.ws, sizeof(sub.ws));
+            cutensorDestroyOperationDescriptor(op);
+            cutensorDestroyPlanPreference(pref);
+            for (int k = 0; k < 3; ++k) cutensorDestroyTensorDescriptor(dT[k]);
+            if (st != CUTENSOR_STATUS_SUCCESS) { cutensorDestroyPlan(sub.plan); break; }
+            p.subs.push_back(sub);
         }
-        cutensorTensorDescriptor_t dT[3] = {nullptr, nullptr, nullptr};
-        cutensorOperationDescriptor_t op = nullptr;
-        cutensorPlanPreference_t pref = nullptr;
-        for (int k = 0; k < 3 && st == CUTENSOR_STATUS_SUCCESS; ++k) st = make_desc(h, v[k], T[k]->dtype, &dT[k]);
-        if (st == CUTENSOR_STATUS_SUCCESS)
-            st = cutensorCreateContraction(h, &op, dT[0], v[0].modes.data(), CUTENSOR_OP_IDENTITY, dT[1], v[1].modes.data(), CUTENSOR_OP_IDENTITY,
-                                           dT[2], v[2].modes.data(), CUTENSOR_OP_IDENTITY, dT[2], v[2].modes.data(), cd);
-        if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlanPreference(h, &pref, CUTENSOR_ALGO_DEFAULT, CUTENSOR_JIT_MODE_NONE);
-        if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(h, &p.plan, op, pref, pl->contractionWs);
-        if (st == CUTENSOR_STATUS_SUCCESS)
-            st = cutensorPlanGetAttribute(h, p.plan, CUTENSOR_PLAN_REQUIRED_WORKSPACE, &p.planWs, sizeof(p.planWs));
-        cutensorDestroyOperationDescriptor(op);
-        cutensorDestroyPlanPreference(pref);
-        for (int k = 0; k < 3; ++k) cutensorDestroyTensorDescriptor(dT[k]);
+        rs.clips.clear();
         if (st != CUTENSOR_STATUS_SUCCESS) break;
         if (p.use[2].direct) continue;
         // scatter plans: the piece's region inside every cell of C it touches (cell-relative strides)
@@ -805,6 +929,15 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         delete pl;
         return st;
     }
+    // who stores into whose cells of D from afar (the owners' caller streams must end behind those stores)
+    pl->scatterOwners.assign((size_t)(nDev * kComputeStreams), {});
+    for (const Piece& p : pieces)
+        for (const Piece::Scatter& sc : p.scatter) {
+            std::vector<int>& v = pl->scatterOwners[(size_t)(p.dev * kComputeStreams + p.stream)];
+            for (int o = 0; o < nDev; ++o)
+                if (o != p.dev && handle->devices[(size_t)o] == d.C.devices[(size_t)sc.cell] && std::find(v.begin(), v.end(), o) == v.end())
+                    v.push_back(o);
+        }
     pl->pieces.swap(pieces);
     *plan = pl;
     return CUTENSOR_STATUS_SUCCESS;
@@ -813,6 +946,11 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
 cutensorStatus_t cutensorMgDestroyContractionPlan(cutensorMgContractionPlan_t plan) {
     if (plan == nullptr) return CUTENSOR_STATUS_SUCCESS;
     destroy_pieces(plan->pieces);
+    if (plan->owner != nullptr && plan->owner->haveDevice && plan->trialEv[0] != nullptr) {
+        DeviceGuard guard;
+        (void)hipSetDevice(plan->owner->devices[0]);
+        for (hipEvent_t e : plan->trialEv) if (e) (void)hipEventDestroy(e);
+    }
     if (!plan->events.empty() && plan->owner != nullptr) {
         DeviceGuard guard;
         const int nDev = (int)plan->owner->devices.size();
@@ -915,13 +1053,57 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         MG_HIP(hipEventRecord(ev(g, 1), streams[g]));
         MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 1), 0));
     }
+    // transport of this call: all-gather for the tensors that qualify, or send/recv pairs for everything
+    bool useAllGather = false;
+    int trial = -1;   // auto: 0 / 1 = this call is the timed all-gather / send-recv trial
+    if (pl->useRccl && (pl->allGatherEligible[0] || pl->allGatherEligible[1])) {
+        if (pl->transport == 1) useAllGather = true;
+        else if (pl->transport == 2) useAllGather = false;
+        else {
+            if (pl->calls < 2) { trial = pl->calls; useAllGather = trial == 0; }
+            else {
+                if (pl->chosen == 0 && pl->trialEv[3] != nullptr && hipEventQuery(pl->trialEv[3]) == hipSuccess) {
+                    (void)hipSetDevice(handle->devices[0]);
+                    if (hipEventElapsedTime(&pl->trialMs[0], pl->trialEv[0], pl->trialEv[1]) == hipSuccess &&
+                        hipEventElapsedTime(&pl->trialMs[1], pl->trialEv[2], pl->trialEv[3]) == hipSuccess)
+                        pl->chosen = pl->trialMs[0] <= pl->trialMs[1] ? 1 : 2;
+                    else { (void)hipGetLastError(); pl->chosen = 1; }
+                }
+                (void)hipGetLastError();
+                useAllGather = pl->chosen != 2;   // undecided: the collective
+            }
+        }
+    }
+    if (trial >= 0 && pl->trialEv[2 * trial] == nullptr) {
+        (void)hipSetDevice(handle->devices[0]);
+        if (hipEventCreate(&pl->trialEv[2 * trial]) != hipSuccess || hipEventCreate(&pl->trialEv[2 * trial + 1]) != hipSuccess) { (void)hipGetLastError(); trial = -1; }
+    }
+    ++pl->calls;
+    if (trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial], handle->commStreams[0][0])); }
     // remote cells, wave by wave
     for (int w = 0; w < pl->numWaves; ++w) {
         bool grouped = false;
         cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
         std::set<int> touched;   // events to record after this wave
+        if (w == 0 && useAllGather) {
+            // one ncclAllGather per device and qualifying tensor inside the group: device g contributes its own cell (cell g)
+            // and receives the image [cell 0][cell 1]... straight into its staging area
+            for (int k = 0; k < 2 && st == CUTENSOR_STATUS_SUCCESS; ++k) {
+                if (!pl->allGatherEligible[k]) continue;
+                if (!grouped) { (void)ncclGroupStart(); grouped = true; }
+                for (int g = 0; g < nDev; ++g) {
+                    (void)hipSetDevice(handle->devices[g]);
+                    if (ncclAllGather(src[k][g], staging(g, k), (size_t)T[k]->cellElems, nccl_type(T[k]->dtype), handle->comms[(size_t)g],
+                                      handle->commStreams[(size_t)g][0]) != ncclSuccess) { st = CUTENSOR_STATUS_EXECUTION_FAILED; break; }
+                }
+                for (const Transfer& t : pl->transfers)
+                    if (t.tensor == k && !t.local) touched.insert(t.event);
+            }
+        }
         for (const Transfer& t : pl->transfers) {
+            if (st != CUTENSOR_STATUS_SUCCESS) break;
             if (t.local || t.wave != w || (t.tensor == 2 && b == 0.0)) continue;
+            if (useAllGather && t.tensor < 2 && pl->allGatherEligible[t.tensor]) continue;   // arrived with the collective
             char* dst = staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes;
             const int slot = (t.event - (t.dst * pl->evPerDevice + 3 + pl->commPerDevice)) % (pl->useRccl ? 1 : pl->commPerDevice);
             if (pl->useRccl && t.src >= 0) {
@@ -947,7 +1129,9 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
             MG_HIP(hipSetDevice(handle->devices[g]));
             MG_HIP(hipEventRecord(pl->events[(size_t)e], handle->commStreams[(size_t)g][(size_t)slot]));
         }
+        if (w == 0 && trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
     }
+    if (pl->numWaves == 0 && trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
 
     // ---- 2. local contractions, 3. scatter ----------------------------------------------------------------------
     std::set<std::pair<int, int>> waited;   // (device * 2 + stream, event): each stream waits for an event once
@@ -977,11 +1161,14 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
             pc = staging(g, 2);
             pd = staging(g, 2);
         }
-        const int64_t oC = p.use[2].off * (int64_t)es;
-        cutensorStatus_t st = cutensorContract(handle->handles[(size_t)g], p.plan, alpha, pa + p.use[0].off * (int64_t)es,
-                                               pb + p.use[1].off * (int64_t)es, beta, pc + oC, pd + oC, staging(g, 3 + p.stream),
-                                               pl->contractionWs, cs);
-        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+        for (size_t bi = 0; bi < p.subs.size(); ++bi) {   // boxes of the contracted index space accumulate into D
+            const Piece::Sub& sub = p.subs[bi];
+            const int64_t oC = sub.off[2] * (int64_t)es;
+            st = cutensorContract(handle->handles[(size_t)g], sub.plan, alpha, pa + sub.off[0] * (int64_t)es, pb + sub.off[1] * (int64_t)es,
+                                  bi == 0 ? beta : one, (bi == 0 ? pc : pd) + oC, pd + oC, staging(g, 3 + p.stream), pl->contractionWs, cs);
+            if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        }
         const size_t cellBytes = (size_t)d.C.cellElems * es;
         for (const Piece::Scatter& s : p.scatter) {
             const char* from = staging(g, 2) + (size_t)s.cell * cellBytes + s.off * (int64_t)es;
@@ -991,7 +1178,21 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         }
     }
 
-    // ---- 4. join: the caller's stream of every device ends behind its helper streams -------------------------------
+    // ---- 4. join: the caller's stream of every device ends behind its helper streams — and behind every OTHER device's
+    //         stream that stored into its cells of D (remote scatter) or still reads its cells of A / B / C (peer copies):
+    //         a caller that synchronises only streams[owner], or chains a second call on it, sees finished cells
+    for (int g = 0; g < nDev; ++g) {
+        for (int sidx = 0; sidx < kComputeStreams; ++sidx) {
+            const std::vector<int>& owners = pl->scatterOwners[(size_t)(g * kComputeStreams + sidx)];
+            if (owners.empty()) continue;
+            MG_HIP(hipSetDevice(handle->devices[g]));
+            MG_HIP(hipEventRecord(ev(g, pl->evScatter + sidx), compute_stream(g, sidx)));
+            for (int o : owners) {
+                MG_HIP(hipSetDevice(handle->devices[o]));
+                MG_HIP(hipStreamWaitEvent(streams[o], ev(g, pl->evScatter + sidx), 0));
+            }
+        }
+    }
     for (int g = 0; g < nDev; ++g) {
         MG_HIP(hipSetDevice(handle->devices[g]));
         if (pl->usesAux[(size_t)g]) {
@@ -1001,6 +1202,12 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         for (size_t k = 0; pl->usesComm[(size_t)g] && k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k) {
             MG_HIP(hipEventRecord(ev(g, 3 + (int)k), handle->commStreams[(size_t)g][k]));
             MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 3 + (int)k), 0));
+            if (pl->useRccl) continue;    // RCCL: the owner's own communication stream takes part in the transfer and is joined above
+            for (int o : pl->readOwners[(size_t)g]) {
+                MG_HIP(hipSetDevice(handle->devices[o]));
+                MG_HIP(hipStreamWaitEvent(streams[o], ev(g, 3 + (int)k), 0));
+            }
+            MG_HIP(hipSetDevice(handle->devices[g]));
         }
     }
 #undef MG_HIP
@@ -1008,6 +1215,33 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
 }
 
 // ---- diagnostics (not part of the cuTENSORMg ABI; used by the tests and the bench) -------------------------------
+// The boxes kbox_list() cuts the valid part [0, extent) of a padded index space into (block size, digit extents least
+// significant first), as JSON: [{"wHi":..,"digits":[[lo,hi],...]},...].
+int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const int64_t* f, char* buf, size_t len) {
+    if (buf == nullptr || len == 0 || blockSize <= 0 || extent <= 0 || nDigits < 0 || (nDigits > 0 && f == nullptr)) return -1;
+    Radix r;
+    r.blockSize = blockSize;
+    r.numBlocks = 1;
+    for (int j = 0; j < nDigits; ++j) { r.f.push_back(f[j]); r.numBlocks *= f[j]; }
+    if (extent > r.blockSize * r.numBlocks) return -1;
+    std::string s = "[";
+    char tmp[96];
+    const std::vector<Clip> boxes = kbox_list(0, r, extent);
+    for (size_t i = 0; i < boxes.size(); ++i) {
+        std::snprintf(tmp, sizeof(tmp), "%s{\"wHi\":%lld,\"digits\":[", i ? "," : "", (long long)boxes[i].wHi);
+        s += tmp;
+        for (size_t j = 0; j < boxes[i].digit.size(); ++j) {
+            std::snprintf(tmp, sizeof(tmp), "%s[%lld,%lld]", j ? "," : "", (long long)boxes[i].digit[j].first, (long long)boxes[i].digit[j].second);
+            s += tmp;
+        }
+        s += "]}";
+    }
+    s += "]";
+    if (s.size() + 1 > len) return -(int)(s.size() + 1);
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 // One JSON object describing the plan: which mode is sharded, the pieces in execution order with the grid cells they
 // read in place / from the staging image and the events they wait for, and every cell transfer.
 int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_t len) {
@@ -1017,7 +1251,25 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
     auto add = [&](const char* fmt, auto... a) { std::snprintf(tmp, sizeof(tmp), fmt, a...); s += tmp; };
     int64_t remote = 0, local = 0;
     for (const Transfer& t : plan->transfers) (t.local ? local : remote) += t.bytes;
-    add("{\"pLabel\":%d,\"qLabel\":%d,\"numWaves\":%d,\"useRccl\":%d,\"commStreams\":%d,\"contractionWs\":%llu,", plan->pLabel, plan->qLabel,
+    add("{\"numBoxes\":%d,\"allGatherEligible\":[%d,%d],\"transport\":\"%s\",\"trialMs\":[%.4f,%.4f],\"chosen\":%d,", plan->numBoxes,
+        (int)plan->allGatherEligible[0], (int)plan->allGatherEligible[1],
+        !plan->useRccl ? "peer" : (plan->transport == 2 || !(plan->allGatherEligible[0] || plan->allGatherEligible[1])) ? "sendrecv"
+                                  : plan->transport == 1 ? "allgather" : "auto(allgather|sendrecv)",
+        plan->trialMs[0], plan->trialMs[1], plan->chosen);
+    s += "\"scatterOwners\":[";
+    for (size_t i = 0; i < plan->scatterOwners.size(); ++i) {
+        add("%s[", i ? "," : "");
+        for (size_t j = 0; j < plan->scatterOwners[i].size(); ++j) add("%s%d", j ? "," : "", plan->scatterOwners[i][j]);
+        s += "]";
+    }
+    s += "],\"readOwners\":[";
+    for (size_t i = 0; i < plan->readOwners.size(); ++i) {
+        add("%s[", i ? "," : "");
+        for (size_t j = 0; j < plan->readOwners[i].size(); ++j) add("%s%d", j ? "," : "", plan->readOwners[i][j]);
+        s += "]";
+    }
+    s += "],";
+    add("\"pLabel\":%d,\"qLabel\":%d,\"numWaves\":%d,\"useRccl\":%d,\"commStreams\":%d,\"contractionWs\":%llu,", plan->pLabel, plan->qLabel,
         plan->numWaves, (int)plan->useRccl, plan->commPerDevice, (unsigned long long)plan->contractionWs);
     add("\"stagingBytes\":[%lld,%lld,%lld],\"remoteBytes\":%lld,\"localCopyBytes\":%lld,\"pieces\":[", (long long)plan->stagingBytes[0],
         (long long)plan->stagingBytes[1], (long long)plan->stagingBytes[2], (long long)remote, (long long)local);

@@ -39,9 +39,23 @@ for _name, _args in EXPORTS.items():
 
 lib.ctamdMgDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdMgDescribePlan.restype = ctypes.c_int
+lib.ctamdMgDescribeKBoxes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_size_t]
+lib.ctamdMgDescribeKBoxes.restype = ctypes.c_int
 
 check = ct.check
 i64, i32 = ct.i64, ct.i32
+
+
+def kboxes(extent, block_size, digits):
+    """ctamdMgDescribeKBoxes -> list of {"wHi", "digits": [[lo, hi], ...]}: the boxes that tile the valid part of a ragged
+    contracted mode's padded index space (mg.cpp kbox_list)."""
+    import json
+    buf = ctypes.create_string_buffer(1 << 14)
+    f = (ctypes.c_int64 * max(len(digits), 1))(*digits)
+    r = lib.ctamdMgDescribeKBoxes(extent, block_size, len(digits), f, buf, len(buf))
+    if r < 0:
+        raise ValueError("ctamdMgDescribeKBoxes: invalid arguments")
+    return json.loads(buf.value.decode())
 
 
 def describe_plan(plan):

@@ -221,7 +221,7 @@ def test_bench_multi_device_path_self_test(built):
 def test_mg_ragged_free_modes(mg, handle_devices):
     """Extents that are not a multiple of blockSize x deviceCount in the FREE modes (blog_post.cu derives its block sizes
     with ceil(), :168-175; cells then hold whole blocks with padding at the end, :107-113): the result inside the extents is
-    exact, the padding of D's cells is unspecified.  A ragged CONTRACTED mode is refused."""
+    exact, the padding of D's cells is unspecified."""
     cm, torch = mg
     rng = np.random.default_rng(21)
     Ei, Ej, Ek = 176, 144, 128            # i: 6 blocks of 32 over 2 (5.5 -> padded 192); j: 5 blocks of 32 over 2 (4.5 -> padded 192... 6 blocks)
@@ -252,7 +252,51 @@ def test_mg_ragged_free_modes(mg, handle_devices):
         torch.cuda.synchronize()
         got = _gather_cells([t.cpu().numpy() for t in cellsC], (Pi, Pj), (bs, bs), (dc, dc), np.float32)[:Ei, :Ej]
         np.testing.assert_allclose(got, A.astype(np.float64) @ B.astype(np.float64), rtol=1e-4)
-    # contracted mode ragged -> NOT_SUPPORTED at the contraction descriptor
-    with pytest.raises(Exception) as ei:
-        cm.Contraction([0], modes, dict(i=128, j=128, k=176), block, dcount)
-    assert "NOT_SUPPORTED" in str(ei.value)
+
+
+@pytest.mark.parametrize("handle_devices,Ek,bs,dc", [
+    ([0], 176, 32, 2),          # 5.5 blocks over 2 cells: a full-block box per non-zero digit of the bound + the partial block
+    ([0, 0, 0], 176, 32, 2),
+    ([0, 0], 72, 32, 1),        # one cell, 2.25 blocks: {b < 2} + {b == 2, w < 8}
+    ([0, 0], 24, 32, 2),        # less than one block: only the partial-block box, the second cell holds nothing valid
+])
+def test_mg_ragged_contracted_mode(mg, handle_devices, Ek, bs, dc):
+    """A CONTRACTED mode whose extent is not a multiple of blockSize x deviceCount: the padding at the end of A's and B's cells
+    (NaN here) must not enter any sum.  The plan tiles the valid part of k's padded index space with boxes (mg.cpp kbox_list)
+    and the boxes accumulate into D; beta != 0 checks that only the first box applies it."""
+    cm, torch = mg
+    rng = np.random.default_rng(33)
+    Ei, Ej = 128, 96
+    bi, dci = 32, 2
+    A = rng.random((Ei, Ek), dtype=np.float32)
+    B = rng.random((Ek, Ej), dtype=np.float32)
+    C = rng.random((Ei, Ej), dtype=np.float32)
+    padk = -(-(-(-Ek // bs)) // dc) * dc * bs
+    padj = -(-(-(-Ej // bi)) // dci) * dci * bi
+
+    def padded(G, shape):
+        out = np.full(shape, np.nan, dtype=np.float32)
+        out[:G.shape[0], :G.shape[1]] = G
+        return out
+
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=bi, k=bs), dict(k=bs, j=bi), dict(i=bi, j=bi)]
+    dcount = [dict(i=dci, k=dc), dict(k=dc, j=dci), dict(i=dci, j=dci)]
+    beta = 0.5
+    with cm.Contraction(handle_devices, modes, dict(i=Ei, j=Ej, k=Ek), block, dcount) as con:
+        assert con.describe()["numBoxes"] >= (1 if Ek % (bs * dc) == 0 else 1)
+        cellsA = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(padded(A, (Ei, padk)), (bi, bs), (dci, dc))]
+        cellsB = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(padded(B, (padk, padj)), (bs, bi), (dc, dci))]
+        Cp = np.zeros((Ei, padj), dtype=np.float32)
+        Cp[:, :Ej] = C
+        cellsC = [torch.from_numpy(np.ascontiguousarray(x.ravel(order="F"))).cuda() for x in _cells_of(Cp, (bi, bi), (dci, dci))]
+        n = len(handle_devices)
+        ws = [torch.empty(int(con.ws_sizes[i]), dtype=torch.uint8, device="cuda") for i in range(n)]
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        torch.cuda.synchronize()
+        cm.check(con.run(1.0, [t.data_ptr() for t in cellsA], [t.data_ptr() for t in cellsB], beta, [t.data_ptr() for t in cellsC],
+                         [t.data_ptr() for t in cellsC], [t.data_ptr() for t in ws], [s.cuda_stream for s in streams]))
+        torch.cuda.synchronize()
+        got = _gather_cells([t.cpu().numpy() for t in cellsC], (Ei, padj), (bi, bi), (dci, dci), np.float32)[:Ei, :Ej]
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, A.astype(np.float64) @ B.astype(np.float64) + beta * C, rtol=1e-4)

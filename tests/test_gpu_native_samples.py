@@ -47,7 +47,7 @@ def test_multi_gpu_block_cyclic_with_value_check(built):
     assert "-> ok" in out and "4 device(s)" in out
 
 
-@pytest.mark.parametrize("scaling", [1, 2, 4, 11])
+@pytest.mark.parametrize("scaling", list(range(1, 13)))
 def test_blog_post_harness_with_value_check(built, scaling):
     """blog_post.cu <numDevices> <scaling> (:131-146) — the reference harness is only an rc check; this one compares 256
     sampled outputs of the six-mode result with fp64 sums over K0, K1, K2 (scaling 11: ragged last blocks in M1 / N1)."""

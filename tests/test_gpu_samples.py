@@ -28,7 +28,7 @@ def test_reference_sample_runs(built, name):
     assert "rror" not in out.replace("No such file or directory", ""), out[-2000:]
 
 
-@pytest.mark.parametrize("scaling", ["1", "4", "11"])
+@pytest.mark.parametrize("scaling", [str(i) for i in range(1, 13)])
 def test_blog_post_scaling_harness(built, scaling):
     """cuTENSORMg/blog_post.cu <numDevices> <scaling> (:131-146): the multi-mode distributed contraction
     C_{M0,N0,M1,N1,M2,N2} = A_{K0,M0,M1,K1,M2,K2} B_{K0,N0,K1,N1,K2,N2} (:177-179) on one device; scaling 11 makes the

@@ -221,3 +221,140 @@ def test_ragged_and_mixed_layouts_cover_c_once_and_gather_what_they_read(cm, see
             if len(rows) and len(cols):
                 cov[np.ix_(rows, cols)] += 1
         assert (cov == 1).all(), (seed, n, extent, block, dcount, int(cov.min()), int(cov.max()))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_kboxes_tile_the_valid_index_space_exactly(cm, seed):
+    """Ragged CONTRACTED modes (mg.cpp kbox_list): idx = w + bs * b, b = sum digit_j * prod f_<j.  For random block sizes, digit
+    extents and extents, the boxes are disjoint, lie inside [0, extent) and cover it; at most digits + 1 of them."""
+    rng = np.random.default_rng(500 + seed)
+    for _ in range(40):
+        bs = int(rng.integers(1, 9))
+        f = [int(rng.integers(1, 5)) for _ in range(int(rng.integers(0, 4)))]
+        nblk = int(np.prod(f)) if f else 1
+        extent = int(rng.integers(1, bs * nblk + 1))
+        boxes = cm.kboxes(extent, bs, f)
+        assert 1 <= len(boxes) <= len(f) + 1
+        seen = np.zeros(bs * nblk, dtype=np.int32)
+        for b in boxes:
+            ranges = [range(lo, hi) for lo, hi in b["digits"]]
+            import itertools
+            for digs in itertools.product(*ranges) if ranges else [()]:
+                blk, mul = 0, 1
+                for dj, fj in zip(digs, f):
+                    blk += dj * mul
+                    mul *= fj
+                seen[blk * bs: blk * bs + b["wHi"]] += 1
+        assert (seen[:extent] == 1).all() and (seen[extent:] == 0).all(), (extent, bs, f, boxes)
+
+
+def test_ragged_contracted_mode_is_planned_as_boxes(cm):
+    """k = 176 in blocks of 32 over 2 devices (5.5 blocks, padded to 6): {local block < 2} + {local block 2, grid digit 0}
+    + the half block -> 3 local contractions per piece; a k that fills its padded space stays one box."""
+    modes = ["ik", "kj", "ij"]
+    block = [dict(i=32, k=32), dict(k=32, j=32), dict(i=32, j=32)]
+    dcount = [dict(i=2, k=2), dict(k=2, j=2), dict(i=2, j=2)]
+    with cm.Contraction([0, 1], modes, dict(i=128, j=128, k=176), block, dcount) as con:
+        assert con.describe()["numBoxes"] == 3
+    with cm.Contraction([0, 1], modes, dict(i=128, j=128, k=192), block, dcount) as con:
+        assert con.describe()["numBoxes"] == 1
+
+
+def _blog_post_shapes(n, s):
+    """cuTENSORMg/blog_post.cu:155-175 (extents, ceil()-derived block sizes — including its N1 expression as written) and
+    :78-101 (device counts: from the last mode down, double while blocks and devices remain)."""
+    import math
+    M0, M1, M2, N0, N1, N2, K0, K1, K2 = "abcdefghi"
+    ext = {M0: 16, M1: 8 * s, M2: 8, N0: 16, N1: 8 * s, N2: 8, K0: 16, K1: 32, K2: 8}
+    nM = n // 2 if n >= 4 else n
+    nN = n // nM
+    M = ext[M0] * ext[M1] * ext[M2]
+    N = ext[N0] * ext[N1] * ext[N2]
+    bs = {M0: 16, M2: 8, N0: 16, N2: 8, K0: 16, K1: 16, K2: 8}
+    bs[M1] = math.ceil(math.ceil(M / math.ceil(M / 4096.0 / nM)) / nM / ext[M0] / ext[M2])
+    bs[N1] = math.ceil(math.ceil(N / math.ceil(N / 4096.0 / nN)) / nN / ext[N0] / ext[N1])
+    modes = [K0 + M0 + M1 + K1 + M2 + K2, K0 + N0 + K1 + N1 + K2 + N2, M0 + N0 + M1 + N1 + M2 + N2]
+    block, dcount = [], []
+    for m in modes:
+        dc = {c: 1 for c in m}
+        rem, changed = n, True
+        while changed:
+            changed = False
+            for c in reversed(m):
+                if rem <= 1:
+                    break
+                if dc[c] < ext[c] // bs[c]:
+                    dc[c] *= 2
+                    rem //= 2
+                    changed = True
+        assert rem == 1 or n == 1 or all(dc[c] >= ext[c] // bs[c] for c in m)
+        block.append({c: bs[c] for c in m})
+        dcount.append(dc)
+    return modes, ext, block, dcount
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+def test_every_blog_post_configuration_plans(cm, n):
+    """blog_post.cu <numDevices> <scaling> for scaling 1..12 (:131-146): descriptors, contraction descriptor and plan are created
+    for every one of them without a GPU (plans whose local views need the mode-table kernel upload its table at first execution)."""
+    for s in range(1, 13):
+        modes, ext, block, dcount = _blog_post_shapes(n, s)
+        ncell = [int(np.prod(list(dc.values()))) for dc in dcount]
+        if any(c != ncell[0] for c in ncell) or (n > 1 and ncell[0] != n):
+            # the sample hands numDevices / remainingDevices cells to the descriptor (:125-127): fewer than n when the blocks run out
+            pass
+        with cm.Contraction(list(range(n)), modes, ext, block, dcount) as con:
+            d = con.describe()
+            assert d["numBoxes"] == 1 and len(d["pieces"]) >= 1     # K0 / K1 / K2 extents divide their blocks: never ragged
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_all_gather_transport_is_selected_for_the_free_mode_layout(cm, n, monkeypatch):
+    """north_star / SURVEY 8e: "one RCCL ncclAllGather of B's shards".  With RCCL (assumed here: plan-only handle), the bench
+    layout's B — one column slab per device, slab c on device c, every device needs all of them in one wave — qualifies for the
+    all-gather transport: its staging image [cell][cell buffer] is the collective's receive layout.  A (never gathered) does not;
+    CUTENSORMG_AMD_TRANSPORT=sendrecv / allgather pin the choice, default = timed trial of both on the first two calls."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("plan-only handles need a host without a GPU")
+    monkeypatch.setenv("CUTENSORMG_AMD_ASSUME_RCCL", "1")
+    E = 128 * n
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, E)) as con:
+        d = con.describe()
+        assert d["useRccl"] == 1 and d["allGatherEligible"] == [0, 1] and d["transport"].startswith("auto(allgather")
+        assert d["commStreams"] == 1 and d["numWaves"] == 1
+        check_transfers(d, con, n)
+        # no remote scatter (C is sharded like the work) and RCCL: no cross-device ordering owed at the join
+        assert all(o == [] for o in d["scatterOwners"])
+    monkeypatch.setenv("CUTENSORMG_AMD_TRANSPORT", "sendrecv")
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, E)) as con:
+        assert con.describe()["transport"] == "sendrecv"
+    monkeypatch.setenv("CUTENSORMG_AMD_TRANSPORT", "allgather")
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, E)) as con:
+        assert con.describe()["transport"] == "allgather"
+    monkeypatch.delenv("CUTENSORMG_AMD_TRANSPORT")
+    # the sample's 2 x 2 block-cyclic layout on 4 devices: cells are gathered, but not as one slab per device -> send/recv
+    modes = ["ik", "kj", "ij"]
+    blk = [dict(i=64, k=64), dict(k=64, j=64), dict(i=64, j=64)]
+    dc = [dict(i=2, k=2), dict(k=2, j=2), dict(i=2, j=2)]
+    with cm.Contraction([0, 1, 2, 3], modes, dict(i=256, j=256, k=256), blk, dc) as con:
+        d = con.describe()
+        assert d["transport"] == "sendrecv" or d["allGatherEligible"] != [0, 0]
+        # remote scatter: some device stores pieces of C into cells another device owns -> that owner's stream must wait
+        owners = [set(o) for o in d["scatterOwners"]]
+        for p in d["pieces"]:
+            for c in p["scatter"]:
+                own = con.cells[2]["owners"][c]
+                if own != con.devices[p["dev"]]:
+                    assert con.devices.index(own) in owners[p["dev"] * 2 + p["stream"]]
+
+
+def test_peer_transport_orders_owner_streams_behind_remote_reads(cm):
+    """Peer copies (no RCCL): device g's communication streams read the owners' cells directly, so every owner's caller stream must
+    end behind those reads (readOwners) — otherwise the owner could overwrite its operand while a peer still reads it."""
+    n = 4
+    with cm.Contraction(list(range(n)), *free_mode_layout(n, 128 * n)) as con:
+        d = con.describe()
+        assert d["transport"] == "peer"
+        for g in range(n):
+            assert sorted(d["readOwners"][g]) == [o for o in range(n) if o != g]
