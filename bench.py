@@ -133,6 +133,7 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True, virtual=F
             call()
         sync_all()
         elapsed = time.perf_counter() - t0
+        d2 = con.describe()    # after the calls: which transport the first-two-calls trial chose
         err = None
         if check:
             # sampled fp64 dot products: C[i, j] lives in row slab i // (E/n) as [j][i_local]; A[i, :] = slab[k][i_local];
@@ -154,7 +155,10 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True, virtual=F
                 "gflops": flop / (elapsed / steps) / 1e9, "sample_protocol_min_ms": best * 1e3,
                 "sample_protocol_gflops": flop / best / 1e9, "flop": flop, "elapsed_s": elapsed,
                 "gather_bytes_per_call": d["remoteBytes"], "local_copy_bytes_per_call": d["localCopyBytes"],
-                "pieces": len(d["pieces"]), "gather_waves": d["numWaves"], "transport": "rccl" if d["useRccl"] else ("peer" if n > 1 else "none"),
+                "pieces": len(d["pieces"]), "gather_waves": d["numWaves"],
+                "transport": (d2["transport"] if n > 1 else "none"), "rccl": bool(d["useRccl"]),
+                "all_gather_eligible": d2.get("allGatherEligible"), "transport_trial_ms": d2.get("trialMs"),
+                "transport_chosen": {0: "undecided", 1: "allgather", 2: "sendrecv"}.get(d2.get("chosen", 0)),
                 "max_rel_err_sampled": err}
     finally:
         con.close()
@@ -207,6 +211,34 @@ def run_mg_child(ndev, steps, warmup, timeout_s, virtual=False):
                 res["error"] = "child exited with %d" % r.returncode
             return res
     return {"error": "child rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+
+
+def run_einsum_ranks(n, steps, warmup, timeout_s=420):
+    """A plain `python bench.py --gpus N` launch (world size 1) on a box with N GPUs: the one-process-per-GPU K-sharded einsum
+    (b cut N ways, RCCL all-reduce of the 36-KB result) is measured by N ranks this process spawns itself, exactly as the driver
+    would launch them; returns rank 0's JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warmup),
+           "--einsum-only", "--no-cpu", "--no-secondary"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "spawned einsum ranks timed out after %d s" % timeout_s}
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "spawned ranks rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
 
 
 def einsum_flow_line(calls=2000):
@@ -392,6 +424,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--mg-timeout", type=int, default=300, help="seconds per attempt of the multi-device child process")
+    ap.add_argument("--einsum-only", action="store_true", help=argparse.SUPPRESS)   # ranks spawned by a plain `--gpus N` launch
     ap.add_argument("--mg-virtual", action="store_true",
                     help="self-test of the N > 1 path on a box with fewer GPUs: the N devices are N logical devices on GPU 0 and the "
                          "shapes are shrunk; the line then says n_gpus = 1 and the numbers are not scaling results")
@@ -440,7 +473,7 @@ def main():
     # ---- cuTENSORMg over the requested devices (N > 1): child process of rank 0 --------------------------------------
     mg = None
     mg_devices = requested if args.mg_virtual else min(requested, visible)
-    if requested > 1:
+    if requested > 1 and not args.einsum_only:
         if rank == 0 and mg_devices > 1:
             mg = run_mg_child(mg_devices, args.steps, args.warmup, args.mg_timeout, virtual=args.mg_virtual)
             if "timed out" in str(mg.get("error", "")) and os.environ.get("CUTENSORMG_AMD_TRANSPORT") != "peer":
@@ -521,6 +554,7 @@ def main():
         elapsed = float(t.item())
     einsum_ms = elapsed / args.steps * 1e3
     einsum_value = world * FLOP / (elapsed / args.steps) / 1e9
+    einsum_1gpu_value = einsum_value / world   # per-GPU rate of the headline at this rank count (= the headline itself at N = 1)
 
     roof = cpu = None
     secondary = []
@@ -599,7 +633,7 @@ def main():
             del pairs
         except Exception as ex:   # noqa: BLE001
             cold = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.einsum_only:
             a_np, b_np = a.cpu().numpy(), b.cpu().numpy()
             ref, cpu = cpu_baseline(a_np, b_np)
             contract(a, b, outs[0])
@@ -607,7 +641,7 @@ def main():
             got = outs[0].cpu().numpy()
             cpu["max_rel_diff_vs_gpu"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
         # ---- the other BASELINE configs, same process ---------------------------------------------------------------
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not args.einsum_only:
             del a, b
             torch.cuda.empty_cache()
             secondary += secondary_single_gpu(torch, ct, ops, h, stream)
@@ -654,11 +688,41 @@ def main():
                 config["multi_device"] = (mg or {}).get("error") or ("only %d GPU visible: cuTENSORMg measured on one device (secondary)" % visible)
             metric = "contraction GFLOP/s, fp32 einsum abcd,dcbe->ae"
             roof_out = roof
+        # ---- like-for-like fields on EVERY line (whatever `value` is): the einsum at this rank count, the cuTENSORMg 16384^3
+        #      contraction at this device count, and its speedup over one device measured in the same child process -----------
+        spawned = None
+        if world == 1 and requested > 1 and visible > 1 and not args.einsum_only and not args.mg_virtual:
+            try:
+                spawned = run_einsum_ranks(min(requested, visible), args.steps, args.warmup)
+            except Exception as ex:   # noqa: BLE001
+                spawned = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            if "error" not in spawned:
+                sp_line = {"workload": spawned["config"]["workload"], "dtype": "f32", "value": spawned["value"], "unit": "GFLOP/s",
+                           "n_gpus": spawned["n_gpus"], "ms_per_step": spawned["ms_per_step"], "scaling": "weak",
+                           "rccl_ranks_seen": spawned.get("rccl_ranks_seen"), "launched_by": "bench.py itself (plain --gpus N launch)"}
+                secondary.append(sp_line)
+            else:
+                secondary.append({"workload": "einsum K-sharded over %d ranks (self-spawned)" % min(requested, visible), "error": spawned["error"]})
+        if use_mg:
+            mg_value, mg_devices, mg_speedup = mg["scaled"]["gflops"], mg["scaled"].get("distinct_devices", mg["scaled"]["devices"]), scaled_line.get("speedup_vs_1")
+        else:
+            mg_one = next((x for x in secondary if "16384^3" in x.get("workload", "") and "value" in x), None)
+            mg_value, mg_devices, mg_speedup = (mg_one["value"], 1, 1.0) if mg_one else (None, 0, None)
+        if spawned is not None and "error" not in spawned:
+            einsum_n_value, einsum_n_gpus, ranks_seen = spawned["value"], spawned["n_gpus"], spawned.get("rccl_ranks_seen")
+        else:
+            einsum_n_value, einsum_n_gpus, ranks_seen = einsum_value, world, (world if gpu_group is not None else (1 if world == 1 else 0))
         line = {
             "metric": metric, "value": value, "unit": "GFLOP/s",
             "n_gpus": n_gpus, "requested_gpus": requested, "steps": args.steps, "warmup": args.warmup, "burn_in_ms": args.burn_in_ms,
             "burn_in_steps": burn_steps, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_is": "mg_value" if use_mg else "einsum_value",
+            "einsum_value": einsum_n_value, "einsum_n_gpus": einsum_n_gpus,
+            "einsum_frac_of_f32_mfma_peak": (einsum_n_value / 1e3 / (PEAK_TFLOPS_F32_MFMA * max(einsum_n_gpus, 1))) if einsum_n_value else None,
+            "mg_value": mg_value, "mg_devices": mg_devices, "speedup_vs_1_same_workload": mg_speedup,
+            "mg_over_one_gpu_einsum": (mg_value / einsum_1gpu_value) if (mg_value and einsum_1gpu_value) else None,
+            "rccl_ranks_seen": ranks_seen,
             "config": config, "roofline": roof_out, "cpu_baseline": cpu,
             "cold_operands_value": cold["value"] if cold and "value" in cold else None, "cold_operands": cold,
             "headline_kernel_roofline": roof if use_mg else None,

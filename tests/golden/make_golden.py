@@ -10,6 +10,10 @@ hold what its test compares against: torch.einsum, evaluated in fp64 (complex128
 dtype.  Extents of 50 are shrunk to 20 (or 10) — recorded in meta together with the source line of the case — wherever an
 operand would exceed 40,000 elements, so that the committed fixtures stay small (< 2 MB in total).
 
+tests/golden/full/*.npz pin the same cases AT THE REFERENCE'S OWN EXTENTS (50): the inputs are not stored (they are redrawn by
+tests/util.py golden_inputs(), the same lines as here; 16 leading values of each operand are stored as a drift probe), the
+output is stored at 4096 fixed random positions together with sum |out| over the whole tensor.
+
 Run from the repo root, in the build container (needs /root/reference):  python tests/golden/make_golden.py
 """
 import ast
@@ -17,8 +21,13 @@ import json
 import os
 import re
 
+import sys
+
 import numpy as np
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tests.util import golden_inputs  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_TEST = "/root/reference/cuTENSOR/python/cutensor/torch/einsum_test.py"
@@ -107,6 +116,16 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), a=a.to(wide).numpy().astype(store), b=b.to(wide).numpy().astype(store),
                             out=out.numpy().astype(store), meta=json.dumps(meta))
         print(name, a_size, b_size, tuple(out.shape), meta["source"])
+        # ---- the same case at the reference's own extents: sampled outputs + a norm ----
+        fa, fb = golden_inputs(c["dtype"], c["a_size"], c["b_size"])
+        fout = torch.einsum(c["equation"], fa.to(wide), fb.to(wide)).numpy()
+        flat = fout.reshape(-1)
+        rng = np.random.default_rng(20250922)
+        idx = np.sort(rng.choice(flat.size, size=min(4096, flat.size), replace=False)).astype(np.int64)
+        fmeta = dict(meta, shrunk=False, extent_50_became=None, out_shape=list(fout.shape))
+        os.makedirs(os.path.join(HERE, "full"), exist_ok=True)
+        np.savez_compressed(os.path.join(HERE, "full", name + ".npz"), idx=idx, out_sampled=flat[idx], sum_abs=np.float64(np.abs(flat).sum()),
+                            a_probe=fa.to(wide).numpy().reshape(-1)[:16], b_probe=fb.to(wide).numpy().reshape(-1)[:16], meta=json.dumps(fmeta))
 
 
 if __name__ == "__main__":

@@ -66,3 +66,30 @@ def test_unsupported_equation_raises(te):
     a = torch.zeros(2, 3, 4, device="cuda")
     with pytest.raises(ValueError):
         torch_einsum.einsum("ab...->a", a)
+
+
+FULL = os.path.join(GOLDEN, "full")
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(FULL) if f.endswith(".npz")))
+def test_golden_cases_at_the_reference_extents(te, name):
+    """The reference's cases at ITS sizes (extents of 50, einsum_test.py:47-124): inputs redrawn as tests/golden/make_golden.py drew
+    them (probe-checked), the engine's output compared at the fixture's 4096 sampled positions and through sum |out|."""
+    from tests.util import golden_inputs
+    torch, torch_einsum = te
+    z = np.load(os.path.join(FULL, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    a, b = golden_inputs(meta["dtype"], meta["a_size"], meta["b_size"])
+    wide = torch.complex128 if a.dtype.is_complex else torch.float64
+    np.testing.assert_array_equal(a.to(wide).numpy().reshape(-1)[:16], z["a_probe"])
+    np.testing.assert_array_equal(b.to(wide).numpy().reshape(-1)[:16], z["b_probe"])
+    out = torch_einsum.einsum(meta["equation"], a.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    assert out.dtype == a.dtype and list(out.shape) == meta["out_shape"]
+    full = out.to(wide).cpu().numpy()
+    got, ref = full.reshape(-1)[z["idx"]], z["out_sampled"]
+    for part in ((np.real, np.imag) if np.iscomplexobj(ref) else (lambda x: x,)):
+        np.testing.assert_allclose(part(got), part(ref), rtol=5e-3, atol=6e-3)      # einsum_test.py:35-42
+    if meta["dtype"] in ("float32", "float64", "complex64", "complex128"):
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(np.abs(full).sum(), float(z["sum_abs"]), rtol=2e-3 if meta["dtype"] in ("float16", "bfloat16") else 1e-5)

@@ -205,6 +205,9 @@ def test_bench_multi_device_path_self_test(built):
     assert "cuTENSORMg" in line["metric"] and "SELF-TEST" in line["config"]["workload"], line
     assert line["config"]["max_rel_err_sampled"] < 1e-4 and line["config"]["gather_bytes_per_call"] == 0      # logical devices: nothing crosses xGMI
     assert line["value"] > 0 and line["config"]["speedup_vs_1"] > 0
+    # like-for-like fields on every line: the value of each workload is named, whatever `value` happens to be
+    assert line["value_is"] == "mg_value" and line["mg_value"] == line["value"] and line["mg_devices"] == 1
+    assert line["speedup_vs_1_same_workload"] == line["config"]["speedup_vs_1"] and line["einsum_value"] > 0 and line["rccl_ranks_seen"] == 1
     kinds = [s["workload"] for s in line["secondary"]]
     assert any("4096^3" in k or "2048^3" in k for k in kinds) and any("einsum.cu" in k for k in kinds), kinds
     # and with one visible GPU and no self-test switch the line says so instead of pretending
@@ -215,6 +218,7 @@ def test_bench_multi_device_path_self_test(built):
     import torch
     if torch.cuda.device_count() == 1:
         assert line["n_gpus"] == 1 and line["requested_gpus"] == 8 and "einsum" in line["metric"] and "multi_device" in line["config"], line
+        assert line["value_is"] == "einsum_value" and line["einsum_value"] == line["value"] and "mg_value" in line
 
 
 @pytest.mark.parametrize("handle_devices", [[0], [0, 0, 0]])

@@ -48,3 +48,15 @@ def assert_close(got, ref, rtol, atol=0.0, what=""):
 
 def c_i64(v):
     return (ctypes.c_int64 * max(len(v), 1))(*v)
+
+
+def golden_inputs(dtype_name, a_size, b_size):
+    """Inputs of a reference test case as tests/golden/make_golden.py draws them (einsum_test.py:131-147 on the CPU generator):
+    torch.manual_seed(0), randn in the case's dtype (16-bit types: fp32 randn rounded once).  Returns (a, b) torch tensors of the
+    case's dtype.  The full-extent fixtures (tests/golden/full) store no inputs, only probes of these to detect generator drift."""
+    import torch
+    tdt = getattr(torch, dtype_name)
+    torch.manual_seed(0)
+    if tdt.is_complex:
+        return torch.randn(*a_size, dtype=tdt), torch.randn(*b_size, dtype=tdt)
+    return torch.randn(*a_size, dtype=torch.float32).to(tdt), torch.randn(*b_size, dtype=torch.float32).to(tdt)
