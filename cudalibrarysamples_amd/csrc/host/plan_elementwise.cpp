@@ -6,6 +6,7 @@
 // jointly contiguous neighbours) and then choose the kernel variant whose vector-width and alignment
 // preconditions hold (see kernels/elementwise.hip and kernels/reduce.hip).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.hpp"
@@ -181,6 +182,14 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
                 const int64_t widest = usesX ? 128 : 256;
                 for (int64_t cand = widest; cand > 64; cand /= 2)
                     if (p.E0 % cand == 0 || p.E0 >= 4 * cand) { t0 = (int)cand; break; }
+            } else if (h16 && p.E1 % 64 == 0) {
+                // 16-bit: the wide kernel handles full tiles only (T0 x T1 elements: 512-B / 256-B written, 256-B / 128-B read segments)
+                if (p.E0 % 256 == 0) t0 = 256;
+                else if (p.E0 % 128 == 0) t0 = 128;
+                if (t0 > 64) {
+                    t1 = (p.E1 % 128 == 0) ? 128 : 64;
+                    if (const char* e = std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1")) { const int v = std::atoi(e); if ((v == 64 || v == 128) && p.E1 % v == 0) t1 = v; }
+                }
             }
         } else if (!usesX && p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
             plan.variant = EW_ROWCOPY; t0 = h16 ? 512 : 256; t1 = 8;
@@ -188,6 +197,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     }
     plan.usesX = usesX;
     p.tile0 = (uint32_t)t0;
+    p.tile1 = (uint32_t)t1;
     p.tiles0 = (p.E0 + t0 - 1) / t0;
     p.tiles1 = (p.E1 + t1 - 1) / t1;
     p.divTiles0 = make_fastdiv(p.tiles0);
@@ -200,8 +210,9 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     p.order = 0;
     p.idsPerXcd = (uint32_t)((nb + 7) / 8);
     p.divRest = make_fastdiv(p.rest.total);
-    if (plan.variant == EW_TRANSPOSE && D.desc.dtype == HIP_R_32F && p.rest.total >= 64 && nb >= 4096 &&
-        p.sA0 * 4 >= (1 << 20) && p.sD1 * 4 >= (1 << 20))
+    const int64_t esz = h16 ? 2 : 4;
+    if (plan.variant == EW_TRANSPOSE && (D.desc.dtype == HIP_R_32F || (h16 && t0 > 64)) && p.rest.total >= 64 && nb >= 4096 &&
+        p.sA0 * esz >= (1 << 20) && p.sD1 * esz >= (1 << 20))
         p.order = 1;
     return CUTENSOR_STATUS_SUCCESS;
 }

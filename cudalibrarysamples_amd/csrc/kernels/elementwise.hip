@@ -89,6 +89,25 @@ __device__ __forceinline__ TileId decode_tile(const Ew2DParams& p, uint32_t b) {
     return t;
 }
 
+// Tile of workgroup-loop index b under the planner's tile order (Ew2DParams::order); false = this index names no tile.
+//   order 0: ids walk dim0 tiles, dim1 tiles, rest.
+//   order 1 (both the rows A is read by and the rows D is written by lie a large pitch apart, e.g. the full reversal
+//   A[a,b,c] -> C[c,b,a] at 2048^3, 16 MiB on both sides): ids walk rest, then dim1, then dim0, and XCD x = workgroup id % 8
+//   takes the x-th eighth of that sequence, so that at any time one XCD works inside a few dim0 / dim1 tiles — a few hundred
+//   distinct pages per XCD instead of every page of both tensors (fp32: 5.79 -> 6.31 TB/s, profiles/r03_transpose_sweep3_rev.jsonl;
+//   the same order WITHOUT the per-XCD split is the worst: 4.14)
+__device__ __forceinline__ bool ordered_tile(const Ew2DParams& p, uint32_t b, TileId& t) {
+    if (p.order == 0) { t = decode_tile(p, b); return true; }
+    const uint32_t id = (b & 7u) * p.idsPerXcd + (b >> 3);
+    if (id >= p.nBlocks) return false;
+    const uint32_t q = ew_fast_div(id, p.divRest);
+    t.rest = id - q * p.rest.total;
+    const uint32_t q2 = ew_fast_div(q, p.divTiles1);
+    t.t1 = q - q2 * p.tiles1;
+    t.t0 = q2;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // EW_TRANSPOSE (fp32): requires sD0 == 1, sA1 == 1, E0 % 4 == 0, E1 % 4 == 0, every other stride
 // a multiple of 4 elements and 16-byte aligned bases.
@@ -117,25 +136,10 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
     float*       D = static_cast<float*>(p.D);
     const int tid = threadIdx.x;
 
-    // order 1 (planner: both the rows A is read by and the rows D is written by lie a large pitch apart, e.g. the full
-    // reversal A[a,b,c] -> C[c,b,a] at 2048^3, 16 MiB on both sides): ids walk rest, then dim1, then dim0, and XCD x =
-    // workgroup id % 8 takes the x-th eighth of that sequence, so that at any time one XCD works inside a few dim0 / dim1
-    // tiles — a few hundred distinct pages per XCD instead of every page of both tensors (5.79 -> 6.31 TB/s,
-    // profiles/r03_transpose_sweep3_rev.jsonl; the same order WITHOUT the per-XCD split is the worst: 4.14)
     const uint32_t nIds = p.order ? 8u * p.idsPerXcd : p.nBlocks;
     for (uint32_t b = blockIdx.x; b < nIds; b += gridDim.x) {
         TileId t;
-        if (p.order) {
-            const uint32_t id = (b & 7u) * p.idsPerXcd + (b >> 3);
-            if (id >= p.nBlocks) continue;
-            const uint32_t q = ew_fast_div(id, p.divRest);
-            t.rest = id - q * p.rest.total;
-            const uint32_t q2 = ew_fast_div(q, p.divTiles1);
-            t.t1 = q - q2 * p.tiles1;
-            t.t0 = q2;
-        } else {
-            t = decode_tile(p, b);
-        }
+        if (!ordered_tile(p, b, t)) continue;
         int64_t oA, oD, oC;
         rest_offsets(p.rest, t.rest, oA, oD, oC);
         const uint32_t i0 = t.t0 * T0, i1 = t.t1 * TT;   // tile origin (dim0, dim1)
@@ -421,6 +425,91 @@ __global__ void __launch_bounds__(256) ew_transpose_h16_kernel(const Ew2DParams 
     }
 }
 
+// 16-bit transposing kernel for FULL tiles of T0 (dim0: 128 / 256 elements = 256-B / 512-B written row segments) x 64 (dim1:
+// 128-B read segments); the planner selects it when the extents divide (no edge guards), the 64 x 64 kernel above otherwise.
+// A lane loads one 8 x 8 block (8 dim0 rows x 16 bytes along dim1), transposes it in registers with byte permutes and parks it
+// as eight 16-byte pieces of the [dim1][dim0] LDS image; the write pass reads 16-byte pieces along dim0.  alpha == 1 without
+// E / C terms is a bit copy.  Same lessons as the fp32 kernel: the WRITTEN segment width is what counts, one workgroup per tile.
+template <bool BF, int T0, int T1>
+__global__ void __launch_bounds__(256) ew_transpose_h16_wide_kernel(const Ew2DParams p) {
+    constexpr int PITCH = T0 + 8;                   // elements; rows stay 16-byte aligned
+    constexpr int OCT = T1 / 8;                     // read: 16-byte octets per dim0 row
+    constexpr int BROWS = 256 / OCT;                //       8-row blocks per pass
+    constexpr int RP = 8 * BROWS;                   //       dim0 rows per pass
+    constexpr int RD_PASSES = (T0 + RP - 1) / RP;
+    constexpr int RD_LANES = (T0 >= RP) ? 256 : (T0 / 8) * OCT;   // a 128 x 64 tile keeps half the lanes busy while reading
+    constexpr int LPW = T0 / 8;                     // write: lanes per dim1 row
+    constexpr int RPW = 256 / LPW;
+    constexpr int WR_PASSES = T1 / RPW;
+    static_assert((T0 == 256 || T0 == 128) && (T1 == 64 || T1 == 128), "tiles built: {128, 256} x {64, 128}");
+    __shared__ __attribute__((aligned(16))) uint16_t tile[T1 * PITCH];   // [dim1][dim0]
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* C = static_cast<const uint16_t*>(p.C);
+    const uint16_t* E = static_cast<const uint16_t*>(p.E);
+    uint16_t*       D = static_cast<uint16_t*>(p.D);
+    const int tid = threadIdx.x;
+    const uint32_t nIds = p.order ? 8u * p.idsPerXcd : p.nBlocks;
+    for (uint32_t b = blockIdx.x; b < nIds; b += gridDim.x) {
+        TileId t;
+        if (!ordered_tile(p, b, t)) continue;
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t i0 = t.t0 * T0, i1 = t.t1 * T1;
+        // ---- read + 8 x 8 register transpose
+        if (tid < RD_LANES) {
+            const int oct = tid % OCT;                                    // dim1 octet
+            const int brow = tid / OCT;                                   // block row inside a pass
+#pragma unroll
+            for (int ps = 0; ps < RD_PASSES; ++ps) {
+                const int r0 = 8 * brow + RP * ps;                        // first dim0 row of the block
+                const uint16_t* src = A + oA + (int64_t)(i0 + r0) * p.sA0 + i1 + 8 * oct;
+                u32x4e v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4e*>(src + (int64_t)k * p.sA0));
+                // out[j] = (v[0].e[j], ..., v[7].e[j]); element j of v[k] is half (j & 1) of word j >> 1
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u32x4e o;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t lo = v[2 * w][j >> 1], hi = v[2 * w + 1][j >> 1];
+                        o[w] = (j & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                    }
+                    *reinterpret_cast<u32x4e*>(&tile[(8 * oct + j) * PITCH + r0]) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- write: 16-byte pieces along dim0
+        {
+            const int l0 = 8 * (tid % LPW);
+            const bool plain = (E == nullptr && C == nullptr && p.alpha == 1.0f);
+            uint16_t* dst = D + oD + (int64_t)(i1 + tid / LPW) * p.sD1 + i0 + l0;
+#pragma unroll
+            for (int pass = 0; pass < WR_PASSES; ++pass) {
+                const int lr = tid / LPW + RPW * pass;
+                u32x4e v = *reinterpret_cast<const u32x4e*>(&tile[lr * PITCH + l0]);
+                if (!plain) {
+                    float a[8];
+                    h16_unpack<BF>(v, a);
+                    const int64_t offD = oD + (int64_t)(i1 + lr) * p.sD1 + i0 + l0;
+                    v = h16_combine<BF>(p, a, E, C, offD, oC + (int64_t)(i1 + lr) * p.sC1 + (int64_t)(i0 + l0) * p.sC0);
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4e*>(dst + (int64_t)(RPW * pass) * p.sD1));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool BF>
+static void launch_h16_wide(const Ew2DParams& p, unsigned grid, hipStream_t stream) {
+    if (p.tile0 == 256 && p.tile1 == 128)      hipLaunchKernelGGL((ew_transpose_h16_wide_kernel<BF, 256, 128>), dim3(grid), dim3(256), 0, stream, p);
+    else if (p.tile0 == 256)                   hipLaunchKernelGGL((ew_transpose_h16_wide_kernel<BF, 256, 64>), dim3(grid), dim3(256), 0, stream, p);
+    else if (p.tile1 == 128)                   hipLaunchKernelGGL((ew_transpose_h16_wide_kernel<BF, 128, 128>), dim3(grid), dim3(256), 0, stream, p);
+    else                                       hipLaunchKernelGGL((ew_transpose_h16_wide_kernel<BF, 128, 64>), dim3(grid), dim3(256), 0, stream, p);
+}
+
 // ---------------------------------------------------------------------------------------------
 // EW_GENERIC: any strides / dtype.  Tile = 64 dim0 elements x 4 dim1 rows, one element per lane.
 // ---------------------------------------------------------------------------------------------
@@ -522,7 +611,7 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
     // for tensors beyond 2^22 tiles.
     unsigned grid = p.nBlocks;
     const unsigned cap = 1u << 22;
-    if (variant == EW_TRANSPOSE && dtype == HIP_R_32F && p.order) grid = 8u * p.idsPerXcd;
+    if (variant == EW_TRANSPOSE && p.order) grid = 8u * p.idsPerXcd;
     if (grid > cap) grid = cap;
     if (variant == EW_TRANSPOSE && dtype == HIP_R_32F) {
         if (p.X != nullptr) {
@@ -535,10 +624,14 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
         }
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_32F) {
         hipLaunchKernelGGL(ew_rowcopy_f32_kernel, dim3(grid), dim3(256), 0, stream, p);
-    } else if (variant == EW_TRANSPOSE && dtype == HIP_R_16BF) {
-        hipLaunchKernelGGL(ew_transpose_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
-    } else if (variant == EW_TRANSPOSE && dtype == HIP_R_16F) {
-        hipLaunchKernelGGL(ew_transpose_h16_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    } else if (variant == EW_TRANSPOSE && (dtype == HIP_R_16BF || dtype == HIP_R_16F)) {
+        const bool bf = dtype == HIP_R_16BF;
+        if (p.tile0 > 64) {
+            if (bf) launch_h16_wide<true>(p, grid, stream); else launch_h16_wide<false>(p, grid, stream);
+        } else {
+            if (bf) hipLaunchKernelGGL(ew_transpose_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+            else    hipLaunchKernelGGL(ew_transpose_h16_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+        }
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_16BF) {
         hipLaunchKernelGGL(ew_rowcopy_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_16F) {

@@ -110,7 +110,8 @@ struct Ew2DParams {
     int64_t     sA0, sA1, sD0, sD1, sC0, sC1;
     uint32_t    tiles0, tiles1;
     uint32_t    tile0;             // EW_TRANSPOSE fp32: tile extent along dim0 (64 / 128 / 256), chosen by the planner
-    uint32_t    order;             // EW_TRANSPOSE fp32: 0 = tile ids walk dim0, dim1, rest; 1 = rest, dim1, dim0 with each XCD
+    uint32_t    tile1;             // EW_TRANSPOSE 16-bit wide kernel: tile extent along dim1 (64 / 128)
+    uint32_t    order;             // EW_TRANSPOSE: 0 = tile ids walk dim0, dim1, rest; 1 = rest, dim1, dim0 with each XCD
                                    // (workgroup id % 8) owning one contiguous eighth of that sequence (elementwise.hip)
     uint32_t    idsPerXcd;         // order 1: ceil(nBlocks / 8)
     FastDiv     divRest;           // order 1: division by rest.total

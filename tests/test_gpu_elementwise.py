@@ -154,13 +154,22 @@ def test_16bit_vector_permutes_are_exact(built, dtype):
         (dict(a=128, b=40, c=64), "abc", "acb", 1),     # shared fastest mode: row copy
         (dict(a=136, b=24, c=72), "abc", "cab", 0),
         (dict(a=37, b=5, c=11), "abc", "cba", 2),       # odd extents: generic
+        # full tiles of the wide transposing kernel (ew_transpose_h16_wide_kernel<T0, T1>): 256 x 128, 128 x 128, 256 x 64, 128 x 64
+        (dict(a=256, b=3, c=512), "abc", "cba", 0),
+        (dict(a=128, b=5, c=384), "abc", "cab", 0),
+        (dict(a=192, b=2, c=256), "abc", "cba", 0),
+        (dict(a=64, b=7, c=128), "abc", "cab", 0),
+        (dict(a=128, b=80, c=256), "abc", "cba", 0),    # rest >= 64: still order 0 (rows < 1 MiB apart), many tiles
     ]
+    wide_seen = set()
     for ext, mA, mD, want in cases:
         eA, eD = [ext[c] for c in mA], [ext[c] for c in mD]
         A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)      # column-major tensor == reversed row-major
         D = torch.zeros(eD[::-1], device="cuda", dtype=tdt)
         plan = ops.permutation_plan(h, eA, mA, eD, mD, dtype=cdt)
         assert plan.describe()["variant"] == want, (plan.describe(), ext, mA, mD)
+        if plan.describe().get("tile0", 64) > 64 and want == 0:
+            wide_seen.add(plan.describe()["tile0"])
         plan.permute(1.0, A.data_ptr(), D.data_ptr())
         torch.cuda.synchronize()
         ref = torch.einsum("%s->%s" % (mA[::-1], mD[::-1]), A)
@@ -172,6 +181,7 @@ def test_16bit_vector_permutes_are_exact(built, dtype):
         torch.cuda.synchronize()
         refb = (0.5 * ref.float() + 2.0 * C.float()).to(tdt)
         torch.testing.assert_close(D.float(), refb.float(), rtol=1e-2 if dtype == "bfloat16" else 2e-3, atol=1e-2)
+    assert wide_seen == {128, 256}, wide_seen
 
 
 def test_permute_tensor_larger_than_4_gib(env):

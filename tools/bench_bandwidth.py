@@ -20,10 +20,12 @@ def main():
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="sampled gather check against torch indexing")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="element type (permutations only for the 16-bit types)")
     args = ap.parse_args()
     import torch
-    from cudalibrarysamples_amd import ops
+    from cudalibrarysamples_amd import ops, cutensor as ct
     n = args.n
+    tdt, cdt, es = {"f32": (torch.float32, ct.R_32F, 4), "bf16": (torch.bfloat16, ct.R_16BF, 2), "f16": (torch.float16, ct.R_16F, 2)}[args.dtype]
     numel = n * n * n
     free, _ = torch.cuda.mem_get_info()
     need = 2 * numel * 4 + (1 << 30)
@@ -39,6 +41,8 @@ def main():
         idx = torch.arange(s, e, device="cuda", dtype=torch.int64)
         A[s:e] = ((idx * 2654435761 + 1234) % 16777216).to(torch.float32) / 16777216.0
         del idx
+    if tdt != torch.float32:
+        A = A.to(tdt)
     ext = dict(a=n, b=n, c=n)
 
     def timed(fn):
@@ -57,11 +61,11 @@ def main():
 
     # ---- permutations (column-major mode lists: first mode is stride-1) ------------------------------
     for mB in ("cab", "cba", "acb"):
-        D = torch.empty(numel, dtype=torch.float32, device="cuda")
-        p = ops.permutation_plan(h, [n, n, n], "abc", [ext[c] for c in mB], mB)
+        D = torch.empty(numel, dtype=tdt, device="cuda")
+        p = ops.permutation_plan(h, [n, n, n], "abc", [ext[c] for c in mB], mB, dtype=cdt)
         ms = timed(lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream))
-        gbs = 2.0 * numel * 4 / (ms * 1e-3) / 1e9
-        line = {"op": "permute abc->" + mB, "n": n, "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
+        gbs = 2.0 * numel * es / (ms * 1e-3) / 1e9
+        line = {"op": "permute abc->" + mB, "dtype": args.dtype, "n": n, "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
                 "plan": p.describe()}
         if args.check:
             At = A.view(n, n, n)    # At[c][b][a] (row-major view of the column-major tensor)
@@ -75,7 +79,7 @@ def main():
         p.destroy()
         del D
     # ---- reductions -------------------------------------------------------------------------------------
-    for mC in ("ac", "c", "a", "bc"):
+    for mC in (("ac", "c", "a", "bc") if args.dtype == "f32" else ()):
         eC = [ext[c] for c in mC]
         outn = int(np.prod(eC))
         D = torch.zeros(outn, dtype=torch.float32, device="cuda")

@@ -48,6 +48,18 @@ print(json.dumps({'mfma_only_tflops': out}))
 PY
 python tools/h16_ksweep.py --zeros 2>/dev/null | tail -1 > $OUT/h16_ksweep.jsonl
 python tools/h16_ksweep.py 2>/dev/null | tail -1 >> $OUT/h16_ksweep.jsonl
+# ---- 2c. permute / reduce at 2048^3 (BASELINE configs[2]): trace, FETCH_SIZE, WRITE_SIZE + L2/EA request counters ---------
+cd /tmp
+BW="python $ROOT/tools/bench_bandwidth.py --n 2048 --reps 3"
+rocprofv3 --kernel-trace --stats -d $OUT/bw_trace -o r -- $BW > $OUT/bw_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/bw_fetch -o r -- $BW > $OUT/bw_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/bw_write -o r -- $BW > $OUT/bw_write.log 2>&1
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/bw_tcc -o r -- $BW > $OUT/bw_tcc.log 2>&1
+for p in trace fetch write tcc; do summ bw_$p bandwidth_2048_$p; done
+cd $ROOT
+python tools/bench_bandwidth.py --n 2048 --check > $OUT/bandwidth_2048.jsonl 2>/dev/null
+python tools/bench_bandwidth.py --n 1024 --check > $OUT/bandwidth_1024.jsonl 2>/dev/null
+samples/bin/einsum --flow --calls 2000 > $OUT/einsum_flow_plan_per_call.jsonl 2>/dev/null
 cd /tmp
 # ---- 3. the whole default bench line (secondary configs included): kernel trace only ------------------------------------
 rocprofv3 --kernel-trace --stats -d $OUT/bench_all_trace -o r -- python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu > $OUT/bench_all_trace.log 2>&1
