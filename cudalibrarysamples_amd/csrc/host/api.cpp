@@ -203,6 +203,65 @@ static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash
     e.key = key; e.proto = std::move(proto); e.stamp = ++h->memoClock;
 }
 
+// Peeling of a "wide" contraction (a group with more than kMaxGroupModes unfusable modes would run on the functional
+// mode-table kernel, measured ~100x slower than the tiled ones): labels of the oversized groups are taken out of the problem,
+// smallest extent first, until the rest fits the tiled kernels — at most kMaxPeelLaunches index combinations, each one launch of
+// the same inner plan on offset operands.  Returns false when the problem is not wide for that reason or would take more launches.
+static constexpr int64_t kMaxPeelLaunches = 64;
+static bool peel_wide_contraction(const cutensorOperationDescriptor& desc, cutensorOperationDescriptor& inner, std::vector<PeelMode>& peel) {
+    if (desc.kind != OpKind::Contraction) return false;
+    if (desc.A.desc.dtype == HIP_C_32F || desc.A.desc.dtype == HIP_C_64F) return false;   // complex: the mode-table kernel is the only one
+    inner = desc;
+    peel.clear();
+    int64_t launches = 1;
+    auto idx = [](const TensorUse& t, int32_t l) { for (size_t i = 0; i < t.modes.size(); ++i) if (t.modes[i] == l) return (int)i; return -1; };
+    for (int round = 0; round < 16; ++round) {
+        ContractionView v;
+        if (build_contraction_view(inner, v, nullptr) != CUTENSOR_STATUS_SUCCESS) return false;
+        if (!v.wide) return !peel.empty();
+        const std::vector<CanonMode>* gs[4] = {&v.L, &v.M, &v.N, &v.K};
+        int32_t bestLabel = 0;
+        int64_t bestExtent = 0;
+        for (int g = 0; g < 4; ++g) {
+            if ((int)gs[g]->size() <= kMaxGroupModes) continue;
+            for (const CanonMode& m : *gs[g]) {
+                // the label's own extent (a canonical mode may be a fused run; peeling its first label shortens the run)
+                const int ia = idx(inner.A, m.label), ib = idx(inner.B, m.label), ic = idx(inner.C, m.label);
+                const int64_t e = ia >= 0 ? inner.A.desc.extent[(size_t)ia] : ib >= 0 ? inner.B.desc.extent[(size_t)ib] : ic >= 0 ? inner.C.desc.extent[(size_t)ic] : 0;
+                if (e < 2) continue;
+                if (bestExtent == 0 || e < bestExtent) { bestLabel = m.label; bestExtent = e; }
+            }
+        }
+        if (bestExtent == 0) return false;                       // wide for another reason (>= 2^31 elements in a group)
+        launches *= bestExtent;
+        if (launches > kMaxPeelLaunches) return false;
+        const int32_t l = bestLabel;
+        PeelMode pm;
+        pm.extent = bestExtent;
+        const int ia = idx(inner.A, l), ib = idx(inner.B, l), ic = idx(inner.C, l), id = idx(inner.D, l);
+        if (ia >= 0) { pm.sA = inner.A.desc.stride[(size_t)ia]; inner.A.desc.extent[(size_t)ia] = 1; }
+        if (ib >= 0) { pm.sB = inner.B.desc.stride[(size_t)ib]; inner.B.desc.extent[(size_t)ib] = 1; }
+        if (ic >= 0) { pm.sC = inner.C.desc.stride[(size_t)ic]; inner.C.desc.extent[(size_t)ic] = 1; }
+        if (id >= 0) { pm.sD = inner.D.desc.stride[(size_t)id]; inner.D.desc.extent[(size_t)id] = 1; }
+        pm.contracted = (ic < 0);
+        peel.push_back(pm);
+    }
+    return false;
+}
+// pointer alignment the offset operands of a peeled contraction still have
+static void peel_fix_alignment(cutensorOperationDescriptor& inner, const std::vector<PeelMode>& peel) {
+    const int64_t es = (int64_t)dtype_size(inner.A.desc.dtype);
+    auto fix = [&](TensorUse& t, int which) {
+        uint32_t a = t.desc.alignment;
+        for (const PeelMode& pm : peel) {
+            const int64_t s = which == 0 ? pm.sA : which == 1 ? pm.sB : which == 2 ? pm.sC : pm.sD;
+            while (a > (uint32_t)es && ((s * es) % (int64_t)a) != 0) a >>= 1;
+        }
+        t.desc.alignment = std::max<uint32_t>(a, (uint32_t)es);
+    };
+    fix(inner.A, 0); fix(inner.B, 1); fix(inner.C, 2); fix(inner.D, 3);
+}
+
 extern "C" {
 
 // ---- handle (contraction.cu:123-124) -----------------------------------------------------------
@@ -715,7 +774,16 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
             if (pick_h16_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
             return CUTENSOR_STATUS_SUCCESS;
         }
-        if (v.dtype != HIP_R_32F || v.wide) return CUTENSOR_STATUS_SUCCESS;
+        if (v.wide) {    // a peeled contraction wants what its inner, tiled problem wants
+            cutensorOperationDescriptor inner;
+            std::vector<PeelMode> peel;
+            if (peel_wide_contraction(*desc, inner, peel)) {
+                peel_fix_alignment(inner, peel);
+                return cutensorEstimateWorkspaceSize(handle, &inner, planPref, workspacePref, workspaceSizeEstimate);
+            }
+            return CUTENSOR_STATUS_SUCCESS;
+        }
+        if (v.dtype != HIP_R_32F) return CUTENSOR_STATUS_SUCCESS;
         // the largest workspace any of the best few candidates would like to have
         std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs);
         uint64_t want = 0;
@@ -999,6 +1067,30 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     if (desc->kind == OpKind::Contraction) {
         st = build_contraction_view(*desc, pl->view, &why);
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (pl->view.wide && !(std::getenv("CUTENSOR_AMD_PEEL") && std::getenv("CUTENSOR_AMD_PEEL")[0] == '0')) {
+            // too many unfusable modes in a group for the tiled kernels: peel the smallest ones into a host loop if that takes
+            // at most kMaxPeelLaunches launches (peel_wide_contraction), else fall through to the mode-table kernel
+            cutensorOperationDescriptor inner;
+            std::vector<PeelMode> peel;
+            if (peel_wide_contraction(*desc, inner, peel)) {
+                peel_fix_alignment(inner, peel);
+                cutensorPlan_t ip = nullptr;
+                if (cutensorCreatePlan(handle, &ip, &inner, pref, workspaceSizeLimit) == CUTENSOR_STATUS_SUCCESS && ip->choice.kernel != -2 &&
+                    ip->sub1 == nullptr) {
+                    pl->sub1 = ip;
+                    pl->peel = peel;
+                    pl->choice = ContractionChoice{};
+                    pl->choice.kernel = -3;
+                    pl->requiredWorkspace = ip->requiredWorkspace;
+                    int64_t launches = 1;
+                    for (const PeelMode& pm : peel) launches *= pm.extent;
+                    CT_LOG("plan: contraction with an oversized mode group -> %zu mode(s) peeled, %lld launches of the tiled inner plan", peel.size(), (long long)launches);
+                    *plan = pl;
+                    return CUTENSOR_STATUS_SUCCESS;
+                }
+                delete ip;
+            }
+        }
         if (pl->view.wide) {
             // mode-table kernel: output modes (L, M, N), then contracted modes, in device memory owned by the plan
             const ContractionView& v = pl->view;
@@ -1239,6 +1331,41 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         return CUTENSOR_STATUS_INVALID_VALUE;
     if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
         return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
+
+    if (plan->choice.kernel == -3) {
+        // peeled contraction: every index combination of the peeled modes is one launch of the inner plan on offset operands;
+        // a combination whose contracted indices are all zero writes its region of D first (caller's beta, caller's C), the
+        // others accumulate into it
+        if (plan->sub1 == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+        const size_t es = dtype_size(plan->dtype);
+        const float onef = 1.f;
+        const double oned = 1.0;
+        const void* one = (plan->scalarType == HIP_R_64F) ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
+        const size_t n = plan->peel.size();
+        std::vector<int64_t> digit(n, 0);
+        for (;;) {
+            int64_t oA = 0, oB = 0, oC = 0, oD = 0;
+            bool first = true;
+            for (size_t i = 0; i < n; ++i) {
+                const PeelMode& pm = plan->peel[i];
+                oA += digit[i] * pm.sA; oB += digit[i] * pm.sB; oC += digit[i] * pm.sC; oD += digit[i] * pm.sD;
+                if (pm.contracted && digit[i] != 0) first = false;
+            }
+            char* d = static_cast<char*>(D) + oD * (int64_t)es;
+            const char* c = first ? (C ? static_cast<const char*>(C) + oC * (int64_t)es : nullptr) : d;
+            const cutensorStatus_t st = cutensorContract(handle, plan->sub1, alpha, static_cast<const char*>(A) + oA * (int64_t)es,
+                                                         static_cast<const char*>(B) + oB * (int64_t)es, first ? beta : one, c, d, workspace,
+                                                         workspaceSize, stream);
+            if (st != CUTENSOR_STATUS_SUCCESS) return st;
+            size_t i = 0;
+            for (; i < n; ++i) {
+                if (++digit[i] < plan->peel[i].extent) break;
+                digit[i] = 0;
+            }
+            if (i == n) break;
+        }
+        return CUTENSOR_STATUS_SUCCESS;
+    }
 
     GettParams p = plan->gett;
     p.A = plan->view.swapped ? B : A;
@@ -1526,6 +1653,26 @@ const char* cutensorGetErrorString(const cutensorStatus_t error) {
 size_t cutensorGetVersion(void) { return CUTENSOR_VERSION; }
 
 // ---- diagnostics (not part of the cuTENSOR ABI; used by the tests and the bench) ----------------
+// A contraction plan that fell to the mode-table kernel because a group has more unfusable modes than the tiled kernels'
+// argument block describes: its canonical modes as (group 0 = L, 1 = M, 2 = N, 3 = K; caller's label; extent), at most maxOut of
+// them; returns how many there are, 0 for every other plan.  cuTENSORMg uses it to peel one digit of an oversized group into a
+// host loop (mg.cpp) instead of running the functional kernel.
+int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut) {
+    if (plan == nullptr || plan->kind != OpKind::Contraction || plan->choice.kernel != -2) return 0;
+    if (plan->view.dtype == HIP_C_32F || plan->view.dtype == HIP_C_64F) return 0;     // complex data: not a matter of mode counts
+    int n = 0;
+    const std::vector<CanonMode>* gs[4] = {&plan->view.L, &plan->view.M, &plan->view.N, &plan->view.K};
+    bool oversized = false;
+    for (int g = 0; g < 4; ++g) oversized = oversized || (int)gs[g]->size() > kMaxGroupModes;
+    if (!oversized) return 0;                                                          // wide for another reason (>= 2^31 elements)
+    for (int g = 0; g < 4; ++g)
+        for (const CanonMode& m : *gs[g]) {
+            if (n < maxOut) { if (group) group[n] = g; if (label) label[n] = m.label; if (extent) extent[n] = m.extent; }
+            ++n;
+        }
+    return n;
+}
+
 // Plan-memo counters of this handle: plans answered by cloning a prototype / plans that went through the planner.
 void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) {
     if (handle == nullptr) return;
@@ -1537,6 +1684,18 @@ void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t*
 int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     if (plan == nullptr || buf == nullptr || len == 0) return -1;
     int n = 0;
+    if (plan->kind == OpKind::Contraction && plan->choice.kernel == -3 && plan->sub1 != nullptr) {
+        // peeled contraction: the inner (tiled) plan's description with the peel in front
+        long long launches = 1;
+        for (const PeelMode& pm : plan->peel) launches *= pm.extent;
+        n = std::snprintf(buf, len, "{\"peeled_modes\":%zu,\"peel_launches\":%lld,", plan->peel.size(), launches);
+        if (n < 0 || (size_t)n >= len) return -1;
+        const int m = ctamdDescribePlan(plan->sub1, buf + n - 1, len - (size_t)n + 1);   // overwrite our '{' + keep theirs: splice below
+        if (m < 0) return -1;
+        // buf now holds  {"peeled_modes":..,"peel_launches":..   followed (from n - 1) by the inner object  {...}: turn its '{' into ','
+        buf[n - 1] = ',';
+        return n - 1 + m;
+    }
     if (plan->kind == OpKind::Contraction) {
         int count = 0;
         const GettKernelInfo* tab = (plan->choice.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);

@@ -159,6 +159,15 @@ struct TrialCounter {
     TrialCounter& operator=(const TrialCounter& o) { timed.store(o.timed.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
 };
 
+// A contraction whose mode groups are too wide for the tiled kernels' argument block, peeled: the modes listed here are walked
+// by the host (one launch of the inner, tiled plan per index combination, operands offset by index x stride); a contracted
+// peeled mode accumulates into D, a free one writes a region of its own.
+struct PeelMode {
+    int64_t extent = 1;
+    int64_t sA = 0, sB = 0, sC = 0, sD = 0;   // element strides of the peeled label in the user's A, B, C, D (0: not carried)
+    bool    contracted = false;
+};
+
 struct cutensorPlan {
     cutensorPlan() = default;
     cutensorPlan(const cutensorPlan&) = default;   // valid only for plans that own nothing (sub1/sub2/wide.modes null): the memo's clones
@@ -167,8 +176,9 @@ struct cutensorPlan {
     std::vector<ctamd::WideMode> wideTab;   // uploaded from this host copy by the first cutensorContract
     // trinary contraction: the two pairwise plans, the intermediate's size and which operand plays which role
     std::shared_ptr<ctamd::BlockSparsePlan> bsp;     // block-sparse contraction: dense plans + block-pair task list
-    cutensorPlan* sub1 = nullptr;
+    cutensorPlan* sub1 = nullptr;                    // (also: the inner plan of a peeled contraction, choice.kernel == -3)
     cutensorPlan* sub2 = nullptr;
+    std::vector<PeelMode> peel;
     uint64_t    tBytes = 0;
     int         triOrder[3] = {0, 1, 2};
     OpKind      kind;

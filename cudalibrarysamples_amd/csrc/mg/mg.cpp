@@ -44,6 +44,8 @@
 #include <cutensor.h>
 #include <cutensorMg.h>
 
+extern "C" int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut);   // libcutensor.so diagnostic
+
 namespace {
 
 struct MgTensor {
@@ -92,7 +94,9 @@ struct Piece {
     // One local contraction per box of the contracted index space: a single box unless a contracted mode is ragged
     // (extent not a multiple of blockSize * deviceCount, blog_post.cu:168-175 derives every block size with ceil()) —
     // then the valid part of the padded index space is a union of boxes (kbox_list) and the boxes accumulate into D.
-    struct Sub { cutensorPlan_t plan = nullptr; uint64_t ws = 0; int64_t off[3] = {0, 0, 0}; };
+    // accumulate: an earlier sub-contraction of this piece already wrote this region of D (the clip sets differ in contracted
+    // labels only) -> beta = 1 on D; otherwise the region is new (first box, or a peeled digit of a free mode) -> the caller's beta
+    struct Sub { cutensorPlan_t plan = nullptr; uint64_t ws = 0; int64_t off[3] = {0, 0, 0}; bool accumulate = false; };
     std::vector<Sub> subs;
     OperandUse use[3];
     struct Scatter { int cell; int64_t off; cutensorPlan_t plan; };
@@ -140,6 +144,7 @@ struct cutensorMgContractionPlan {
     uint64_t contractionWs = 0;                // per compute stream
     int pLabel = -1, qLabel = -1;
     int numBoxes = 1;                          // local contractions per piece (> 1: a contracted mode is ragged)
+    int peeled = 0;                            // how many times a digit of an oversized mode group was peeled into a host loop
     bool useRccl = false;
     // events (created on first execution): per device {start, localReady, auxDone, commDone[k]...}, then one per (device, wave)
     std::vector<hipEvent_t> events;
@@ -878,7 +883,12 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         cutensorHandle_t h = handle->handles[p.dev];
         const Shard s{p.dev, p.lo, p.hi};
         Restrict rs = restrict_of(s, p.q0, p.q1);
-        for (const std::vector<Clip>& box : boxes) {
+        // work list of clip sets: the boxes of the contracted index space, each possibly split further ("peeled") below
+        std::vector<std::vector<Clip>> todo(boxes.rbegin(), boxes.rend());
+        std::set<std::string> written;     // regions of D (clips of C's labels) some sub-contraction of this piece already produces
+        while (!todo.empty() && st == CUTENSOR_STATUS_SUCCESS) {
+            const std::vector<Clip> box = todo.back();
+            todo.pop_back();
             rs.clips = box;
             View v[3];
             Piece::Sub sub;
@@ -902,6 +912,55 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             cutensorDestroyPlanPreference(pref);
             for (int k = 0; k < 3; ++k) cutensorDestroyTensorDescriptor(dT[k]);
             if (st != CUTENSOR_STATUS_SUCCESS) { cutensorDestroyPlan(sub.plan); break; }
+            // Peeling: a local view with more than four unfusable modes in a group (block-cyclic (w, digit, digit...) splits of
+            // several modes — blog_post.cu on 8 devices, scaling >= 2) would run on the functional mode-table kernel (measured
+            // 650 GFLOP/s against 70,000+ for the tiled kernels).  Instead one block-index digit of the oversized group — the
+            // one with the smallest extent — is taken out of the view and walked by the host: extent-many tiled contractions.
+            int32_t grp[64], lab[64];
+            int64_t ext[64];
+            const int nm = (p.subs.size() + todo.size() < 512) ? ctamdPlanModeTableGroups(sub.plan, grp, lab, ext, 64) : 0;
+            if (nm > 0 && !env_is("CUTENSORMG_AMD_PEEL", "0")) {
+                int count[4] = {0, 0, 0, 0};
+                for (int i = 0; i < std::min(nm, 64); ++i) ++count[grp[i]];
+                int best = -1;
+                for (int i = 0; i < std::min(nm, 64); ++i) {
+                    if (count[grp[i]] <= 4 || (lab[i] & 7) == 7 || ext[i] < 2) continue;        // only digits (not w) of an oversized group
+                    if (best < 0 || ext[i] < ext[best]) best = i;
+                }
+                if (best >= 0) {
+                    const int li = lab[best] >> 3, dj = lab[best] & 7;
+                    std::vector<Clip> base = box;
+                    Clip* c = nullptr;
+                    for (Clip& x : base) if (x.label == li) c = &x;
+                    if (c == nullptr) {        // first restriction of this label: everything it had in the view
+                        Clip fresh;
+                        fresh.label = li;
+                        fresh.wHi = radix[(size_t)li].blockSize;
+                        for (size_t j = 0; j < radix[(size_t)li].f.size(); ++j) fresh.digit.push_back({0, radix[(size_t)li].f[j]});
+                        if (li == rs.qLabel && rs.qDigit >= 0) fresh.digit[(size_t)rs.qDigit] = {rs.c0, rs.c1};   // the piece's run of q's coordinate
+                        base.push_back(fresh);
+                        c = &base.back();
+                    }
+                    const std::pair<int64_t, int64_t> range = c->digit[(size_t)dj];
+                    if (li != rs.pLabel && range.second - range.first >= 2) {
+                        cutensorDestroyPlan(sub.plan);
+                        for (int64_t val = range.second - 1; val >= range.first; --val) {      // pushed in reverse: executed in ascending order
+                            c->digit[(size_t)dj] = {val, val + 1};
+                            todo.push_back(base);
+                        }
+                        ++pl->peeled;
+                        continue;
+                    }
+                }
+            }
+            std::string region;
+            for (const Clip& c : box) {
+                if (find_label(d.mC, universe[(size_t)c.label]) < 0) continue;     // a contracted label: same region of D
+                region += std::to_string(c.label) + ":" + std::to_string(c.wHi);
+                for (const auto& r : c.digit) region += "," + std::to_string(r.first) + "-" + std::to_string(r.second);
+                region += ";";
+            }
+            sub.accumulate = !written.insert(region).second;
             p.subs.push_back(sub);
         }
         rs.clips.clear();
@@ -1166,7 +1225,7 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
             const Piece::Sub& sub = p.subs[bi];
             const int64_t oC = sub.off[2] * (int64_t)es;
             st = cutensorContract(handle->handles[(size_t)g], sub.plan, alpha, pa + sub.off[0] * (int64_t)es, pb + sub.off[1] * (int64_t)es,
-                                  bi == 0 ? beta : one, (bi == 0 ? pc : pd) + oC, pd + oC, staging(g, 3 + p.stream), pl->contractionWs, cs);
+                                  sub.accumulate ? one : beta, (sub.accumulate ? pd : pc) + oC, pd + oC, staging(g, 3 + p.stream), pl->contractionWs, cs);
             if (st != CUTENSOR_STATUS_SUCCESS) return st;
         }
         const size_t cellBytes = (size_t)d.C.cellElems * es;
@@ -1251,7 +1310,12 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
     auto add = [&](const char* fmt, auto... a) { std::snprintf(tmp, sizeof(tmp), fmt, a...); s += tmp; };
     int64_t remote = 0, local = 0;
     for (const Transfer& t : plan->transfers) (t.local ? local : remote) += t.bytes;
-    add("{\"numBoxes\":%d,\"allGatherEligible\":[%d,%d],\"transport\":\"%s\",\"trialMs\":[%.4f,%.4f],\"chosen\":%d,", plan->numBoxes,
+    {
+        size_t subs = 0;
+        for (const Piece& p : plan->pieces) subs += p.subs.size();
+        add("{\"peeled\":%d,\"localContractions\":%llu,", plan->peeled, (unsigned long long)subs);
+    }
+    add("\"numBoxes\":%d,\"allGatherEligible\":[%d,%d],\"transport\":\"%s\",\"trialMs\":[%.4f,%.4f],\"chosen\":%d,", plan->numBoxes,
         (int)plan->allGatherEligible[0], (int)plan->allGatherEligible[1],
         !plan->useRccl ? "peer" : (plan->transport == 2 || !(plan->allGatherEligible[0] || plan->allGatherEligible[1])) ? "sendrecv"
                                   : plan->transport == 1 ? "allgather" : "auto(allgather|sendrecv)",

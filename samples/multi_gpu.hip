@@ -107,9 +107,12 @@ int main(int argc, char** argv) {
         int nDev = 1, scaling = 2;
         for (int i = 1; i < argc; ++i)
             if (std::string(argv[i]) == "--blog" && i + 2 < argc) { nDev = std::atoi(argv[i + 1]); scaling = std::atoi(argv[i + 2]); }
-        nDev = std::min(nDev, visible);
+        // --virtual: the n devices are n logical devices on GPU 0 (the layouts, plans and kernels of an n-GPU run, value-checked
+        // on a one-GPU box; the sample itself falls back to i % numDevices the same way, contraction_multi_gpu.cu:159-167)
+        const bool virt = sample::arg_flag(argc, argv, "--virtual");
+        if (!virt) nDev = std::min(nDev, visible);
         devices.resize((size_t)nDev);
-        std::iota(devices.begin(), devices.end(), 0);
+        if (virt) std::fill(devices.begin(), devices.end(), 0); else std::iota(devices.begin(), devices.end(), 0);
         const int32_t M0 = 0, M1 = 1, M2 = 2, N0 = 3, N1 = 4, N2 = 5, K0 = 6, K1 = 7, K2 = 8;
         extent[M0] = 16; extent[M1] = 8 * scaling; extent[M2] = 8; extent[N0] = 16; extent[N1] = 8 * scaling; extent[N2] = 8;
         extent[K0] = 16; extent[K1] = 32; extent[K2] = 8;                                          // blog_post.cu:155-164

@@ -285,6 +285,47 @@ def test_many_mode_contraction_uses_the_mode_table_kernel(built, dtype):
     np.testing.assert_allclose(got, ref, rtol=1e-5 if dtype == "float32" else 1e-13, atol=1e-5 if dtype == "float32" else 1e-13)
 
 
+@pytest.mark.parametrize("case", [
+    # (A modes, B modes, C modes, extents, expected peeled modes): K modes sit between A's free modes so that nothing fuses
+    ("akblcmdef", "xkylm", "xfaebdcy", dict(a=6, b=5, c=4, d=3, e=7, f=2, k=8, l=6, m=5, x=9, y=4), 2),        # 6 free modes of A
+    ("apbqcrdse", "xpqrsy", "axbycde", dict(a=5, b=4, c=6, d=3, e=8, p=2, q=3, r=4, s=5, x=7, y=6), 1),          # 5 free modes of A
+    ("paqbrcsdte", "xpyqzrst", "abxcydze", dict(a=4, b=3, c=5, d=2, e=6, p=3, q=4, r=2, s=5, t=3, x=4, y=3, z=2), 2),   # 5 contracted + 5 free
+])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_oversized_mode_groups_are_peeled_onto_the_tiled_kernels(built, case, dtype):
+    """A group with five or six unfusable modes exceeds the tiled kernels' four digits per group.  Up to 64 launches the plan
+    peels the smallest modes of that group into a host loop over ONE tiled inner plan (operands offset by index x stride; a
+    peeled contracted mode accumulates into D, a peeled free mode writes its own region with the caller's beta) instead of
+    handing the whole problem to the mode-table kernel (measured ~100x slower in cuTENSORMg's blog_post.cu layouts at 8 devices).
+    Parity against numpy.einsum in fp64, alpha / beta != 1 / 0, C aliasing D."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    mA, mB, mC, ext, want_peeled = case
+    h = ops.Handle()
+    bf = dtype == "bfloat16"
+    A = make_tensor([ext[c] for c in mA], 41, np.float32, -1, 1)
+    B = make_tensor([ext[c] for c in mB], 42, np.float32, -1, 1)
+    C = make_tensor([ext[c] for c in mC], 43, np.float32, -1, 1)
+    tdt = torch.bfloat16 if bf else torch.float32
+    dA, dB, dC = to_device(A).to(tdt), to_device(B).to(tdt), to_device(C).to(tdt)
+    if bf:   # the reference values are computed from the rounded inputs
+        A = np.reshape(dA.float().cpu().numpy(), A.shape, order="F")
+        B = np.reshape(dB.float().cpu().numpy(), B.shape, order="F")
+        C = np.reshape(dC.float().cpu().numpy(), C.shape, order="F")
+    plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
+                                dtype=ct.R_16BF if bf else ct.R_32F, workspace_limit=1 << 24)
+    d = plan.describe()
+    assert d.get("peeled_modes") == want_peeled and d["kname"] != "gett_wide_kernel" and 2 <= d["peel_launches"] <= 64, d
+    ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    plan.contract(1.5, dA.data_ptr(), dB.data_ptr(), -0.5, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), plan.required_workspace)
+    torch.cuda.synchronize()
+    got = np.reshape(dC.float().cpu().numpy(), C.shape, order="F")
+    ref = 1.5 * np.einsum("%s,%s->%s" % (mA, mB, mC), A.astype(np.float64), B.astype(np.float64)) - 0.5 * C
+    scale = float(np.max(np.abs(ref)))
+    np.testing.assert_allclose(got, ref, rtol=1e-2 if bf else 1e-5, atol=(1e-2 if bf else 1e-5) * scale)
+    plan.destroy()
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_complex_contraction_with_conjugation(built, dtype):
     """Complex data (cuTENSOR/contraction_jit.cu:31-41, std::complex<float> tensors and scalars) runs on the mode-table
