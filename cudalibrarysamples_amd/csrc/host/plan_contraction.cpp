@@ -393,6 +393,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // SIMD); 16..23: eight free-running waves, K-tile of 32, deep LDS ring, one barrier per K-tile
     static const int variant = [] {
         const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
+        if (e && e[0] == '4' && e[1] == 's') return 24;
+        if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4') return 8;
         if (e && e[0] == 's') return 16;
         return 0;
@@ -425,7 +427,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 16, 8}) {      // ping-pong rows, streamed (free-running waves, deep ring), four waves
+    for (int other : {0, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

@@ -926,6 +926,203 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4_kernel(const GettParams p) 
 }
 
 
+// =====================================================================================================
+// Four-wave REGISTER-STAGED variant (CUTENSOR_AMD_H16_WAVES=4r; round 3): the tile, LDS images, fragment reads and epilogue of
+// gett_h16w4_kernel, but the operands reach LDS through registers — buffer_load_dwordx4 into a staging set, ds_write_b128 a
+// K-tile later — instead of by LDS-DMA.  Why: with ONE wave per SIMD every instruction the wave issues sits in front of its own
+// MFMAs, and an LDS-DMA instruction holds the issue port for 60-100+ cycles (gett_f32_stream.hip header) against the 32 cycles an
+// MFMA covers: gett_h16w4_kernel loses 21 % of its cycles to the 16 pieces per K-tile even when nothing waits for them
+// (ablation 2, profiles/r03_h16_w4_status.txt), and a deeper ring does not help (gett_h16w4s_kernel, profiles/r03_h16_w4s_status.txt).
+// A plain buffer load and a ds_write issue in a few cycles each.  A lane loads exactly the 16-byte unit the LDS-DMA form would
+// (same HOperand source offsets) and writes it where the DMA would have put it (piece base + 16 * lane), so the LDS images are
+// identical.  Two staging sets of 16 pieces (128 registers of the wave's 512): while the set of tile t + 1 is written to the
+// free buffer (k-steps 1, 2 of tile t), the loads of tile t + 2 are already in flight into the other set (k-steps 0, 1) —
+// five k-steps (1.1-1.7 us) ahead of their ds_write.  All waits are the compiler's (no LDS-DMA, nothing hidden from its
+// counters); ONE barrier per K-tile.
+// =====================================================================================================
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(256, 1) gett_h16w4r_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
+    HOperand<LA, 4> oa;
+    HOperand<LB, 4> ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    bA += oa.base;
+    bB += ob.base;
+
+    uint32_t offK[4], offF[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { offK[s] = h_offK(lane, s); offF[s] = h_offF(lane, s); }
+
+    HOdometer odo;
+    odo.init(p.gK, tile0 * kHBK);
+
+    typedef uint32_t stg_t __attribute__((ext_vector_type(4)));
+    stg_t stg[2][16];                              // two staging sets: piece n = 0..15 of a K-tile (half q = n >> 2, piece i = n & 3)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CTAMD_R_LOAD(SET, N)                                                                                        \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        if constexpr (q_ < 2)                                                                                      \
+            stg[SET][N] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(bA + odo.offA), 0, -1, 0x00020000), \
+                                                                (int)oa.src[q_][i_], 0, 0);                        \
+        else                                                                                                       \
+            stg[SET][N] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(bB + odo.offB), 0, -1, 0x00020000), \
+                                                                (int)ob.src[q_ - 2][i_], 0, 0);                    \
+    }
+#else
+#define CTAMD_R_LOAD(SET, N) { stg[SET][N] = stg_t{0u, 0u, 0u, 0u}; }
+#endif
+    // piece N of the K-tile in staging set SET -> ring buffer P, where the LDS-DMA form would have put it
+#define CTAMD_R_STORE(P, SET, N)                                                                                    \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        *reinterpret_cast<stg_t*>(lds + ((P) * 4 + q_) * kHalfBytes + (wave + 4 * i_) * 1024 + lane * 16) = stg[SET][N]; \
+    }
+#define CTAMD_R_LOAD16(SET)                                                                                          \
+    CTAMD_R_LOAD(SET, 0) CTAMD_R_LOAD(SET, 1) CTAMD_R_LOAD(SET, 2) CTAMD_R_LOAD(SET, 3) CTAMD_R_LOAD(SET, 4) CTAMD_R_LOAD(SET, 5)        \
+    CTAMD_R_LOAD(SET, 6) CTAMD_R_LOAD(SET, 7) CTAMD_R_LOAD(SET, 8) CTAMD_R_LOAD(SET, 9) CTAMD_R_LOAD(SET, 10) CTAMD_R_LOAD(SET, 11)     \
+    CTAMD_R_LOAD(SET, 12) CTAMD_R_LOAD(SET, 13) CTAMD_R_LOAD(SET, 14) CTAMD_R_LOAD(SET, 15)
+#define CTAMD_R_STORE16(P, SET)                                                                                      \
+    CTAMD_R_STORE(P, SET, 0) CTAMD_R_STORE(P, SET, 1) CTAMD_R_STORE(P, SET, 2) CTAMD_R_STORE(P, SET, 3) CTAMD_R_STORE(P, SET, 4)        \
+    CTAMD_R_STORE(P, SET, 5) CTAMD_R_STORE(P, SET, 6) CTAMD_R_STORE(P, SET, 7) CTAMD_R_STORE(P, SET, 8) CTAMD_R_STORE(P, SET, 9)        \
+    CTAMD_R_STORE(P, SET, 10) CTAMD_R_STORE(P, SET, 11) CTAMD_R_STORE(P, SET, 12) CTAMD_R_STORE(P, SET, 13) CTAMD_R_STORE(P, SET, 14)   \
+    CTAMD_R_STORE(P, SET, 15)
+
+    // ---- prologue: tile 0 -> set 0 -> buffer 0; tile 1 -> set 1 (stays in registers until tile 0's k-steps 1, 2) ----
+    int tNext = 0;                                 // K-tile the odometer describes
+    CTAMD_R_LOAD16(0)
+    ++tNext;
+    if (tNext < nTiles) odo.advance(p.gK);         // past the end the last tile is loaded again (never multiplied)
+    CTAMD_R_LOAD16(1)
+    ++tNext;
+    if (tNext < nTiles) odo.advance(p.gK);
+    CTAMD_R_STORE16(0, 0)
+    CTAMD_H_LGKM0();
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s & 1
+
+    const char* const aSlot0 = lds + wr * kHalfBytes;          // A-half wr of buffer 0 (buffer 1: + 4 slots)
+    const char* const bSlot0 = lds + (2 + wc) * kHalfBytes;    // B-half wc of buffer 0
+#define CTAMD_R_READ(P, S, SET, F)                                                                                  \
+    {                                                                                                              \
+        if constexpr ((F) < 4) b[SET][F] = h_read_frag<LB>(bSlot0 + (P) * 4 * kHalfBytes, 32 * (F), S, offK, offF[F]);          \
+        else a[SET][(F) - 4] = h_read_frag<LA>(aSlot0 + (P) * 4 * kHalfBytes, 32 * ((F) - 4), S, offK, offF[(F) - 4]);        \
+    }
+#define CTAMD_R_MFMA(SET, M) acc[(M) >> 2][(M) & 3] = h_mfma<BF>(a[SET][(M) >> 2], b[SET][(M) & 3], acc[(M) >> 2][(M) & 3]);
+    // one group = two MFMAs of k-step S with one fragment read of the following step and, by k-step, one load / one store / both
+    //   KIND 0: load piece F of tile t + 2 (set LS)                 (k-step 0: pieces 0..7)
+    //   KIND 1: load piece 8 + F (set LS) and store piece F (set SS -> buffer P ^ 1)   (k-step 1)
+    //   KIND 2: store piece 8 + F                                  (k-step 2)
+    //   KIND 3: nothing (k-step 3; the read comes from the other buffer)
+#define CTAMD_R_GROUP(P, S, F, KIND, LS, SS)                                                                        \
+    if constexpr ((S) < 3) { CTAMD_R_READ(P, (S) + 1, ((S) + 1) & 1, F) } else { CTAMD_R_READ((P) ^ 1, 0, 0, F) }  \
+    CTAMD_R_MFMA((S) & 1, 2 * (F))                                                                                 \
+    if constexpr ((KIND) == 0) { CTAMD_R_LOAD(LS, F) }                                                             \
+    if constexpr ((KIND) == 1) { CTAMD_R_LOAD(LS, 8 + (F)) CTAMD_R_STORE((P) ^ 1, SS, F) }                         \
+    if constexpr ((KIND) == 2) { CTAMD_R_STORE((P) ^ 1, SS, 8 + (F)) }                                             \
+    CTAMD_R_MFMA((S) & 1, 2 * (F) + 1)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_R_STEP(P, S, KIND, LS, SS)                                                                            \
+    CTAMD_R_GROUP(P, S, 0, KIND, LS, SS) CTAMD_R_GROUP(P, S, 1, KIND, LS, SS) CTAMD_R_GROUP(P, S, 2, KIND, LS, SS) CTAMD_R_GROUP(P, S, 3, KIND, LS, SS) \
+    CTAMD_R_GROUP(P, S, 4, KIND, LS, SS) CTAMD_R_GROUP(P, S, 5, KIND, LS, SS) CTAMD_R_GROUP(P, S, 6, KIND, LS, SS) CTAMD_R_GROUP(P, S, 7, KIND, LS, SS)
+    // tile in buffer P; staging set P holds nothing live (its tile is in LDS), set P ^ 1 holds tile t + 1
+#define CTAMD_R_TILE(P)                                                                                             \
+    CTAMD_R_STEP(P, 0, 0, P, (P) ^ 1)                                                                              \
+    CTAMD_R_STEP(P, 1, 1, P, (P) ^ 1)                                                                              \
+    ++tNext;                                                                                                       \
+    if (tNext < nTiles) odo.advance(p.gK);                                                                         \
+    CTAMD_R_STEP(P, 2, 2, P, (P) ^ 1)                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_H_LGKM0();                                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_R_STEP(P, 3, 3, P, (P) ^ 1)
+
+    // first fragments of tile 0
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        b[0][f] = h_read_frag<LB>(bSlot0, 32 * f, 0, offK, offF[f]);
+        a[0][f] = h_read_frag<LA>(aSlot0, 32 * f, 0, offK, offF[f]);
+    }
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_R_TILE(0) CTAMD_R_TILE(1) }
+    if (t < nTiles) { CTAMD_R_TILE(0) }
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t n = nW + (lane & 31);
+                    float* row = P + (size_t)m * Nt;
+                    if (n < Nt) row[n] = c0[r];
+                    if (n + 32 < Nt) row[n + 32] = c1[r];
+                    if (n + 64 < Nt) row[n + 64] = c2[r];
+                    if (n + 96 < Nt) row[n + 96] = c3[r];
+                }
+            }
+        };
+        store_partial(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
+        store_partial(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
+        store_partial(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
+        store_partial(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // four passes: the four fragments of accumulator row i
+        ep.park(0, acc[i][0], lane); ep.park(1, acc[i][1], lane); ep.park(2, acc[i][2], lane); ep.park(3, acc[i][3], lane);
+        const uint32_t mB = mW + 32 * i;
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4r(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gett_h16w4r_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 // Epilogue of the 2 (M) x 4 (N) wave grid with 128 x 64 per wave (gett_h16s_kernel): split-K partial
 // tile or D = alpha * acc + beta * C with one rounding to the 16-bit type.
 template <bool BF>
@@ -1219,6 +1416,201 @@ __global__ void __launch_bounds__(512, 2) gett_h16s_kernel(const GettParams p) {
     h_epilogue_128x64<BF>(p, acc, m0, n0, wr, wc, slice, l, lane, lds, wave);
 }
 
+// =====================================================================================================
+// Four-wave STREAMED variant (CUTENSOR_AMD_H16_WAVES=4s; round 3, a measured alternative and an autotuning candidate):
+// the 128 x 128 wave tile of gett_h16w4_kernel (one wave per SIMD, half the LDS read traffic per MFMA of the 2 x 4
+// arrangement) on the K-tile-32 / NS-deep-ring machinery of gett_h16s_kernel.  Why: the four-wave kernel above keeps only
+// TWO 64-deep K-tiles in LDS, so a tile's pieces are requested 3-4 k-steps (0.6-0.85 us) before they are needed — less than
+// the loaded L2 / fabric latency — and the wave waits at every tile boundary (its LDS-DMA "costs" 21 % of the cycles on
+// zero-filled operands, profiles/r03_h16_w4_status.txt, although the issue slots themselves cost ~7 %).  Here a ring of
+// NS = 4 or 5 stages of 32 KiB keeps NS - 1 K-tiles (96-128 KiB per CU, 3-4 k-tile times = 1.3-1.7 us on zeros) in flight
+// behind a counted vmcnt.  Per 32-deep K-tile a wave issues 32 MFMAs (two k-steps of 16), 16 fragment reads (two register
+// sets), 8 LDS-DMA pieces, and meets the workgroup once — in front of k-step 1, whose fragments are already in registers.
+// =====================================================================================================
+template <bool BF, int LA, int LB, int NS>
+__global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[NS * 4 * kSHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kSBK, tilesPerSlice = p.kPerSlice / kSBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    const uint64_t bA0 = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)));
+    const uint64_t bB0 = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)));
+    // a half-tile is eight 1-KiB pieces; wave w stages pieces w and w + 4 of each of the four half-tiles
+    HOperandS<LA> oaLo, oaHi;
+    HOperandS<LB> obLo, obHi;
+    oaLo.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    oaHi.init(p.gM, p.gK.stride[0][0], m0, wave + 4, lane);
+    obLo.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    obHi.init(p.gN, p.gK.stride[1][0], n0, wave + 4, lane);
+    const uint64_t bALo = bA0 + oaLo.base, bAHi = bA0 + oaHi.base, bBLo = bB0 + obLo.base, bBHi = bB0 + obHi.base;
+
+    uint32_t offK[2], offF[4];
+    offK[0] = h_offK32(lane, 0);
+    offK[1] = h_offK32(lane, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offF[i] = h_offF(lane, i);
+
+    HOdometerS odo;
+    odo.init(p.gK, tile0 * kSBK);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+    // piece n = 0..7 of the K-tile the odometer describes, into ring buffer P: half q = n >> 1 (A0, A1, B0, B1), lo / hi piece
+#define CTAMD_Q_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 1;                                                                               \
+        constexpr bool hi_ = ((N) & 1) != 0;                                                                       \
+        const uint32_t slot_ = ldsBase + ((P) * 4 + q_) * kSHalfBytes;                                             \
+        if constexpr (q_ < 2 && !hi_) oaLo.template issue<PAD>(h_make_rsrc(bALo + odo.offA), q_, slot_, wave);     \
+        else if constexpr (q_ < 2)    oaHi.template issue<PAD>(h_make_rsrc(bAHi + odo.offA), q_, slot_, wave + 4); \
+        else if constexpr (!hi_)      obLo.template issue<PAD>(h_make_rsrc(bBLo + odo.offB), q_ - 2, slot_, wave); \
+        else                          obHi.template issue<PAD>(h_make_rsrc(bBHi + odo.offB), q_ - 2, slot_, wave + 4); \
+    }
+    int tNext = 0;                                // K-tile the odometer describes
+#define CTAMD_Q_FILL(P)                                                                                             \
+    if constexpr ((P) < NS) {                                                                                      \
+        CTAMD_Q_DMA((P) < NS ? (P) : 0, 0, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 1, true)                          \
+        CTAMD_Q_DMA((P) < NS ? (P) : 0, 2, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 3, true)                          \
+        CTAMD_Q_DMA((P) < NS ? (P) : 0, 4, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 5, true)                          \
+        CTAMD_Q_DMA((P) < NS ? (P) : 0, 6, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 7, true)                          \
+        ++tNext;                                                                                                   \
+        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+    }
+    CTAMD_Q_FILL(0) CTAMD_Q_FILL(1) CTAMD_Q_FILL(2) CTAMD_Q_FILL(3) CTAMD_Q_FILL(4)
+    CTAMD_H_VMCNT(8 * (NS - 1));                  // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s
+
+    const char* const aSlot0 = lds + wr * kSHalfBytes;          // A-half wr of buffer 0 (buffer P: + 4 P slots)
+    const char* const bSlot0 = lds + (2 + wc) * kSHalfBytes;    // B-half wc of buffer 0
+    // fragment F = 0..7 of k-step S from buffer P into register set SET: F < 4 -> B columns 32 F, else A rows 32 (F - 4)
+#define CTAMD_Q_READ(P, S, SET, F)                                                                                  \
+    {                                                                                                              \
+        if constexpr ((F) < 4) b[SET][F] = h_read_frag32<LB>(bSlot0 + (P) * 4 * kSHalfBytes, 32 * (F), S, offK, offF[F]);               \
+        else a[SET][(F) - 4] = h_read_frag32<LA>(aSlot0 + (P) * 4 * kSHalfBytes, 32 * ((F) - 4), S, offK, offF[(F) - 4]);               \
+    }
+#define CTAMD_Q_MFMA(SET, M) acc[(M) >> 2][(M) & 3] = h_mfma<BF>(a[SET][(M) >> 2], b[SET][(M) & 3], acc[(M) >> 2][(M) & 3]);
+    // k-step 0 of the tile in buffer P: one fragment read of k-step 1 per two MFMAs of k-step 0
+#define CTAMD_Q_G0(P, G)                                                                                            \
+    CTAMD_Q_READ(P, 1, 1, G)                                                                                       \
+    CTAMD_Q_MFMA(0, 2 * (G)) CTAMD_Q_MFMA(0, 2 * (G) + 1)                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (behind the barrier): one read of the next tile's k-step 0 (buffer PN) and one piece of tile t + NS (into buffer
+    // P, which nobody reads any more) per two MFMAs
+#define CTAMD_Q_G1(P, PN, G)                                                                                        \
+    CTAMD_Q_READ(PN, 0, 0, G)                                                                                      \
+    CTAMD_Q_MFMA(1, 2 * (G))                                                                                       \
+    CTAMD_Q_DMA(P, G, false)                                                                                       \
+    CTAMD_Q_MFMA(1, 2 * (G) + 1)                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_Q_SYNC()                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        CTAMD_H_LGKM0();                                                                                           \
+        CTAMD_H_VMCNT(8 * (NS - 2));              /* tile t + 1 has landed (this wave's pieces) */                 \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_Q_TILE(P)                                                                                             \
+    {                                                                                                              \
+        constexpr int PN_ = ((P) + 1) % NS;                                                                        \
+        CTAMD_Q_G0(P, 0) CTAMD_Q_G0(P, 1) CTAMD_Q_G0(P, 2) CTAMD_Q_G0(P, 3)                                        \
+        CTAMD_Q_G0(P, 4) CTAMD_Q_G0(P, 5) CTAMD_Q_G0(P, 6) CTAMD_Q_G0(P, 7)                                        \
+        CTAMD_Q_SYNC()                                                                                             \
+        CTAMD_Q_G1(P, PN_, 0) CTAMD_Q_G1(P, PN_, 1) CTAMD_Q_G1(P, PN_, 2) CTAMD_Q_G1(P, PN_, 3)                    \
+        CTAMD_Q_G1(P, PN_, 4) CTAMD_Q_G1(P, PN_, 5) CTAMD_Q_G1(P, PN_, 6) CTAMD_Q_G1(P, PN_, 7)                    \
+        ++tNext;                                                                                                   \
+        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+    }
+
+    // first fragments of tile 0
+    CTAMD_Q_READ(0, 0, 0, 0) CTAMD_Q_READ(0, 0, 0, 1) CTAMD_Q_READ(0, 0, 0, 2) CTAMD_Q_READ(0, 0, 0, 3)
+    CTAMD_Q_READ(0, 0, 0, 4) CTAMD_Q_READ(0, 0, 0, 5) CTAMD_Q_READ(0, 0, 0, 6) CTAMD_Q_READ(0, 0, 0, 7)
+    {
+        int t = 0;
+        if constexpr (NS == 4) {
+            for (; t + 3 < nTiles; t += 4) { CTAMD_Q_TILE(0) CTAMD_Q_TILE(1) CTAMD_Q_TILE(2) CTAMD_Q_TILE(3) }
+            if (t < nTiles) { CTAMD_Q_TILE(0) }
+            if (t + 1 < nTiles) { CTAMD_Q_TILE(1) }
+            if (t + 2 < nTiles) { CTAMD_Q_TILE(2) }
+        } else {
+            for (; t + 4 < nTiles; t += 5) { CTAMD_Q_TILE(0) CTAMD_Q_TILE(1) CTAMD_Q_TILE(2) CTAMD_Q_TILE(3) CTAMD_Q_TILE(4) }
+            if (t < nTiles) { CTAMD_Q_TILE(0) }
+            if (t + 1 < nTiles) { CTAMD_Q_TILE(1) }
+            if (t + 2 < nTiles) { CTAMD_Q_TILE(2) }
+            if (t + 3 < nTiles) { CTAMD_Q_TILE(3) }
+        }
+    }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t n = nW + (lane & 31);
+                    float* row = P + (size_t)m * Nt;
+                    if (n < Nt) row[n] = c0[r];
+                    if (n + 32 < Nt) row[n + 32] = c1[r];
+                    if (n + 64 < Nt) row[n + 64] = c2[r];
+                    if (n + 96 < Nt) row[n + 96] = c3[r];
+                }
+            }
+        };
+        store_partial(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
+        store_partial(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
+        store_partial(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
+        store_partial(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // four passes: the four fragments of accumulator row i
+        ep.park(0, acc[i][0], lane); ep.park(1, acc[i][1], lane); ep.park(2, acc[i][2], lane); ep.park(3, acc[i][3], lane);
+        const uint32_t mB = mW + 32 * i;
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4s(const GettParams& p, hipStream_t stream) {
+    static const int ns = [] { const char* e = getenv("CUTENSOR_AMD_H16_STAGES"); return e ? atoi(e) : 5; }();
+    if (ns == 4) hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16s(const GettParams& p, hipStream_t stream) {
     static const int ns = [] { const char* e = getenv("CUTENSOR_AMD_H16_STAGES"); return e ? atoi(e) : 5; }();
@@ -1362,6 +1754,10 @@ namespace ctamd {
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 2, 1, 0, &launch_h16w4<bf, la, lb>, 0},
 #define CTAMD_H16S_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kSBK, 2, 4, 1, la, lb, 512, 4, 1, 0, &launch_h16s<bf, la, lb>, 0},
+#define CTAMD_H16W4R_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 3, 1, 0, &launch_h16w4r<bf, la, lb>, 0},
+#define CTAMD_H16W4S_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kSBK, 2, 2, 1, la, lb, 256, 5, 1, 0, &launch_h16w4s<bf, la, lb>, 0},
 static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)
@@ -1376,7 +1772,17 @@ static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16S_ENTRY(true, LAY_K, LAY_K) CTAMD_H16S_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16S_ENTRY(true, LAY_F, LAY_K) CTAMD_H16S_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16S_ENTRY(false, LAY_K, LAY_K) CTAMD_H16S_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16S_ENTRY(false, LAY_F, LAY_K) CTAMD_H16S_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16S_ENTRY(false, LAY_F, LAY_K) CTAMD_H16S_ENTRY(false, LAY_F, LAY_F)
+    // entries 24..31: the four-wave streamed variant (128 x 128 wave tiles on the K-tile-32 ring), same order
+    CTAMD_H16W4S_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4S_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4S_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4S_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4S_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4S_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4S_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4S_ENTRY(false, LAY_F, LAY_F)
+    // entries 32..39: the four-wave register-staged variant (no LDS-DMA), same order
+    CTAMD_H16W4R_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4R_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4R_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4R_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4R_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4R_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4R_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4R_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16_kernels(int* count) {
     *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
