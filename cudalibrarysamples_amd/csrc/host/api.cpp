@@ -1673,6 +1673,14 @@ int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t*
     return n;
 }
 
+// Launches of the inner plan a peeled contraction plan makes per call (peel_wide_contraction); 0 for every other plan.
+int ctamdPlanPeelLaunches(const cutensorPlan_t plan) {
+    if (plan == nullptr || plan->kind != OpKind::Contraction || plan->choice.kernel != -3) return 0;
+    long long n = 1;
+    for (const PeelMode& pm : plan->peel) n *= pm.extent;
+    return (int)n;
+}
+
 // Plan-memo counters of this handle: plans answered by cloning a prototype / plans that went through the planner.
 void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) {
     if (handle == nullptr) return;

@@ -44,6 +44,7 @@
 #include <cutensor.h>
 #include <cutensorMg.h>
 
+extern "C" int ctamdPlanPeelLaunches(const cutensorPlan_t plan);
 extern "C" int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut);   // libcutensor.so diagnostic
 
 namespace {
@@ -1311,9 +1312,18 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
     int64_t remote = 0, local = 0;
     for (const Transfer& t : plan->transfers) (t.local ? local : remote) += t.bytes;
     {
-        size_t subs = 0;
-        for (const Piece& p : plan->pieces) subs += p.subs.size();
-        add("{\"peeled\":%d,\"localContractions\":%llu,", plan->peeled, (unsigned long long)subs);
+        size_t subs = 0, libPeeled = 0, modeTable = 0;
+        for (const Piece& p : plan->pieces) {
+            subs += p.subs.size();
+            for (const Piece::Sub& sub : p.subs) {
+                if (ctamdPlanPeelLaunches(sub.plan) > 0) ++libPeeled;
+                if (ctamdPlanModeTableGroups(sub.plan, nullptr, nullptr, nullptr, 0) > 0) ++modeTable;
+            }
+        }
+        // peeled: digits this plan walks itself; libraryPeeled: local contractions the single-GPU library peels (one tiled inner
+        // plan launched per index combination); modeTable: local contractions left to the functional mode-table kernel
+        add("{\"peeled\":%d,\"libraryPeeled\":%llu,\"modeTable\":%llu,\"localContractions\":%llu,", plan->peeled, (unsigned long long)libPeeled,
+            (unsigned long long)modeTable, (unsigned long long)subs);
     }
     add("\"numBoxes\":%d,\"allGatherEligible\":[%d,%d],\"transport\":\"%s\",\"trialMs\":[%.4f,%.4f],\"chosen\":%d,", plan->numBoxes,
         (int)plan->allGatherEligible[0], (int)plan->allGatherEligible[1],

@@ -308,8 +308,9 @@ def test_every_blog_post_configuration_plans(cm, n):
             assert d["numBoxes"] == 1 and len(d["pieces"]) >= 1     # K0 / K1 / K2 extents divide their blocks: never ragged
             # a group of the local view with > 4 unfusable modes is peeled (one tiled contraction per value of its smallest
             # block-index digit) instead of being left to the mode-table kernel: 8 devices from scaling 2, 4 devices from scaling 9
-            assert (d["peeled"] > 0) == ((n == 8 and s >= 2) or (n == 4 and s >= 9)), (n, s, d["peeled"])
-            assert d["localContractions"] >= len(d["pieces"])
+            # (by the single-GPU library — one tiled inner plan per index combination — or, where its budget refuses, by this plan)
+            assert (d["peeled"] + d["libraryPeeled"] > 0) == ((n == 8 and s >= 2) or (n == 4 and s >= 9)), (n, s, d["peeled"], d["libraryPeeled"])
+            assert d["modeTable"] == 0 and d["localContractions"] >= len(d["pieces"])
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])
