@@ -138,7 +138,7 @@ namespace {
 // any experiment knob that changes what cutensorCreatePlan decides: the memo stands aside while one is set
 bool plan_env_override() {
     return std::getenv("CUTENSOR_AMD_FORCE") || std::getenv("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD") ||
-           std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1");
+           std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types

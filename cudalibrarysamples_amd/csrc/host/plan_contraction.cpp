@@ -313,6 +313,11 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 
         const uint64_t tilesM = (v.totM + k.bm - 1) / k.bm, tilesN = (v.totN + k.bn - 1) / k.bn;
         const uint64_t tiles = tilesM * tilesN * v.totL;
+        // nontemporal operand stream: only when every operand byte is read exactly once (one tile row and one tile column) AND the
+        // operands are well beyond the 256-MiB Infinity Cache (> 1.4 x), i.e. back-to-back calls cannot find them on-die anyway (measured:
+        // headline shape 201 MB: +3.6 % from HBM, -5.5 % cache-resident; b = 96, 302 MB: -5 %; b = 128, 403 MB: +6 %; profiles/r03_headline_nt.txt)
+        static const bool ntAnySize = std::getenv("CUTENSOR_AMD_NT") != nullptr;   // tests: exercise the nt kernels on small read-once shapes
+        if (k.nt && !(tilesM == 1 && tilesN == 1 && (ntAnySize || 4.0 * L * (M * K + N * K) > 1.4 * 256.0 * 1024.0 * 1024.0))) continue;
         const uint64_t kTiles = (v.totK + k.bk - 1) / k.bk;
         // split-K candidates: 1, and powers of two up to what keeps >= 4 K-tiles per slice
         std::vector<uint32_t> splits = {1};
@@ -355,6 +360,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
             const double tFix = (c.splitK > 1) ? 3.0e-6 : 0.0;
             c.estimateUs = (std::max(tCompute, tMem) + tFix + 2.0e-6) * 1e6;
             if (k.fragPartials && k.pf == 3) c.estimateUs *= 0.999;   // tie-break for memory-bound estimates: the 3-deep ring wins by ~2 %
+            if (k.nt) c.estimateUs *= 0.96;                            // eligible (see above): ahead of its default-policy twin
             out.push_back(c);
         }
     }

@@ -73,9 +73,10 @@ __device__ __forceinline__ void store_wt_16(f32x4 v, BufRsrc rsrc, uint32_t byte
     (void)v; (void)rsrc; (void)byteOff;
 #endif
 }
+template <int AUX = 0>   // AUX = 2: nontemporal ("nt") — streamed once, not worth a line of the Infinity Cache
 __device__ __forceinline__ void lds_dma_16(BufRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, float* dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)laneBytes, (int)tileBytes, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)laneBytes, (int)tileBytes, 0, AUX);
 #else
     (void)rsrc; (void)laneBytes; (void)tileBytes; (void)dst;
 #endif
@@ -120,10 +121,11 @@ struct StreamOperand {
     }
 
     // issue this wave's pieces of one tile: X + src + offK bytes (wave-uniform) -> stage + piece
+    template <int AUX = 0>
     __device__ __forceinline__ void issue(BufRsrc X, uint32_t offKBytes, float* stage, int wave) const {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i)
-            lds_dma_16(X, src[i], offKBytes, stage + (wave + 4 * i) * 256);
+            lds_dma_16<AUX>(X, src[i], offKBytes, stage + (wave + 4 * i) * 256);
     }
 
     // per-lane constant part of the fragment address (floats) for the 16-row fragment at rbase
@@ -207,6 +209,7 @@ struct StreamCfg {
     static constexpr int ABL = ABL_;   // measurement-only: 1 = no refills (LDS + MFMA only), 2 = no MFMA (memory path only),
                                        // 3 = full kernel + wait-time accounting (slots 8-10 of the timing buffer),
                                        // 4 = full kernel (correct results), data movers at s_setprio 3
+                                       // 5 = full kernel (correct results), operands streamed with the nontemporal policy
     static constexpr int TM = BM / 32, TN = BN / 32;    // 16 x 16 fragments per wave (2 x 2 waves)
 };
 
@@ -297,8 +300,9 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         odo.init(p.gK, kBegin);
         auto issue = [&](int slot) {
             float* stage = lds + slot * STAGE;
-            oa.issue(A, odo.offA, stage, wave);
-            ob.issue(B, odo.offB, stage + OpA::FLOATS, wave);
+            constexpr int AUX = (Cfg::ABL == 5) ? 2 : 0;       // 5 = correct results, nontemporal operand stream
+            oa.template issue<AUX>(A, odo.offA, stage, wave);
+            ob.template issue<AUX>(B, odo.offB, stage + OpA::FLOATS, wave);
             odo.advance(p.gK);
         };
         if (tlog != nullptr && tid == 256) tlog[7] = __builtin_readcyclecounter();   // setup done, first issue
@@ -847,12 +851,20 @@ static hipError_t launch_stream(const GettParams& p, hipStream_t stream) {
 #define CTAMD_STREAM_ABL(bm, bn, la, lb, s, abl) \
     {bm, bn, kStreamBK, 2, 2, 1, la, lb, 512, s, 1, abl, &launch_stream<StreamCfg<bm, bn, la, lb, s, abl>>, 1},
 
+#define CTAMD_STREAM_NT(bm, bn, la, lb, s) \
+    {bm, bn, kStreamBK, 2, 2, 1, la, lb, 512, s, 1, 0, &launch_stream<StreamCfg<bm, bn, la, lb, s, 5>>, 1, 1},
+
 static const GettKernelInfo g_stream_table[] = {
     CTAMD_STREAM_KERNELS(CTAMD_STREAM_ENTRY)
     CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 1)
     CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 2)
     CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 3)
-    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 4)};
+    CTAMD_STREAM_ABL(96, 96, LAY_K, LAY_F, 4, 4)
+    // nontemporal operand stream (StreamCfg ABL = 5: correct results): the 3-deep 96 x 96 ring for the four layouts.  Measured on the
+    // headline shape: operands resident in the Infinity Cache 108 vs 114 TFLOP/s for the default policy (worse), operands from HBM
+    // 102-104 vs 99-100 (better) — so the planner ranks these only when the operands cannot be cache-resident (plan_contraction.cpp)
+    CTAMD_STREAM_NT(96, 96, LAY_K, LAY_F, 3) CTAMD_STREAM_NT(96, 96, LAY_F, LAY_F, 3)
+    CTAMD_STREAM_NT(96, 96, LAY_F, LAY_K, 3) CTAMD_STREAM_NT(96, 96, LAY_K, LAY_K, 3)};
 
 const GettKernelInfo* gett_f32_stream_kernels(int* count) {
     *count = (int)(sizeof(g_stream_table) / sizeof(g_stream_table[0]));

@@ -23,6 +23,8 @@ struct GettKernelInfo {
     hipError_t (*launch)(const GettParams&, hipStream_t);
     int fragPartials;    // 1: split-K partials are written in accumulator order (padded tiles), folded by
                          //    launch_splitk_reduce_frag; 0: row-major [M][N], launch_splitk_reduce
+    int nt;              // 1: operands are streamed with the nontemporal policy (no Infinity-Cache allocation): ranked only for
+                         //    problems that read every operand byte once and whose operands exceed the Infinity Cache anyway
 };
 
 // fp32 data, fp32 MFMA (v_mfma_f32_16x16x4_f32)

@@ -128,6 +128,29 @@ def test_every_candidate_kernel_and_split(env):
     kernels = {k for k, _ in seen}
     planned = {i for i in range(ct.lib.ctamdKernelCount()) if not ct.lib.ctamdKernelIsAblation(i)}
     missing = planned - kernels
+    # what is left are the nontemporal-stream twins of the ring kernel: ranked only for read-once problems beyond the Infinity
+    # Cache (test_read_once_contraction_beyond_the_infinity_cache_streams_nontemporal); a child process with CUTENSOR_AMD_NT set
+    # (read once per process) sweeps them on small one-tile shapes of all four layouts
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import torch, test_gpu_contraction as t\n"
+        "from cudalibrarysamples_amd import cutensor as ct, ops\n"
+        "env = (ct, ops, ops.Handle(), torch)\n"
+        "seen = set()\n"
+        "for ext, mA, mB, mC in [(dict(m=96, n=96, k=512), 'km', 'kn', 'mn'), (dict(m=96, n=96, k=512), 'mk', 'nk', 'mn'),\n"
+        "                        (dict(m=96, n=96, k=512), 'mk', 'kn', 'nm'), (dict(a=96, b=4, c=4, d=64, e=96), 'dcba', 'ebcd', 'ea')]:\n"
+        "    p0 = ops.contraction_plan(env[2], [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC, workspace_limit=1 << 28)\n"
+        "    n = ct.lib.ctamdCountCandidates(env[2].h, p0.op, 1 << 28); p0.destroy()\n"
+        "    for r in range(n):\n"
+        "        seen.add(t.run_contraction(env, ext, mA, mB, mC, alpha=1.25, beta=0.5, algo=r, seed=r)['kernel'])\n"
+        "print('KERNELS', sorted(seen))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, CUTENSOR_AMD_NT="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    nt_seen = set(eval(r.stdout.split("KERNELS", 1)[1].strip()))
+    missing -= nt_seen
     assert not missing, "GETT kernels never exercised: %s" % sorted(missing)
     assert any(s for _, s in seen)
 
@@ -170,6 +193,31 @@ def test_headline_einsum_full_size(env):
     np.testing.assert_allclose(row_ref[0], ref[5], rtol=1e-6)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4)
     del row
+
+
+def test_read_once_contraction_beyond_the_infinity_cache_streams_nontemporal(env):
+    """The headline equation with b = 128 (operands 2 x 201 MB = 1.5 x the 256-MiB Infinity Cache, one output tile: every operand
+    byte is read exactly once): the planner takes the nontemporal-stream twin of the ring kernel (GettKernelInfo::nt; measured +6 %
+    there, -5 % at b = 96 where most of the operands still fit); all 9216 outputs against fp64.  The headline itself (b = 64,
+    2 x 100 MB) keeps the default policy: back-to-back calls find it on-die."""
+    ct, ops, h, torch = env
+    ext = dict(a=96, b=128, c=64, d=64, e=96)
+    p = ops.contraction_plan(h, [ext[c] for c in "dcba"], "dcba", [ext[c] for c in "ebcd"], "ebcd", [96, 96], "ea", workspace_limit=1 << 30)
+    d = p.describe()
+    small = ops.contraction_plan(h, [64, 64, 64, 96], "dcba", [96, 64, 64, 64], "ebcd", [96, 96], "ea", workspace_limit=1 << 30)
+    assert d["kname"] == "gett_f32_stream_kernel" and d["kernel"] != small.describe()["kernel"] and d["splitK"] > 1, (d, small.describe())
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    A = torch.rand((96, 128, 64, 64), generator=g, device="cuda")     # row-major [a][b][c][d] == column-major modes d, c, b, a
+    B = torch.rand((64, 64, 128, 96), generator=g, device="cuda")     # [d][c][b][e]
+    C = torch.empty((96, 96), device="cuda")
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    ref = torch.einsum("abcd,dcbe->ae", A.double(), B.double())
+    torch.testing.assert_close(C.double(), ref, rtol=1e-4, atol=0.0)
+    p.destroy()
+    small.destroy()
 
 
 def test_contraction_sample_full_size_sampled(env):
