@@ -81,6 +81,21 @@ __global__ void __launch_bounds__(256) reduce_col_f32_kernel(const ReduceParams 
     f32x4 acc;
     for (int e = 0; e < 4; ++e) acc[e] = red_identity<float>(op);
     uint32_t r = rBegin;
+    // eight rows (8 x 16 B per lane) in flight per iteration while the reduced index walks ONE mode with a constant stride (the
+    // common case: no per-row offset arithmetic between the loads); four rows otherwise
+    if (p.red.n == 1) {
+        const int64_t step = p.red.stride[0][0];
+        const float* q = A + (int64_t)r * step;
+        for (; r + 8 <= rEnd; r += 8, q += 8 * step) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q + (int64_t)u * step));
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = red_apply<float>(op, acc[e], v[u][e]);
+        }
+    }
     for (; r + 4 <= rEnd; r += 4) {
         f32x4 v[4];
 #pragma unroll
