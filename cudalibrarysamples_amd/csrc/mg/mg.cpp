@@ -884,11 +884,15 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         cutensorHandle_t h = handle->handles[p.dev];
         const Shard s{p.dev, p.lo, p.hi};
         Restrict rs = restrict_of(s, p.q0, p.q1);
-        // work list of clip sets: the boxes of the contracted index space, each possibly split further ("peeled") below
-        std::vector<std::vector<Clip>> todo(boxes.rbegin(), boxes.rend());
-        std::set<std::string> written;     // regions of D (clips of C's labels) some sub-contraction of this piece already produces
+        // work list of clip sets: the boxes of the contracted index space, each possibly split further ("peeled") below.  acc: an
+        // earlier entry already writes this region of D — every box after the first (the boxes tile the CONTRACTED index space, all
+        // cover the piece's whole output), and every value but the first of a peeled contracted digit; peeled free digits inherit.
+        struct Work { std::vector<Clip> clips; bool acc; };
+        std::vector<Work> todo;
+        for (size_t bi = boxes.size(); bi-- > 0;) todo.push_back(Work{boxes[bi], bi > 0});
         while (!todo.empty() && st == CUTENSOR_STATUS_SUCCESS) {
-            const std::vector<Clip> box = todo.back();
+            const std::vector<Clip> box = todo.back().clips;
+            const bool boxAcc = todo.back().acc;
             todo.pop_back();
             rs.clips = box;
             View v[3];
@@ -945,23 +949,17 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
                     const std::pair<int64_t, int64_t> range = c->digit[(size_t)dj];
                     if (li != rs.pLabel && range.second - range.first >= 2) {
                         cutensorDestroyPlan(sub.plan);
+                        const bool contractedDigit = find_label(d.mC, universe[(size_t)li]) < 0;
                         for (int64_t val = range.second - 1; val >= range.first; --val) {      // pushed in reverse: executed in ascending order
                             c->digit[(size_t)dj] = {val, val + 1};
-                            todo.push_back(base);
+                            todo.push_back(Work{base, boxAcc || (contractedDigit && val > range.first)});
                         }
                         ++pl->peeled;
                         continue;
                     }
                 }
             }
-            std::string region;
-            for (const Clip& c : box) {
-                if (find_label(d.mC, universe[(size_t)c.label]) < 0) continue;     // a contracted label: same region of D
-                region += std::to_string(c.label) + ":" + std::to_string(c.wHi);
-                for (const auto& r : c.digit) region += "," + std::to_string(r.first) + "-" + std::to_string(r.second);
-                region += ";";
-            }
-            sub.accumulate = !written.insert(region).second;
+            sub.accumulate = boxAcc;
             p.subs.push_back(sub);
         }
         rs.clips.clear();

@@ -65,3 +65,13 @@ def test_blog_post_layouts_of_multi_device_runs_on_logical_devices(built, ndev, 
     assert "-> ok" in out and ("on %d device(s)" % ndev) in out
     gflops = float(out.split("GFLOPs/s")[0].split(",")[-1])
     assert gflops > 5000.0, out      # the mode-table kernel would be ~650
+
+
+def test_blog_post_layout_with_the_plan_level_peel(built):
+    """The same 8-device layout with the single-GPU library's peel switched off (CUTENSOR_AMD_PEEL=0): cuTENSORMg's own peel — a
+    block-index digit of the oversized group walked by the piece loop — keeps the local contractions on the tiled kernels."""
+    import os
+    exe = os.path.join(BIN, "multi_gpu")
+    r = subprocess.run([exe, "--blog", "8", "12", "--virtual"], capture_output=True, text=True, timeout=600, env=dict(os.environ, CUTENSOR_AMD_PEEL="0"))
+    assert r.returncode == 0 and "-> ok" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    assert float(r.stdout.split("GFLOPs/s")[0].split(",")[-1]) > 5000.0, r.stdout
