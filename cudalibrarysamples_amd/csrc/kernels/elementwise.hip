@@ -9,10 +9,13 @@
 // modes plus a linearised remainder (Ew2DParams).  Roofline: HBM; algorithmic bytes per element =
 // 2 * sizeof(T) (+ sizeof(T) when a gamma*C term is read) — elementwise_permute.cu:208.
 //
-//   EW_TRANSPOSE  D's stride-1 mode (dim0) differs from A's stride-1 mode (dim1).  A 64 x 64 tile
-//                 is read with 16-byte lanes along dim1 (256-B contiguous segments per row),
-//                 transposed 4x4 in registers, parked in LDS as [dim1][dim0] and written with
-//                 16-byte lanes along dim0.  Both HBM sides see >= 256-B segments.
+//   EW_TRANSPOSE  D's stride-1 mode (dim0) differs from A's stride-1 mode (dim1).  A T0 x 64 tile (T0 = 64 / 128 / 256
+//                 along dim0, chosen by the planner: the width of the WRITTEN row segment is what decides the rate) is read
+//                 with 16-byte lanes along dim1 (256-B contiguous segments per row), transposed 4x4 in registers, parked in
+//                 LDS as [dim1][dim0] and written with 16-byte lanes along dim0 (256-B / 512-B / 1-KiB segments).  One
+//                 workgroup per tile; interior tiles take an unguarded path (all loads issued before the first use); for
+//                 doubly-strided transposes the tile order goes rest-first with one contiguous eighth per XCD.  16-bit data:
+//                 the same with 8 x 8 register transposes on {128, 256} x {64, 128} tiles (ew_transpose_h16_wide_kernel).
 //   EW_ROWCOPY    A and D share the stride-1 mode: 16-byte lanes along it, 8 dim1-rows per
 //                 workgroup, no LDS.
 //   EW_GENERIC    anything else (odd extents, unaligned bases, 2- and 8-byte types): one element
