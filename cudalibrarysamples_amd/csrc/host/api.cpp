@@ -213,6 +213,10 @@ static bool peel_wide_contraction(const cutensorOperationDescriptor& desc, cuten
     if (desc.A.desc.dtype == HIP_C_32F || desc.A.desc.dtype == HIP_C_64F) return false;   // complex: the mode-table kernel is the only one
     inner = desc;
     peel.clear();
+    // 16-bit data: a peeled CONTRACTED mode would accumulate through D, i.e. round every partial sum to the 16-bit type — the
+    // kernels' contract is fp32 accumulation and ONE rounding.  Only free / batch modes are peeled for these types; an oversized K
+    // group stays with the mode-table kernel (which accumulates in full precision).
+    const bool h16 = dtype_size(desc.A.desc.dtype) == 2;
     int64_t launches = 1;
     auto idx = [](const TensorUse& t, int32_t l) { for (size_t i = 0; i < t.modes.size(); ++i) if (t.modes[i] == l) return (int)i; return -1; };
     for (int round = 0; round < 16; ++round) {
@@ -224,6 +228,7 @@ static bool peel_wide_contraction(const cutensorOperationDescriptor& desc, cuten
         int64_t bestExtent = 0;
         for (int g = 0; g < 4; ++g) {
             if ((int)gs[g]->size() <= kMaxGroupModes) continue;
+            if (g == 3 && h16) return false;
             for (const CanonMode& m : *gs[g]) {
                 // the label's own extent (a canonical mode may be a fused run; peeling its first label shortens the run)
                 const int ia = idx(inner.A, m.label), ib = idx(inner.B, m.label), ic = idx(inner.C, m.label);

@@ -877,6 +877,9 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         boxes.swap(next);
     }
     if (boxes.empty() || boxes.size() > 64) st = CUTENSOR_STATUS_NOT_SUPPORTED;
+    // 16-bit data: boxes accumulate through D, which would round every partial sum to the 16-bit type (the kernels' contract is fp32
+    // accumulation and one rounding) — a ragged contracted mode stays unsupported for these types
+    if (boxes.size() > 1 && es == 2) st = CUTENSOR_STATUS_NOT_SUPPORTED;
     pl->numBoxes = (int)boxes.size();
     for (Piece& p : pieces) {
         if (st != CUTENSOR_STATUS_SUCCESS) break;
@@ -930,6 +933,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
                 int best = -1;
                 for (int i = 0; i < std::min(nm, 64); ++i) {
                     if (count[grp[i]] <= 4 || (lab[i] & 7) == 7 || ext[i] < 2) continue;        // only digits (not w) of an oversized group
+                    if (es == 2 && grp[i] == 3) continue;                                     // 16-bit data: never accumulate through D
                     if (best < 0 || ext[i] < ext[best]) best = i;
                 }
                 if (best >= 0) {

@@ -363,7 +363,13 @@ def test_oversized_mode_groups_are_peeled_onto_the_tiled_kernels(built, case, dt
     plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
                                 dtype=ct.R_16BF if bf else ct.R_32F, workspace_limit=1 << 24)
     d = plan.describe()
-    assert d.get("peeled_modes") == want_peeled and d["kname"] != "gett_wide_kernel" and 2 <= d["peel_launches"] <= 64, d
+    k_oversized = sum(1 for c in set(mA) & set(mB) if c not in mC) > 4
+    if bf and k_oversized:
+        # 16-bit data: a peeled contracted mode would accumulate through D (one rounding to bf16 per launch instead of one in all);
+        # an oversized K group therefore stays with the mode-table kernel, which accumulates in full precision
+        assert d["kname"] == "gett_wide_kernel" and "peeled_modes" not in d, d
+    else:
+        assert d.get("peeled_modes") == want_peeled and d["kname"] != "gett_wide_kernel" and 2 <= d["peel_launches"] <= 64, d
     ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
     plan.contract(1.5, dA.data_ptr(), dB.data_ptr(), -0.5, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), plan.required_workspace)
     torch.cuda.synchronize()

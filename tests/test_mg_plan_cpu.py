@@ -258,6 +258,10 @@ def test_ragged_contracted_mode_is_planned_as_boxes(cm):
         assert con.describe()["numBoxes"] == 3
     with cm.Contraction([0, 1], modes, dict(i=128, j=128, k=192), block, dcount) as con:
         assert con.describe()["numBoxes"] == 1
+    # 16-bit data: the boxes would accumulate through D with one rounding to the 16-bit type each -> still refused
+    with pytest.raises(Exception) as ei:
+        cm.Contraction([0, 1], modes, dict(i=128, j=128, k=176), block, dcount, dtype=14)      # HIP_R_16BF
+    assert "NOT_SUPPORTED" in str(ei.value)
 
 
 def _blog_post_shapes(n, s):

@@ -18,6 +18,8 @@ def main():
                                                            "streaming fp32 and the 16-bit MFMA kernels")
     ap.add_argument("--all-types", action="store_true", help="also fp64, fp16 and complex<float> (the functional kernels)")
     ap.add_argument("--strided", action="store_true", help="give a third of the tensors padded (non-packed) strides")
+    ap.add_argument("--many-modes", action="store_true", help="3-6 small modes per group: groups beyond the tiled kernels' four digits "
+                                                              "(peeled into a host loop up to 64 launches, mode-table kernel beyond)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -28,13 +30,17 @@ def main():
     for case in range(args.cases):
         dtype = rnd.choice(["float32", "float32", "bfloat16"] + (["float64", "float16", "complex64"] if args.all_types else []))
         nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
-        labels = list("abcdefghij")
+        if args.many_modes:
+            nM, nN, nK, nL = rnd.randint(2, 6), rnd.randint(1, 5), rnd.randint(1, 6), rnd.choice([0, 0, 1, 2])
+        labels = list("abcdefghijklmnopqrstuvwxyz")
         rnd.shuffle(labels)
         M, N, K, L = [labels.pop() for _ in range(nM)], [labels.pop() for _ in range(nN)], [labels.pop() for _ in range(nK)], [labels.pop() for _ in range(nL)]
         ext = {}
         table = ((M, [8, 16, 24, 40, 96, 100, 7]), (N, [8, 16, 32, 48, 96, 13]), (K, [4, 8, 32, 64, 64, 96, 5]), (L, [2, 3]))
         if args.aligned:
             table = ((M, [8, 16, 24, 40, 96, 104, 264]), (N, [8, 16, 32, 48, 96, 120]), (K, [64, 64, 128, 192]), (L, [2, 3]))
+        if args.many_modes:
+            table = ((M, [2, 3, 4, 5, 8]), (N, [2, 3, 4, 6, 8]), (K, [2, 3, 4, 8]), (L, [2, 3]))
         for g, choices in table:
             for c in g:
                 ext[c] = rnd.choice(choices)
@@ -80,7 +86,8 @@ def main():
             fails += 1
             continue
         d = plan.describe()
-        kinds[(d.get("kname"), d["splitK"] > 1)] = kinds.get((d.get("kname"), d["splitK"] > 1), 0) + 1
+        kname = d.get("kname") + ("+peel" if d.get("peeled_modes") else "")
+        kinds[(kname, d["splitK"] > 1)] = kinds.get((kname, d["splitK"] > 1), 0) + 1
         ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
         plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
         torch.cuda.synchronize()
