@@ -184,6 +184,29 @@ def test_16bit_vector_permutes_are_exact(built, dtype):
     assert wide_seen == {128, 256}, wide_seen
 
 
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_full_reversal_takes_the_rest_first_per_xcd_tile_order(env, dtype):
+    """A[a,b,c] -> C[c,b,a] at 512^3 (bf16: 1024 x 512 x 1024): both the rows A is read by (pitch a*b) and the rows D is written by (pitch c*b) lie 1 MiB
+    apart, so the planner walks the tiles rest-first with one contiguous eighth of the id space per XCD (Ew2DParams::order = 1;
+    elementwise.hip ordered_tile).  Bit-exact against torch, fp32 and bf16 (wide 16-bit tiles), with a ragged variant whose
+    id space does not divide by eight."""
+    ct, ops, h, torch = env
+    tdt = getattr(torch, dtype)
+    cdt = ct.R_32F if dtype == "float32" else ct.R_16BF
+    wide = 1 if dtype == "float32" else 2        # 16-bit data: twice the extents for the same 1-MiB pitches
+    for n_a, n_b, n_c in ((512 * wide, 512, 512 * wide), (512 * wide, 515, 512 * wide)):
+        A = torch.rand((n_c, n_b, n_a), device="cuda").to(tdt)                 # column-major modes a, b, c
+        D = torch.empty((n_a, n_b, n_c), device="cuda", dtype=tdt)            # column-major modes c, b, a
+        p = ops.permutation_plan(h, [n_a, n_b, n_c], "abc", [n_c, n_b, n_a], "cba", dtype=cdt)
+        d = p.describe()
+        assert d["variant"] == 0 and d["order"] == 1 and d["tile0"] == 256, d
+        p.permute(1.0, A.data_ptr(), D.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(D, A.permute(2, 1, 0).contiguous())
+        p.destroy()
+        del A, D
+
+
 def test_permute_tensor_larger_than_4_gib(env):
     """Maximum sizes: a 5.4-GB matrix transposed and transposed back is bit-identical (64-bit element offsets in the
     tile kernels), and a strided sample of the intermediate matches the definition."""

@@ -18,6 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--wide", action="store_true", help="extents that are multiples of 64 / 128 / 256 (and near misses): the wide transposing tiles, "
+                                                        "their edge tiles and the rest-first tile order")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -74,11 +76,11 @@ def main():
         tdt = getattr(torch, dtype)
         n = rnd.randint(1, 5)
         labels = rnd.sample("abcdefgh", n)
-        ext = {c: rnd.choice(EXTENTS) for c in labels}
+        ext = {c: rnd.choice([64, 128, 192, 256, 320, 384, 512, 72, 136, 260, 2, 3, 5] if args.wide else EXTENTS) for c in labels}
         vol = 1
         for c in labels:
             vol *= ext[c]
-        if vol > (1 << 22):
+        if vol > (1 << (25 if args.wide else 22)):
             continue
         alpha, gamma, beta = rnd.choice([1.0, 0.5, -1.25]), rnd.choice([0.0, 1.0, -0.5]), rnd.choice([1.0, 0.25])
         try:
