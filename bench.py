@@ -260,6 +260,47 @@ def einsum_flow_line(calls=2000):
             "max_rel_diff_flow_vs_plan_once": d["max_rel_diff_flow_vs_plan_once"]}
 
 
+def live_pmc_traffic(timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then
+    WRITE_SIZE — never combined with tracing) over a short headline-only child of this script, read from the rocpd databases and
+    corrected as MI355X_MICROARCH.md prescribes (KiB units; FETCH_SIZE counts a wide coalesced read stream at half its bytes).
+    Returns a dict or None (no rocprofv3, a pass failed, nothing collected): the committed figure of the latest profile is then used."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, os.path.abspath(__file__), "--steps", "100", "--warmup", "10",
+                   "--no-cpu", "--no-secondary", "--no-pmc", "--burn-in-ms", "0"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            rows = list(c.execute("select kernel_name, avg(value), count(*) from counters_collection where kernel_name like '%ctamd%gett%' "
+                                  "and counter_name = ? group by kernel_name order by count(*) desc", (counter,)))
+            c.close()
+            if not rows:
+                return None
+            vals[counter] = {"kernel": rows[0][0][:100], "mean_KiB_per_launch": rows[0][1], "launches": rows[0][2]}
+        read_b = 2.0 * 1024.0 * vals["FETCH_SIZE"]["mean_KiB_per_launch"]
+        write_b = 1024.0 * vals["WRITE_SIZE"]["mean_KiB_per_launch"]
+        return {"hbm_bytes_per_launch": read_b + write_b, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+                "launches": min(vals["FETCH_SIZE"]["launches"], vals["WRITE_SIZE"]["launches"]), "kernel": vals["FETCH_SIZE"]["kernel"]}
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def newest_traffic_file():
     """profiles/*pmc_traffic_einsum.json of the latest round (names sort by round prefix; the un-prefixed round-1 file last)."""
     import glob
@@ -422,6 +463,8 @@ def main():
     ap.add_argument("--algo", type=str, default="default", help="default | patient | <candidate index>")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two live rocprofv3 --pmc passes for roofline.traffic (the committed "
+                                                          "figure of the latest profile is reported instead)")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--mg-timeout", type=int, default=300, help="seconds per attempt of the multi-device child process")
     ap.add_argument("--einsum-only", action="store_true", help=argparse.SUPPRESS)   # ranks spawned by a plain `--gpus N` launch
@@ -595,15 +638,24 @@ def main():
         # Counters cannot be read from inside the timed process, so the committed per-launch figure of the same kernel is
         # reported, else null.
         traffic = None
+        traffic_live = None
         traffic_file = newest_traffic_file()
         try:
             with open(traffic_file) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         except (OSError, ValueError, TypeError):
             traffic = None
+        traffic_committed = traffic
+        if world == 1 and not args.no_pmc and not args.no_secondary and not args.einsum_only:
+            traffic_live = live_pmc_traffic()     # measured in this run; the committed figure stays beside it
+            if traffic_live:
+                traffic = traffic_live["hbm_bytes_per_launch"]
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak if peak else None, "traffic": traffic,
-                "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, bytes per launch)" % os.path.relpath(traffic_file, ROOT)) if traffic else None,
+                "traffic_source": ("live: two rocprofv3 --pmc passes (FETCH_SIZE x 2 x 1024, WRITE_SIZE x 1024) over %d launches of a headline-only child of this run"
+                                   % traffic_live["launches"]) if traffic_live else
+                                  (("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, bytes per launch)" % os.path.relpath(traffic_file, ROOT)) if traffic else None),
+                "traffic_committed": traffic_committed, "traffic_over_algorithmic": (traffic / BYTES) if traffic else None,
                 "kernel": "%s<%dx%dx%d,w%dx%dx%d> (table index %d)" % (desc.get("kname", "gett_f32_kernel"), desc["bm"], desc["bn"], desc["bk"],
                                                                        desc["wm"], desc["wn"], desc["wk"], desc.get("kernel", -1)),
                 "launches": n, "mean_us": batch_ms * 1e3,
