@@ -401,6 +401,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
         if (e && e[0] == '4' && e[1] == 's') return 24;
         if (e && e[0] == '4' && e[1] == 'r') return 32;
+        if (e && e[0] == '4' && e[1] == 'v') return 40;
+        if (e && e[0] == '4' && e[1] == 'x') return 48;
         if (e && e[0] == '4') return 8;
         if (e && e[0] == 's') return 16;
         return 0;
@@ -433,8 +435,9 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
+    for (int other : {0, 48, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
+        if (other == 48 && layoutIdx % 4 != 0) continue;   // the 16x16x32 form exists for two K-contiguous operands; the other entries alias 40..47
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;
         out.push_back(c);

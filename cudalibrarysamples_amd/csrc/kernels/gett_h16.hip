@@ -37,440 +37,9 @@
 //
 // Roofline: bf16/fp16 MFMA (4096 flop/clk/CU dense); algorithmic flops = 2*L*M*N*K, algorithmic bytes =
 // |A| + |B| + |D| (16-bit elements).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include "params.h"
-#include "launch.h"
-#include "gett_common.h"
+#include "gett_h16_common.h"
 
 namespace ctamd {
-
-constexpr int kHBK   = 64;            // K-tile
-constexpr int kHTile = 256;           // BM = BN
-constexpr int kHalfBytes = 16384;     // one half-tile: 128 rows x 64 k x 2 B
-
-typedef short    s16x4 __attribute__((ext_vector_type(4)));
-typedef short    s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float    f32x16 __attribute__((ext_vector_type(16)));
-
-// Raw buffer descriptor (stride 0, num_records 2^32 - 1, gfx9 raw-buffer format word), built from
-// readfirstlane'd words so that the compiler knows it is wave-uniform: an inline-asm "s" operand that is
-// not provably uniform is silently given VGPRs.
-typedef int HRsrc __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint64_t h_uniform64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-// descriptor whose base is the (wave-uniform) byte address `addr`
-__device__ __forceinline__ HRsrc h_make_rsrc(uint64_t addr) {
-    HRsrc r;
-    r[0] = (int)(uint32_t)addr;
-    r[1] = (int)((uint32_t)(addr >> 32) & 0xffffu);
-    r[2] = -1;
-    r[3] = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ int64_t h_wave_min(int64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int64_t w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
-
-// 64 lanes x 16 B -> the 1-KiB LDS piece at byte address ldsByte (wave-uniform).  Hidden from the
-// compiler's wait-count bookkeeping on purpose: completion is counted by hand (CTAMD_H_VMCNT).
-// s_nop 4: the SGPR operands may come straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).
-template <bool PAD = true>
-__device__ __forceinline__ void h_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t ldsByte) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (PAD)
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc) : "memory");
-    else   // main loop: every SGPR operand was produced by the scalar ALU, or long ago
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(ldsByte), "v"(laneBytes), "s"(rsrc) : "memory");
-#else
-    (void)rsrc; (void)laneBytes; (void)ldsByte;
-#endif
-}
-
-#define CTAMD_H_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
-#define CTAMD_H_LGKM0()  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-template <bool BF>
-__device__ __forceinline__ f32x16 h_mfma(s16x8 a, s16x8 b, f32x16 c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    else              return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-#else
-    (void)a; (void)b; return c;
-#endif
-}
-
-__device__ __forceinline__ float h_to_float(uint16_t v, bool bf) {
-    if (bf) return __uint_as_float((uint32_t)v << 16);
-    return (float)__builtin_bit_cast(_Float16, v);
-}
-__device__ __forceinline__ uint16_t h_from_float(float f, bool bf) {
-    if (bf) {   // round to nearest even; NaN stays NaN
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    }
-    return __builtin_bit_cast(uint16_t, (_Float16)f);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Epilogue of the 16-bit kernels: D = alpha * acc + beta * C, one rounding to the 16-bit type.
-// An MFMA accumulator fragment holds one output column per lane (32 consecutive n in lanes 0-31, 16 rows in the 16
-// registers).  Storing it from the registers means 16 two-byte stores per lane and fragment (two-byte stores cost ~12x the
-// time per byte of 16-byte ones), and — worse — fully unrolled address arithmetic and conversions for every one of them:
-// the first form of this epilogue was 100+ KB of straight-line code that every workgroup streamed through once, and the
-// instruction fetch alone cost 30 us of a workgroup's 150 us on 8192^3 (K-sweep: 37 us fixed cost per workgroup, 7 us
-// without the epilogue).  Now a wave parks four fragments at a time in 16 KiB of LDS of its own (the operand ring is dead by
-// then: 64 ds_write_b32 in accumulator order, the only unrolled part) and a ROLLED loop of eight iterations turns them into
-// 16-byte row pieces: every lane reads 8 consecutive n of one row, adds beta * C, converts (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
-// and issues one 16-byte global store (rows of 64 contiguous bytes, 4 lanes each).  The vector form needs 8 consecutive n
-// contiguous and 16-byte aligned in D (and in C when beta != 0): checked once per workgroup (wave-uniform); otherwise a rolled
-// element-wise loop stores from the same LDS image with any strides.
-// ---------------------------------------------------------------------------------------------------------------------
-template <bool BF>
-__device__ __forceinline__ uint16_t h_round16(float f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (BF) return __builtin_bit_cast(uint16_t, (__bf16)f);      // round to nearest even, NaN stays NaN
-    else              return __builtin_bit_cast(uint16_t, (_Float16)f);
-#else
-    (void)f; return 0;
-#endif
-}
-
-struct HEpilogue {
-    const uint16_t* C;
-    uint16_t*       D;
-    float alpha, beta;
-    uint32_t Mtot, Ntot;
-    bool vecD, vecC;
-    bool flat;           // M and N are single modes: offsets are one multiplication, no digit decomposition
-    float* scratch;      // this wave's 16 KiB of LDS: four fragments [32 rows][32 n] fp32
-
-    __device__ __forceinline__ void init(const GettParams& p, uint32_t l, char* lds, int wave, int bytesPerWave = 16384) {
-        C = static_cast<const uint16_t*>(p.C);
-        D = static_cast<uint16_t*>(p.D);
-        int64_t oD, oC;
-        group_offset2<2>(p.gL, p.cStrideL, l, oD, oC);
-        D += oD;
-        C += oC;
-        alpha = p.alpha; beta = p.beta;
-        Mtot = p.gM.total; Ntot = p.gN.total;
-        scratch = reinterpret_cast<float*>(lds + wave * bytesPerWave);
-        // 8 consecutive n stay inside the fastest N mode and are contiguous; every other stride keeps 16-byte alignment
-        bool d = (p.gN.div[0].d % 8u == 0u) && p.gN.stride[1][0] == 1 && (reinterpret_cast<uintptr_t>(D) % 16u == 0u);
-        bool c = d && p.cStrideN[0] == 1 && (reinterpret_cast<uintptr_t>(C) % 16u == 0u);
-#pragma unroll
-        for (int i = 0; i < kMaxGroupModes; ++i) {
-            d = d && (p.gM.stride[1][i] % 8 == 0) && (i == 0 || p.gN.stride[1][i] % 8 == 0);
-            c = c && (p.cStrideM[i] % 8 == 0) && (i == 0 || p.cStrideN[i] % 8 == 0);
-        }
-        vecD = d; vecC = c;
-        flat = p.gM.n <= 1 && p.gN.n <= 1;
-    }
-    __device__ __forceinline__ void offsets(const GettParams& p, uint32_t m, uint32_t n, int64_t& offD, int64_t& offC) const {
-        if (flat) {
-            offD = (int64_t)m * p.gM.stride[1][0] + (int64_t)n * p.gN.stride[1][0];
-            offC = (int64_t)m * p.cStrideM[0] + (int64_t)n * p.cStrideN[0];
-        } else {
-            int64_t dm, cm, dn, cn;
-            group_offset2<1>(p.gM, p.cStrideM, m, dm, cm);
-            group_offset2<1>(p.gN, p.cStrideN, n, dn, cn);
-            offD = dm + dn; offC = cm + cn;
-        }
-    }
-
-    // park fragment F (0..3) of the current pass: element (row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31) = acc[r]
-    __device__ __forceinline__ void park(int F, const f32x16& acc, int lane) const {
-        float* st = scratch + F * 1024;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = alpha * acc[r];
-    }
-
-    // ---- 64-column form (the default kernel: a wave's two B-side fragments are adjacent columns) --------------------------
-    // Staging image [16 rows][64 columns] fp32 = 4 KiB per wave at `scratch`: half HALF (rows 16 HALF + [0,16)) of the fragment
-    // pair (c0: columns 0-31, c1: columns 32-63).  One store instruction then writes 8 rows x 128 contiguous bytes (whole cache
-    // lines; tools/ubench/store_pattern.hip: 128 MiB of such stores drain in 25.8 us against 34.2 us for 64-byte row pieces).
-    template <int HALF>
-    __device__ __forceinline__ void park_pair(const f32x16& c0, const f32x16& c1, int lane) const {
-        float* st = scratch + ((lane >> 5) * 4) * 64 + (lane & 31);
-#pragma unroll
-        for (int r = 8 * HALF; r < 8 * HALF + 8; ++r) {
-            const int row = (r & 3) + 8 * ((r >> 2) & 1);
-            st[row * 64]      = alpha * c0[r];
-            st[row * 64 + 32] = alpha * c1[r];
-        }
-    }
-    // rows mB + [0,16), columns nB + [0,64)
-    template <bool BF, int ST = 0>
-    __device__ __forceinline__ void flush_pair(const GettParams& p, uint32_t mB, uint32_t nB, int lane) const {
-        if (vecD && (beta == 0.f || vecC)) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int cidx = lane + 64 * it, row = cidx >> 3, piece = cidx & 7;
-                const float* src = scratch + row * 64 + piece * 8;
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-                const uint32_t m = mB + row, n = nB + 8 * piece;
-                if (m < Mtot && n < Ntot) {
-                    int64_t offD, offC;
-                    offsets(p, m, n, offD, offC);
-                    if (beta != 0.f) {
-                        const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
-#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
-                        CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
-                        CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
-#undef CTAMD_EP_C
-                    }
-                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
-                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // not read again by this kernel; keeps the operand panels in L2
-                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
-                    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
-                }
-            }
-            return;
-        }
-#pragma unroll 1
-        for (int row = 0; row < 16; ++row) {           // element-wise form (any strides): lane = column
-            const uint32_t m = mB + row, n = nB + lane;
-            if (m < Mtot && n < Ntot) {
-                int64_t offD, offC;
-                offsets(p, m, n, offD, offC);
-                float val = scratch[row * 64 + lane];
-                if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-                D[offD] = h_round16<BF>(val);
-            }
-        }
-    }
-
-    // ---- four-fragment form (four-wave and streamed kernels) ------------------------------------------------------------
-    // store the four parked fragments; fragment f covers rows mB + mHi (f >> 1) + mLo (f & 1) + [0, 32), columns alike
-    // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a scratch allocation is paid for at
-    // every dispatch)
-    // ST (measurement): 0 = nontemporal stores, 1 = plain, 2 = write-through (sc1)
-    template <bool BF, int ST = 0>
-    __device__ __forceinline__ void flush(const GettParams& p, uint32_t mB0, uint32_t mHi, uint32_t mLo, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane) const {
-        if (vecD) {
-#pragma unroll 2
-            for (int it = 0; it < 8; ++it) {              // fragment it >> 1, chunks (it & 1) * 64 + lane of its 128
-                const int f = it >> 1;
-                const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
-                const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
-                const int cidx = lane + 64 * (it & 1), row = cidx >> 2, piece = cidx & 3;
-                const float* src = scratch + f * 1024 + row * 32 + piece * 8;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
-                const uint32_t m = mB + row, n = nB + 8 * piece;
-                if (m < Mtot && n < Ntot) {
-                    int64_t offD, offC;
-                    offsets(p, m, n, offD, offC);
-                    f32x4 v0 = lo, v1 = hi;              // explicit elements below: nothing here may become a stack array
-                    if (beta != 0.f) {
-                        if (vecC) {
-                            const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
-#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
-                            CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
-                            CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
-#undef CTAMD_EP_C
-                        } else {
-#define CTAMD_EP_CS(E, V, I) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(C[oC_], BF); }
-                            CTAMD_EP_CS(0, v0, 0) CTAMD_EP_CS(1, v0, 1) CTAMD_EP_CS(2, v0, 2) CTAMD_EP_CS(3, v0, 3)
-                            CTAMD_EP_CS(4, v1, 0) CTAMD_EP_CS(5, v1, 1) CTAMD_EP_CS(6, v1, 2) CTAMD_EP_CS(7, v1, 3)
-#undef CTAMD_EP_CS
-                        }
-                    }
-                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
-                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // the result is not read again by this kernel
-                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
-                    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
-                }
-            }
-            return;
-        }
-        // element-wise form (any strides): lane = column, one row per iteration
-#pragma unroll 1
-        for (int it = 0; it < 4 * 32; ++it) {
-            const int f = it >> 5, row = it & 31;
-            const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
-            const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
-            if (lane < 32) {
-                const uint32_t m = mB + row, n = nB + lane;
-                if (m < Mtot && n < Ntot) {
-                    int64_t offD, offC;
-                    offsets(p, m, n, offD, offC);
-                    float val = scratch[f * 1024 + row * 32 + lane];
-                    if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-                    D[offD] = h_round16<BF>(val);
-                }
-            }
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
-// One operand (A rows or B columns) of the streamed K-tile.
-// ---------------------------------------------------------------------------------------------
-// IL (the default kernel's B operand): half-tile h holds the 32-row stripes {64 j + 32 h + [0,32)}, j = 0..3, of the 256 rows
-// instead of rows 128 h + [0,128) — the two fragments a wave owns (stripe j = wc of either half) are then ADJACENT columns of
-// the output tile, and the epilogue stores whole 128-byte lines.
-template <int LAY, int NW = 8, bool IL = false>
-struct HOperand {
-    static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
-    // Byte offset of this lane's 16-byte unit, [half-tile][piece i of this wave], for the K-tile at k = 0 — relative to
-    // `base`, the smallest such offset in the wave: a workgroup tile spans far less than 2^32 bytes whatever the size of
-    // the tensor, and `base` (64 bits, wave-uniform) goes into the buffer descriptor.
-    uint32_t src[2][kPieces];
-    uint64_t base;
-
-    __device__ __forceinline__ void init(const ModeGroup& gFree, int64_t strideK0, uint32_t row0, int wave, int lane) {
-        int64_t off[2][kPieces];
-        int64_t mn = INT64_MAX;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < kPieces; ++i) {
-                const int c = wave + NW * i;                     // 1-KiB piece of the half-tile
-                if constexpr (LAY == LAY_K) {
-                    const int r = 8 * c + (lane >> 3), p = lane & 7;
-                    const int u = p ^ ((r >> 1) & 7);
-                    uint32_t row = row0 + (IL ? 64 * (r >> 5) + 32 * h + (r & 31) : 128 * h + r);
-                    if (row >= gFree.total) row = gFree.total - 1;   // clamped rows feed outputs that are never stored
-                    off[h][i] = (group_offset<0>(gFree, row) + 8 * u) * 2;
-                } else {
-                    const int kk = 4 * c + (lane >> 4), p = lane & 15;
-                    const int u = p ^ (4 * ((lane >> 4) & 3));
-                    uint32_t row = row0 + (IL ? 64 * (u >> 2) + 32 * h + 8 * (u & 3) : 128 * h + 8 * u);
-                    if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
-                    off[h][i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
-                }
-                mn = off[h][i] < mn ? off[h][i] : mn;
-            }
-        const int64_t mnW = (int64_t)h_uniform64((uint64_t)h_wave_min(mn));
-        base = (uint64_t)mnW;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < kPieces; ++i) src[h][i] = (uint32_t)(off[h][i] - mnW);
-    }
-
-    // X: descriptor of (operand + batch offset + this wave's base + the K-tile's offset)
-    template <bool PAD = true>
-    __device__ __forceinline__ void issue(HRsrc X, int h, uint32_t slotByte, int wave) const {
-#pragma unroll
-        for (int i = 0; i < kPieces; ++i) h_dma16<PAD>(X, src[h][i], slotByte + (uint32_t)(wave + NW * i) * 1024u);
-    }
-    template <bool PAD = true>
-    __device__ __forceinline__ void issue_piece(HRsrc X, int h, int i, uint32_t slotByte, int wave) const {
-        h_dma16<PAD>(X, src[h][i], slotByte + (uint32_t)(wave + NW * i) * 1024u);
-    }
-};
-
-// Per-lane constant parts of the fragment addresses (bytes inside a half-tile slot).
-//   LAY_K: offK[s], s = 16-k step 0..3, for any 32-row fragment base rb: + rb * 128
-//   LAY_F: offF, depends on (rb >> 5) through the swizzle; + s * 4096 + h * 1024
-__device__ __forceinline__ uint32_t h_offK(int lane, int s) {
-    const int x0 = (lane >> 5) ^ ((lane >> 1) & 7);
-    return (uint32_t)((lane & 31) * 128 + (((x0 ^ (2 * s)) & 7) << 4));
-}
-__device__ __forceinline__ uint32_t h_offF(int lane, int rbq) {
-    const int g = lane >> 4, i = lane & 15;
-    const int kk = 8 * (g >> 1) + (i >> 2);
-    const int u = (((rbq ^ (i >> 2)) & 3) << 2) | (2 * (g & 1) + ((i >> 1) & 1));
-    return (uint32_t)(kk * 256 + (u << 4) + 8 * (i & 1));
-}
-
-template <int LAY>
-__device__ __forceinline__ s16x8 h_read_frag(const char* slot, int rb, int s, const uint32_t (&offK)[4], uint32_t offF) {
-    if constexpr (LAY == LAY_K) {
-        return *reinterpret_cast<const s16x8*>(slot + rb * 128 + offK[s]);
-    } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-        typedef s16x4 __attribute__((address_space(3))) * lptr;
-        const char* p = slot + s * 4096 + offF;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 1024));
-        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#else
-        (void)slot; (void)rb; (void)s; (void)offK; (void)offF; return s16x8{};
-#endif
-    }
-}
-
-// A fresh copy of the kernel's argument block (the kernel's only parameter, at offset 0 of the kernarg segment), read
-// through a laundered pointer so that the loads cannot be merged with earlier ones: only the fields used are loaded.
-__device__ __forceinline__ void h_reload_params(GettParams& q) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    typedef const __attribute__((address_space(4))) uint32_t* wptr;
-    wptr w = (wptr)kp;
-    uint32_t* d = reinterpret_cast<uint32_t*>(&q);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(GettParams) / 4); ++i) d[i] = w[i];
-#else
-    (void)q;
-#endif
-}
-
-// Wave-uniform walk over the K-tiles of the contraction: byte offsets of tile t in A and B.  Fast-K: the
-// fastest contracted digit's extent is a multiple of kHBK, so a tile never straddles a digit boundary.
-struct HOdometer {
-    uint32_t j0, n0, j1, e1, hi;
-    uint64_t offA, offB, stepA, stepB, wrapA, wrapB;      // bytes, modulo 2^64
-    __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
-        const uint32_t E0 = gK.div[0].d;
-        n0 = sgpr(E0 / kHBK);
-        e1 = sgpr(gK.div[1].d);
-        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
-        j0 = sgpr((k0 - q0 * E0) / kHBK);
-        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
-        j1 = sgpr(q0 - hi * e1);
-        offA = h_uniform64((uint64_t)(group_offset<0>(gK, k0) * 2));
-        offB = h_uniform64((uint64_t)(group_offset<1>(gK, k0) * 2));
-        stepA = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[0][0] * 2));
-        stepB = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[1][0] * 2));
-        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
-        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
-    }
-    __device__ __forceinline__ void carry(const ModeGroup& gK) {
-        const uint32_t k = hi * e1 * gK.div[0].d;
-        if (k < gK.total) {
-            offA = h_uniform64((uint64_t)(group_offset<0>(gK, k) * 2));
-            offB = h_uniform64((uint64_t)(group_offset<1>(gK, k) * 2));
-        }
-    }
-    __device__ __forceinline__ void advance(const ModeGroup& gK) {
-        const bool c0 = (j0 + 1 == n0);
-        j0 = c0 ? 0u : j0 + 1;
-        offA += c0 ? wrapA : stepA;
-        offB += c0 ? wrapB : stepB;
-        j1 += c0 ? 1u : 0u;
-        if (j1 == e1) {   // carry beyond the second digit (rare)
-            j1 = 0;
-            hi += 1;
-            carry(gK);
-        }
-    }
-};
 
 // TIMED (measurement-only instantiation, selected with CUTENSOR_AMD_H16_TIMED=1): waves 0 and 4 of workgroup 0
 // record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
@@ -1427,7 +996,10 @@ __global__ void __launch_bounds__(512, 2) gett_h16s_kernel(const GettParams p) {
 // behind a counted vmcnt.  Per 32-deep K-tile a wave issues 32 MFMAs (two k-steps of 16), 16 fragment reads (two register
 // sets), 8 LDS-DMA pieces, and meets the workgroup once — in front of k-step 1, whose fragments are already in registers.
 // =====================================================================================================
-template <bool BF, int LA, int LB, int NS>
+// SPREAD (CUTENSOR_AMD_H16_SPREAD=1, round 3 probe): the eight pieces of a K-tile go out one per FOUR MFMAs over a whole tile time —
+// the A pieces (0..3) in k-step 1 of tile t, the B pieces (4..7) in k-step 0 of tile t + 1 — instead of one per two MFMAs
+// in k-step 1 only; the deep ring is what allows it (the two-buffer kernel's issue window ends at its landing deadline).
+template <bool BF, int LA, int LB, int NS, bool SPREAD = false>
 __global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[NS * 4 * kSHalfBytes];
     prefetch_kernarg<(int)sizeof(GettParams)>();
@@ -1486,17 +1058,20 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p)
         else                          obHi.template issue<PAD>(h_make_rsrc(bBHi + odo.offB), q_ - 2, slot_, wave + 4); \
     }
     int tNext = 0;                                // K-tile the odometer describes
+    // SPREAD: the last buffer only gets its A pieces here and the odometer stays on that tile (k-step 0 of tile 0 sends the rest)
 #define CTAMD_Q_FILL(P)                                                                                             \
     if constexpr ((P) < NS) {                                                                                      \
         CTAMD_Q_DMA((P) < NS ? (P) : 0, 0, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 1, true)                          \
         CTAMD_Q_DMA((P) < NS ? (P) : 0, 2, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 3, true)                          \
-        CTAMD_Q_DMA((P) < NS ? (P) : 0, 4, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 5, true)                          \
-        CTAMD_Q_DMA((P) < NS ? (P) : 0, 6, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 7, true)                          \
-        ++tNext;                                                                                                   \
-        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+        if constexpr (!(SPREAD && (P) == NS - 1)) {                                                                \
+            CTAMD_Q_DMA((P) < NS ? (P) : 0, 4, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 5, true)                      \
+            CTAMD_Q_DMA((P) < NS ? (P) : 0, 6, true) CTAMD_Q_DMA((P) < NS ? (P) : 0, 7, true)                      \
+            ++tNext;                                                                                               \
+            if (tNext < nTiles) odo.advance(p.gK);                                                                 \
+        }                                                                                                          \
     }
     CTAMD_Q_FILL(0) CTAMD_Q_FILL(1) CTAMD_Q_FILL(2) CTAMD_Q_FILL(3) CTAMD_Q_FILL(4)
-    CTAMD_H_VMCNT(8 * (NS - 1));                  // this wave's pieces of tile 0
+    CTAMD_H_VMCNT(8 * (NS - 1) - (SPREAD ? 4 : 0));   // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
 
     f32x16 acc[4][4];
@@ -1520,14 +1095,17 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p)
     // k-step 0 of the tile in buffer P: one fragment read of k-step 1 per two MFMAs of k-step 0
 #define CTAMD_Q_G0(P, G)                                                                                            \
     CTAMD_Q_READ(P, 1, 1, G)                                                                                       \
-    CTAMD_Q_MFMA(0, 2 * (G)) CTAMD_Q_MFMA(0, 2 * (G) + 1)                                                          \
+    CTAMD_Q_MFMA(0, 2 * (G))                                                                                       \
+    if constexpr (SPREAD && ((G) & 1)) CTAMD_Q_DMA(((P) + NS - 1) % NS, 4 + ((G) >> 1), false)                     \
+    CTAMD_Q_MFMA(0, 2 * (G) + 1)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
     // k-step 1 (behind the barrier): one read of the next tile's k-step 0 (buffer PN) and one piece of tile t + NS (into buffer
     // P, which nobody reads any more) per two MFMAs
 #define CTAMD_Q_G1(P, PN, G)                                                                                        \
     CTAMD_Q_READ(PN, 0, 0, G)                                                                                      \
     CTAMD_Q_MFMA(1, 2 * (G))                                                                                       \
-    CTAMD_Q_DMA(P, G, false)                                                                                       \
+    if constexpr (!SPREAD) CTAMD_Q_DMA(P, G, false)                                                                \
+    else if constexpr (((G) & 1) == 0) CTAMD_Q_DMA(P, (G) >> 1, false)                                             \
     CTAMD_Q_MFMA(1, 2 * (G) + 1)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_Q_SYNC()                                                                                              \
@@ -1541,11 +1119,11 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p)
         constexpr int PN_ = ((P) + 1) % NS;                                                                        \
         CTAMD_Q_G0(P, 0) CTAMD_Q_G0(P, 1) CTAMD_Q_G0(P, 2) CTAMD_Q_G0(P, 3)                                        \
         CTAMD_Q_G0(P, 4) CTAMD_Q_G0(P, 5) CTAMD_Q_G0(P, 6) CTAMD_Q_G0(P, 7)                                        \
+        if constexpr (SPREAD) { ++tNext; if (tNext < nTiles) odo.advance(p.gK); }                                  \
         CTAMD_Q_SYNC()                                                                                             \
         CTAMD_Q_G1(P, PN_, 0) CTAMD_Q_G1(P, PN_, 1) CTAMD_Q_G1(P, PN_, 2) CTAMD_Q_G1(P, PN_, 3)                    \
         CTAMD_Q_G1(P, PN_, 4) CTAMD_Q_G1(P, PN_, 5) CTAMD_Q_G1(P, PN_, 6) CTAMD_Q_G1(P, PN_, 7)                    \
-        ++tNext;                                                                                                   \
-        if (tNext < nTiles) odo.advance(p.gK);                                                                     \
+        if constexpr (!SPREAD) { ++tNext; if (tNext < nTiles) odo.advance(p.gK); }                                 \
     }
 
     // first fragments of tile 0
@@ -1606,7 +1184,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4s_kernel(const GettParams p)
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4s(const GettParams& p, hipStream_t stream) {
     static const int ns = [] { const char* e = getenv("CUTENSOR_AMD_H16_STAGES"); return e ? atoi(e) : 5; }();
-    if (ns == 4) hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    static const bool spread = [] { const char* e = getenv("CUTENSOR_AMD_H16_SPREAD"); return e && e[0] == '1'; }();
+    if (spread) hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 4, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    else if (ns == 4) hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gett_h16w4s_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -1784,9 +1364,21 @@ static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16W4R_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4R_ENTRY(false, LAY_K, LAY_F)
     CTAMD_H16W4R_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4R_ENTRY(false, LAY_F, LAY_F)};
 
+// entries 40..47: the four-wave kernel with the lean instruction stream (gett_h16v.hip), 48..55: its 16x16x32 form; same order
 const GettKernelInfo* gett_h16_kernels(int* count) {
-    *count = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
-    return g_h16_table;
+    constexpr int nHere = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
+    struct All { GettKernelInfo e[nHere + 16]; int n; };
+    static const All all = [] {
+        All a{};
+        for (int i = 0; i < nHere; ++i) a.e[i] = g_h16_table[i];
+        int nv = 0;
+        const GettKernelInfo* v = gett_h16v_kernels(&nv);
+        a.n = nHere;
+        for (int i = 0; i < nv && i < 16; ++i) a.e[a.n++] = v[i];
+        return a;
+    }();
+    *count = all.n;
+    return all.e;
 }
 
 }  // namespace ctamd

@@ -1,0 +1,532 @@
+// gett_h16v.hip — the four-wave 16-bit GETT kernel with a LEAN instruction stream (CUTENSOR_AMD_H16_WAVES=4v; round 3).
+//
+// Same arithmetic, tile (256 x 256 x 64), LDS images, source-side swizzles, MFMA order, barrier placement and epilogue as
+// gett_h16w4_kernel (gett_h16.hip): 4 waves as 2 (M) x 2 (N), one per SIMD, a 128 x 128 quadrant each (4 x 4 accumulator
+// fragments, 256 AGPRs), two 64-deep K-tiles in LDS, ONE barrier per K-tile.  What changes is everything BETWEEN the MFMAs.
+// With one wave per SIMD every instruction the wave issues sits in front of its own MFMAs (nothing else fills the issue slots),
+// and the matrix pipe only stays busy while at most ~6 other instructions separate two MFMAs.  The compiler's version of the
+// four-wave loop carried ~230 non-MFMA instructions per K-tile (64 MFMAs), the vendor's hand-written kernel of the same
+// structure ~95 (NOTES.md, profiles/r03_h16_vendor_pmc_instruction_mix.txt).  Here:
+//   * LDS-DMA destination: M0 = (one SGPR: ring base + wave * 1 KiB) + a literal, formed by the s_add_u32 that writes M0 —
+//     instead of 32 loop-invariant SGPR addresses, most of which lived in VGPR lanes (v_readlane -> s_mov m0 per piece);
+//   * fragment reads: 16 address registers (operand x buffer x k-step or fragment), every other term in the 16-bit offset
+//     field of the ds_read — instead of a v_add per read;
+//   * K odometer: the descriptor bases themselves advance (s_add_u32 / s_addc_u32 by a selected step), digit 0 by a countdown,
+//     and ONE countdown covers both rare events (carry past the second K digit, end of the K range: steps become zero);
+//     ~14 scalar instructions per K-tile spread over three MFMA pairs — instead of ~60 in one block behind a branch.
+// Roofline and algorithmic bytes as in gett_h16.hip.
+#include "gett_h16_common.h"
+
+namespace ctamd {
+
+typedef __attribute__((address_space(3))) const s16x8* VLdsVec8;
+typedef s16x4 __attribute__((address_space(3))) * VLdsVec4;
+
+// 64 lanes x 16 B -> the 1-KiB LDS piece at byte address waveLds + IMM (waveLds wave-uniform).  PAD: the SGPR operands may come
+// straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).  Completion is counted by hand (CTAMD_H_VMCNT).
+template <uint32_t IMM, bool PAD>
+__device__ __forceinline__ void v_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t waveLds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PAD)
+        asm volatile("s_nop 4\n\ts_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(waveLds), "v"(laneBytes), "s"(rsrc), "i"(IMM) : "memory", "scc");
+    else
+        asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(waveLds), "v"(laneBytes), "s"(rsrc), "i"(IMM) : "memory", "scc");
+#else
+    (void)rsrc; (void)laneBytes; (void)waveLds;
+#endif
+}
+
+__device__ __forceinline__ HRsrc v_rsrc(uint64_t addr) {      // addr is a valid device address: bits 48..63 are zero
+    HRsrc r;
+    r[0] = (int)(uint32_t)addr;
+    r[1] = (int)(uint32_t)(addr >> 32);
+    r[2] = -1;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// One fragment (32 rows x 16 k) from LDS byte address base + IMM.  LAY_K: one ds_read_b128; LAY_F: two transposing reads.
+template <int LAY, int IMM>
+__device__ __forceinline__ s16x8 v_read(uint32_t base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LAY == LAY_K) {
+        return *(VLdsVec8)(uintptr_t)(base + (uint32_t)IMM);
+    } else {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM + 1024u));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#else
+    (void)base; return s16x8{};
+#endif
+}
+
+// K odometer over the descriptor bases (bytes).  K index = j0 * 64 + E0 * (j1 + e1 * hi) as in HOdometer; here digit 0 is a
+// countdown and `untilEvent` counts the advances up to the next rare event.  Exactly nTiles - 1 advances move the bases
+// (K-tiles 1 .. nTiles - 1 of this workgroup's slice); any further call leaves them where they are (the last tile is re-staged,
+// never read).
+struct VOdometer {
+    uint64_t addrA, addrB, stepA, stepB, wrapA, wrapB;     // hot
+    uint32_t untilWrap, n0, untilEvent;                    // hot
+    uint32_t left, carryLen, hi, e1, carryPending;         // cold (event path)
+    uint64_t baseA, baseB;                                 // cold: descriptor bases at K index 0
+
+    __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0, uint32_t nTiles, uint64_t bA, uint64_t bB) {
+        const uint32_t E0 = gK.div[0].d;
+        n0 = sgpr(E0 / kHBK);
+        e1 = sgpr(gK.div[1].d);
+        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
+        const uint32_t j0 = (k0 - q0 * E0) / kHBK;
+        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
+        const uint32_t j1 = q0 - hi * e1;
+        baseA = bA;
+        baseB = bB;
+        addrA = h_uniform64(bA + (uint64_t)(group_offset<0>(gK, k0) * 2));
+        addrB = h_uniform64(bB + (uint64_t)(group_offset<1>(gK, k0) * 2));
+        stepA = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[0][0] * 2));
+        stepB = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[1][0] * 2));
+        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
+        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
+        untilWrap = sgpr(n0 - j0);
+        carryLen = sgpr(n0 * e1);
+        const uint32_t untilCarry = (e1 - j1) * n0 - j0;
+        left = sgpr(nTiles - 1u);
+        carryPending = 0;
+        untilEvent = 1;
+        next_segment(untilCarry);
+    }
+    // the valid advances that are left are cut into segments that end at a carry past digit 1 or at the end of the K range
+    __device__ __forceinline__ void next_segment(uint32_t toCarry) {
+        if (left == 0u) {
+            stepA = stepB = wrapA = wrapB = 0;
+            untilEvent = 0x7fffffffu;
+            carryPending = 0;
+        } else {
+            const uint32_t seg = toCarry < left ? toCarry : left;
+            left = sgpr(left - seg);
+            carryPending = sgpr(seg == toCarry ? 1u : 0u);
+            untilEvent = sgpr(seg);
+        }
+    }
+    __device__ __forceinline__ void advance_a() {          // digit 0 and the A base
+        untilWrap -= 1u;
+        addrA += (untilWrap == 0u) ? wrapA : stepA;
+    }
+    __device__ __forceinline__ void advance_b() {          // the B base, digit 0 reloaded
+        addrB += (untilWrap == 0u) ? wrapB : stepB;
+        untilWrap = (untilWrap == 0u) ? n0 : untilWrap;
+    }
+    __device__ __forceinline__ void advance_event(const ModeGroup& gK) {
+        untilEvent -= 1u;
+        if (__builtin_expect(untilEvent == 0u, 0)) {
+            if (carryPending != 0u) {                      // the advance just made wrapped digit 1: bases from the full index
+                hi += 1u;
+                const uint32_t k = hi * e1 * gK.div[0].d;
+                if (k < gK.total) {
+                    addrA = h_uniform64(baseA + (uint64_t)(group_offset<0>(gK, k) * 2));
+                    addrB = h_uniform64(baseB + (uint64_t)(group_offset<1>(gK, k) * 2));
+                }
+            }
+            next_segment(carryLen);
+        }
+    }
+};
+
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    HOperand<LA, 4> oa;
+    HOperand<LB, 4> ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    // descriptor base = operand + batch offset + this wave's smallest piece offset (+ the K-tile's offset: the odometer)
+    const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
+    const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
+    VOdometer odo;
+    odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+
+    // fragment-read address registers: [buffer][k-step] for a K-contiguous operand (immediate: 4096 x fragment), [buffer][fragment]
+    // for a free-contiguous one (immediate: 4096 x k-step); opaque, so that they stay registers instead of becoming an add per read
+    uint32_t rdA[2][4], rdB[2][4];
+#pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            rdA[P][x] = ldsBase + (uint32_t)((P * 4 + wr) * kHalfBytes) + (LA == LAY_K ? h_offK(lane, x) : h_offF(lane, x));
+            rdB[P][x] = ldsBase + (uint32_t)((P * 4 + 2 + wc) * kHalfBytes) + (LB == LAY_K ? h_offK(lane, x) : h_offF(lane, x));
+            asm volatile("" : "+v"(rdA[P][x]));
+            asm volatile("" : "+v"(rdB[P][x]));
+        }
+
+    // piece N = 0..15 of the K-tile the odometer describes, into buffer P: operand half q = N >> 2 (A0, A1, B0, B1), piece i = N & 3
+    // of this wave (1-KiB piece wave + 4 i of the half-tile)
+#define CTAMD_V_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        constexpr uint32_t imm_ = (uint32_t)(((P) * 4 + q_) * kHalfBytes + i_ * 4096);                             \
+        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[q_][i_], waveLds);                      \
+        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[q_ - 2][i_], waveLds);                                   \
+    }
+#define CTAMD_V_DMA8(P, N0, PAD)                                                                                    \
+    CTAMD_V_DMA(P, (N0) + 0, PAD) CTAMD_V_DMA(P, (N0) + 1, PAD) CTAMD_V_DMA(P, (N0) + 2, PAD) CTAMD_V_DMA(P, (N0) + 3, PAD) \
+    CTAMD_V_DMA(P, (N0) + 4, PAD) CTAMD_V_DMA(P, (N0) + 5, PAD) CTAMD_V_DMA(P, (N0) + 6, PAD) CTAMD_V_DMA(P, (N0) + 7, PAD)
+#define CTAMD_V_ADVANCE() { odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK); }
+
+    // ---- prologue: K-tile 0 complete, the first half of K-tile 1 ---------------------------------------------
+    CTAMD_V_DMA8(0, 0, true) CTAMD_V_DMA8(0, 8, true)
+    CTAMD_V_ADVANCE()
+    CTAMD_V_DMA8(1, 0, true)
+    CTAMD_H_VMCNT(8);                             // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s & 1
+
+    // fragment F = 0..7 of k-step S from buffer P into register set SET: F < 4 -> B columns 32 F, else A rows 32 (F - 4)
+#define CTAMD_V_READ(P, S, SET, F)                                                                                  \
+    {                                                                                                              \
+        if constexpr ((F) < 4) {                                                                                   \
+            if constexpr (LB == LAY_K) b[SET][F] = v_read<LB, 4096 * (F)>(rdB[P][S]);                              \
+            else b[SET][F] = v_read<LB, 4096 * (S)>(rdB[P][F]);                                                    \
+        } else {                                                                                                   \
+            if constexpr (LA == LAY_K) a[SET][(F) - 4] = v_read<LA, 4096 * ((F) - 4)>(rdA[P][S]);                  \
+            else a[SET][(F) - 4] = v_read<LA, 4096 * (S)>(rdA[P][(F) - 4]);                                        \
+        }                                                                                                          \
+    }
+#define CTAMD_V_MFMA(SET, M) acc[(M) >> 2][(M) & 3] = h_mfma<BF>(a[SET][(M) >> 2], b[SET][(M) & 3], acc[(M) >> 2][(M) & 3]);
+    // k-step S < 3: one fragment read of step S + 1 per two MFMAs of step S.  k-step 0 also carries the second half (pieces
+    // 8..15) of the tile being staged into the other buffer; k-step 1 the odometer (three pairs)
+#define CTAMD_V_PAIR(P, S, F)                                                                                       \
+    CTAMD_V_READ(P, (S) + 1, ((S) + 1) & 1, F) CTAMD_V_MFMA((S) & 1, 2 * (F))                                      \
+    if constexpr ((S) == 0) CTAMD_V_DMA((P) ^ 1, 8 + (F), false)                                                   \
+    if constexpr ((S) == 1 && (F) == 1) odo.advance_a();                                                           \
+    if constexpr ((S) == 1 && (F) == 3) odo.advance_b();                                                           \
+    if constexpr ((S) == 1 && (F) == 5) odo.advance_event(p.gK);                                                   \
+    CTAMD_V_MFMA((S) & 1, 2 * (F) + 1)                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_V_STEP(P, S)                                                                                          \
+    CTAMD_V_PAIR(P, S, 0) CTAMD_V_PAIR(P, S, 1) CTAMD_V_PAIR(P, S, 2) CTAMD_V_PAIR(P, S, 3)                        \
+    CTAMD_V_PAIR(P, S, 4) CTAMD_V_PAIR(P, S, 5) CTAMD_V_PAIR(P, S, 6) CTAMD_V_PAIR(P, S, 7)
+    // k-step 3 (behind the barrier): reads of the next tile's step 0 (other buffer), the first half (pieces 0..7) of tile
+    // t + 2 into this buffer, MFMAs of step 3 — a read and a piece alternate, one per MFMA
+#define CTAMD_V_LAST2(P, F)                                                                                         \
+    CTAMD_V_READ((P) ^ 1, 0, 0, F)                                                                                 \
+    CTAMD_V_MFMA(1, 2 * (F)) __builtin_amdgcn_sched_barrier(0);                                                    \
+    CTAMD_V_DMA(P, F, false)                                                                                       \
+    CTAMD_V_MFMA(1, 2 * (F) + 1) __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_V_TILE(P)                                                                                             \
+    CTAMD_V_STEP(P, 0) CTAMD_V_STEP(P, 1) CTAMD_V_STEP(P, 2)                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_H_LGKM0();                                                                                               \
+    CTAMD_H_VMCNT(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_V_LAST2(P, 0) CTAMD_V_LAST2(P, 1) CTAMD_V_LAST2(P, 2) CTAMD_V_LAST2(P, 3)                                \
+    CTAMD_V_LAST2(P, 4) CTAMD_V_LAST2(P, 5) CTAMD_V_LAST2(P, 6) CTAMD_V_LAST2(P, 7)
+
+    // first fragments of tile 0
+    CTAMD_V_READ(0, 0, 0, 0) CTAMD_V_READ(0, 0, 0, 1) CTAMD_V_READ(0, 0, 0, 2) CTAMD_V_READ(0, 0, 0, 3)
+    CTAMD_V_READ(0, 0, 0, 4) CTAMD_V_READ(0, 0, 0, 5) CTAMD_V_READ(0, 0, 0, 6) CTAMD_V_READ(0, 0, 0, 7)
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_V_TILE(0) CTAMD_V_TILE(1) }
+    if (t < nTiles) { CTAMD_V_TILE(0) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        auto store_partial = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < Mt) {
+                    const uint32_t n = nW + (lane & 31);
+                    float* row = P + (size_t)m * Nt;
+                    if (n < Nt) row[n] = c0[r];
+                    if (n + 32 < Nt) row[n + 32] = c1[r];
+                    if (n + 64 < Nt) row[n + 64] = c2[r];
+                    if (n + 96 < Nt) row[n + 96] = c3[r];
+                }
+            }
+        };
+        store_partial(acc[0][0], acc[0][1], acc[0][2], acc[0][3], mW);
+        store_partial(acc[1][0], acc[1][1], acc[1][2], acc[1][3], mW + 32);
+        store_partial(acc[2][0], acc[2][1], acc[2][2], acc[2][3], mW + 64);
+        store_partial(acc[3][0], acc[3][1], acc[3][2], acc[3][3], mW + 96);
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // four passes: the four fragments of accumulator row i
+        ep.park(0, acc[i][0], lane); ep.park(1, acc[i][1], lane); ep.park(2, acc[i][2], lane); ep.park(3, acc[i][3], lane);
+        const uint32_t mB = mW + 32 * i;
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+    }
+}
+
+// =====================================================================================================
+// gett_h16w4x_kernel (CUTENSOR_AMD_H16_WAVES=4x): the kernel above on v_mfma_f32_16x16x32_{bf16,f16}.
+// Why the other shape: under the power limit a stream of nothing but 16x16x32 MFMAs sustains 2.03-2.05 PFLOP/s on U(-1,1)
+// operands where 32x32x16 sustains 1.78-1.81 (tools/ubench/mfma16_issue.hip) — half the accumulator read-modify-write traffic
+// per flop (K = 32 per instruction).  The instruction is issued from inline asm: through the builtin the compiler's hazard
+// recognizer spaces independent 4-pass MFMAs 27 cycles apart instead of 16 (same microbenchmark), so the hazards are kept by
+// construction here — an accumulator is touched once per 64 MFMAs, an operand register set is rewritten a k-step after its
+// last use, and the epilogue waits out the last write.
+// Wave tile 128 x 128 = 8 x 8 accumulator fragments of 16 x 16 (256 AGPRs); K-tile 64 = two k-steps of 32; per k-step 64 MFMAs,
+// 16 fragment reads (one per four MFMAs) into the other of two register sets (2 x 16 x 4 VGPRs).  Tile t: k-step 0 (reads of
+// k-step 1, the odometer), the tile barrier, k-step 1 (reads of tile t + 1's k-step 0 and the 16 LDS-DMA pieces of tile t + 2,
+// one per four MFMAs).  Same LDS image as every 16-bit kernel: a 16-row fragment of the K-contiguous image is rows x 4 units
+// (lane & 15 = row, lane >> 4 = k-unit); both operands K-contiguous only (the other layouts run gett_h16w4v_kernel).
+// =====================================================================================================
+template <bool BF>
+__device__ __forceinline__ void x_mfma(f32x4& c, const s16x8& a, const s16x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+    (void)c; (void)a; (void)b;
+#endif
+}
+// byte offset of this lane's 16 bytes of a 16-row fragment, k-step s (0, 1), inside a K-contiguous half-tile (rows 16 f: + 2048 f)
+__device__ __forceinline__ uint32_t x_offK(int lane, int s) {
+    const int row = lane & 15, unit = (lane >> 4) + 4 * s;
+    return (uint32_t)(row * 128 + (((unit ^ (row >> 1)) & 7) << 4));
+}
+
+template <bool BF>
+__global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    HOperand<LAY_K, 4> oa, ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
+    const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
+    VOdometer odo;
+    odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+    uint32_t rdA[2][2], rdB[2][2];                 // [buffer][k-step]; immediate: 2048 x fragment
+#pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            rdA[P][s] = ldsBase + (uint32_t)((P * 4 + wr) * kHalfBytes) + x_offK(lane, s);
+            rdB[P][s] = ldsBase + (uint32_t)((P * 4 + 2 + wc) * kHalfBytes) + x_offK(lane, s);
+            asm volatile("" : "+v"(rdA[P][s]));
+            asm volatile("" : "+v"(rdB[P][s]));
+        }
+
+#define CTAMD_X_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        constexpr uint32_t imm_ = (uint32_t)(((P) * 4 + q_) * kHalfBytes + i_ * 4096);                             \
+        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[q_][i_], waveLds);                      \
+        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[q_ - 2][i_], waveLds);                                   \
+    }
+#define CTAMD_X_DMA8(P, N0, PAD)                                                                                    \
+    CTAMD_X_DMA(P, (N0) + 0, PAD) CTAMD_X_DMA(P, (N0) + 1, PAD) CTAMD_X_DMA(P, (N0) + 2, PAD) CTAMD_X_DMA(P, (N0) + 3, PAD) \
+    CTAMD_X_DMA(P, (N0) + 4, PAD) CTAMD_X_DMA(P, (N0) + 5, PAD) CTAMD_X_DMA(P, (N0) + 6, PAD) CTAMD_X_DMA(P, (N0) + 7, PAD)
+
+    // ---- prologue: K-tiles 0 and 1; the odometer stays on tile 1 (k-step 0 of tile t moves it to tile t + 2) -------------
+    CTAMD_X_DMA8(0, 0, true) CTAMD_X_DMA8(0, 8, true)
+    odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+    CTAMD_X_DMA8(1, 0, true) CTAMD_X_DMA8(1, 8, true)
+    CTAMD_H_VMCNT(16);                            // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[2][8], b[2][8];                       // two register sets: k-step s uses set s
+
+    // fragment Q = 0..15 of k-step S from buffer P into register set S: Q < 8 -> B columns 16 Q, else A rows 16 (Q - 8)
+#define CTAMD_X_READ(P, S, Q)                                                                                       \
+    {                                                                                                              \
+        if constexpr ((Q) < 8) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][S]);                                     \
+        else a[S][(Q) - 8] = v_read<LAY_K, 2048 * ((Q) - 8)>(rdA[P][S]);                                           \
+    }
+#define CTAMD_X_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
+    // k-step 0, group Q: one read of k-step 1 (same buffer) and four MFMAs; three of the groups carry the odometer
+#define CTAMD_X_G0(P, Q)                                                                                            \
+    CTAMD_X_READ(P, 1, Q)                                                                                          \
+    CTAMD_X_MFMA(0, 4 * (Q)) CTAMD_X_MFMA(0, 4 * (Q) + 1)                                                          \
+    if constexpr ((Q) == 2) odo.advance_a();                                                                       \
+    if constexpr ((Q) == 5) odo.advance_b();                                                                       \
+    if constexpr ((Q) == 8) odo.advance_event(p.gK);                                                               \
+    CTAMD_X_MFMA(0, 4 * (Q) + 2) CTAMD_X_MFMA(0, 4 * (Q) + 3)                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into
+    // this buffer, four MFMAs
+#define CTAMD_X_G1(P, Q)                                                                                            \
+    CTAMD_X_READ((P) ^ 1, 0, Q)                                                                                    \
+    CTAMD_X_MFMA(1, 4 * (Q)) CTAMD_X_MFMA(1, 4 * (Q) + 1)                                                          \
+    CTAMD_X_DMA(P, Q, false)                                                                                       \
+    CTAMD_X_MFMA(1, 4 * (Q) + 2) CTAMD_X_MFMA(1, 4 * (Q) + 3)                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_X_TILE(P)                                                                                             \
+    CTAMD_X_G0(P, 0) CTAMD_X_G0(P, 1) CTAMD_X_G0(P, 2) CTAMD_X_G0(P, 3) CTAMD_X_G0(P, 4) CTAMD_X_G0(P, 5)          \
+    CTAMD_X_G0(P, 6) CTAMD_X_G0(P, 7) CTAMD_X_G0(P, 8) CTAMD_X_G0(P, 9) CTAMD_X_G0(P, 10) CTAMD_X_G0(P, 11)        \
+    CTAMD_X_G0(P, 12) CTAMD_X_G0(P, 13) CTAMD_X_G0(P, 14) CTAMD_X_G0(P, 15)                                        \
+    CTAMD_H_LGKM0();                                                                                               \
+    CTAMD_H_VMCNT(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_X_G1(P, 0) CTAMD_X_G1(P, 1) CTAMD_X_G1(P, 2) CTAMD_X_G1(P, 3) CTAMD_X_G1(P, 4) CTAMD_X_G1(P, 5)          \
+    CTAMD_X_G1(P, 6) CTAMD_X_G1(P, 7) CTAMD_X_G1(P, 8) CTAMD_X_G1(P, 9) CTAMD_X_G1(P, 10) CTAMD_X_G1(P, 11)        \
+    CTAMD_X_G1(P, 12) CTAMD_X_G1(P, 13) CTAMD_X_G1(P, 14) CTAMD_X_G1(P, 15)
+
+    // first fragments of tile 0
+    CTAMD_X_READ(0, 0, 0) CTAMD_X_READ(0, 0, 1) CTAMD_X_READ(0, 0, 2) CTAMD_X_READ(0, 0, 3)
+    CTAMD_X_READ(0, 0, 4) CTAMD_X_READ(0, 0, 5) CTAMD_X_READ(0, 0, 6) CTAMD_X_READ(0, 0, 7)
+    CTAMD_X_READ(0, 0, 8) CTAMD_X_READ(0, 0, 9) CTAMD_X_READ(0, 0, 10) CTAMD_X_READ(0, 0, 11)
+    CTAMD_X_READ(0, 0, 12) CTAMD_X_READ(0, 0, 13) CTAMD_X_READ(0, 0, 14) CTAMD_X_READ(0, 0, 15)
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_X_TILE(0) CTAMD_X_TILE(1) }
+    if (t < nTiles) { CTAMD_X_TILE(0) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+
+    const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    // accumulator fragment (i, j): element r of lane = row 16 i + 4 (lane >> 4) + r, column 16 j + (lane & 15)
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = mW + 16 * i + 4 * (lane >> 4) + r;
+                if (m < Mt) {
+                    float* row = P + (size_t)m * Nt;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t n = nW + 16 * j + (lane & 15);
+                        if (n < Nt) row[n] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // four passes of 32 rows: the epilogue's image is four 32 x 32 fp32 fragments
+#pragma unroll
+        for (int F = 0; F < 4; ++F)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {         // 16 x 16 quarter (h >> 1, h & 1) of 32 x 32 fragment F
+                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (lane >> 4)) * 32 + 16 * (h & 1) + (lane & 15);
+                const f32x4& c = acc[2 * i + (h >> 1)][2 * F + (h & 1)];
+                st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
+            }
+        const uint32_t mB = mW + 32 * i;
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream);
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
+    if constexpr (LA == LAY_K && LB == LAY_K) {
+        hipLaunchKernelGGL((gett_h16w4x_kernel<BF>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    } else {
+        return launch_h16w4v<BF, LA, LB>(p, stream);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gett_h16w4v_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F) — the order of gett_h16.hip's table
+#define CTAMD_H16W4V_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 6, 1, 0, &launch_h16w4v<bf, la, lb>, 0},
+#define CTAMD_H16W4X_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, (la == LAY_K && lb == LAY_K) ? 7 : 6, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
+static const GettKernelInfo g_h16v_table[] = {
+    CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4V_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4V_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(false, LAY_F, LAY_F)
+    // entries 8..15 of this table (48..55 of the 16-bit family): the 16x16x32 form where it exists (both operands K-contiguous)
+    CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_F)};
+
+const GettKernelInfo* gett_h16v_kernels(int* count) {
+    *count = (int)(sizeof(g_h16v_table) / sizeof(g_h16v_table[0]));
+    return g_h16v_table;
+}
+
+}  // namespace ctamd

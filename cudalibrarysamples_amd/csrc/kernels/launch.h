@@ -36,6 +36,7 @@ const GettKernelInfo* gett_f32_stream_kernels(int* count);
 
 // bf16 / fp16 data, fp32 accumulation (v_mfma_f32_32x32x16_{bf16,f16}), gett_h16.hip
 const GettKernelInfo* gett_h16_kernels(int* count);
+const GettKernelInfo* gett_h16v_kernels(int* count);   // gett_h16v.hip: appended to the table above as entries 40..47
 
 // simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,
