@@ -390,12 +390,13 @@ def secondary_single_gpu(torch, ct, ops, h, stream):
         flop = 2.0 * n ** 3
         tf = flop / (ms * 1e-3) / 1e12
         d = p.describe()
-        # what this box sustains on nothing but bf16 MFMAs, on zeros (= nominal peak) and on U(-1,1) register data (power-limited,
-        # differs by box): the GETT kernel cannot beat the second number on the same kind of data
+        # what this box sustains on nothing but bf16 MFMAs of the kernel's shape (16x16x32 since round 3; the 32x32x16 stream beside
+        # it), on zeros (= nominal peak) and on U(-1,1) register data (power-limited, differs by box): the GETT kernel cannot beat the
+        # second number on the same kind of data
         ceil = {}
-        for name, kind in (("zeros", 0), ("uniform", 1)):
+        for name, kind, shape in (("zeros", 0, 1), ("uniform", 1, 1), ("uniform_32x32x16", 1, 0)):
             v = ctypes.c_float(0)
-            if ct.lib.ctamdMeasureMfmaCeiling(1, kind, ctypes.byref(v)) == 0:
+            if ct.lib.ctamdMeasureMfmaCeilingShape(1, kind, shape, ctypes.byref(v)) == 0:
                 ceil[name] = float(v.value)
         ms2 = timed_batch(torch, fn, reps=30)                 # again, after the ceiling runs (same clock state), keep the better
         ms = min(ms, ms2)

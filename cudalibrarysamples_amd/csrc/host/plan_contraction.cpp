@@ -396,7 +396,9 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c.family = 1;
     c.kernel = (v.dtype == HIP_R_16BF ? 0 : 4) + (v.layA == LAY_F ? 2 : 0) + (v.layB == LAY_F ? 1 : 0);
     // entries 0..7: eight waves, two rows alternated by barriers (ping-pong); 8..15: four waves per workgroup (one per
-    // SIMD); 16..23: eight free-running waves, K-tile of 32, deep LDS ring, one barrier per K-tile
+    // SIMD); 16..23: eight free-running waves, K-tile of 32, deep LDS ring, one barrier per K-tile; 24..31: four waves on that
+    // ring; 32..39: four waves, register-staged; 40..47: four waves, lean instruction stream (gett_h16v.hip); 48..55: the same on
+    // the 16x16x32 MFMA — the default since round 3 (+8-14 % under the power limit on every layout)
     static const int variant = [] {
         const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
         if (e && e[0] == '4' && e[1] == 's') return 24;
@@ -405,7 +407,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && e[0] == '4' && e[1] == 'x') return 48;
         if (e && e[0] == '4') return 8;
         if (e && e[0] == 's') return 16;
-        return 0;
+        if (e && (e[0] == '8' || e[0] == 'p')) return 0;
+        return 48;
     }();
     c.kernel += variant;
     if (c.kernel >= count) return false;
@@ -437,7 +440,6 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
     for (int other : {0, 48, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
-        if (other == 48 && layoutIdx % 4 != 0) continue;   // the 16x16x32 form exists for two K-contiguous operands; the other entries alias 40..47
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;
         out.push_back(c);

@@ -1267,10 +1267,42 @@ __global__ void __launch_bounds__(256, 1) mfma_ceiling_kernel(const s16x8* __res
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// the same for v_mfma_f32_16x16x32_{bf16,f16} (the default 16-bit kernel's instruction, gett_h16v.hip), issued from inline asm like there
+template <bool BF>
+__global__ void __launch_bounds__(256, 1) mfma16_ceiling_kernel(const s16x8* __restrict__ data, float* out, int iters) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    s16x8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = data[(i * 2 + 0) * 256 + threadIdx.x];
+        b[i] = data[(i * 2 + 1) * 256 + threadIdx.x];
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {   // 32 x (16x16x32) = the flops of 16 x (32x32x16)
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i & 15]) : "v"(a[i & 7]), "v"(b[(i >> 1) & 7]));
+            else              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i & 15]) : "v"(a[i & 7]), "v"(b[(i >> 1) & 7]));
+#endif
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
 }  // namespace ctamd
 
-// dataKind 0: zeros, 1: U(-1,1) (fixed seed).  Returns 0 and the sustained TFLOP/s (after ~40 ms of burn-in), or -1.
-extern "C" int ctamdMeasureMfmaCeiling(int bf16, int dataKind, float* tflops) {
+// dataKind 0: zeros, 1: U(-1,1) (fixed seed); shape 0: 32x32x16, 1: 16x16x32.  Returns 0 and the sustained TFLOP/s (after ~40 ms of
+// burn-in), or -1.
+extern "C" int ctamdMeasureMfmaCeilingShape(int bf16, int dataKind, int shape, float* tflops);
+extern "C" int ctamdMeasureMfmaCeiling(int bf16, int dataKind, float* tflops) { return ctamdMeasureMfmaCeilingShape(bf16, dataKind, 0, tflops); }
+extern "C" int ctamdMeasureMfmaCeilingShape(int bf16, int dataKind, int shape, float* tflops) {
     using namespace ctamd;
     if (tflops == nullptr) return -1;
     hipDeviceProp_t prop;
@@ -1302,8 +1334,13 @@ extern "C" int ctamdMeasureMfmaCeiling(int bf16, int dataKind, float* tflops) {
         hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
         const int iters = 20000;       // ~12-25 ms per launch
         auto launch = [&]() {
-            if (bf16) hipLaunchKernelGGL((mfma_ceiling_kernel<true>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
-            else      hipLaunchKernelGGL((mfma_ceiling_kernel<false>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+            if (shape == 1) {
+                if (bf16) hipLaunchKernelGGL((mfma16_ceiling_kernel<true>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+                else      hipLaunchKernelGGL((mfma16_ceiling_kernel<false>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+            } else {
+                if (bf16) hipLaunchKernelGGL((mfma_ceiling_kernel<true>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+                else      hipLaunchKernelGGL((mfma_ceiling_kernel<false>), dim3(cus), dim3(256), 0, nullptr, d, out, iters);
+            }
         };
         for (int w = 0; w < 3; ++w) launch();
         (void)hipEventRecord(e0, nullptr);

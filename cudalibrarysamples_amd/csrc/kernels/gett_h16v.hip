@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
     if (t < nTiles) { CTAMD_V_TILE(0) }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
 
+    const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // fresh: nothing lane-derived lives across the loop for the epilogue
     const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
     if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
         const uint32_t Mt = p.gM.total, Nt = p.gN.total;
@@ -275,9 +276,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
         auto store_partial = [&](const f32x16& c0, const f32x16& c1, const f32x16& c2, const f32x16& c3, uint32_t mBase) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t m = mBase + (r & 3) + 8 * (r >> 2) + 4 * (laneE >> 5);
                 if (m < Mt) {
-                    const uint32_t n = nW + (lane & 31);
+                    const uint32_t n = nW + (laneE & 31);
                     float* row = P + (size_t)m * Nt;
                     if (n < Nt) row[n] = c0[r];
                     if (n + 32 < Nt) row[n + 32] = c1[r];
@@ -297,9 +298,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
     ep.init(p, l, lds, wave);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                 // four passes: the four fragments of accumulator row i
-        ep.park(0, acc[i][0], lane); ep.park(1, acc[i][1], lane); ep.park(2, acc[i][2], lane); ep.park(3, acc[i][3], lane);
+        ep.park(0, acc[i][0], laneE); ep.park(1, acc[i][1], laneE); ep.park(2, acc[i][2], laneE); ep.park(3, acc[i][3], laneE);
         const uint32_t mB = mW + 32 * i;
-        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
     }
 }
 
@@ -314,8 +315,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
 // Wave tile 128 x 128 = 8 x 8 accumulator fragments of 16 x 16 (256 AGPRs); K-tile 64 = two k-steps of 32; per k-step 64 MFMAs,
 // 16 fragment reads (one per four MFMAs) into the other of two register sets (2 x 16 x 4 VGPRs).  Tile t: k-step 0 (reads of
 // k-step 1, the odometer), the tile barrier, k-step 1 (reads of tile t + 1's k-step 0 and the 16 LDS-DMA pieces of tile t + 2,
-// one per four MFMAs).  Same LDS image as every 16-bit kernel: a 16-row fragment of the K-contiguous image is rows x 4 units
-// (lane & 15 = row, lane >> 4 = k-unit); both operands K-contiguous only (the other layouts run gett_h16w4v_kernel).
+// one per four MFMAs).  Same LDS images as every 16-bit kernel: a 16-row fragment of the K-contiguous image is rows x 4 units
+// (lane & 15 = row, lane >> 4 = k-unit, one ds_read_b128); of the free-contiguous image two transposing reads (x_offF).
 // =====================================================================================================
 template <bool BF>
 __device__ __forceinline__ void x_mfma(f32x4& c, const s16x8& a, const s16x8& b) {
@@ -332,7 +333,16 @@ __device__ __forceinline__ uint32_t x_offK(int lane, int s) {
     return (uint32_t)(row * 128 + (((unit ^ (row >> 1)) & 7) << 4));
 }
 
-template <bool BF>
+// the same for a free-contiguous half-tile (image [64 k][128 rows], 256-byte k-rows, unit p of k-row k holds row-unit p ^ 4 (k & 3)):
+// a 16-lane group g fetches the 4 k x 16 rows block (k = 8 g + [0,4), rows of fragment f) that ds_read_b64_tr_b16 turns into
+// "lane = row, four k"; the second read (+ 1024 B) brings k + 4.  fq = f >> 1 is inside the swizzle, the rest are immediates:
+// + 32 (f & 1) + 8192 s.
+__device__ __forceinline__ uint32_t x_offF(int lane, int fq) {
+    const int g = lane >> 4, i = lane & 15, q = (i >> 2) & 3, b = (i >> 1) & 1;
+    return (uint32_t)((8 * g + (i >> 2)) * 256 + ((b | (((fq ^ q) & 3) << 2)) << 4) + 8 * (i & 1));
+}
+
+template <bool BF, int LA, int LB>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     prefetch_kernarg<(int)sizeof(GettParams)>();
@@ -358,7 +368,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
-    HOperand<LAY_K, 4> oa, ob;
+    HOperand<LA, 4> oa;
+    HOperand<LB, 4> ob;
     oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
     ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
@@ -368,16 +379,23 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
-    uint32_t rdA[2][2], rdB[2][2];                 // [buffer][k-step]; immediate: 2048 x fragment
+    // fragment-read address registers: K-contiguous operand [buffer][k-step] (immediate 2048 x fragment), free-contiguous operand
+    // [buffer][fragment >> 1] (immediate 32 x (fragment & 1) + 8192 x k-step)
+    constexpr int nRdA = (LA == LAY_K) ? 2 : 4, nRdB = (LB == LAY_K) ? 2 : 4;
+    uint32_t rdA[2][nRdA], rdB[2][nRdB];
 #pragma unroll
-    for (int P = 0; P < 2; ++P)
+    for (int P = 0; P < 2; ++P) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            rdA[P][s] = ldsBase + (uint32_t)((P * 4 + wr) * kHalfBytes) + x_offK(lane, s);
-            rdB[P][s] = ldsBase + (uint32_t)((P * 4 + 2 + wc) * kHalfBytes) + x_offK(lane, s);
-            asm volatile("" : "+v"(rdA[P][s]));
-            asm volatile("" : "+v"(rdB[P][s]));
+        for (int x = 0; x < nRdA; ++x) {
+            rdA[P][x] = ldsBase + (uint32_t)((P * 4 + wr) * kHalfBytes) + (LA == LAY_K ? x_offK(lane, x) : x_offF(lane, x));
+            asm volatile("" : "+v"(rdA[P][x]));
         }
+#pragma unroll
+        for (int x = 0; x < nRdB; ++x) {
+            rdB[P][x] = ldsBase + (uint32_t)((P * 4 + 2 + wc) * kHalfBytes) + (LB == LAY_K ? x_offK(lane, x) : x_offF(lane, x));
+            asm volatile("" : "+v"(rdB[P][x]));
+        }
+    }
 
 #define CTAMD_X_DMA(P, N, PAD)                                                                                      \
     {                                                                                                              \
@@ -407,8 +425,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     // fragment Q = 0..15 of k-step S from buffer P into register set S: Q < 8 -> B columns 16 Q, else A rows 16 (Q - 8)
 #define CTAMD_X_READ(P, S, Q)                                                                                       \
     {                                                                                                              \
-        if constexpr ((Q) < 8) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][S]);                                     \
-        else a[S][(Q) - 8] = v_read<LAY_K, 2048 * ((Q) - 8)>(rdA[P][S]);                                           \
+        if constexpr ((Q) < 8) {                                                                                   \
+            if constexpr (LB == LAY_K) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][(S) % nRdB]);                    \
+            else b[S][Q] = v_read<LAY_F, 32 * ((Q) & 1) + 8192 * (S)>(rdB[P][((Q) >> 1) % nRdB]);                  \
+        } else {                                                                                                   \
+            if constexpr (LA == LAY_K) a[S][(Q) - 8] = v_read<LAY_K, 2048 * ((Q) - 8)>(rdA[P][(S) % nRdA]);        \
+            else a[S][(Q) - 8] = v_read<LAY_F, 32 * ((Q) & 1) + 8192 * (S)>(rdA[P][(((Q) - 8) >> 1) % nRdA]);      \
+        }                                                                                                          \
     }
 #define CTAMD_X_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
     // k-step 0, group Q: one read of k-step 1 (same buffer) and four MFMAs; three of the groups carry the odometer
@@ -450,9 +473,12 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     if (t < nTiles) { CTAMD_X_TILE(0) }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake (one
+    // spilled register = a scratch allocation at every dispatch)
+    const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
     const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
-    // accumulator fragment (i, j): element r of lane = row 16 i + 4 (lane >> 4) + r, column 16 j + (lane & 15)
+    // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
     if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
         const uint32_t Mt = p.gM.total, Nt = p.gN.total;
         float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
@@ -460,12 +486,12 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t m = mW + 16 * i + 4 * (lane >> 4) + r;
+                const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
                 if (m < Mt) {
                     float* row = P + (size_t)m * Nt;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const uint32_t n = nW + 16 * j + (lane & 15);
+                        const uint32_t n = nW + 16 * j + (laneE & 15);
                         if (n < Nt) row[n] = acc[i][j][r];
                     }
                 }
@@ -481,25 +507,19 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
         for (int F = 0; F < 4; ++F)
 #pragma unroll
             for (int h = 0; h < 4; ++h) {         // 16 x 16 quarter (h >> 1, h & 1) of 32 x 32 fragment F
-                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (lane >> 4)) * 32 + 16 * (h & 1) + (lane & 15);
+                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);
                 const f32x4& c = acc[2 * i + (h >> 1)][2 * F + (h & 1)];
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
         const uint32_t mB = mW + 32 * i;
-        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, lane);
+        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
     }
 }
 
 template <bool BF, int LA, int LB>
-static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream);
-template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
-    if constexpr (LA == LAY_K && LB == LAY_K) {
-        hipLaunchKernelGGL((gett_h16w4x_kernel<BF>), dim3(p.nBlocks), dim3(256), 0, stream, p);
-        return hipGetLastError();
-    } else {
-        return launch_h16w4v<BF, LA, LB>(p, stream);
-    }
+    hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 template <bool BF, int LA, int LB>
@@ -512,13 +532,13 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
 #define CTAMD_H16W4V_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 6, 1, 0, &launch_h16w4v<bf, la, lb>, 0},
 #define CTAMD_H16W4X_ENTRY(bf, la, lb) \
-    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, (la == LAY_K && lb == LAY_K) ? 7 : 6, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 7, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
 static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4V_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(false, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(false, LAY_F, LAY_F)
-    // entries 8..15 of this table (48..55 of the 16-bit family): the 16x16x32 form where it exists (both operands K-contiguous)
+    // entries 8..15 of this table (48..55 of the 16-bit family): the 16x16x32 form
     CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_F)

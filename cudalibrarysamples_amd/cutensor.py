@@ -121,6 +121,8 @@ lib.ctamdEinsumReplan.argtypes = [_vp, _vp, ctypes.c_uint64, ctypes.POINTER(ctyp
 lib.ctamdEinsumReplan.restype = ctypes.c_int
 lib.ctamdMeasureMfmaCeiling.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 lib.ctamdMeasureMfmaCeiling.restype = ctypes.c_int
+lib.ctamdMeasureMfmaCeilingShape.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+lib.ctamdMeasureMfmaCeilingShape.restype = ctypes.c_int
 lib.ctamdEinsumExecute.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
 lib.ctamdEinsumRawPlan.argtypes = [_vp]
 lib.ctamdEinsumRawPlan.restype = _vp

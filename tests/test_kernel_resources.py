@@ -48,6 +48,17 @@ def test_default_16_bit_kernels_use_no_scratch(built, tmp_path):
     assert not bad, bad
 
 
+def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(built, tmp_path):
+    """gett_h16v.hip: the default 16-bit kernel (gett_h16w4x_kernel, 16x16x32 MFMA) and its 32x32x16 sibling — one wave per SIMD,
+    256 accumulator registers + 256 others, no private segment (a scratch allocation is paid for at every dispatch)."""
+    k = _kernel_notes(_code_object(tmp_path, "gett_h16v"))
+    hot = {n: v for n, v in k.items() if "gett_h16w4x_kernel" in n or "gett_h16w4v_kernel" in n}
+    assert len(hot) == 16, sorted(k)
+    bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+    assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
+
+
 def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
     k = _kernel_notes(_code_object(tmp_path, "gett_f32_stream"))
     hot = {n: v for n, v in k.items() if "gett_f32_stream_kernel" in n}
