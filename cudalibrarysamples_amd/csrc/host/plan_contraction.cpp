@@ -427,6 +427,10 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c.kPerSlice = (uint32_t)(tilesPerSlice * 64);
     c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
     c.estimateUs = std::ceil(tiles * c.splitK / (double)numCUs) * (2.0 * tab[c.kernel].bm * tab[c.kernel].bn * (double)c.kPerSlice) / (4096.0 * 2.4e9 * 0.5) * 1e6;
+    // short K ranges: a workgroup of the four-wave kernels spends ~14 us outside its main loop (prologue + a 256 x 256 epilogue on
+    // four waves) against ~10 us for the eight-wave kernel, and wins ~0.13 us per K-tile inside it (tools/h16_shape_sweep.py:
+    // K = 512 -> 0.088 ms with eight waves, 0.102 ms with four; K = 4096 the other way round) — the planner's own choice only
+    if (variant == 48 && std::getenv("CUTENSOR_AMD_H16_WAVES") == nullptr && tilesPerSlice <= 16) c.kernel -= 48;
     return true;
 }
 
