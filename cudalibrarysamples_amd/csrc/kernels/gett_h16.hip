@@ -1,5 +1,7 @@
 // gett_h16.hip — bf16 / fp16 GETT kernels for gfx950 (MI355X, CDNA4): 16-bit data, fp32 accumulation
-// on v_mfma_f32_32x32x16_{bf16,f16}.
+// on v_mfma_f32_32x32x16_{bf16,f16}.  Since round 3 the family's default for long K ranges is gett_h16w4x_kernel in
+// gett_h16v.hip (four waves, v_mfma_f32_16x16x32); the eight-wave kernel below serves K ranges of <= 16 K-tiles per workgroup,
+// the others are measured alternatives and autotuning candidates.  Shared pieces: gett_h16_common.h.
 //
 // Reference call sites: cuTENSOR/contraction.cu:261-265 with the types of :33-40 set to 16-bit data
 // (BASELINE configs[3]: C[m,n] = sum_k A[m,k] B[k,n], M = N = K = 8192) and the PyTorch binding's
