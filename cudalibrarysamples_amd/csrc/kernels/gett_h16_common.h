@@ -295,7 +295,10 @@ struct HEpilogue {
 // IL (the default kernel's B operand): half-tile h holds the 32-row stripes {64 j + 32 h + [0,32)}, j = 0..3, of the 256 rows
 // instead of rows 128 h + [0,128) — the two fragments a wave owns (stripe j = wc of either half) are then ADJACENT columns of
 // the output tile, and the epilogue stores whole 128-byte lines.
-template <int LAY, int NW = 8, bool IL = false>
+// SWZ (free-contiguous image only; gett_h16w4x_kernel): unit p of k-row k holds row-unit p ^ 4 (k & 3) ^ 2 ((k >> 3) & 1) — the
+// 16-row fragments of the 16x16x32 MFMA take 32 bytes of a k-row per 16-lane group, and without the second term the two groups
+// that a transposing read serves together (k-rows 8 g + .. and 8 (g + 1) + ..) land on the same banks.
+template <int LAY, int NW = 8, bool IL = false, int SWZ = 0>
 struct HOperand {
     static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
     // Byte offset of this lane's 16-byte unit, [half-tile][piece i of this wave], for the K-tile at k = 0 — relative to
@@ -320,7 +323,7 @@ struct HOperand {
                     off[h][i] = (group_offset<0>(gFree, row) + 8 * u) * 2;
                 } else {
                     const int kk = 4 * c + (lane >> 4), p = lane & 15;
-                    const int u = p ^ (4 * ((lane >> 4) & 3));
+                    const int u = p ^ (4 * ((lane >> 4) & 3)) ^ (SWZ ? 2 * ((kk >> 3) & 1) : 0);
                     uint32_t row = row0 + (IL ? 64 * (u >> 2) + 32 * h + 8 * (u & 3) : 128 * h + 8 * u);
                     if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
                     off[h][i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;

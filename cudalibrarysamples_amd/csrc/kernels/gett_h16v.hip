@@ -333,13 +333,16 @@ __device__ __forceinline__ uint32_t x_offK(int lane, int s) {
     return (uint32_t)(row * 128 + (((unit ^ (row >> 1)) & 7) << 4));
 }
 
-// the same for a free-contiguous half-tile (image [64 k][128 rows], 256-byte k-rows, unit p of k-row k holds row-unit p ^ 4 (k & 3)):
-// a 16-lane group g fetches the 4 k x 16 rows block (k = 8 g + [0,4), rows of fragment f) that ds_read_b64_tr_b16 turns into
-// "lane = row, four k"; the second read (+ 1024 B) brings k + 4.  fq = f >> 1 is inside the swizzle, the rest are immediates:
-// + 32 (f & 1) + 8192 s.
-__device__ __forceinline__ uint32_t x_offF(int lane, int fq) {
+// the same for a free-contiguous half-tile (image [64 k][128 rows], 256-byte k-rows, HOperand's SWZ = 1 form: unit p of k-row k holds
+// row-unit p ^ 4 (k & 3) ^ 2 ((k >> 3) & 1)): a 16-lane group g fetches the 4 k x 16 rows block (k = 8 g + [0,4), rows of fragment f)
+// that ds_read_b64_tr_b16 turns into "lane = row, four k"; the second read (+ 1024 B) brings k + 4.  The block is 32 contiguous
+// bytes in each of its four k-rows: quarter (f >> 1) ^ (k & 3) of the row, half (f & 1) ^ (g & 1) of the quarter — the groups g and
+// g + 1 that one read serves together never share a bank.  Both f >> 1 and f & 1 sit inside the swizzle: one address register per
+// (f >> 1, f & 1), k-step and + 4 as immediates (8192 s, 1024).
+__device__ __forceinline__ uint32_t x_offF(int lane, int f) {
     const int g = lane >> 4, i = lane & 15, q = (i >> 2) & 3, b = (i >> 1) & 1;
-    return (uint32_t)((8 * g + (i >> 2)) * 256 + ((b | (((fq ^ q) & 3) << 2)) << 4) + 8 * (i & 1));
+    const int unit = b | ((((f & 1) ^ (g & 1)) & 1) << 1) | ((((f >> 1) ^ q) & 3) << 2);
+    return (uint32_t)((8 * g + (i >> 2)) * 256 + (unit << 4) + 8 * (i & 1));
 }
 
 template <bool BF, int LA, int LB>
@@ -368,8 +371,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
-    HOperand<LA, 4> oa;
-    HOperand<LB, 4> ob;
+    HOperand<LA, 4, false, 1> oa;
+    HOperand<LB, 4, false, 1> ob;
     oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
     ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
@@ -380,8 +383,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
     // fragment-read address registers: K-contiguous operand [buffer][k-step] (immediate 2048 x fragment), free-contiguous operand
-    // [buffer][fragment >> 1] (immediate 32 x (fragment & 1) + 8192 x k-step)
-    constexpr int nRdA = (LA == LAY_K) ? 2 : 4, nRdB = (LB == LAY_K) ? 2 : 4;
+    // [buffer][fragment] (immediate 8192 x k-step)
+    constexpr int nRdA = (LA == LAY_K) ? 2 : 8, nRdB = (LB == LAY_K) ? 2 : 8;
     uint32_t rdA[2][nRdA], rdB[2][nRdB];
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
@@ -427,10 +430,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     {                                                                                                              \
         if constexpr ((Q) < 8) {                                                                                   \
             if constexpr (LB == LAY_K) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][(S) % nRdB]);                    \
-            else b[S][Q] = v_read<LAY_F, 32 * ((Q) & 1) + 8192 * (S)>(rdB[P][((Q) >> 1) % nRdB]);                  \
+            else b[S][Q] = v_read<LAY_F, 8192 * (S)>(rdB[P][(Q) % nRdB]);                                          \
         } else {                                                                                                   \
             if constexpr (LA == LAY_K) a[S][(Q) - 8] = v_read<LAY_K, 2048 * ((Q) - 8)>(rdA[P][(S) % nRdA]);        \
-            else a[S][(Q) - 8] = v_read<LAY_F, 32 * ((Q) & 1) + 8192 * (S)>(rdA[P][(((Q) - 8) >> 1) % nRdA]);      \
+            else a[S][(Q) - 8] = v_read<LAY_F, 8192 * (S)>(rdA[P][((Q) - 8) % nRdA]);                              \
         }                                                                                                          \
     }
 #define CTAMD_X_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
