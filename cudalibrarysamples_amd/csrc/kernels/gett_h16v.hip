@@ -345,9 +345,15 @@ __device__ __forceinline__ uint32_t x_offF(int lane, int f) {
     return (uint32_t)((8 * g + (i >> 2)) * 256 + (unit << 4) + 8 * (i & 1));
 }
 
-template <bool BF, int LA, int LB>
+// TIMED (measurement-only instantiation, CUTENSOR_AMD_H16_TIMED=1 with the planner's default kernel, layout mk,kn): wave 0 of every
+// workgroup records shader cycles at entry / first MFMA / end of the main loop / exit and the wall clock at entry / exit into
+// p.timing (the layout tools/h16_wg_timeline.py reads).  XST (measurement, CUTENSOR_AMD_H16_XST): how the epilogue's 16-byte stores are
+// issued — 0 nontemporal (the default), 1 plain, 2 write-through.
+template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
+    unsigned long long wgStamp[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (TIMED) { wgStamp[0] = __builtin_readcyclecounter(); wgStamp[4] = wall_clock64(); }
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -471,11 +477,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     CTAMD_X_READ(0, 0, 4) CTAMD_X_READ(0, 0, 5) CTAMD_X_READ(0, 0, 6) CTAMD_X_READ(0, 0, 7)
     CTAMD_X_READ(0, 0, 8) CTAMD_X_READ(0, 0, 9) CTAMD_X_READ(0, 0, 10) CTAMD_X_READ(0, 0, 11)
     CTAMD_X_READ(0, 0, 12) CTAMD_X_READ(0, 0, 13) CTAMD_X_READ(0, 0, 14) CTAMD_X_READ(0, 0, 15)
+    if constexpr (TIMED) wgStamp[1] = __builtin_readcyclecounter();
     int t = 0;
     for (; t + 1 < nTiles; t += 2) { CTAMD_X_TILE(0) CTAMD_X_TILE(1) }
     if (t < nTiles) { CTAMD_X_TILE(0) }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    if constexpr (TIMED) wgStamp[2] = __builtin_readcyclecounter();
     // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake (one
     // spilled register = a scratch allocation at every dispatch)
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -515,12 +523,28 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
         const uint32_t mB = mW + 32 * i;
-        ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
+        ep.template flush<BF, XST>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
+    }
+    if constexpr (TIMED) {
+        if (p.timing != nullptr && wave == 0 && laneE == 0) {
+            wgStamp[3] = __builtin_readcyclecounter();            // the stores are issued, not waited for
+            wgStamp[5] = wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
+            p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+        }
     }
 }
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
+    if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / store modes
+        static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
+        static const int xst = [] { const char* e = getenv("CUTENSOR_AMD_H16_XST"); return e ? atoi(e) : 0; }();
+        if (timed && xst == 1) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 1>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 2) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 2>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+    }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
