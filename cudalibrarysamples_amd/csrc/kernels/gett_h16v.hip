@@ -512,6 +512,38 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     __syncthreads();                              // every wave has finished reading the operand ring
     HEpilogue ep;
     ep.init(p, l, lds, wave);
+    if (XST != 3 && ep.vecD && ep.beta == 0.f) {
+        // beta == 0 and 16-byte lanes in D: the accumulators are rounded ONCE on their way into LDS (alpha * acc -> 16 bit), a pass of
+        // 32 rows x 128 columns is an image of 272-byte rows (16 bytes of padding: the 2-byte writes of a 16-lane group and the
+        // 16-byte reads of a row both spread over the banks), and the way out is eight 16-byte reads + nontemporal stores per lane —
+        // whole 256-byte row segments, no conversion behind the LDS.  Half the instructions of the fp32 image below.
+        uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
+        constexpr int kPitch = 136;               // 16-bit elements per image row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4& c = acc[2 * i + a2][j];
+                    uint16_t* st = stage + (16 * a2 + 4 * (laneE >> 4)) * kPitch + 16 * j + (laneE & 15);
+                    st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                    st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+                }
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int q = it * 64 + laneE, row = q >> 4, cc = q & 15;
+                const s16x8 v = *reinterpret_cast<const s16x8*>(stage + row * kPitch + 8 * cc);
+                const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
+                if (m < ep.Mtot && n < ep.Ntot) {
+                    int64_t offD, offC;
+                    ep.offsets(p, m, n, offD, offC);
+                    if constexpr (XST == 1) *reinterpret_cast<s16x8*>(ep.D + offD) = v;
+                    else __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                 // four passes of 32 rows: the epilogue's image is four 32 x 32 fp32 fragments
 #pragma unroll
@@ -523,7 +555,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
         const uint32_t mB = mW + 32 * i;
-        ep.template flush<BF, XST>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
+        ep.template flush<BF, (XST == 1 ? 1 : 0)>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
     }
     if constexpr (TIMED) {
         if (p.timing != nullptr && wave == 0 && laneE == 0) {
@@ -542,7 +574,7 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
         static const int xst = [] { const char* e = getenv("CUTENSOR_AMD_H16_XST"); return e ? atoi(e) : 0; }();
         if (timed && xst == 1) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 1>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
-        if (timed && xst == 2) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 2>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 3) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 3>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
