@@ -53,7 +53,7 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     256 accumulator registers + 256 others, no private segment (a scratch allocation is paid for at every dispatch)."""
     k = _kernel_notes(_code_object(tmp_path, "gett_h16v"))
     hot = {n: v for n, v in k.items() if "gett_h16w4x_kernel" in n or "gett_h16w4v_kernel" in n}
-    assert len(hot) == 16, sorted(k)
+    assert len(hot) >= 16, sorted(k)          # 8 + 8 layouts x types, plus the measurement-only instantiations
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
