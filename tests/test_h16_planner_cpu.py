@@ -1,0 +1,84 @@
+"""Which 16-bit GETT kernel the planner picks (csrc/host/plan_contraction.cpp pick_h16_choice / rank_h16_choices), host-only:
+BASELINE configs[3] (bf16 C[m,n] = A[m,k] B[k,n], M = N = K = 8192, `contraction.cu:33-40` retyped) must run the four-wave
+16x16x32 kernel of gett_h16v.hip on all four operand layouts, K ranges of <= 16 K-tiles per workgroup the eight-wave kernel,
+CUTENSOR_AMD_H16_WAVES overrides both (child process: the switch is read once), and every variant stays an autotuning candidate."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    return ct, ops
+
+
+def _plan(ct, ops, h, M, N, K, mA="mk", mB="kn", dtype=None, **kw):
+    extA = [M, K] if mA == "mk" else [K, M]
+    extB = [K, N] if mB == "kn" else [N, K]
+    return ops.contraction_plan(h, extA, mA, extB, mB, [M, N], "mn", dtype=dtype if dtype is not None else ct.R_16BF,
+                                workspace_limit=1 << 30, **kw)
+
+
+@pytest.mark.parametrize("mA,mB", [("mk", "kn"), ("km", "kn"), ("mk", "nk"), ("km", "nk")])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_headline_16_bit_shape_runs_the_16x16x32_kernel(env, mA, mB, dtype):
+    ct, ops = env
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+    p = _plan(ct, ops, h, 8192, 8192, 8192, mA, mB, dtype=ct.R_16BF if dtype == "bf16" else ct.R_16F)
+    d = p.describe()
+    assert d["kname"] == "gett_h16w4x_kernel" and d["splitK"] == 1 and d["blocks"] == 1024, d
+    assert (d["bm"], d["bn"], d["bk"]) == (256, 256, 64), d
+    p.destroy()
+
+
+def test_short_k_ranges_stay_on_the_eight_wave_kernel(env):
+    ct, ops = env
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+    for (M, N, K, want, split) in [(8192, 8192, 512, "gett_h16_kernel", 1),        # 8 K-tiles per workgroup
+                                   (8192, 8192, 1024, "gett_h16_kernel", 1),       # 16
+                                   (8192, 8192, 1088, "gett_h16w4x_kernel", 1),    # 17
+                                   (2048, 2048, 2048, "gett_h16_kernel", 4),       # split-K: 8 K-tiles per slice
+                                   (2048, 2048, 16384, "gett_h16w4x_kernel", 4)]:  # 64 per slice
+        p = _plan(ct, ops, h, M, N, K)
+        d = p.describe()
+        assert (d["kname"], d["splitK"]) == (want, split), (M, N, K, d)
+        p.destroy()
+
+
+def test_every_variant_stays_an_autotuning_candidate(env):
+    ct, ops = env
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+    names = []
+    for r in range(7):
+        p = _plan(ct, ops, h, 8192, 8192, 8192, algo=r, cache_mode=ct.CACHE_MODE_NONE)
+        names.append(p.describe()["kname"])
+        p.destroy()
+    assert names[0] == "gett_h16w4x_kernel", names
+    assert set(names) == {"gett_h16w4x_kernel", "gett_h16_kernel", "gett_h16w4v_kernel", "gett_h16w4r_kernel", "gett_h16s_kernel",
+                          "gett_h16w4s_kernel", "gett_h16w4_kernel"}, names
+
+
+@pytest.mark.parametrize("waves,want", [("8", "gett_h16_kernel"), ("4", "gett_h16w4_kernel"), ("4v", "gett_h16w4v_kernel"),
+                                        ("4x", "gett_h16w4x_kernel"), ("s", "gett_h16s_kernel")])
+def test_the_switch_overrides_the_planner(built, waves, want):
+    code = ("import json, sys; sys.path.insert(0, %r); from cudalibrarysamples_amd import cutensor as ct, ops; h = ops.Handle(); "
+            "out = []\n"
+            "for K in (512, 8192):\n"
+            "    p = ops.contraction_plan(h, [8192, K], 'mk', [K, 8192], 'kn', [8192, 8192], 'mn', dtype=ct.R_16BF); out.append(p.describe()['kname']); p.destroy()\n"
+            "print(json.dumps(out))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CUTENSOR_AMD_H16_WAVES=waves))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == [want, want], r.stdout
