@@ -42,8 +42,8 @@ from cudalibrarysamples_amd import cutensor as ct
 import torch
 torch.cuda.init()
 out = {}
-for name, kind in (('zeros', 0), ('uniform', 1)):
-    v = ctypes.c_float(0); ct.lib.ctamdMeasureMfmaCeiling(1, kind, ctypes.byref(v)); out[name] = v.value
+for name, kind, shape in (('zeros', 0, 1), ('uniform', 1, 1), ('uniform_32x32x16', 1, 0)):   # the default kernel's MFMA shape is 16x16x32
+    v = ctypes.c_float(0); ct.lib.ctamdMeasureMfmaCeilingShape(1, kind, shape, ctypes.byref(v)); out[name] = v.value
 print(json.dumps({'mfma_only_tflops': out}))
 PY
 python tools/h16_ksweep.py --zeros 2>/dev/null | tail -1 > $OUT/h16_ksweep.jsonl
