@@ -59,6 +59,29 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
 
 
+def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tmp_path):
+    """gett_h16w4x_kernel issues its MFMAs from inline asm (the compiler's hazard recognizer pads independent 4-pass MFMAs to 27
+    cycles), so the compiler does not know that the accumulators are written late: in every instantiation the two `s_nop 15` of the
+    kernel must lie between the last MFMA and the first instruction that reads an accumulator register, and no accumulator may be
+    spilled (a spill store right behind an asm MFMA would read the register before the matrix pipe has written it)."""
+    co = _code_object(tmp_path, "gett_h16v")
+    k = _kernel_notes(co)
+    names = [n for n in k if "gett_h16w4x_kernel" in n]
+    assert len(names) >= 8, sorted(k)
+    for name in names:
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
+                             capture_output=True, text=True).stdout.splitlines()
+        ins = [l.split("//")[0].strip() for l in dis if l.startswith("\t")]
+        mfma = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f32_16x16x32")]
+        assert len(mfma) >= 3 * 128, (name, len(mfma))                    # two unrolled K-tiles and the tail
+        reads = [i for i, l in enumerate(ins) if i > mfma[-1] and (l.startswith("v_accvgpr_read") or l.startswith("v_accvgpr_mov")
+                                                                   or re.search(r"(store|write)\S* .*\ba\[?\d", l))]
+        assert reads, name
+        between = ins[mfma[-1] + 1:reads[0]]
+        assert sum(1 for l in between if l.startswith("s_nop 15")) >= 2, (name, between)
+        assert not any(l.startswith("scratch_") for l in ins), name
+
+
 def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
     k = _kernel_notes(_code_object(tmp_path, "gett_f32_stream"))
     hot = {n: v for n, v in k.items() if "gett_f32_stream_kernel" in n}
