@@ -347,8 +347,8 @@ __device__ __forceinline__ uint32_t x_offF(int lane, int f) {
 
 // TIMED (measurement-only instantiation, CUTENSOR_AMD_H16_TIMED=1 with the planner's default kernel, layout mk,kn): wave 0 of every
 // workgroup records shader cycles at entry / first MFMA / end of the main loop / exit and the wall clock at entry / exit into
-// p.timing (the layout tools/h16_wg_timeline.py reads).  XST (measurement, CUTENSOR_AMD_H16_XST): how the epilogue's 16-byte stores are
-// issued — 0 nontemporal (the default), 1 plain, 2 write-through.
+// p.timing (the layout tools/h16_wg_timeline.py reads).  XST (measurement, CUTENSOR_AMD_H16_XST, with TIMED only): 0 the default,
+// 1 plain instead of nontemporal stores in the epilogue, 3 always the fp32 LDS image (the general path) instead of the 16-bit one.
 template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
