@@ -28,6 +28,10 @@ const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_64F    = &kCompute[5];
 
 namespace {
 
+// launches of cutensorContract by kernel kind since the library was loaded (ctamdLaunchCounts): 0 = gett_simple_kernel (scalar FMA
+// fallback), 1 = gett_wide_kernel (mode table), 2 = fp32 MFMA families, 3 = aligned 16-bit MFMA family, 4 = general MFMA family
+std::atomic<uint64_t> g_launchCounts[5];
+
 bool valid_compute(cutensorComputeDescriptor_t c) { return c >= &kCompute[0] && c <= &kCompute[5]; }
 
 int log_level() {
@@ -138,7 +142,8 @@ namespace {
 // any experiment knob that changes what cutensorCreatePlan decides: the memo stands aside while one is set
 bool plan_env_override() {
     return std::getenv("CUTENSOR_AMD_FORCE") || std::getenv("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD") ||
-           std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT");
+           std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT") || std::getenv("CUTENSOR_AMD_H16_WAVES") ||
+           std::getenv("CUTENSOR_AMD_KORDER") || std::getenv("CUTENSOR_AMD_ABLATION") || std::getenv("CUTENSOR_AMD_PEEL") || std::getenv("CUTENSOR_AMD_GEN");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
@@ -210,7 +215,6 @@ static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash
 static constexpr int64_t kMaxPeelLaunches = 64;
 static bool peel_wide_contraction(const cutensorOperationDescriptor& desc, cutensorOperationDescriptor& inner, std::vector<PeelMode>& peel) {
     if (desc.kind != OpKind::Contraction) return false;
-    if (desc.A.desc.dtype == HIP_C_32F || desc.A.desc.dtype == HIP_C_64F) return false;   // complex: the mode-table kernel is the only one
     inner = desc;
     peel.clear();
     // 16-bit data: a peeled CONTRACTED mode would accumulate through D, i.e. round every partial sum to the 16-bit type — the
@@ -776,7 +780,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
         if (!v.wide && (v.dtype == HIP_R_16BF || v.dtype == HIP_R_16F)) {   // split-K partials of the 16-bit MFMA kernel
             ContractionChoice hc;
-            if (pick_h16_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
+            if (pick_h16_choice(v, cap, handle->numCUs, hc) || pick_gen_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
             return CUTENSOR_STATUS_SUCCESS;
         }
         if (v.wide) {    // a peeled contraction wants what its inner, tiled problem wants
@@ -1082,6 +1086,26 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 cutensorPlan_t ip = nullptr;
                 if (cutensorCreatePlan(handle, &ip, &inner, pref, workspaceSizeLimit) == CUTENSOR_STATUS_SUCCESS && ip->choice.kernel != -2 &&
                     ip->sub1 == nullptr) {
+                    // A peeled CONTRACTED mode accumulates into D: every launch after the first reads D as its C operand.  The inner
+                    // plan carries the caller's C layout (and its conjugation); when that differs from D's, the accumulate launches
+                    // get a second inner plan whose C descriptor is D's.
+                    bool contracted = false;
+                    for (const PeelMode& pm : peel) contracted = contracted || pm.contracted;
+                    if (contracted && (inner.C.desc.stride != inner.D.desc.stride || inner.C.op != CUTENSOR_OP_IDENTITY)) {
+                        cutensorOperationDescriptor inner2 = inner;
+                        inner2.C = inner.D;
+                        inner2.C.op = CUTENSOR_OP_IDENTITY;
+                        cutensorPlan_t ip2 = nullptr;
+                        if (cutensorCreatePlan(handle, &ip2, &inner2, pref, workspaceSizeLimit) != CUTENSOR_STATUS_SUCCESS || ip2->choice.kernel == -2 ||
+                            ip2->sub1 != nullptr) {
+                            delete ip2;
+                            delete ip;
+                            delete pl;
+                            return CUTENSOR_STATUS_NOT_SUPPORTED;
+                        }
+                        pl->sub2 = ip2;
+                        ip->requiredWorkspace = std::max(ip->requiredWorkspace, ip2->requiredWorkspace);
+                    }
                     pl->sub1 = ip;
                     pl->peel = peel;
                     pl->choice = ContractionChoice{};
@@ -1095,6 +1119,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 }
                 delete ip;
             }
+        }
+        {
+            const bool cplx = pl->view.dtype == HIP_C_32F || pl->view.dtype == HIP_C_64F;
+            const bool genOff = std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == '0';
+            // complex data only multiplies on the general MFMA family or on the mode-table kernel (complex scalars of the data's type)
+            if (cplx && (genOff || desc->scalarType != pl->view.dtype || (pl->view.dtype == HIP_C_32F && pl->accumulate64))) pl->view.wide = true;
         }
         if (pl->view.wide) {
             // mode-table kernel: output modes (L, M, N), then contracted modes, in device memory owned by the plan
@@ -1130,10 +1160,18 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         const bool mfmaPath = pl->view.dtype == HIP_R_32F && !pl->accumulate64;
         const bool h16Path = !mfmaPath && !pl->accumulate64 && desc->scalarType == HIP_R_32F &&
                              (pl->view.dtype == HIP_R_16BF || pl->view.dtype == HIP_R_16F);
+        // general MFMA family: 16-bit shapes the aligned kernels refuse, fp64 (double scalars), complex (complex scalars)
+        const bool genPath = h16Path || (pl->view.dtype == HIP_R_64F && desc->scalarType == HIP_R_64F) ||
+                             (pl->view.dtype == HIP_C_32F && desc->scalarType == HIP_C_32F && !pl->accumulate64) ||
+                             (pl->view.dtype == HIP_C_64F && desc->scalarType == HIP_C_64F);
         ContractionChoice pick;   // kernel = -1: simple kernel
         std::vector<ContractionChoice> ch;
         if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs);
         else if (h16Path) ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+        if (ch.empty() && genPath && !(std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == '0')) {
+            ContractionChoice g;
+            if (pick_gen_choice(pl->view, workspaceSizeLimit, handle->numCUs, g)) ch.push_back(g);
+        }
         if (!ch.empty()) {
             size_t idx = 0;
             const bool useCache = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE;
@@ -1186,14 +1224,22 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 }
                 if (useCache && patient) {
                     std::lock_guard<std::mutex> g(handle->mtx);
-                    if (handle->planCache.size() < handle->planCacheCapacity)
+                    if (handle->planCache.size() < handle->planCacheCapacity) {
                         handle->planCache[key] = PlanCacheEntry{key, ch[idx].kernel, ch[idx].splitK};
+                        handle->planMemo.clear();   // a DEFAULT prototype memoised earlier must not shadow the measured choice
+                    }
                 }
             }
             pick = ch[idx];
         }
         pl->choice = pick;
         fill_gett_params(pl->view, pick, pl->gett, pl->skr);
+        {   // conjugation follows the operands into their kernel roles (kernel-A is the user's B when swapped)
+            const bool cA = desc->A.op == CUTENSOR_OP_CONJ, cB = desc->B.op == CUTENSOR_OP_CONJ;
+            pl->gett.conjA = pl->view.swapped ? cB : cA;
+            pl->gett.conjB = pl->view.swapped ? cA : cB;
+            pl->gett.conjC = desc->C.op == CUTENSOR_OP_CONJ;
+        }
         pl->requiredWorkspace = pick.workspace;
         // Per-XCD K split (one output tile, split-K over whole XCD rows): see calibrate_xcd_split
         if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK >= 64 && pl->view.totL == 1 && pl->gett.tilesM * pl->gett.tilesN == 1) {
@@ -1230,7 +1276,14 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (log_level() > 0) {
             int count = 0;
             const GettKernelInfo* tab = gett_f32_kernels(&count);
-            if (pick.family == 1)
+            if (pick.family == 2) {
+                int gc = 0;
+                const GettKernelInfo* gt = gett_gen_kernels(&gc);
+                CT_LOG("plan: contraction (general MFMA family) dtype=%d L=%llu M=%llu N=%llu K=%llu swapped=%d -> gen kernel %d (%dx%dx%d orientA=%d orientB=%d V=%d) splitK=%u",
+                       (int)pl->view.dtype, (unsigned long long)pl->view.totL, (unsigned long long)pl->view.totM, (unsigned long long)pl->view.totN,
+                       (unsigned long long)pl->view.totK, (int)pl->view.swapped, pick.kernel, gt[pick.kernel].bm, gt[pick.kernel].bn, gt[pick.kernel].bk,
+                       gt[pick.kernel].layA, gt[pick.kernel].layB, gt[pick.kernel].vec, pick.splitK);
+            } else if (pick.family == 1)
                 CT_LOG("plan: contraction (16-bit MFMA) L=%llu M=%llu N=%llu K=%llu layA=%d layB=%d swapped=%d -> h16 kernel %d",
                        (unsigned long long)pl->view.totL, (unsigned long long)pl->view.totM, (unsigned long long)pl->view.totN,
                        (unsigned long long)pl->view.totK, pl->view.layA, pl->view.layB, (int)pl->view.swapped, pick.kernel);
@@ -1343,9 +1396,9 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         // others accumulate into it
         if (plan->sub1 == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
         const size_t es = dtype_size(plan->dtype);
-        const float onef = 1.f;
-        const double oned = 1.0;
-        const void* one = (plan->scalarType == HIP_R_64F) ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
+        const float onef[2] = {1.f, 0.f};      // (real, imaginary): also the complex one
+        const double oned[2] = {1.0, 0.0};
+        const void* one = (plan->scalarType == HIP_R_64F || plan->scalarType == HIP_C_64F) ? static_cast<const void*>(oned) : static_cast<const void*>(onef);
         const size_t n = plan->peel.size();
         std::vector<int64_t> digit(n, 0);
         for (;;) {
@@ -1358,7 +1411,8 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             }
             char* d = static_cast<char*>(D) + oD * (int64_t)es;
             const char* c = first ? (C ? static_cast<const char*>(C) + oC * (int64_t)es : nullptr) : d;
-            const cutensorStatus_t st = cutensorContract(handle, plan->sub1, alpha, static_cast<const char*>(A) + oA * (int64_t)es,
+            // accumulate launches read D in D's own layout (sub2, when the caller's C is laid out differently or conjugated)
+            const cutensorStatus_t st = cutensorContract(handle, (!first && plan->sub2) ? plan->sub2 : plan->sub1, alpha, static_cast<const char*>(A) + oA * (int64_t)es,
                                                          static_cast<const char*>(B) + oB * (int64_t)es, first ? beta : one, c, d, workspace,
                                                          workspaceSize, stream);
             if (st != CUTENSOR_STATUS_SUCCESS) return st;
@@ -1379,6 +1433,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     p.D = D;
     p.alpha = (float)a; p.beta = (float)b;
     p.alpha64 = a; p.beta64 = b;
+    p.alphaIm = aIm; p.betaIm = bIm;
     p.timing = handle->timingBuffer.load(std::memory_order_relaxed);
     // incremental-autotuning trial: one event pair around everything this call launches, read later (resolve_pending_measurements)
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1414,12 +1469,15 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         w.alpha = p.alpha; w.beta = p.beta; w.alpha64 = a; w.beta64 = b;
         w.alphaIm = aIm; w.betaIm = bIm;
         err = launch_gett_wide(w, (int)plan->dtype, plan->accumulate64, stream);
+        g_launchCounts[1].fetch_add(1, std::memory_order_relaxed);
     } else if (plan->choice.kernel < 0) {
+        g_launchCounts[0].fetch_add(1, std::memory_order_relaxed);
         p.partial = nullptr;
         err = launch_gett_simple(p, (int)plan->dtype, plan->accumulate64, stream);
-    } else if (plan->choice.family == 1) {
+    } else if (plan->choice.family == 1 || plan->choice.family == 2) {
         int count = 0;
-        const GettKernelInfo* tab = gett_h16_kernels(&count);
+        const GettKernelInfo* tab = plan->choice.family == 2 ? gett_gen_kernels(&count) : gett_h16_kernels(&count);
+        g_launchCounts[plan->choice.family == 2 ? 4 : 3].fetch_add(1, std::memory_order_relaxed);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (handle->prof.enabled.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
@@ -1439,6 +1497,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     } else {
         int count = 0;
         const GettKernelInfo* tab = gett_f32_kernels(&count);
+        g_launchCounts[2].fetch_add(1, std::memory_order_relaxed);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         if (plan->fusedFold) {
             uint32_t slot;
@@ -1686,6 +1745,13 @@ int ctamdPlanPeelLaunches(const cutensorPlan_t plan) {
     return (int)n;
 }
 
+// cutensorContract launches by kernel kind since the library was loaded: out[0] gett_simple_kernel (scalar FMA fallback), [1]
+// gett_wide_kernel (mode table), [2] fp32 MFMA families, [3] aligned 16-bit MFMA family, [4] general MFMA family.  Lets a test that
+// drives the library through someone else's binding (the reference's own einsum.cc) assert which kernels its cases ran on.
+void ctamdLaunchCounts(uint64_t out[5]) {
+    for (int i = 0; i < 5; ++i) out[i] = g_launchCounts[i].load(std::memory_order_relaxed);
+}
+
 // Plan-memo counters of this handle: plans answered by cloning a prototype / plans that went through the planner.
 void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) {
     if (handle == nullptr) return;
@@ -1711,7 +1777,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
     }
     if (plan->kind == OpKind::Contraction) {
         int count = 0;
-        const GettKernelInfo* tab = (plan->choice.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
+        const GettKernelInfo* tab = (plan->choice.family == 2) ? gett_gen_kernels(&count) : (plan->choice.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
         const int k = plan->choice.kernel;
         n = std::snprintf(buf, len,
                           "{\"op\":\"contraction\",\"family\":%d,\"L\":%llu,\"M\":%llu,\"N\":%llu,\"K\":%llu,\"swapped\":%d,\"layA\":%d,\"layB\":%d,"
@@ -1725,8 +1791,10 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold,
                           (unsigned long long)plan->gett.xcdTiles,
-                          k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 1 ? (tab[k].threads == 256 ? (tab[k].bk == 32 ? "gett_h16w4s_kernel" : tab[k].pf == 3 ? "gett_h16w4r_kernel" : tab[k].pf == 6 ? "gett_h16w4v_kernel" : tab[k].pf == 7 ? "gett_h16w4x_kernel" : "gett_h16w4_kernel") : tab[k].pf == 4 ? "gett_h16s_kernel" : "gett_h16_kernel") : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
+                          k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 2 ? "gett_gen_kernel" : plan->choice.family == 1 ? (tab[k].threads == 256 ? (tab[k].bk == 32 ? "gett_h16w4s_kernel" : tab[k].pf == 3 ? "gett_h16w4r_kernel" : tab[k].pf == 6 ? "gett_h16w4v_kernel" : tab[k].pf == 7 ? "gett_h16w4x_kernel" : "gett_h16w4_kernel") : tab[k].pf == 4 ? "gett_h16s_kernel" : "gett_h16_kernel") : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
+        if (n > 0 && (size_t)n < len && plan->choice.family == 2 && k >= 0)
+            n += std::snprintf(buf + n, len - n, ",\"orientA\":%d,\"orientB\":%d,\"vec\":%d,\"elem\":%d", tab[k].layA, tab[k].layB, tab[k].vec, tab[k].elem);
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
         for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)
             n += std::snprintf(buf + n, len - n, "%s[%lld,%lld,%lld]", i ? "," : "", (long long)plan->view.K[i].extent,

@@ -89,12 +89,14 @@ struct ContractionView {
     uint64_t totL = 1, totM = 1, totN = 1, totK = 1;
     bool     wide = false;               // a group has more than kMaxGroupModes unfusable modes (or >= 2^31 elements):
                                          // only the mode-table kernel (gett_wide_kernel) can run it
+    uint32_t alignA = 0, alignB = 0;     // descriptor alignment (bytes) of kernel-A / kernel-B
 };
 
 // One executable choice for a contraction.
 struct ContractionChoice {
     int      kernel = -1;      // index into the family's kernel table; -1 = simple kernel
-    int      family = 0;       // 0 = gett_f32_kernels() (fp32 data), 1 = gett_h16_kernels() (bf16 / fp16 data)
+    int      family = 0;       // 0 = gett_f32_kernels() (fp32 data), 1 = gett_h16_kernels() (bf16 / fp16 data, aligned shapes),
+                               // 2 = gett_gen_kernels() (general MFMA family: any 16-bit shape, fp64, complex)
     uint32_t splitK = 1;
     uint32_t kPerSlice = 0;
     uint64_t workspace = 0;
@@ -107,6 +109,8 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
                                                         int numCUs);
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
+// general MFMA family (kernels/gett_gen.inc): false only for fp32 data and for views the tiled kernels cannot describe
+bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
 // 16-bit family: the default kernel variant first, then the other variants of the same tile / split (the candidates
 // CUTENSOR_ALGO_DEFAULT_PATIENT and incremental autotuning measure)
 std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64_t wsLimit, int numCUs);

@@ -222,8 +222,9 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
         v.layA = v.layB = LAY_S;
         return CUTENSOR_STATUS_SUCCESS;
     }
-    if (v.dtype == HIP_C_32F || v.dtype == HIP_C_64F) {   // complex data: the mode-table kernel is the only one that multiplies it
-        v.wide = true;
+    v.alignA = v.swapped ? op.B.desc.alignment : op.A.desc.alignment;
+    v.alignB = v.swapped ? op.A.desc.alignment : op.B.desc.alignment;
+    if (v.dtype == HIP_C_32F || v.dtype == HIP_C_64F) {   // complex data: the general MFMA family (pick_gen_choice) decides its own lanes
         v.layA = v.layB = LAY_S;
         return CUTENSOR_STATUS_SUCCESS;
     }
@@ -451,6 +452,104 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// General MFMA family (kernels/gett_gen.inc): bf16 / fp16 shapes the aligned kernels refuse, fp64, complex64 / complex128.
+// Per operand: the orientation of its staged units (along k when the fastest contracted mode is its stride-1 mode, along rows
+// when the fastest free mode is) and the widest unit V its extents, strides and pointer alignment admit; the kernel runs both
+// operands at the smaller V.  Tile: the large one when it still fills the chip.  Split-K (16-bit data only: fp32 partials through
+// the existing fold) when the output tiles alone leave most CUs idle.
+// ---------------------------------------------------------------------------------------------
+static int gen_elem_of(hipDataType t) {
+    switch (t) {
+        case HIP_R_16BF: return GEN_BF16;
+        case HIP_R_16F:  return GEN_F16;
+        case HIP_R_64F:  return GEN_F64;
+        case HIP_C_32F:  return GEN_C32;
+        case HIP_C_64F:  return GEN_C64;
+        default:         return -1;
+    }
+}
+
+// widest unit (elements) operand `slotA` admits with units along k (orient 1) or along rows (orient 0); 1 = element gathers
+static int gen_operand_vec(const ContractionView& v, bool slotA, int orient, int maxV) {
+    const std::vector<CanonMode>& freeG = slotA ? v.M : v.N;
+    const std::vector<CanonMode>& lead = orient ? v.K : freeG;
+    if (lead.empty()) return 1;
+    const CanonMode& m0 = lead.front();
+    if ((slotA ? m0.sA : m0.sB) != 1) return 1;
+    const int64_t es = (int64_t)dtype_size(v.dtype);
+    const uint32_t align = slotA ? v.alignA : v.alignB;
+    for (int V = maxV; V > 1; V >>= 1) {
+        if (m0.extent % V != 0 || align % (uint32_t)(V * es) != 0) continue;
+        bool ok = true;
+        for (const std::vector<CanonMode>* g : {&freeG, &v.K, &v.L})
+            for (const CanonMode& m : *g) {
+                if (&m == &m0) continue;
+                if ((slotA ? m.sA : m.sB) % V != 0) ok = false;
+            }
+        if (ok) return V;
+    }
+    return 1;
+}
+
+bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c) {
+    const int elem = gen_elem_of(v.dtype);
+    if (elem < 0 || v.wide) return false;
+    const int maxV = (elem == GEN_C64) ? 1 : (elem == GEN_F64 || elem == GEN_C32) ? 2 : 8;
+    int orient[2], vec[2];
+    for (int o = 0; o < 2; ++o) {
+        const bool slotA = o == 0;
+        const int vK = gen_operand_vec(v, slotA, 1, maxV), vF = gen_operand_vec(v, slotA, 0, maxV);
+        if (vK > 1 && vK >= vF) { orient[o] = 1; vec[o] = vK; }
+        else if (vF > 1)        { orient[o] = 0; vec[o] = vF; }
+        else {
+            // element gathers: neighbouring lanes along whichever direction has the smaller stride
+            const std::vector<CanonMode>& freeG = slotA ? v.M : v.N;
+            const int64_t sK = v.K.empty() ? INT64_MAX : std::llabs(slotA ? v.K.front().sA : v.K.front().sB);
+            const int64_t sF = freeG.empty() ? INT64_MAX : std::llabs(slotA ? freeG.front().sA : freeG.front().sB);
+            orient[o] = (sK <= sF) ? 1 : 0;
+            vec[o] = 1;
+        }
+    }
+    int V = std::min(vec[0], vec[1]);
+    if (elem <= GEN_F16 && V == 4) V = 2;          // instantiated widths: 8 / 2 / 1 (16-bit), 2 / 1 (fp64, complex64), 1 (complex128)
+    int count = 0;
+    const GettKernelInfo* tab = gett_gen_kernels(&count);
+    // candidates of this (type, V, orientation pair): the table lists the larger tile first
+    int big = -1, small = -1;
+    for (int i = 0; i < count; ++i)
+        if (tab[i].elem == elem && tab[i].vec == V && tab[i].layA == orient[0] && tab[i].layB == orient[1]) {
+            if (big < 0) big = i;
+            small = i;
+        }
+    if (big < 0) return false;
+    auto tiles_of = [&](int k) {
+        return std::ceil((double)v.totM / tab[k].bm) * std::ceil((double)v.totN / tab[k].bn) * (double)v.totL;
+    };
+    c = ContractionChoice{};
+    c.family = 2;
+    c.kernel = (tiles_of(big) >= 0.6 * numCUs) ? big : small;
+    const GettKernelInfo& k = tab[c.kernel];
+    const double tiles = tiles_of(c.kernel);
+    const uint64_t kTiles = (v.totK + k.bk - 1) / k.bk;
+    uint64_t split = 1;
+    if (elem <= GEN_F16 && tiles * 2.0 <= (double)numCUs && kTiles >= 8) {
+        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
+        const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
+        while (split > 1 && split * perSliceBytes > wsLimit) --split;
+        if (split < 2) split = 1;
+    }
+    const uint64_t tilesPerSlice = (kTiles + split - 1) / split;
+    c.splitK = (uint32_t)((kTiles + tilesPerSlice - 1) / tilesPerSlice);
+    c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
+    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
+    // rough time: the family's MFMA rate for the type at ~50 % utilisation (only used for logs / describe)
+    const double flopPerClkCU = (elem <= GEN_F16) ? 4096.0 : (elem == GEN_C32) ? 256.0 : 128.0;
+    const double flops = ((elem >= GEN_C32) ? 8.0 : 2.0) * k.bm * k.bn * (double)c.kPerSlice;
+    c.estimateUs = std::ceil(tiles * c.splitK / (double)numCUs) * flops / (flopPerClkCU * 2.4e9 * 0.5) * 1e6 + 2.0;
+    return true;
+}
+
 static void fill_group(ModeGroup& g, const std::vector<CanonMode>& modes) {
     std::memset(&g, 0, sizeof(g));
     g.n = (int32_t)modes.size();
@@ -485,7 +584,7 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
         p.cStrideL[i] = v.L[i].sC;
     }
     int count = 0;
-    const GettKernelInfo* tab = (c.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
+    const GettKernelInfo* tab = (c.family == 2) ? gett_gen_kernels(&count) : (c.family == 1) ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
     int bm = 16, bn = 16, bk = 16;
     if (c.kernel >= 0 && c.kernel < count) { bm = tab[c.kernel].bm; bn = tab[c.kernel].bn; bk = tab[c.kernel].bk; }
     (void)bk;
@@ -502,7 +601,7 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
     r.splitK = c.splitK;
     r.tilesM = p.tilesM; r.tilesN = p.tilesN;
     r.fragTM = (uint32_t)bm / 32u; r.fragTN = (uint32_t)bn / 32u;
-    r.outType = (c.family == 1) ? (v.dtype == HIP_R_16BF ? 1 : 2) : 0;
+    r.outType = (c.family == 1 || c.family == 2) ? (v.dtype == HIP_R_16BF ? 1 : 2) : 0;   // family 2 splits K for 16-bit data only
 }
 
 }  // namespace ctamd

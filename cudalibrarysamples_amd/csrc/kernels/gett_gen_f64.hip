@@ -1,0 +1,82 @@
+// gett_gen_f64.hip — fp64 instantiations of the general MFMA GETT kernel (gett_gen.inc): v_mfma_f64_16x16x4_f64.
+//   V = 2: 16-byte lanes (two doubles) — 128 x 128 x 16 and 64 x 64 x 16 tiles;  V = 1: 8-byte gathers — 64 x 64 x 16
+#include "gett_gen.inc"
+
+namespace ctamd {
+
+static const GettKernelInfo g_gen_f64_table[] = {
+    CTAMD_GEN_ORIENTS(GEN_F64, 128, 128, 16, 2)
+    CTAMD_GEN_ORIENTS(GEN_F64, 64, 64, 16, 2)
+    CTAMD_GEN_ORIENTS(GEN_F64, 64, 64, 16, 1)};
+
+const GettKernelInfo* gett_gen_f64_kernels(int* count) {
+    *count = (int)(sizeof(g_gen_f64_table) / sizeof(g_gen_f64_table[0]));
+    return g_gen_f64_table;
+}
+
+}  // namespace ctamd
+
+// ---------------------------------------------------------------------------------------------
+// What the chip sustains on nothing but v_mfma_f64_16x16x4_f64 (the fp64 general kernels' roofline; the microarchitecture guide
+// quotes no fp64 matrix figure, so it is measured): 256 threads per CU, eight independent accumulators per wave, operands held
+// in registers.  dataKind 0: zeros (issue rate at full clock), 1: U(-1, 1).  Returns TFLOP/s (2 * 16 * 16 * 4 flop per MFMA).
+// ---------------------------------------------------------------------------------------------
+namespace ctamd {
+__global__ void __launch_bounds__(256) mfma_f64_ceiling_kernel(const double* __restrict__ src, double* __restrict__ out, int iters) {
+    const int tid = threadIdx.x;
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = src[tid + 256 * i]; b[i] = src[tid + 256 * (4 + i)]; }
+    f64x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f64x4{0., 0., 0., 0.};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+    }
+    f64x4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += acc[i];
+    out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+}  // namespace ctamd
+
+extern "C" int ctamdMeasureMfmaCeilingF64(int dataKind, float* tflops) {
+    using namespace ctamd;
+    if (tflops == nullptr) return -1;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    const int cus = prop.multiProcessorCount;
+    const size_t n = 256 * 8;
+    double h[256 * 8];
+    uint32_t lcg = 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        lcg = lcg * 1664525u + 1013904223u;
+        h[i] = dataKind == 0 ? 0.0 : 2.0 * (double)(lcg >> 8) / 16777216.0 - 1.0;
+    }
+    double *d = nullptr, *out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    if (hipMalloc((void**)&d, n * 8) == hipSuccess && hipMalloc((void**)&out, (size_t)cus * 256 * 8) == hipSuccess &&
+        hipMemcpy(d, h, n * 8, hipMemcpyHostToDevice) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        const int iters = 5000;
+        auto launch = [&]() { hipLaunchKernelGGL(mfma_f64_ceiling_kernel, dim3(cus), dim3(256), 0, nullptr, d, out, iters); };
+        for (int w = 0; w < 3; ++w) launch();
+        (void)hipEventRecord(e0, nullptr);
+        for (int w = 0; w < 3; ++w) launch();
+        (void)hipEventRecord(e1, nullptr);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f) {
+            const double flops = 3.0 * (double)cus * 4 * iters * 8 * 2.0 * 16 * 16 * 4;
+            *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+            rc = 0;
+        }
+    }
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    if (out) (void)hipFree(out);
+    return rc;
+}

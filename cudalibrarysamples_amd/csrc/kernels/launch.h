@@ -25,7 +25,12 @@ struct GettKernelInfo {
                          //    launch_splitk_reduce_frag; 0: row-major [M][N], launch_splitk_reduce
     int nt;              // 1: operands are streamed with the nontemporal policy (no Infinity-Cache allocation): ranked only for
                          //    problems that read every operand byte once and whose operands exceed the Infinity Cache anyway
+    int elem;            // general family (gett_gen_kernels): GenElem of the instantiation
+    int vec;             // general family: elements per staged unit = per global load (both operands)
 };
+
+// element types of the general MFMA family (gett_gen.inc)
+enum GenElem : int { GEN_BF16 = 0, GEN_F16 = 1, GEN_F64 = 2, GEN_C32 = 3, GEN_C64 = 4 };
 
 // fp32 data, fp32 MFMA (v_mfma_f32_16x16x4_f32)
 const GettKernelInfo* gett_f32_kernels(int* count);
@@ -37,6 +42,14 @@ const GettKernelInfo* gett_f32_stream_kernels(int* count);
 // bf16 / fp16 data, fp32 accumulation (v_mfma_f32_32x32x16_{bf16,f16}), gett_h16.hip
 const GettKernelInfo* gett_h16_kernels(int* count);
 const GettKernelInfo* gett_h16v_kernels(int* count);   // gett_h16v.hip: appended to the table above as entries 40..47
+
+// general MFMA family: bf16 / fp16 shapes the aligned kernels above refuse (no 16-byte lanes, K not in whole 64-deep tiles), fp64,
+// complex64 / complex128 — register-staged, any strides and extents (gett_gen.inc; the table is the concatenation of the three
+// translation units gett_gen_h16.hip / gett_gen_f64.hip / gett_gen_cplx.hip)
+const GettKernelInfo* gett_gen_kernels(int* count);
+const GettKernelInfo* gett_gen_h16_kernels(int* count);
+const GettKernelInfo* gett_gen_f64_kernels(int* count);
+const GettKernelInfo* gett_gen_cplx_kernels(int* count);
 
 // simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,

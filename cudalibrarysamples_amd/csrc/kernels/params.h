@@ -51,6 +51,10 @@ struct GettParams {
     int64_t     cStrideM[kMaxGroupModes];
     int64_t     cStrideN[kMaxGroupModes];
     int64_t     cStrideL[kMaxGroupModes];
+    // complex data (general MFMA family, gett_gen.inc): imaginary parts of the scalars (real parts in alpha64 / beta64),
+    // conjugation of kernel-A / kernel-B / C
+    double      alphaIm, betaIm;
+    int32_t     conjA, conjB, conjC;
 };
 
 // ---------------------------------------------------------------------------------------------

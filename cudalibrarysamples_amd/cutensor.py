@@ -21,7 +21,7 @@ lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 
 # ---- enums (include/cutensor/types.h) ----------------------------------------------------------
 R_32F, R_64F, R_16F, R_16BF = 0, 1, 2, 14
-C_32F, C_64F = 4, 5   # complex data: contractions only (mode-table kernel)
+C_32F, C_64F = 4, 5   # complex data: contractions only (general MFMA family; mode-table kernel beyond four modes per group)
 STATUS_SUCCESS, STATUS_NOT_INITIALIZED, STATUS_INVALID_VALUE = 0, 1, 7
 STATUS_NOT_SUPPORTED, STATUS_INSUFFICIENT_WORKSPACE, STATUS_IO_ERROR = 15, 19, 21
 OP_IDENTITY, OP_ADD, OP_MUL, OP_MAX, OP_MIN = 1, 3, 5, 6, 7
@@ -101,6 +101,8 @@ lib.ctamdDescribePlan.argtypes = [_vp, ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdCountCandidates.argtypes = [_vp, _vp, ctypes.c_uint64]
 lib.ctamdPlanMemoStats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
 lib.ctamdPlanMemoStats.restype = None
+lib.ctamdLaunchCounts.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+lib.ctamdLaunchCounts.restype = None
 lib.ctamdSetTimingBuffer.argtypes = [_vp, _vp]
 lib.ctamdSetTimingBuffer.restype = None
 lib.ctamdSetSplitKFold.argtypes = [_vp, ctypes.c_int]
@@ -133,6 +135,14 @@ def plan_memo_stats(handle):
     h, m, e = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint32(0)
     lib.ctamdPlanMemoStats(handle, ctypes.byref(h), ctypes.byref(m), ctypes.byref(e))
     return h.value, m.value, e.value
+
+
+def launch_counts():
+    """cutensorContract launches by kernel kind since the library was loaded: dict with the keys simple (scalar FMA fallback),
+    wide (mode-table kernel), f32 (fp32 MFMA families), h16 (aligned 16-bit MFMA family), gen (general MFMA family)."""
+    out = (ctypes.c_uint64 * 5)()
+    lib.ctamdLaunchCounts(out)
+    return dict(zip(("simple", "wide", "f32", "h16", "gen"), [int(v) for v in out]))
 
 
 def compute_desc(name):

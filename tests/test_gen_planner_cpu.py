@@ -1,0 +1,123 @@
+"""Which contractions the planner hands to the general MFMA family (csrc/host/plan_contraction.cpp pick_gen_choice ->
+csrc/kernels/gett_gen.inc), host-only.  The point of the family: every 16-bit case of the reference's own regression list
+(cuTENSOR/python/cutensor/torch/einsum_test.py:84-123, extents of 50: no 16-byte lanes, K not in whole 64-deep tiles), its
+fp64 case (:109-115) and its complex cases (:55-68) run on the matrix cores instead of the one-output-per-lane FMA kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = os.path.join(ROOT, "tests", "golden", "full")
+DT = {"float16": "R_16F", "bfloat16": "R_16BF", "float64": "R_64F", "complex64": "C_32F", "complex128": "C_64F", "float32": "R_32F"}
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    return ct, ops, ops.Handle()
+
+
+def _plan_for_equation(env, equation, a_size, b_size, dtype_name):
+    """The descriptor set Einsum<> builds for a row-major framework tensor (einsum.cu:63-223: modes and extents reversed)."""
+    import oracle
+    ct, ops, h = env
+    p = oracle.einsum_parse(equation, a_size, b_size)
+    assert p is not None, equation
+    return ops.contraction_plan(h, p["extentA"], p["modesA"], p["extentB"], p["modesB"], p["extentC"], p["modesC"],
+                                dtype=getattr(ct, DT[dtype_name]), workspace_limit=1 << 28)
+
+
+@pytest.mark.parametrize("name", sorted(f[:-4] for f in os.listdir(FULL) if f.endswith(".npz")))
+def test_reference_cases_at_their_own_extents_run_on_mfma_kernels(env, name):
+    meta = json.loads(str(np.load(os.path.join(FULL, name + ".npz"))["meta"]))
+    plan = _plan_for_equation(env, meta["equation"], meta["a_size"], meta["b_size"], meta["dtype"])
+    d = plan.describe()
+    if meta["dtype"] == "float32":
+        assert d["family"] == 0 and d["kernel"] >= 0, d
+    else:
+        assert d["family"] == 2 and d["kernel"] >= 0 and d["kname"] == "gett_gen_kernel", (meta, d)
+        if meta["dtype"] in ("float16", "bfloat16") and len(d["Kdigits"]) == 1 and all(e % 2 == 0 for e in meta["a_size"] + meta["b_size"]):
+            # even extents and ONE contracted digit: each operand's stride-1 mode leads a group -> 4-byte pairs, not 2-byte gathers
+            # (with two contracted digits the operands may disagree on which one is contiguous: 'mlik,lkjm->lij' gathers)
+            assert d["vec"] >= 2, (meta, d)
+    plan.destroy()
+
+
+def test_vector_width_and_orientation_follow_the_layout(env):
+    ct, ops, h = env
+    def plan(M, N, K, mA, mB, dtype, **kw):
+        extA = [M, K] if mA == "mk" else [K, M]
+        extB = [K, N] if mB == "kn" else [N, K]
+        return ops.contraction_plan(h, extA, mA, extB, mB, [M, N], "mn", dtype=dtype, workspace_limit=1 << 28, **kw)
+    # 16-byte lanes but K not a multiple of 64: the aligned family refuses, the general family takes it at V = 8
+    for (mA, mB, oa, ob) in (("mk", "kn", 0, 1), ("km", "nk", 1, 0), ("km", "kn", 1, 1), ("mk", "nk", 0, 0)):
+        p = plan(2048, 2048, 1000, mA, mB, ct.R_16BF)
+        d = p.describe()
+        # the planner may have swapped the operands (D's stride-1 mode becomes kernel-N): compare as a set when it did
+        got = (d["orientA"], d["orientB"]) if not d["swapped"] else (d["orientB"], d["orientA"])
+        assert d["family"] == 2 and d["vec"] == 8 and got == (oa, ob) and (d["bm"], d["bn"], d["bk"]) == (128, 128, 64), (mA, mB, d)
+        p.destroy()
+    # whole 64-deep K-tiles and 16-byte lanes: still the aligned LDS-DMA family
+    p = plan(2048, 2048, 1024, "mk", "kn", ct.R_16BF)
+    assert p.describe()["family"] == 1
+    p.destroy()
+    # odd extents: 2-byte gathers
+    p = plan(37, 29, 51, "mk", "kn", ct.R_16F)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 1 and (d["bm"], d["bn"], d["bk"]) == (64, 64, 32), d
+    p.destroy()
+    # element alignment only (descriptor alignment 2): no lanes wider than an element
+    p = plan(64, 64, 64, "km", "kn", ct.R_16BF, alignment=2)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 1, d
+    p.destroy()
+    # fp64: 16-byte lanes = two doubles; large problem -> 128 x 128 tile, small -> 64 x 64
+    p = plan(4096, 4096, 4096, "km", "kn", ct.R_64F)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 2 and (d["bm"], d["bn"], d["bk"]) == (128, 128, 16) and d["blocks"] == 1024, d
+    p.destroy()
+    p = plan(50, 50, 50, "km", "kn", ct.R_64F)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 2 and (d["bm"], d["bn"]) == (64, 64), d
+    p.destroy()
+    p = plan(51, 49, 50, "mk", "kn", ct.R_64F)
+    assert p.describe()["vec"] == 1
+    p.destroy()
+    # complex
+    p = plan(2048, 2048, 2048, "km", "kn", ct.C_32F)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 2 and d["bk"] == 16, d
+    p.destroy()
+    p = plan(300, 300, 300, "km", "kn", ct.C_64F)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 1 and (d["bm"], d["bn"], d["bk"]) == (64, 64, 8), d
+    p.destroy()
+
+
+def test_split_k_of_16_bit_data_and_workspace_invariant(env):
+    ct, ops, h = env
+    # one output tile, deep ragged K: split over the CUs, fp32 partials within the estimate (contraction.cu:239 asserts required <= estimate)
+    p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF)
+    d = p.describe()
+    assert d["family"] == 2 and d["splitK"] > 1 and p.required_workspace == d["splitK"] * 64 * 48 * 4, d
+    assert p.required_workspace <= p.workspace_estimate
+    p.destroy()
+    # no workspace allowed: no split
+    p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
+    d = p.describe()
+    assert d["family"] == 2 and d["splitK"] == 1 and p.required_workspace == 0, d
+    p.destroy()
+
+
+def test_many_mode_complex_keeps_the_mode_table_kernel(env):
+    """More than four unfusable modes in a group and too many launches to peel (cuTENSOR/contraction_jit.cu:50-56 shape class)."""
+    ct, ops, h = env
+    mA = "badcfehgjilknm"
+    mB = "ponmlkqrst"[::-1]
+    mC = "".join(c for c in "abcdefghijopqrst" if (c in mA) != (c in mB))
+    ext = {c: (3 if c in "aq" else 2) for c in set(mA + mB)}
+    p = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC, dtype=ct.C_32F)
+    assert p.describe()["kname"] == "gett_wide_kernel"
+    p.destroy()

@@ -382,8 +382,9 @@ def test_oversized_mode_groups_are_peeled_onto_the_tiled_kernels(built, case, dt
 
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 def test_complex_contraction_with_conjugation(built, dtype):
-    """Complex data (cuTENSOR/contraction_jit.cu:31-41, std::complex<float> tensors and scalars) runs on the mode-table
-    kernel: D = alpha * conj(A) * B + beta * C with complex alpha / beta against numpy in complex128."""
+    """Complex data (cuTENSOR/contraction_jit.cu:31-41, std::complex<float> tensors and scalars) runs on the general MFMA
+    family (four real MFMAs per complex product; CUTENSOR_AMD_GEN=0 or more than four modes per group: the mode-table
+    kernel): D = alpha * conj(A) * B + beta * C with complex alpha / beta against numpy in complex128."""
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
     h = ops.Handle()
@@ -401,7 +402,7 @@ def test_complex_contraction_with_conjugation(built, dtype):
     plan = ops.contraction_plan(h, [ext[c] for c in "mkl"], "mkl", [ext[c] for c in "knl"], "knl", [ext[c] for c in "mnl"], "mnl",
                                 dtype=cdt, opA=ct.OP_CONJ)
     assert plan.scalar_type == cdt
-    assert plan.describe()["kname"] == "gett_wide_kernel"
+    assert plan.describe()["kname"] == "gett_gen_kernel"
     alpha, beta = 1.1 - 0.3j, 0.25 + 0.5j
     plan.contract(alpha, dA.data_ptr(), dB.data_ptr(), beta, dC.data_ptr(), dC.data_ptr())
     torch.cuda.synchronize()

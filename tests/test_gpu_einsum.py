@@ -31,6 +31,7 @@ def test_golden_cases(te, name):
     out = torch_einsum.einsum(meta["equation"], a, b)
     torch.cuda.synchronize()
     assert out.dtype == dtype
+    _assert_mfma_kernel(torch_einsum, meta["equation"], a, b)
     if dtype.is_complex:
         got, ref = out.to(torch.complex128).cpu().numpy(), z["out"].astype(np.complex128)
         assert list(got.shape) == list(ref.shape)
@@ -44,6 +45,15 @@ def test_golden_cases(te, name):
     np.testing.assert_allclose(got, ref, rtol=5e-3, atol=6e-3)
     if meta["dtype"] in ("float32", "float64"):
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def _assert_mfma_kernel(torch_einsum, equation, a, b):
+    """Green parity on a fallback is weaker evidence than it looks: every golden case must have run on a matrix-core kernel —
+    fp32 on the fp32 MFMA families, every other type (16-bit at these unaligned extents, fp64, complex) on the general MFMA
+    family, none on gett_simple_kernel / gett_wide_kernel."""
+    d = torch_einsum._plans[(equation, tuple(a.shape), tuple(b.shape), a.dtype, False, False)].describe()
+    assert d["kernel"] >= 0 and d["kname"] not in ("gett_simple_kernel", "gett_wide_kernel"), d
+    assert d["family"] == (0 if str(a.dtype) == "torch.float32" else 2), d
 
 
 def test_demo_equations(te):
@@ -86,6 +96,7 @@ def test_golden_cases_at_the_reference_extents(te, name):
     out = torch_einsum.einsum(meta["equation"], a.cuda(), b.cuda())
     torch.cuda.synchronize()
     assert out.dtype == a.dtype and list(out.shape) == meta["out_shape"]
+    _assert_mfma_kernel(torch_einsum, meta["equation"], a, b)
     full = out.to(wide).cpu().numpy()
     got, ref = full.reshape(-1)[z["idx"]], z["out_sampled"]
     for part in ((np.real, np.imag) if np.iscomplexobj(ref) else (lambda x: x,)):

@@ -102,10 +102,11 @@ def test_multi_mode_contraction_bf16(env):
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=5e-2)
 
 
-def test_unaligned_shapes_fall_back(env):
-    """Extents that do not admit 16-byte lanes / 64-deep K-tiles still give correct results (simple kernel)."""
+def test_unaligned_shapes_run_on_the_general_mfma_family(env):
+    """Extents that do not admit 16-byte lanes / 64-deep K-tiles: the general MFMA family (gett_gen.inc, 2-byte gathers here),
+    not the scalar FMA kernel (tests/test_gpu_gen.py covers that family)."""
     got, ref, d = _run(env, dict(m=37, n=29, k=50), "mk", "kn", "mn", seed=9, expect_mfma=False)
-    assert d["kernel"] < 0 or d["family"] == 0
+    assert d["family"] == 2 and d["kname"] == "gett_gen_kernel" and d["vec"] == 1, d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
 
 

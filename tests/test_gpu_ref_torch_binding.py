@@ -47,7 +47,12 @@ def ref_test_module(built):
     return mod
 
 
-def _run(mod, name):
+def _run(mod, name, expect_gen=False):
+    """Runs one of the reference's test methods.  The reference's binding drives libcutensor.so directly, so which kernels its
+    contractions ran on is read from the library's launch counters: never the scalar FMA fallback (gett_simple_kernel), and for
+    the 16-bit / fp64 / complex cases the general MFMA family."""
+    from cudalibrarysamples_amd import cutensor as ours     # same libcutensor.so the reference binding is linked against
+    before = ours.launch_counts()
     suite = unittest.defaultTestLoader.loadTestsFromName(name, mod.EinsumTest)
     assert suite.countTestCases() == 1, name
     res = unittest.TestResult()
@@ -55,12 +60,20 @@ def _run(mod, name):
     problems = res.errors + res.failures
     assert not problems, problems[0][1]
     assert res.testsRun == 1 and not res.skipped
+    after = ours.launch_counts()
+    delta = {k: after[k] - before[k] for k in after}
+    assert delta["simple"] == 0, (name, delta)
+    if expect_gen:          # (this also shows that the counters see the reference binding's launches: one library instance)
+        assert delta["gen"] > 0, (name, delta)
+
+# reference cases whose data type is not fp32 (einsum_test.py:55-68 complex, :84-115 fp16 / fp64): general MFMA family
+NON_F32 = {"1_test_0_complex_", "2_test_1", "5_test_4", "6_test_5", "7_test_6", "8_test_7", "9_test_8"}
 
 
 @pytest.mark.parametrize("case", BINARY)
 def test_reference_einsum_equivalent_results(ref_test_module, case):
     """einsum_test.py:127-151 — EinsumFunction.apply forward + backward vs torch.einsum."""
-    _run(ref_test_module, "test_einsum_equivalent_results_" + case)
+    _run(ref_test_module, "test_einsum_equivalent_results_" + case, expect_gen=case in NON_F32)
 
 
 @pytest.mark.parametrize("case", GENERAL)
@@ -116,7 +129,11 @@ def test_reference_binding_bf16(ref_test_module):
     torch.manual_seed(0)
     a = torch.randn(20, 50, 50, 50, device="cuda", dtype=torch.bfloat16)
     b = torch.randn(50, 50, 50, 20, device="cuda", dtype=torch.bfloat16)
+    from cudalibrarysamples_amd import cutensor as ours
+    before = ours.launch_counts()
     got = ct.EinsumFunction.apply("mlik,lkjm->lij", a, b)
+    after = ours.launch_counts()
+    assert after["gen"] > before["gen"] and after["simple"] == before["simple"], (before, after)
     ref = torch.einsum("mlik,lkjm->lij", a.double(), b.double())
     # K = 20*50 terms of N(0,1) products: |ref| ~ 32; bf16 output rounding 2^-8 relative
     torch.testing.assert_close(got.double(), ref, rtol=1e-2, atol=0.25)
