@@ -46,6 +46,8 @@ BYTES = 4.0 * (EXT["a"] * EXT["b"] * EXT["c"] * EXT["d"] + EXT["d"] * EXT["c"] *
 PEAK_TFLOPS_F32_MFMA = 157.3      # 256 CU x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
 PEAK_TFLOPS_BF16_MFMA = 2516.6    # 256 CU x 4096 flop/clk x 2.4 GHz, dense
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec (6.3 TB/s measured float4 copy)
+PEAK_TFLOPS_F64_MFMA = 78.6       # v_mfma_f64_16x16x4_f64: 256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz (the guide quotes no fp64 matrix rate; the
+                                  # instruction's issue interval is measured by ctamdMeasureMfmaCeilingF64, tools/bench_gen.py)
 MG_SCALED_EXTENT = 16384
 MG_SAMPLE_EXTENT = 4096
 
@@ -294,11 +296,72 @@ def live_pmc_traffic(timeout_s=150):
         read_b = 2.0 * 1024.0 * vals["FETCH_SIZE"]["mean_KiB_per_launch"]
         write_b = 1024.0 * vals["WRITE_SIZE"]["mean_KiB_per_launch"]
         return {"hbm_bytes_per_launch": read_b + write_b, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+                "raw_FETCH_SIZE_KiB": vals["FETCH_SIZE"]["mean_KiB_per_launch"], "raw_WRITE_SIZE_KiB": vals["WRITE_SIZE"]["mean_KiB_per_launch"],
                 "launches": min(vals["FETCH_SIZE"]["launches"], vals["WRITE_SIZE"]["launches"]), "kernel": vals["FETCH_SIZE"]["kernel"]}
     except (subprocess.TimeoutExpired, OSError, sqlite3.Error, KeyError):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_pmc_traffic_of(cmd, kernel_like, timeout_s=240):
+    """HBM bytes per launch of the kernels matching `kernel_like` (SQL LIKE pattern) in a child command, measured IN THIS RUN by two
+    separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE; never combined with tracing).  Raw counter values are reported next to
+    the corrected figure: FETCH_SIZE x 2 is the guide's correction for wide coalesced read streams (MI355X_MICROARCH.md, HBM
+    section: 128-byte requests tallied at 64 bytes); narrower access patterns are not calibrated, so `correction` names what was applied."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "-d", out, "-o", "r", "--"] + cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            rows = list(c.execute("select kernel_name, avg(value), count(*) from counters_collection where kernel_name like ? "
+                                  "and counter_name = ? group by kernel_name order by count(*) desc", (kernel_like, counter)))
+            c.close()
+            if not rows:
+                return None
+            vals[counter] = {"kernel": rows[0][0][:100], "mean_KiB_per_launch": rows[0][1], "launches": rows[0][2]}
+        read_b = 2.0 * 1024.0 * vals["FETCH_SIZE"]["mean_KiB_per_launch"]
+        write_b = 1024.0 * vals["WRITE_SIZE"]["mean_KiB_per_launch"]
+        return {"hbm_bytes_per_launch": read_b + write_b, "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+                "raw_FETCH_SIZE_KiB": vals["FETCH_SIZE"]["mean_KiB_per_launch"], "raw_WRITE_SIZE_KiB": vals["WRITE_SIZE"]["mean_KiB_per_launch"],
+                "correction": "FETCH_SIZE x 2 (wide coalesced reads are tallied at half their bytes on gfx950), WRITE_SIZE x 1; KiB units",
+                "launches": min(vals["FETCH_SIZE"]["launches"], vals["WRITE_SIZE"]["launches"]), "kernel": vals["FETCH_SIZE"]["kernel"]}
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def newest_trace_summary():
+    """(relative path, {kernel substring: (avg_us, min_us, calls)}) of the newest committed rocprofv3 kernel-trace summary of the
+    headline command (profiles/r*_einsum_trace.summary.txt): lets a reader reproduce roofline.frac from the line alone."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*einsum_trace.summary.txt")))
+    if not files:
+        return None, {}
+    out = {}
+    try:
+        for ln in open(files[-1]):
+            for key in ("gett_f32_stream_kernel", "splitk_reduce_frag_flat_kernel"):
+                if key in ln and key not in out:
+                    cols = ln.split()
+                    out[key] = (float(cols[-4]), float(cols[-3]), int(cols[-5]))
+    except (OSError, ValueError, IndexError):
+        return None, {}
+    return os.path.relpath(files[-1], ROOT), out
 
 
 def newest_traffic_file():
@@ -452,6 +515,83 @@ def secondary_single_gpu(torch, ct, ops, h, stream):
     return out
 
 
+def secondary_general_family(torch, ct, ops, h):
+    """The general MFMA family (csrc/kernels/gett_gen.inc) on the shapes the round-3 review names: fp64 4096^3 against the nominal
+    v_mfma_f64_16x16x4_f64 rate (256 CU x 4 SIMD x 2048 flop / 64 clk x 2.4 GHz = 78.6 TFLOP/s), complex64 2048^3 against the fp32
+    MFMA peak (8 real flop per complex multiply-add), and the reference's own fp16 regression case 'mlik,lkjm->lij' at
+    (20,50,50,50) (einsum_test.py:98-107), which ran on the scalar FMA kernel before this family existed."""
+    out = []
+
+    def gemm(label, n, tdt, cdt, flop_per_mac, peak, reps):
+        try:
+            mk = (lambda: (torch.rand((n, n), device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)) if not tdt.is_complex else \
+                (lambda: torch.complex(torch.rand((n, n), device="cuda") * 2 - 1, torch.rand((n, n), device="cuda") * 2 - 1).to(tdt))
+            A, B = mk(), mk()
+            D = torch.empty((n, n), device="cuda", dtype=tdt)
+            p = ops.contraction_plan(h, [n, n], "km", [n, n], "kn", [n, n], "mn", dtype=cdt)
+            ms = timed_batch(torch, lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr()), reps=reps)
+            d = p.describe()
+            tf = flop_per_mac * n ** 3 / (ms * 1e-3) / 1e12
+            out.append({"workload": label, "dtype": str(tdt).replace("torch.", ""), "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms,
+                        "kernel": "%s<%dx%dx%d,V%s>" % (d["kname"], d["bm"], d["bn"], d["bk"], d.get("vec")),
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                     "algorithmic_flop": flop_per_mac * n ** 3}})
+            p.destroy()
+        except Exception as ex:   # noqa: BLE001
+            out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
+
+    gemm("contraction fp64 C[m,n]=A[k,m]B[k,n] M=N=K=4096 (einsum.cu:36-41 with double), v_mfma_f64_16x16x4_f64", 4096, torch.float64, ct.R_64F,
+         2.0, PEAK_TFLOPS_F64_MFMA, 5)
+    gemm("contraction complex64 M=N=K=2048 (python/einsum.h:51-63), four real fp32 MFMAs per complex product", 2048, torch.complex64, ct.C_32F,
+         8.0, PEAK_TFLOPS_F32_MFMA, 10)
+    try:
+        from cudalibrarysamples_amd import torch_einsum
+        eq = "mlik,lkjm->lij"
+        a = torch.randn(20, 50, 50, 50, device="cuda").half()
+        b = torch.randn(50, 50, 50, 20, device="cuda").half()
+        res = torch_einsum.einsum(eq, a, b)
+        pl = torch_einsum._plans[(eq, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
+        ws = torch_einsum._get_workspace(a.device, pl.required_workspace)
+        ms = timed_batch(torch, lambda: pl.execute(a, b, res, ws), reps=200)
+        ref = torch.einsum(eq, a.double(), b.double())
+        d = pl.describe()
+        out.append({"workload": "einsum 'mlik,lkjm->lij' fp16 at (20,50,50,50) x (50,50,50,20) — the reference's own test 7 (einsum_test.py:98-107)",
+                    "dtype": "f16", "value": 2.0 * 50 * 50 * 50 * 1000 / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "us_per_call": ms * 1e3,
+                    "kernel": "%s<%dx%dx%d,V%s>" % (d["kname"], d["bm"], d["bn"], d["bk"], d.get("vec")),
+                    "before_this_family_us_per_call": 70.9, "before_kernel": "gett_simple_kernel (profiles/r04a_bench_gen_before.jsonl, CUTENSOR_AMD_GEN=0)",
+                    "max_err_over_max_ref": float((res.double() - ref).abs().max() / ref.abs().max())})
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "einsum mlik,lkjm->lij fp16", "error": "%s: %s" % (type(ex).__name__, ex)})
+    torch.cuda.empty_cache()
+    return out
+
+
+def add_secondary_traffic(secondary):
+    """roofline.traffic of the bf16 / permute / reduce secondary lines, measured live like the headline's: two rocprofv3 --pmc passes
+    over a short child that runs only that workload (tools/bench_h16.py, tools/bench_bandwidth.py --only ...)."""
+    jobs = [("bf16 C[m,n]", [sys.executable, os.path.join(ROOT, "tools", "bench_h16.py"), "--reps", "5"], "%ctamd%gett_h16%"),
+            ("elementwise_permute.cu", [sys.executable, os.path.join(ROOT, "tools", "bench_bandwidth.py"), "--n", "2048", "--reps", "1", "--only", "permute:cab"],
+             "%ctamd%ew_transpose%"),
+            ("reduction.cu", [sys.executable, os.path.join(ROOT, "tools", "bench_bandwidth.py"), "--n", "2048", "--reps", "1", "--only", "reduce:ac"],
+             "%ctamd%reduce_col%")]
+    for key, cmd, like in jobs:
+        line = next((x for x in secondary if key in x.get("workload", "") and "roofline" in x), None)
+        if line is None:
+            continue
+        try:
+            t = live_pmc_traffic_of(cmd, like)
+        except Exception:   # noqa: BLE001
+            t = None
+        r = line["roofline"]
+        if t:
+            r["traffic"] = t["hbm_bytes_per_launch"]
+            r["traffic_over_algorithmic"] = t["hbm_bytes_per_launch"] / r["algorithmic_bytes"] if r.get("algorithmic_bytes") else None
+            r["traffic_raw"] = {"FETCH_SIZE_KiB": t["raw_FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": t["raw_WRITE_SIZE_KiB"], "correction": t["correction"]}
+            r["traffic_source"] = "live: two rocprofv3 --pmc passes over %d launches of %s in a child of this run" % (t["launches"], t["kernel"][:60])
+        else:
+            r["traffic"] = None
+
+
 # ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -603,6 +743,7 @@ def main():
     roof = cpu = None
     secondary = []
     cold = None
+    sample_protocol = None
     if rank == 0:
         # ---- roofline of the dominant kernel: one HIP event pair on the launch stream -----------------------------------
         # GETT kernel alone, in the same steady state as the timed loop: the fold is switched off (per-handle diagnostic),
@@ -664,25 +805,64 @@ def main():
                 "gapped_mean_us": gapped_mean_us, "gapped_min_us": gapped_min_us,
                 "algorithmic_flop_per_launch": FLOP, "algorithmic_bytes_per_launch": BYTES,
                 "hbm_equiv_TBps": BYTES / (batch_ms * 1e-3) / 1e12,
-                "cus": cus, "clock_ghz": clock_ghz, "nominal_peak": PEAK_TFLOPS_F32_MFMA}
+                "cus": cus, "clock_ghz": clock_ghz, "nominal_peak": PEAK_TFLOPS_F32_MFMA,
+                # `frac` is the GETT kernel alone; the whole step (GETT kernel + fold of the split-K partials) is `value`:
+                "whole_step_frac": (FLOP / (einsum_ms * 1e-3) / 1e12) / peak if peak else None,
+                "traffic_raw": ({"FETCH_SIZE_KiB": traffic_live["raw_FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": traffic_live["raw_WRITE_SIZE_KiB"],
+                                 "correction": "FETCH_SIZE x 2 (wide coalesced reads tallied at half their bytes on gfx950), WRITE_SIZE x 1"}
+                                if traffic_live else None)}
+        trace_file, trace_rows = newest_trace_summary()
+        if trace_file and "gett_f32_stream_kernel" in trace_rows:
+            k_avg, k_min, k_calls = trace_rows["gett_f32_stream_kernel"]
+            roof["rocprof_trace"] = {"file": trace_file, "kernel_avg_us": k_avg, "kernel_min_us": k_min, "calls": k_calls,
+                                     "frac_from_trace_avg": FLOP / (k_avg * 1e-6) / 1e12 / peak if peak else None,
+                                     "fold_avg_us": trace_rows.get("splitk_reduce_frag_flat_kernel", (None,))[0],
+                                     "what": "rocprofv3 --kernel-trace --stats of this command on the round's profiling box (cold and gapped launches included)"}
+        # ---- the sample's own protocol (contraction.cu:252-270): device sync, GPUTimer (event pair) around ONE cutensorContract,
+        #      event sync, minimum of 3 — every call starts on an idle, drained device ----------------------------------------------
+        try:
+            sp = []
+            host_c = torch.zeros((EXT["a"], EXT["e"]), dtype=torch.float32).pin_memory()
+            for _ in range(3):
+                outs[0].copy_(host_c)                  # contraction.cu:256: C is re-sent from the host before every run
+                torch.cuda.synchronize()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                contract(a, b, outs[0])
+                s1.record()
+                s1.synchronize()
+                sp.append(s0.elapsed_time(s1) * 1e3)
+            sample_protocol = {"min_us": min(sp), "all_us": sp, "gflops": FLOP / (min(sp) * 1e-6) / 1e9,
+                               "frac_of_nominal_f32_mfma_peak": FLOP / (min(sp) * 1e-6) / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                               "what": "contraction.cu:252-270 / utils.cuh:163-202: cudaDeviceSynchronize, event pair around ONE call (GETT kernel + fold), "
+                                       "minimum of 3 — an idle device before every call, so the clock ramp and the launch gap are inside the number"}
+        except Exception as ex:   # noqa: BLE001
+            sample_protocol = {"error": "%s: %s" % (type(ex).__name__, ex)}
         # ---- HBM-cold variant of the headline: four rotating (A, B) pairs = 805 MB of operands, beyond the 256-MiB
         #      Infinity Cache, so no step finds its inputs on-die ------------------------------------------------------------
         try:
             pairs = [(a, b)]
             for k in range(3):
                 pairs.append((torch.rand(a.shape, generator=g, device="cuda"), torch.rand(b.shape, generator=g, device="cuda")))
-            for i in range(max(args.warmup, 20)):
+            # >= 500 steps whatever --steps is (a 20-step sample is 1 ms: it measured 88.6 TFLOP/s on the round-3 driver box where 2000
+            # steps gave 96-106), after >= 100 untimed steps of the same rotation; wall clock and one event pair around the same loop
+            cold_steps, cold_warm = max(args.steps, 500), max(args.warmup, 100)
+            for i in range(cold_warm):
                 contract(*pairs[i % 4], outs[i % nbuf])
             torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t1 = time.perf_counter()
-            for i in range(args.steps):
+            c0.record()
+            for i in range(cold_steps):
                 contract(*pairs[i % 4], outs[i % nbuf])
+            c1.record()
             torch.cuda.synchronize()
-            cold_s = (time.perf_counter() - t1) / args.steps
+            cold_s = (time.perf_counter() - t1) / cold_steps
             cold = {"value": FLOP / cold_s / 1e9, "unit": "GFLOP/s", "ms_per_step": cold_s * 1e3, "operand_bytes_rotated": 4 * BYTES,
+                    "steps": cold_steps, "warmup": cold_warm, "ms_per_step_events": c0.elapsed_time(c1) / cold_steps,
                     "frac_of_nominal_f32_mfma_peak": FLOP / cold_s / 1e12 / PEAK_TFLOPS_F32_MFMA,
                     "hbm_TBps": BYTES / cold_s / 1e12,
-                    "what": "same %d steps, (A, B) rotate over 4 distinct pairs (805 MB > 256-MiB Infinity Cache): operands come from HBM" % args.steps}
+                    "what": "%d steps (never fewer than 500), (A, B) rotate over 4 distinct pairs (805 MB > 256-MiB Infinity Cache): operands come from HBM" % cold_steps}
             del pairs
         except Exception as ex:   # noqa: BLE001
             cold = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -698,6 +878,9 @@ def main():
             del a, b
             torch.cuda.empty_cache()
             secondary += secondary_single_gpu(torch, ct, ops, h, stream)
+            secondary += secondary_general_family(torch, ct, ops, h)
+            if not args.no_pmc:
+                add_secondary_traffic(secondary)
             try:
                 secondary.append(einsum_flow_line())
             except Exception as ex:   # noqa: BLE001
@@ -778,9 +961,11 @@ def main():
             "rccl_ranks_seen": ranks_seen,
             "config": config, "roofline": roof_out, "cpu_baseline": cpu,
             "cold_operands_value": cold["value"] if cold and "value" in cold else None, "cold_operands": cold,
-            "headline_kernel_roofline": roof if use_mg else None,
+            "sample_protocol": sample_protocol,
             "secondary": secondary,
         }
+        if use_mg:
+            line["headline_kernel_roofline"] = roof
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

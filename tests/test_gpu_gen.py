@@ -163,7 +163,9 @@ def test_complex_conjugation_and_complex_scalars(env, dtype, conj):
 def test_split_k_of_16_bit_data(env, dtype):
     d = run(env, dict(m=64, n=48, k=4000), "km", "kn", "mn", dtype, alpha=0.5, beta=1.5, seed=16)
     assert d["splitK"] > 1, d
-    d = run(env, dict(m=50, n=50, k=3001), "mk", "nk", "mn", dtype, seed=17)
+    d = run(env, dict(m=50, n=50, k=3001), "mk", "nk", "mn", dtype, seed=17)      # free-contiguous pairs, odd K
+    assert d["splitK"] > 1 and d["vec"] == 2, d
+    d = run(env, dict(m=51, n=49, k=3001), "km", "kn", "mn", dtype, seed=21)      # 2-byte gathers
     assert d["splitK"] > 1 and d["vec"] == 1, d
     d = run(env, dict(m=64, n=48, k=4000), "km", "kn", "mn", dtype, seed=18, ws_limit=0)
     assert d["splitK"] == 1, d

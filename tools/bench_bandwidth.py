@@ -21,7 +21,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="sampled gather check against torch indexing")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="element type (permutations only for the 16-bit types)")
+    ap.add_argument("--only", default="", help="comma list of cases, e.g. permute:cab,reduce:ac (default: all) — bench.py's PMC children")
     args = ap.parse_args()
+    only = set(x for x in args.only.split(",") if x)
     import torch
     from cudalibrarysamples_amd import ops, cutensor as ct
     n = args.n
@@ -61,6 +63,8 @@ def main():
 
     # ---- permutations (column-major mode lists: first mode is stride-1) ------------------------------
     for mB in ("cab", "cba", "acb"):
+        if only and "permute:" + mB not in only:
+            continue
         D = torch.empty(numel, dtype=tdt, device="cuda")
         p = ops.permutation_plan(h, [n, n, n], "abc", [ext[c] for c in mB], mB, dtype=cdt)
         ms = timed(lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream))
@@ -80,6 +84,8 @@ def main():
         del D
     # ---- reductions -------------------------------------------------------------------------------------
     for mC in (("ac", "c", "a", "bc") if args.dtype == "f32" else ()):
+        if only and "reduce:" + mC not in only:
+            continue
         eC = [ext[c] for c in mC]
         outn = int(np.prod(eC))
         D = torch.zeros(outn, dtype=torch.float32, device="cuda")
