@@ -406,6 +406,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4' && e[1] == 'v') return 40;
         if (e && e[0] == '4' && e[1] == 'x') return 48;
+        if (e && e[0] == '4' && e[1] == 'm') return 56;
         if (e && e[0] == '4') return 8;
         if (e && e[0] == 's') return 16;
         if (e && (e[0] == '8' || e[0] == 'p')) return 0;
@@ -417,11 +418,17 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
     const uint64_t kTiles = v.totK / 64;
     uint64_t split = 1;
-    if (tiles * 2.0 <= (double)numCUs && kTiles >= 8) {
-        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
+    const double slots = (double)numCUs * (tab[c.kernel].bm == 128 ? 2.0 : 1.0);      // the 128 x 128 kernel runs two workgroups per CU
+    if (tiles * 2.0 <= slots && kTiles >= 8) {
+        split = std::min<uint64_t>((uint64_t)(slots / tiles), kTiles / 4);
         const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
         while (split > 1 && split * perSliceBytes > wsLimit) --split;
         if (split < 2) split = 1;
+    }
+    if (const char* fs = std::getenv("CUTENSOR_AMD_H16_SPLITK")) {   // measurement knob: this many slices (if the workspace allows)
+        const uint64_t want = std::strtoull(fs, nullptr, 10);
+        if (want >= 1 && want <= kTiles && want * v.totL * v.totM * v.totN * 4ull <= std::max<uint64_t>(wsLimit, 1)) split = want;
+        if (want == 1) split = 1;
     }
     const uint64_t tilesPerSlice = (kTiles + split - 1) / split;
     c.splitK = (uint32_t)((kTiles + tilesPerSlice - 1) / tilesPerSlice);
@@ -443,7 +450,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 48, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
+    for (int other : {0, 48, 56, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

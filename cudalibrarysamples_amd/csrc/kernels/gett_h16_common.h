@@ -298,20 +298,21 @@ struct HEpilogue {
 // SWZ (free-contiguous image only; gett_h16w4x_kernel): unit p of k-row k holds row-unit p ^ 4 (k & 3) ^ 2 ((k >> 3) & 1) — the
 // 16-row fragments of the 16x16x32 MFMA take 32 bytes of a k-row per 16-lane group, and without the second term the two groups
 // that a transposing read serves together (k-rows 8 g + .. and 8 (g + 1) + ..) land on the same banks.
-template <int LAY, int NW = 8, bool IL = false, int SWZ = 0>
+// NH: half-tiles of 128 rows this operand stages per K-tile (2: the 256-row tiles; 1: the 128 x 128 mid-size kernel).
+template <int LAY, int NW = 8, bool IL = false, int SWZ = 0, int NH = 2>
 struct HOperand {
     static constexpr int kPieces = 16 / NW;   // 1-KiB pieces of a half-tile this wave stages
     // Byte offset of this lane's 16-byte unit, [half-tile][piece i of this wave], for the K-tile at k = 0 — relative to
     // `base`, the smallest such offset in the wave: a workgroup tile spans far less than 2^32 bytes whatever the size of
     // the tensor, and `base` (64 bits, wave-uniform) goes into the buffer descriptor.
-    uint32_t src[2][kPieces];
+    uint32_t src[NH][kPieces];
     uint64_t base;
 
     __device__ __forceinline__ void init(const ModeGroup& gFree, int64_t strideK0, uint32_t row0, int wave, int lane) {
-        int64_t off[2][kPieces];
+        int64_t off[NH][kPieces];
         int64_t mn = INT64_MAX;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
                 const int c = wave + NW * i;                     // 1-KiB piece of the half-tile
@@ -333,7 +334,7 @@ struct HOperand {
         const int64_t mnW = (int64_t)h_uniform64((uint64_t)h_wave_min(mn));
         base = (uint64_t)mnW;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) src[h][i] = (uint32_t)(off[h][i] - mnW);
     }

@@ -581,6 +581,225 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+
+// =====================================================================================================
+// gett_h16w4m_kernel (CUTENSOR_AMD_H16_WAVES=4m): the 128 x 128 x 64 sibling of gett_h16w4x_kernel for MID-SIZE problems.
+// One 256 x 256 tile per CU leaves a 2048^3 problem on 64 of the 256 CUs (or pays a split-K fold), and a workgroup of the large
+// kernels spends ~11 us outside its main loop whatever K is.  Here: the same instruction (v_mfma_f32_16x16x32 from inline asm),
+// the same LDS images / source-side swizzles / LDS-DMA staging / K odometer, but a 64 x 64 quadrant per wave = 4 x 4 accumulator
+// fragments (64 AGPRs), ONE 128-row half-tile per operand and K-tile (32 KiB), two K-tiles in LDS (64 KiB) — so TWO workgroups
+// share a CU (launch bounds 256 x 2): one workgroup's prologue, tile barrier and epilogue sit under the other's MFMAs, which is
+// what the persistent-workgroup form of the large kernel would have to build by hand.  Per K-tile and wave: 32 MFMAs, 16 fragment
+// reads (one per two MFMAs, into the other of two register sets), 8 LDS-DMA pieces (one per two MFMAs of k-step 1, tile t + 2).
+// Twice the LDS-DMA bytes per flop of the 256 x 256 tile: the kernel for problems whose 256 x 256 tiles do not fill the chip, not
+// for the 8192^3 class.  Epilogue: the 16-bit image of gett_h16w4x_kernel in passes of 32 rows x 64 columns (beta = 0, 16-byte
+// lanes in D), else one pass of four 32 x 32 fp32 fragments through HEpilogue::flush.
+// =====================================================================================================
+constexpr int kMTile = 128;
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kMTile, n0 = nt * kMTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    HOperand<LA, 4, false, 1, 1> oa;
+    HOperand<LB, 4, false, 1, 1> ob;
+    oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+    ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+    const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
+    const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
+    VOdometer odo;
+    odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+    // fragment-read address registers.  This wave's fragments are f = 4 wr + i (A) / 4 wc + j (B) of the 128-row half-tile.
+    // K-contiguous operand: [buffer][k-step], the fragment in the immediate (2048 x i on top of 8192 x wr in the register);
+    // free-contiguous operand: [buffer][fragment] (the fragment index sits inside the swizzle), the k-step in the immediate (8192 x s)
+    constexpr int nRdA = (LA == LAY_K) ? 2 : 4, nRdB = (LB == LAY_K) ? 2 : 4;
+    uint32_t rdA[2][nRdA], rdB[2][nRdB];
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int x = 0; x < nRdA; ++x) {
+            rdA[P][x] = ldsBase + (uint32_t)((2 * P) * kHalfBytes) + (LA == LAY_K ? (uint32_t)(8192 * wr) + x_offK(lane, x) : x_offF(lane, 4 * wr + x));
+            asm volatile("" : "+v"(rdA[P][x]));
+        }
+#pragma unroll
+        for (int x = 0; x < nRdB; ++x) {
+            rdB[P][x] = ldsBase + (uint32_t)((2 * P + 1) * kHalfBytes) + (LB == LAY_K ? (uint32_t)(8192 * wc) + x_offK(lane, x) : x_offF(lane, 4 * wc + x));
+            asm volatile("" : "+v"(rdB[P][x]));
+        }
+    }
+
+    // piece N = 0..7 of the K-tile the odometer describes, into buffer P: operand q = N >> 2 (A, B), piece i = N & 3 of this wave
+#define CTAMD_M_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        constexpr uint32_t imm_ = (uint32_t)(((P) * 2 + q_) * kHalfBytes + i_ * 4096);                             \
+        if constexpr (q_ == 0) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[0][i_], waveLds);                      \
+        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[0][i_], waveLds);                                        \
+    }
+#define CTAMD_M_DMA8(P, PAD)                                                                                        \
+    CTAMD_M_DMA(P, 0, PAD) CTAMD_M_DMA(P, 1, PAD) CTAMD_M_DMA(P, 2, PAD) CTAMD_M_DMA(P, 3, PAD)                    \
+    CTAMD_M_DMA(P, 4, PAD) CTAMD_M_DMA(P, 5, PAD) CTAMD_M_DMA(P, 6, PAD) CTAMD_M_DMA(P, 7, PAD)
+
+    // ---- prologue: K-tiles 0 and 1; the odometer stays on tile 1 (k-step 0 of tile t moves it to tile t + 2) -------------
+    CTAMD_M_DMA8(0, true)
+    odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+    CTAMD_M_DMA8(1, true)
+    CTAMD_H_VMCNT(8);                             // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s
+
+    // fragment Q = 0..7 of k-step S from buffer P into register set S: Q < 4 -> B columns 16 Q, else A rows 16 (Q - 4)
+#define CTAMD_M_READ(P, S, Q)                                                                                       \
+    {                                                                                                              \
+        if constexpr ((Q) < 4) {                                                                                   \
+            if constexpr (LB == LAY_K) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][(S) % nRdB]);                    \
+            else b[S][Q] = v_read<LAY_F, 8192 * (S)>(rdB[P][(Q) % nRdB]);                                          \
+        } else {                                                                                                   \
+            if constexpr (LA == LAY_K) a[S][(Q) - 4] = v_read<LAY_K, 2048 * ((Q) - 4)>(rdA[P][(S) % nRdA]);        \
+            else a[S][(Q) - 4] = v_read<LAY_F, 8192 * (S)>(rdA[P][((Q) - 4) % nRdA]);                              \
+        }                                                                                                          \
+    }
+#define CTAMD_M_MFMA(S, M) x_mfma<BF>(acc[(M) >> 2][(M) & 3], a[S][(M) >> 2], b[S][(M) & 3]);
+    // k-step 0, group Q: one read of k-step 1 (same buffer) and two MFMAs; three of the groups carry the odometer
+#define CTAMD_M_G0(P, Q)                                                                                            \
+    CTAMD_M_READ(P, 1, Q)                                                                                          \
+    CTAMD_M_MFMA(0, 2 * (Q))                                                                                       \
+    if constexpr ((Q) == 1) odo.advance_a();                                                                       \
+    if constexpr ((Q) == 3) odo.advance_b();                                                                       \
+    if constexpr ((Q) == 5) odo.advance_event(p.gK);                                                               \
+    CTAMD_M_MFMA(0, 2 * (Q) + 1)                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into this
+    // buffer, two MFMAs
+#define CTAMD_M_G1(P, Q)                                                                                            \
+    CTAMD_M_READ((P) ^ 1, 0, Q)                                                                                    \
+    CTAMD_M_MFMA(1, 2 * (Q))                                                                                       \
+    CTAMD_M_DMA(P, Q, false)                                                                                       \
+    CTAMD_M_MFMA(1, 2 * (Q) + 1)                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_M_TILE(P)                                                                                             \
+    CTAMD_M_G0(P, 0) CTAMD_M_G0(P, 1) CTAMD_M_G0(P, 2) CTAMD_M_G0(P, 3)                                            \
+    CTAMD_M_G0(P, 4) CTAMD_M_G0(P, 5) CTAMD_M_G0(P, 6) CTAMD_M_G0(P, 7)                                            \
+    CTAMD_H_LGKM0();                                                                                               \
+    CTAMD_H_VMCNT(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_M_G1(P, 0) CTAMD_M_G1(P, 1) CTAMD_M_G1(P, 2) CTAMD_M_G1(P, 3)                                            \
+    CTAMD_M_G1(P, 4) CTAMD_M_G1(P, 5) CTAMD_M_G1(P, 6) CTAMD_M_G1(P, 7)
+
+    // first fragments of tile 0
+    CTAMD_M_READ(0, 0, 0) CTAMD_M_READ(0, 0, 1) CTAMD_M_READ(0, 0, 2) CTAMD_M_READ(0, 0, 3)
+    CTAMD_M_READ(0, 0, 4) CTAMD_M_READ(0, 0, 5) CTAMD_M_READ(0, 0, 6) CTAMD_M_READ(0, 0, 7)
+    int t = 0;
+    for (; t + 1 < nTiles; t += 2) { CTAMD_M_TILE(0) CTAMD_M_TILE(1) }
+    if (t < nTiles) { CTAMD_M_TILE(0) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+
+    const uint32_t mW = m0 + 64 * wr, nW = n0 + 64 * wc;      // this wave's quadrant
+    // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
+    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
+                if (m < Mt) {
+                    float* row = P + (size_t)m * Nt;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t n = nW + 16 * j + (laneE & 15);
+                        if (n < Nt) row[n] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);                     // 16 KiB of the (dead) ring per wave
+    if (ep.vecD && ep.beta == 0.f) {
+        // beta == 0 and 16-byte lanes in D: rounded once on the way into a 16-bit image of 32 rows x 64 columns (144-byte rows: the
+        // 2-byte writes of a 16-lane group and the 16-byte reads of a row both spread over the banks), out as 16-byte reads +
+        // nontemporal stores of whole 128-byte row segments
+        uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
+        constexpr int kPitch = 72;                // 16-bit elements per image row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4& c = acc[2 * i + a2][j];
+                    uint16_t* st = stage + (16 * a2 + 4 * (laneE >> 4)) * kPitch + 16 * j + (laneE & 15);
+                    st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                    st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + laneE, row = q >> 3, cc = q & 7;
+                const s16x8 v = *reinterpret_cast<const s16x8*>(stage + row * kPitch + 8 * cc);
+                const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
+                if (m < ep.Mtot && n < ep.Ntot) {
+                    int64_t offD, offC;
+                    ep.offsets(p, m, n, offD, offC);
+                    __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                }
+            }
+        }
+    } else {
+        // one pass: the wave's 64 x 64 quadrant as four 32 x 32 fp32 fragments F = 2 (row block) + (column block)
+#pragma unroll
+        for (int F = 0; F < 4; ++F)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {         // 16 x 16 quarter (h >> 1, h & 1) of fragment F
+                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);
+                const f32x4& c = acc[2 * (F >> 1) + (h >> 1)][2 * (F & 1) + (h & 1)];
+                st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
+            }
+        ep.template flush<BF>(p, mW, 32u, 0u, nW, 0u, 32u, laneE);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gett_h16w4v_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
@@ -592,6 +811,8 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 6, 1, 0, &launch_h16w4v<bf, la, lb>, 0},
 #define CTAMD_H16W4X_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 7, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
+#define CTAMD_H16W4M_ENTRY(bf, la, lb) \
+    {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 8, 1, 0, &launch_h16w4m<bf, la, lb>, 0},
 static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
@@ -601,7 +822,12 @@ static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4X_ENTRY(false, LAY_F, LAY_F)
+    // entries 16..23 (56..63 of the family): the 128 x 128 mid-size sibling, two workgroups per CU
+    CTAMD_H16W4M_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4M_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4M_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4M_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4M_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4M_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16v_kernels(int* count) {
     *count = (int)(sizeof(g_h16v_table) / sizeof(g_h16v_table[0]));

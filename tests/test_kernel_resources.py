@@ -28,15 +28,25 @@ def _code_object(tmp_path, name):
 def _kernel_notes(co):
     """{kernel symbol: {field: int}} from the code object's metadata note."""
     out = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
-    kernels, cur = {}, None
+    # one block per kernel, opened by "  - .agpr_count:" (keys are sorted: .group_segment_fixed_size comes BEFORE .name, so the fields
+    # are collected per block and attached to the block's name at its end)
+    kernels, fields, name = {}, {}, None
+
+    def close():
+        if name is not None:
+            kernels[name] = dict(fields)
     for line in out.splitlines():
+        if re.match(r"\s*- \.agpr_count:", line):
+            close()
+            fields, name = {}, None
         m = re.match(r"\s*\.name:\s+(\S+)", line)
         if m and m.group(1).startswith("_Z"):
-            cur = kernels.setdefault(m.group(1), {})
+            name = m.group(1)
             continue
-        m = re.match(r"\s*\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|group_segment_fixed_size):\s+(\d+)", line)
-        if m and cur is not None:
-            cur[m.group(1)] = int(m.group(2))
+        m = re.match(r"\s*(?:- )?\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|agpr_count|group_segment_fixed_size):\s+(\d+)", line)
+        if m:
+            fields[m.group(1)] = int(m.group(2))
+    close()
     return kernels
 
 
@@ -57,6 +67,11 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
+    # the 128 x 128 mid-size sibling: no scratch, two K-tiles of 32 KiB, and few enough registers for two workgroups per CU
+    mid = {n: v for n, v in k.items() if "gett_h16w4m_kernel" in n}
+    assert len(mid) == 8, sorted(k)
+    assert not {n: v for n, v in mid.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}, mid
+    assert all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in mid.values()), mid
 
 
 def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tmp_path):
@@ -66,14 +81,14 @@ def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tm
     spilled (a spill store right behind an asm MFMA would read the register before the matrix pipe has written it)."""
     co = _code_object(tmp_path, "gett_h16v")
     k = _kernel_notes(co)
-    names = [n for n in k if "gett_h16w4x_kernel" in n]
-    assert len(names) >= 8, sorted(k)
+    names = [n for n in k if "gett_h16w4x_kernel" in n or "gett_h16w4m_kernel" in n]
+    assert len(names) >= 16, sorted(k)
     for name in names:
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
                              capture_output=True, text=True).stdout.splitlines()
         ins = [l.split("//")[0].strip() for l in dis if l.startswith("\t")]
         mfma = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f32_16x16x32")]
-        assert len(mfma) >= 3 * 128, (name, len(mfma))                    # two unrolled K-tiles and the tail
+        assert len(mfma) >= (3 * 128 if "w4x" in name else 3 * 32), (name, len(mfma))      # two unrolled K-tiles and the tail
         reads = [i for i, l in enumerate(ins) if i > mfma[-1] and (l.startswith("v_accvgpr_read") or l.startswith("v_accvgpr_mov")
                                                                    or re.search(r"(store|write)\S* .*\ba\[?\d", l))]
         assert reads, name
@@ -102,8 +117,8 @@ def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, 
     co = _code_object(tmp_path, obj)
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + symbol, co], check=True,
                          capture_output=True, text=True).stdout
-    # the burst: s_load_dword sN, s[a:b], 0x40 * i — one per 64-byte line of the 816-byte argument block
+    # the burst: s_load_dword sN, s[a:b], 0x40 * i — one per 64-byte line of the 848-byte argument block
     loads = re.findall(r"s_load_dword (s\d+), s\[\d+:\d+\], (0x[0-9a-f]+)", dis)
-    burst = {int(off, 16): reg for reg, off in loads if int(off, 16) % 64 == 0 and int(off, 16) < 832}
-    assert sorted(burst) == [64 * i for i in range(13)], loads[:20]
-    assert len(set(burst.values())) == 13, burst          # thirteen lines, thirteen different destination registers
+    burst = {int(off, 16): reg for reg, off in loads if int(off, 16) % 64 == 0 and int(off, 16) < 896}
+    assert sorted(burst) == [64 * i for i in range(14)], loads[:20]
+    assert len(set(burst.values())) == 14, burst          # fourteen lines, fourteen different destination registers
