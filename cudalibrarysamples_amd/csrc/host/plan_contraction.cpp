@@ -406,6 +406,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4' && e[1] == 'v') return 40;
         if (e && e[0] == '4' && e[1] == 'x') return 48;
+        if (e && e[0] == '4' && e[1] == 'm' && e[2] == '4') return 64;
         if (e && e[0] == '4' && e[1] == 'm') return 56;
         if (e && e[0] == '4') return 8;
         if (e && e[0] == 's') return 16;
@@ -418,7 +419,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
     const uint64_t kTiles = v.totK / 64;
     uint64_t split = 1;
-    const double slots = (double)numCUs * (tab[c.kernel].bm == 128 ? 2.0 : 1.0);      // the 128 x 128 kernel runs two workgroups per CU
+    const double slots = (double)numCUs * (tab[c.kernel].bm == 128 && tab[c.kernel].pf == 8 ? 2.0 : 1.0);   // the 128 x 128 kernel on the two-deep ring runs two workgroups per CU
     if (tiles * 2.0 <= slots && kTiles >= 8) {
         split = std::min<uint64_t>((uint64_t)(slots / tiles), kTiles / 4);
         const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
@@ -450,7 +451,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 48, 56, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
+    for (int other : {0, 48, 56, 64, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

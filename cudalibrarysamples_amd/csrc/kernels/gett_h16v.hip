@@ -595,10 +595,17 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
 // for the 8192^3 class.  Epilogue: the 16-bit image of gett_h16w4x_kernel in passes of 32 rows x 64 columns (beta = 0, 16-byte
 // lanes in D), else one pass of four 32 x 32 fp32 fragments through HEpilogue::flush.
 // =====================================================================================================
+//
+// R = ring depth in K-tiles.  R = 2 (64 KiB, two workgroups per CU): tile t + 2 is staged during k-step 1 of tile t and must have
+// landed one and a half K-tiles (~770 MFMA cycles) later — enough when a second workgroup fills the gaps, not for a workgroup that
+// has its CU to itself (2048^3: 1430 cycles per K-tile against 512 of MFMA issue, profiles/r04c_h16_shape_sweep.txt).  R = 4
+// (128 KiB, one workgroup per CU): tile t + 4 is staged during tile t, the tile barrier waits for tile t + 1 only (counted
+// vmcnt: the 16 pieces of tiles t + 2, t + 3 stay in flight) — the form for problems with at most one 128 x 128 tile per CU.
 constexpr int kMTile = 128;
-template <bool BF, int LA, int LB>
-__global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
+template <bool BF, int LA, int LB, int R = 2>
+__global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(const GettParams p) {
+    static_assert(R == 2 || R == 4, "ring of two or four K-tiles");
+    __shared__ __attribute__((aligned(16))) char lds[R * 2 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -637,9 +644,9 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     // K-contiguous operand: [buffer][k-step], the fragment in the immediate (2048 x i on top of 8192 x wr in the register);
     // free-contiguous operand: [buffer][fragment] (the fragment index sits inside the swizzle), the k-step in the immediate (8192 x s)
     constexpr int nRdA = (LA == LAY_K) ? 2 : 4, nRdB = (LB == LAY_K) ? 2 : 4;
-    uint32_t rdA[2][nRdA], rdB[2][nRdB];
+    uint32_t rdA[R][nRdA], rdB[R][nRdB];
 #pragma unroll
-    for (int P = 0; P < 2; ++P) {
+    for (int P = 0; P < R; ++P) {
 #pragma unroll
         for (int x = 0; x < nRdA; ++x) {
             rdA[P][x] = ldsBase + (uint32_t)((2 * P) * kHalfBytes) + (LA == LAY_K ? (uint32_t)(8192 * wr) + x_offK(lane, x) : x_offF(lane, 4 * wr + x));
@@ -664,11 +671,17 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     CTAMD_M_DMA(P, 0, PAD) CTAMD_M_DMA(P, 1, PAD) CTAMD_M_DMA(P, 2, PAD) CTAMD_M_DMA(P, 3, PAD)                    \
     CTAMD_M_DMA(P, 4, PAD) CTAMD_M_DMA(P, 5, PAD) CTAMD_M_DMA(P, 6, PAD) CTAMD_M_DMA(P, 7, PAD)
 
-    // ---- prologue: K-tiles 0 and 1; the odometer stays on tile 1 (k-step 0 of tile t moves it to tile t + 2) -------------
+    // ---- prologue: K-tiles 0 .. R - 1; the odometer stays on tile R - 1 (k-step 0 of tile t moves it to tile t + R) ---------
     CTAMD_M_DMA8(0, true)
     odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
     CTAMD_M_DMA8(1, true)
-    CTAMD_H_VMCNT(8);                             // this wave's pieces of tile 0
+    if constexpr (R == 4) {
+        odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+        CTAMD_M_DMA8(2, true)
+        odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+        CTAMD_M_DMA8(3, true)
+    }
+    CTAMD_H_VMCNT(8 * (R - 1));                   // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
 
     f32x4 acc[4][4];
@@ -702,7 +715,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into this
     // buffer, two MFMAs
 #define CTAMD_M_G1(P, Q)                                                                                            \
-    CTAMD_M_READ((P) ^ 1, 0, Q)                                                                                    \
+    CTAMD_M_READ(((P) + 1) % R, 0, Q)                                                                              \
     CTAMD_M_MFMA(1, 2 * (Q))                                                                                       \
     CTAMD_M_DMA(P, Q, false)                                                                                       \
     CTAMD_M_MFMA(1, 2 * (Q) + 1)                                                                                   \
@@ -711,7 +724,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     CTAMD_M_G0(P, 0) CTAMD_M_G0(P, 1) CTAMD_M_G0(P, 2) CTAMD_M_G0(P, 3)                                            \
     CTAMD_M_G0(P, 4) CTAMD_M_G0(P, 5) CTAMD_M_G0(P, 6) CTAMD_M_G0(P, 7)                                            \
     CTAMD_H_LGKM0();                                                                                               \
-    CTAMD_H_VMCNT(0);                                                                                              \
+    CTAMD_H_VMCNT(8 * (R - 2));      /* tile t + 1 has landed; the pieces of tiles t + 2 .. t + R - 1 stay in flight */     \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     CTAMD_M_G1(P, 0) CTAMD_M_G1(P, 1) CTAMD_M_G1(P, 2) CTAMD_M_G1(P, 3)                                            \
@@ -721,8 +734,15 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     CTAMD_M_READ(0, 0, 0) CTAMD_M_READ(0, 0, 1) CTAMD_M_READ(0, 0, 2) CTAMD_M_READ(0, 0, 3)
     CTAMD_M_READ(0, 0, 4) CTAMD_M_READ(0, 0, 5) CTAMD_M_READ(0, 0, 6) CTAMD_M_READ(0, 0, 7)
     int t = 0;
-    for (; t + 1 < nTiles; t += 2) { CTAMD_M_TILE(0) CTAMD_M_TILE(1) }
-    if (t < nTiles) { CTAMD_M_TILE(0) }
+    if constexpr (R == 2) {
+        for (; t + 1 < nTiles; t += 2) { CTAMD_M_TILE(0) CTAMD_M_TILE(1) }
+        if (t < nTiles) { CTAMD_M_TILE(0) }
+    } else {
+        for (; t + 3 < nTiles; t += 4) { CTAMD_M_TILE(0) CTAMD_M_TILE(1) CTAMD_M_TILE(2) CTAMD_M_TILE(3) }
+        if (t < nTiles) { CTAMD_M_TILE(0) }
+        if (t + 1 < nTiles) { CTAMD_M_TILE(1) }
+        if (t + 2 < nTiles) { CTAMD_M_TILE(2) }
+    }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -794,9 +814,9 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4m_kernel(const GettParams p)
     }
 }
 
-template <bool BF, int LA, int LB>
+template <bool BF, int LA, int LB, int R>
 static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB, R>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -812,7 +832,9 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
 #define CTAMD_H16W4X_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 7, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
 #define CTAMD_H16W4M_ENTRY(bf, la, lb) \
-    {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 8, 1, 0, &launch_h16w4m<bf, la, lb>, 0},
+    {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 8, 1, 0, &launch_h16w4m<bf, la, lb, 2>, 0},
+#define CTAMD_H16W4M4_ENTRY(bf, la, lb) \
+    {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 9, 1, 0, &launch_h16w4m<bf, la, lb, 4>, 0},
 static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
@@ -827,7 +849,12 @@ static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4M_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4M_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4M_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4M_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4M_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4M_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M_ENTRY(false, LAY_F, LAY_F)
+    // entries 24..31 (64..71 of the family): the same with a four-deep K-tile ring, one workgroup per CU
+    CTAMD_H16W4M4_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4M4_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4M4_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4M4_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4M4_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4M4_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16v_kernels(int* count) {
     *count = (int)(sizeof(g_h16v_table) / sizeof(g_h16v_table[0]));

@@ -69,9 +69,11 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
     # the 128 x 128 mid-size sibling: no scratch, two K-tiles of 32 KiB, and few enough registers for two workgroups per CU
     mid = {n: v for n, v in k.items() if "gett_h16w4m_kernel" in n}
-    assert len(mid) == 8, sorted(k)
+    assert len(mid) == 16, sorted(k)          # ring of two K-tiles (two workgroups per CU) and of four (one)
     assert not {n: v for n, v in mid.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}, mid
-    assert all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in mid.values()), mid
+    two = {n: v for n, v in mid.items() if n.endswith("Li2EEEvNS_10GettParamsE")}
+    assert len(two) == 8 and all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in two.values()), mid
+    assert all(v.get("group_segment_fixed_size") == 131072 for n, v in mid.items() if n not in two), mid
 
 
 def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tmp_path):
@@ -82,7 +84,7 @@ def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tm
     co = _code_object(tmp_path, "gett_h16v")
     k = _kernel_notes(co)
     names = [n for n in k if "gett_h16w4x_kernel" in n or "gett_h16w4m_kernel" in n]
-    assert len(names) >= 16, sorted(k)
+    assert len(names) >= 24, sorted(k)
     for name in names:
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
                              capture_output=True, text=True).stdout.splitlines()
