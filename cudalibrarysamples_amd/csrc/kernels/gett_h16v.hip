@@ -596,7 +596,9 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
 // lanes in D), else one pass of four 32 x 32 fp32 fragments through HEpilogue::flush.
 // =====================================================================================================
 //
-// R = ring depth in K-tiles.  R = 2 (64 KiB, two workgroups per CU): tile t + 2 is staged during k-step 1 of tile t and must have
+// R = ring depth in K-tiles (R = 4 also spreads the LDS-DMA pieces of a tile evenly over a K-tile time: one piece per four MFMAs
+// in both k-steps instead of one per two MFMAs in k-step 1 only — issued in bursts the pieces ask the texture path for twice its
+// 64 B/clk and the MFMAs behind them wait: ~1000 cycles per K-tile measured with the burst, profiles/r04d_*).  R = 2 (64 KiB, two workgroups per CU): tile t + 2 is staged during k-step 1 of tile t and must have
 // landed one and a half K-tiles (~770 MFMA cycles) later — enough when a second workgroup fills the gaps, not for a workgroup that
 // has its CU to itself (2048^3: 1430 cycles per K-tile against 512 of MFMA issue, profiles/r04c_h16_shape_sweep.txt).  R = 4
 // (128 KiB, one workgroup per CU): tile t + 4 is staged during tile t, the tile barrier waits for tile t + 1 only (counted
@@ -676,12 +678,14 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
     CTAMD_M_DMA8(1, true)
     if constexpr (R == 4) {
+        // the deep ring spreads a tile's eight pieces over one K-tile time (four behind the barrier of tile t, four in front of the
+        // barrier of tile t + 1): tiles 0 .. 2 and the first half of tile 3 here, its second half rides in k-step 0 of tile 0
         odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
         CTAMD_M_DMA8(2, true)
         odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
-        CTAMD_M_DMA8(3, true)
+        CTAMD_M_DMA(3, 0, true) CTAMD_M_DMA(3, 1, true) CTAMD_M_DMA(3, 2, true) CTAMD_M_DMA(3, 3, true)
     }
-    CTAMD_H_VMCNT(8 * (R - 1));                   // this wave's pieces of tile 0
+    CTAMD_H_VMCNT(R == 2 ? 8 : 20);               // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
 
     f32x4 acc[4][4];
@@ -704,12 +708,18 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     }
 #define CTAMD_M_MFMA(S, M) x_mfma<BF>(acc[(M) >> 2][(M) & 3], a[S][(M) >> 2], b[S][(M) & 3]);
     // k-step 0, group Q: one read of k-step 1 (same buffer) and two MFMAs; three of the groups carry the odometer
+    // (R = 4: the groups also carry pieces 4..7 of tile t + 3 into the buffer behind this one, then the odometer moves on)
 #define CTAMD_M_G0(P, Q)                                                                                            \
     CTAMD_M_READ(P, 1, Q)                                                                                          \
     CTAMD_M_MFMA(0, 2 * (Q))                                                                                       \
-    if constexpr ((Q) == 1) odo.advance_a();                                                                       \
-    if constexpr ((Q) == 3) odo.advance_b();                                                                       \
-    if constexpr ((Q) == 5) odo.advance_event(p.gK);                                                               \
+    if constexpr (R == 2) {                                                                                        \
+        if constexpr ((Q) == 1) odo.advance_a();                                                                   \
+        if constexpr ((Q) == 3) odo.advance_b();                                                                   \
+        if constexpr ((Q) == 5) odo.advance_event(p.gK);                                                           \
+    } else {                                                                                                       \
+        if constexpr ((Q) % 2 == 0) CTAMD_M_DMA(((P) + R - 1) % R, 4 + (Q) / 2, false)                             \
+        if constexpr ((Q) == 7) { odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK); }                     \
+    }                                                                                                              \
     CTAMD_M_MFMA(0, 2 * (Q) + 1)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
     // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into this
@@ -717,7 +727,8 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
 #define CTAMD_M_G1(P, Q)                                                                                            \
     CTAMD_M_READ(((P) + 1) % R, 0, Q)                                                                              \
     CTAMD_M_MFMA(1, 2 * (Q))                                                                                       \
-    CTAMD_M_DMA(P, Q, false)                                                                                       \
+    if constexpr (R == 2) CTAMD_M_DMA(P, Q, false)                                                                 \
+    else if constexpr ((Q) % 2 == 0) CTAMD_M_DMA(P, (Q) / 2, false)         /* pieces 0..3 of tile t + 4 */          \
     CTAMD_M_MFMA(1, 2 * (Q) + 1)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_M_TILE(P)                                                                                             \
