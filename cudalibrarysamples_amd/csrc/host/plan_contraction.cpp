@@ -413,33 +413,79 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && (e[0] == '8' || e[0] == 'p')) return 0;
         return 48;
     }();
-    c.kernel += variant;
-    if (c.kernel >= count) return false;
-    const double tiles = std::ceil((double)v.totM / tab[c.kernel].bm) * std::ceil((double)v.totN / tab[c.kernel].bn) * (double)v.totL;
-    // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
+    const int layoutIdx = c.kernel;
     const uint64_t kTiles = v.totK / 64;
+    const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
+    const bool forced = std::getenv("CUTENSOR_AMD_H16_WAVES") != nullptr;
+    auto tiles_of = [&](int var) {
+        const GettKernelInfo& k = tab[layoutIdx + var];
+        return std::ceil((double)v.totM / k.bm) * std::ceil((double)v.totN / k.bn) * (double)v.totL;
+    };
+    // workgroup slots of the chip: the 128 x 128 kernel on the two-deep ring (variant 56) runs two workgroups per CU
+    auto slots_of = [&](int var) { return (double)numCUs * (var == 56 ? 2.0 : 1.0); };
+    // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
+    auto auto_split = [&](int var) -> uint64_t {
+        const double tiles = tiles_of(var), slots = slots_of(var);
+        uint64_t split = 1;
+        if (tiles * 2.0 <= slots && kTiles >= 8) {
+            split = std::min<uint64_t>((uint64_t)(slots / tiles), kTiles / 4);
+            while (split > 1 && split * perSliceBytes > wsLimit) --split;
+            if (split < 2) split = 1;
+        }
+        return split;
+    };
+    // Time model (us) of a variant at a split, from the shape sweeps of round 4 (profiles/r04*_h16_shape_sweep*: 8192^3 .. 256^2 x 16384 on
+    // all variants): rounds x (fixed cost per workgroup + K-tiles x time per K-tile) + the fold.  Only has to ORDER the candidates.
+    //   256 x 256, four waves (48):  11 us fixed, 1.00 us per K-tile      256 x 256, eight waves (0): 10 us fixed, 1.13 us per K-tile
+    //   128 x 128, ring 2 (56), two workgroups per CU: 5 us fixed, 0.92 us per K-tile (0.68 with the CU to itself)
+    //   128 x 128, ring 4 (64), one workgroup per CU:  4.5 us fixed, 0.46 us per K-tile
+    //   fold (splitk_reduce_wide_kernel): 3 us + partial bytes written and read back at ~5 TB/s
+    auto model_us = [&](int var, uint64_t split) {
+        const double wgs = tiles_of(var) * (double)split, slots = slots_of(var);
+        const double kt = std::ceil((double)kTiles / (double)split);
+        double fix, per;
+        if (var == 64) { fix = 4.5; per = 0.46; }
+        else if (var == 56) { fix = 5.0; per = wgs <= (double)numCUs ? 0.68 : 0.92; }
+        else if (kt <= 16) { fix = 10.0; per = 1.13; }
+        else { fix = 11.0; per = 1.0; }
+        double t = std::ceil(wgs / slots) * (fix + kt * per);
+        if (split > 1) t += 3.0 + 2.0 * (double)split * (double)perSliceBytes / 5.0e6;
+        return t;
+    };
+    int var = variant;
     uint64_t split = 1;
-    const double slots = (double)numCUs * (tab[c.kernel].bm == 128 && tab[c.kernel].pf == 8 ? 2.0 : 1.0);   // the 128 x 128 kernel on the two-deep ring runs two workgroups per CU
-    if (tiles * 2.0 <= slots && kTiles >= 8) {
-        split = std::min<uint64_t>((uint64_t)(slots / tiles), kTiles / 4);
-        const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
-        while (split > 1 && split * perSliceBytes > wsLimit) --split;
-        if (split < 2) split = 1;
+    if (forced) {
+        if (layoutIdx + var >= count) return false;
+        split = auto_split(var);
+    } else {
+        // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below) and
+        // the 128 x 128 mid-size family, each without split-K and at its automatic split
+        double best = 1e30;
+        for (int cand : {48, 64, 56}) {
+            if (layoutIdx + cand >= count) continue;
+            const uint64_t as = auto_split(cand);
+            for (uint64_t sp : {(uint64_t)1, as}) {
+                const double t = model_us(cand, sp);
+                if (t < best) { best = t; var = cand; split = sp; }
+                if (as == 1) break;
+            }
+        }
     }
+    c.kernel = layoutIdx + var;
     if (const char* fs = std::getenv("CUTENSOR_AMD_H16_SPLITK")) {   // measurement knob: this many slices (if the workspace allows)
         const uint64_t want = std::strtoull(fs, nullptr, 10);
-        if (want >= 1 && want <= kTiles && want * v.totL * v.totM * v.totN * 4ull <= std::max<uint64_t>(wsLimit, 1)) split = want;
+        if (want >= 1 && want <= kTiles && want * perSliceBytes <= std::max<uint64_t>(wsLimit, 1)) split = want;
         if (want == 1) split = 1;
     }
     const uint64_t tilesPerSlice = (kTiles + split - 1) / split;
     c.splitK = (uint32_t)((kTiles + tilesPerSlice - 1) / tilesPerSlice);
     c.kPerSlice = (uint32_t)(tilesPerSlice * 64);
-    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
-    c.estimateUs = std::ceil(tiles * c.splitK / (double)numCUs) * (2.0 * tab[c.kernel].bm * tab[c.kernel].bn * (double)c.kPerSlice) / (4096.0 * 2.4e9 * 0.5) * 1e6;
+    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * perSliceBytes : 0ull;
+    c.estimateUs = model_us(var, c.splitK);
     // short K ranges: a workgroup of the four-wave kernels spends ~14 us outside its main loop (prologue + a 256 x 256 epilogue on
     // four waves) against ~10 us for the eight-wave kernel, and wins ~0.13 us per K-tile inside it (tools/h16_shape_sweep.py:
     // K = 512 -> 0.088 ms with eight waves, 0.102 ms with four; K = 4096 the other way round) — the planner's own choice only
-    if (variant == 48 && std::getenv("CUTENSOR_AMD_H16_WAVES") == nullptr && tilesPerSlice <= 16) c.kernel -= 48;
+    if (var == 48 && !forced && tilesPerSlice <= 16) c.kernel -= 48;
     return true;
 }
 

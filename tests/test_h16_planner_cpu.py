@@ -40,18 +40,39 @@ def test_headline_16_bit_shape_runs_the_16x16x32_kernel(env, mA, mB, dtype):
 
 
 def test_short_k_ranges_stay_on_the_eight_wave_kernel(env):
-    ct, ops = env
+    ct, ops, h = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
     for (M, N, K, want, split) in [(8192, 8192, 512, "gett_h16_kernel", 1),        # 8 K-tiles per workgroup
                                    (8192, 8192, 1024, "gett_h16_kernel", 1),       # 16
                                    (8192, 8192, 1088, "gett_h16w4x_kernel", 1),    # 17
-                                   (2048, 2048, 2048, "gett_h16_kernel", 4),       # split-K: 8 K-tiles per slice
                                    (2048, 2048, 16384, "gett_h16w4x_kernel", 4)]:  # 64 per slice
         p = _plan(ct, ops, h, M, N, K)
         d = p.describe()
         assert (d["kname"], d["splitK"]) == (want, split), (M, N, K, d)
+        p.destroy()
+
+
+def test_mid_size_problems_run_the_128_tile_family(env):
+    """Problems whose 256 x 256 tiles leave most CUs idle (round 3: split-K over the 256 x 256 kernels + a fold: 2048^3 at 0.41 PFLOP/s,
+    1024^3 at 0.08): at most one 128 x 128 tile per CU -> the four-deep-ring kernel, one workgroup per CU, no split unless the tiles
+    are very few; up to two per CU -> the two-deep-ring kernel, two workgroups per CU; a full chip of 256 x 256 tiles -> as before."""
+    ct, ops, h = env
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+    for (M, N, K, want, split, blocks) in [(2048, 2048, 2048, "gett_h16w4m4_kernel", 1, 256),
+                                           (1024, 1024, 1024, "gett_h16w4m4_kernel", 1, 64),
+                                           (4096, 1024, 4096, "gett_h16w4m4_kernel", 1, 256),
+                                           (1000, 1000, 1024, "gett_h16w4m4_kernel", 1, 64),
+                                           (512, 512, 65536, "gett_h16w4m4_kernel", 16, 256),
+                                           (2048, 4096, 4096, "gett_h16w4m_kernel", 1, 512),
+                                           (4096, 4096, 4096, "gett_h16w4x_kernel", 1, 256)]:
+        p = _plan(ct, ops, h, M, N, K)
+        d = p.describe()
+        assert (d["kname"], d["splitK"], d["blocks"]) == (want, split, blocks), (M, N, K, d)
+        assert (d["bm"], d["bn"]) == ((128, 128) if "w4m" in want else (256, 256)), d
         p.destroy()
 
 
