@@ -40,7 +40,7 @@ def test_headline_16_bit_shape_runs_the_16x16x32_kernel(env, mA, mB, dtype):
 
 
 def test_short_k_ranges_stay_on_the_eight_wave_kernel(env):
-    ct, ops, h = env
+    ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
@@ -58,7 +58,7 @@ def test_mid_size_problems_run_the_128_tile_family(env):
     """Problems whose 256 x 256 tiles leave most CUs idle (round 3: split-K over the 256 x 256 kernels + a fold: 2048^3 at 0.41 PFLOP/s,
     1024^3 at 0.08): at most one 128 x 128 tile per CU -> the four-deep-ring kernel, one workgroup per CU, no split unless the tiles
     are very few; up to two per CU -> the two-deep-ring kernel, two workgroups per CU; a full chip of 256 x 256 tiles -> as before."""
-    ct, ops, h = env
+    ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
