@@ -97,10 +97,13 @@ struct Piece {
     // then the valid part of the padded index space is a union of boxes (kbox_list) and the boxes accumulate into D.
     // accumulate: an earlier sub-contraction of this piece already wrote this region of D (the clip sets differ in contracted
     // labels only) -> beta = 1 on D; otherwise the region is new (first box, or a peeled digit of a free mode) -> the caller's beta
-    struct Sub { cutensorPlan_t plan = nullptr; uint64_t ws = 0; int64_t off[3] = {0, 0, 0}; bool accumulate = false; };
+    // hv: the three operand views (extents, element strides, mode labels; offsets are off[]) the local plan was built from — kept for
+    // ctamdMgReplayOnHost, which walks the plan over host memory
+    struct HostView { std::vector<int64_t> extent, stride; std::vector<int32_t> modes; };
+    struct Sub { cutensorPlan_t plan = nullptr; uint64_t ws = 0; int64_t off[3] = {0, 0, 0}; bool accumulate = false; HostView hv[3]; };
     std::vector<Sub> subs;
     OperandUse use[3];
-    struct Scatter { int cell; int64_t off; cutensorPlan_t plan; };
+    struct Scatter { int cell; int64_t off; cutensorPlan_t plan; HostView hv; };
     std::vector<Scatter> scatter; // staged C -> owner cells
     std::vector<int> waitEvents;  // transfer events (indices into the plan's event table) this piece waits for
     double flops = 0.0;
@@ -829,6 +832,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             }
         }
         p.waitEvents.assign(ev.begin(), ev.end());
+        if (env_is("CUTENSORMG_AMD_TEST_DROP_WAITS", "1")) p.waitEvents.clear();   // fault injection: tests/test_mg_replay_cpu.py proves its ordering check live
     }
     for (int k = 0; k < 3; ++k)
         if (!staged[k]) pl->stagingBytes[k] = 0;
@@ -903,6 +907,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             for (int k = 0; k < 3; ++k) {
                 v[k] = make_view(*T[k], *M[k], universe, radix, rs, !p.use[k].direct);
                 sub.off[k] = v[k].offset;
+                sub.hv[k].extent = v[k].extent; sub.hv[k].stride = v[k].stride; sub.hv[k].modes = v[k].modes;
             }
             if (p.subs.empty()) for (int k = 0; k < 3; ++k) p.use[k].off = v[k].offset;
             cutensorTensorDescriptor_t dT[3] = {nullptr, nullptr, nullptr};
@@ -974,7 +979,8 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         for (int c : p.use[2].cells) {
             cutensorTensorDescriptor_t ds = nullptr;
             cutensorOperationDescriptor_t po = nullptr;
-            Piece::Scatter sc{c, cellView.offset, nullptr};
+            Piece::Scatter sc{c, cellView.offset, nullptr, {}};
+            sc.hv.extent = cellView.extent; sc.hv.stride = cellView.stride; sc.hv.modes = cellView.modes;
             st = make_desc(h, cellView, d.C.dtype, &ds);
             if (st == CUTENSOR_STATUS_SUCCESS)
                 st = cutensorCreatePermutation(h, &po, ds, cellView.modes.data(), CUTENSOR_OP_IDENTITY, ds, cellView.modes.data(), cd);
@@ -1302,6 +1308,109 @@ int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const 
     if (s.size() + 1 > len) return -(int)(s.size() + 1);
     std::memcpy(buf, s.c_str(), s.size() + 1);
     return (int)s.size();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host replay of a plan (test hook; not part of the cuTENSORMg ABI).  No multi-GPU box is reachable from the build container, so
+// the N > 1 data path — which cells travel where, the [cell][cell buffer] staging images, the strided local views, the boxes of
+// a ragged contracted mode, peeled digits, the scatter of staged C, and the events a piece waits for — is EXECUTED here over host
+// memory instead of only being inspected: A / B / C / D are arrays of HOST cell buffers, every transfer is a memcpy into a host
+// staging image, every local contraction is handed to `contract` (the caller's reference implementation: the tests pass the CPU
+// oracle) on exactly the views, offsets, scalars and C / D aliasing cutensorMgContraction passes to cutensorContract, every
+// scatter is a strided copy.  Staging images start as NaN.  Ordering is checked, not simulated: before a piece runs, every cell
+// it reads from a staging image must have arrived by a local copy (caller's stream; the auxiliary stream starts behind them) or
+// by a transfer whose event the piece's stream has waited for so far — a missing wait is an error even though the replay itself
+// is sequential.  Returns 0, or a negative code with a message in `err`.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef struct { int32_t n; const int64_t* extent; const int64_t* stride; const int32_t* modes; } ctamdMgHostView;
+typedef int (*ctamdMgHostContractFn)(void* user, int dtype, const ctamdMgHostView* A, const void* a, const ctamdMgHostView* B, const void* b,
+                                     const ctamdMgHostView* C, const void* c, void* d, double alpha, double beta);
+
+int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, const void* const A[], const void* const B[], double beta,
+                        const void* const C[], void* const D[], ctamdMgHostContractFn contract, void* user, char* err, size_t errLen) {
+    auto fail = [&](int code, const std::string& msg) {
+        if (err != nullptr && errLen > 0) { std::snprintf(err, errLen, "%s", msg.c_str()); }
+        return code;
+    };
+    if (plan == nullptr || A == nullptr || B == nullptr || D == nullptr || contract == nullptr) return fail(-1, "invalid arguments");
+    const cutensorMgContractionPlan* pl = plan;
+    const cutensorMgContractionDescriptor& d = pl->desc;
+    const int nDev = (int)pl->usesAux.size();
+    const size_t es = elem_size(d.A.dtype);
+    const void* const* src[3] = {A, B, C};
+    if (beta != 0.0 && C == nullptr) return fail(-1, "beta != 0 without C");
+    // staging images per device: NaN everywhere (an all-ones bit pattern is a NaN for fp16 / bf16 / fp32 / fp64)
+    std::vector<std::vector<std::vector<char>>> stage((size_t)nDev, std::vector<std::vector<char>>(3));
+    for (int g = 0; g < nDev; ++g)
+        for (int k = 0; k < 3; ++k) stage[(size_t)g][(size_t)k].assign((size_t)pl->stagingBytes[k], (char)0xff);
+    auto staging = [&](int g, int k) { return stage[(size_t)g][(size_t)k].data(); };
+    // ---- 1. gather: every transfer the device path issues (same skip rule for C cells when beta == 0) ------------------------------
+    std::map<std::pair<int, std::pair<int, int>>, int> arrivedBy;   // (device, (tensor, cell)) -> event, -1 = local copy
+    for (const Transfer& t : pl->transfers) {
+        if (t.tensor == 2 && beta == 0.0) continue;
+        if ((size_t)(t.cell + 1) * (size_t)t.bytes > stage[(size_t)t.dst][(size_t)t.tensor].size())
+            return fail(-2, "a transfer lands outside its staging image");
+        if (src[t.tensor][t.cell] == nullptr) return fail(-1, "missing cell buffer");
+        std::memcpy(staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes, src[t.tensor][t.cell], (size_t)t.bytes);
+        arrivedBy[std::make_pair(t.dst, std::make_pair(t.tensor, t.cell))] = t.local ? -1 : t.event;
+    }
+    // ---- 2. pieces in execution order ---------------------------------------------------------------------------------------------
+    std::vector<std::set<int>> waited((size_t)(nDev * kComputeStreams));
+    for (size_t pi = 0; pi < pl->pieces.size(); ++pi) {
+        const Piece& p = pl->pieces[pi];
+        const int g = p.dev;
+        std::set<int>& w = waited[(size_t)(g * kComputeStreams + p.stream)];
+        for (int e : p.waitEvents) w.insert(e);
+        for (int k = 0; k < 3; ++k) {
+            if (p.use[k].direct || (k == 2 && beta == 0.0)) continue;
+            for (int c : p.use[k].cells) {
+                auto it = arrivedBy.find(std::make_pair(g, std::make_pair(k, c)));
+                if (it == arrivedBy.end()) return fail(-3, "piece " + std::to_string(pi) + " reads a cell nothing transferred (tensor " + std::to_string(k) + ", cell " + std::to_string(c) + ")");
+                if (it->second >= 0 && w.count(it->second) == 0)
+                    return fail(-4, "piece " + std::to_string(pi) + " reads tensor " + std::to_string(k) + " cell " + std::to_string(c) + " without having waited for event " + std::to_string(it->second));
+            }
+        }
+        const char* pa = p.use[0].direct ? static_cast<const char*>(A[p.use[0].cell]) : staging(g, 0);
+        const char* pb = p.use[1].direct ? static_cast<const char*>(B[p.use[1].cell]) : staging(g, 1);
+        const char* pc;
+        char* pd;
+        if (p.use[2].direct) {
+            pc = (beta != 0.0) ? static_cast<const char*>(C[p.use[2].cell]) : static_cast<const char*>(D[p.use[2].cell]);
+            pd = static_cast<char*>(D[p.use[2].cell]);
+        } else {
+            pc = staging(g, 2);
+            pd = staging(g, 2);
+        }
+        for (const Piece::Sub& sub : p.subs) {
+            ctamdMgHostView hv[3];
+            for (int k = 0; k < 3; ++k) hv[k] = ctamdMgHostView{(int32_t)sub.hv[k].extent.size(), sub.hv[k].extent.data(), sub.hv[k].stride.data(), sub.hv[k].modes.data()};
+            const int64_t oC = sub.off[2] * (int64_t)es;
+            const int rc = contract(user, (int)d.A.dtype, &hv[0], pa + sub.off[0] * (int64_t)es, &hv[1], pb + sub.off[1] * (int64_t)es, &hv[2],
+                                    (sub.accumulate ? pd : pc) + oC, pd + oC, alpha, sub.accumulate ? 1.0 : beta);
+            if (rc != 0) return fail(-5, "the contraction callback failed on piece " + std::to_string(pi));
+        }
+        // ---- 3. scatter: the piece's region of every staged C cell goes to the owner's cell (identity permutation on strided views)
+        const size_t cellBytes = (size_t)d.C.cellElems * es;
+        for (const Piece::Scatter& sc : p.scatter) {
+            const char* from = staging(g, 2) + (size_t)sc.cell * cellBytes + sc.off * (int64_t)es;
+            char* to = static_cast<char*>(D[sc.cell]) + sc.off * (int64_t)es;
+            const size_t n = sc.hv.extent.size();
+            std::vector<int64_t> idx(n, 0);
+            for (;;) {
+                int64_t o = 0;
+                for (size_t i = 0; i < n; ++i) o += idx[i] * sc.hv.stride[i];
+                std::memcpy(to + o * (int64_t)es, from + o * (int64_t)es, es);
+                size_t i = 0;
+                for (; i < n; ++i) {
+                    if (++idx[i] < sc.hv.extent[i]) break;
+                    idx[i] = 0;
+                }
+                if (i == n) break;
+            }
+        }
+    }
+    return 0;
 }
 
 // One JSON object describing the plan: which mode is sharded, the pieces in execution order with the grid cells they

@@ -42,8 +42,42 @@ lib.ctamdMgDescribePlan.restype = ctypes.c_int
 lib.ctamdMgDescribeKBoxes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, ctypes.c_size_t]
 lib.ctamdMgDescribeKBoxes.restype = ctypes.c_int
 
+
+
+class HostView(ctypes.Structure):
+    """ctamdMgHostView: one operand view of a local contraction (extents, element strides, mode labels 8 * label + digit)."""
+    _fields_ = [("n", ctypes.c_int32), ("extent", _i64p), ("stride", _i64p), ("modes", _i32p)]
+
+
+HOST_CONTRACT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(HostView), ctypes.c_void_p, ctypes.POINTER(HostView),
+                                    ctypes.c_void_p, ctypes.POINTER(HostView), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double)
+lib.ctamdMgReplayOnHost.argtypes = [_vp, ctypes.c_double, _vpp, _vpp, ctypes.c_double, _vpp, _vpp, HOST_CONTRACT_FN, ctypes.c_void_p,
+                                    ctypes.c_char_p, ctypes.c_size_t]
+lib.ctamdMgReplayOnHost.restype = ctypes.c_int
+
 check = ct.check
 i64, i32 = ct.i64, ct.i32
+
+
+def replay_on_host(plan, alpha, A, B, beta, C, D, contract):
+    """ctamdMgReplayOnHost: executes the plan over HOST cell buffers (lists of addresses) — transfers as memcpy into NaN-filled host
+    staging images, local contractions through `contract(dtype, viewA, ptrA, viewB, ptrB, viewC, ptrC, ptrD, alpha, beta) -> 0`
+    (views as (extent, stride, modes) tuples), scatters as strided copies, and checks that every piece has waited for the events
+    that carry the cells it reads.  Returns (rc, message).  A test hook: the caller supplies the reference contraction."""
+    def cb(user, dtype, va, pa, vb, pb, vc, pc, pd, al, be):
+        try:
+            views = [(list(v.contents.extent[:v.contents.n]), list(v.contents.stride[:v.contents.n]), list(v.contents.modes[:v.contents.n]))
+                     for v in (va, vb, vc)]
+            return int(contract(dtype, views[0], pa, views[1], pb, views[2], pc, pd, al, be))
+        except Exception:   # noqa: BLE001  (an exception must not cross the C frame)
+            import traceback
+            traceback.print_exc()
+            return -1
+    fn = HOST_CONTRACT_FN(cb)
+    err = ctypes.create_string_buffer(512)
+    rc = lib.ctamdMgReplayOnHost(plan, float(alpha), ptr_array(A), ptr_array(B), float(beta), ptr_array(C) if C is not None else None,
+                                 ptr_array(D), fn, None, err, len(err))
+    return rc, err.value.decode()
 
 
 def kboxes(extent, block_size, digits):
