@@ -90,6 +90,7 @@ struct OperandUse {               // how one piece sees one tensor (0 = A, 1 = B
 struct Piece {
     int dev = 0;                  // index into the handle's device list
     int64_t lo = 0, hi = 0;       // range of the sharded mode p
+    int64_t lo2 = 0, hi2 = 0;     // range of the second sharded mode p2 (hi2 == 0: there is none)
     int64_t q0 = 0, q1 = 0;       // range of q's grid coordinate (q1 == 0: q is not cut)
     int stream = 0;               // 0 = caller's stream, 1 = auxiliary stream
     // One local contraction per box of the contracted index space: a single box unless a contracted mode is ragged
@@ -147,6 +148,7 @@ struct cutensorMgContractionPlan {
     int64_t stagingBytes[3] = {0, 0, 0};
     uint64_t contractionWs = 0;                // per compute stream
     int pLabel = -1, qLabel = -1;
+    int p2Label = -1;                          // second sharded mode (p shorter than 16 x devices), -1: none
     int numBoxes = 1;                          // local contractions per piece (> 1: a contracted mode is ragged)
     int peeled = 0;                            // how many times a digit of an oversized mode group was peeled into a host loop
     bool useRccl = false;
@@ -212,6 +214,10 @@ struct Clip {
 };
 struct Restrict {
     int pLabel = -1; int64_t lo = 0, hi = 0;
+    int p2Label = -1; int64_t lo2 = 0, hi2 = 0;     // second sharded mode (short first modes: blog_post.cu at small scalings), same semantics
+    bool is_p(int li) const { return li == pLabel || li == p2Label; }
+    int64_t plo(int li) const { return li == pLabel ? lo : lo2; }
+    int64_t phi(int li) const { return li == pLabel ? hi : hi2; }
     int qLabel = -1; int qDigit = -1; int64_t c0 = 0, c1 = 0;
     std::vector<Clip> clips;
     const Clip* clip_of(int li) const {
@@ -278,20 +284,21 @@ View make_view(const MgTensor& t, const std::vector<int32_t>& labels, const std:
         const int li = find_label(universe, labels[i]);
         const Radix& r = radix[li];
         const int nGrid = grid_digits(r, t.deviceCount[i]);
-        const bool isP = li == rs.pLabel, isQ = li == rs.qLabel;
+        const bool isP = rs.is_p(li), isQ = li == rs.qLabel;
+        const int64_t pLo = isP ? rs.plo(li) : 0, pHi = isP ? rs.phi(li) : 0;
         const Clip* clip = rs.clip_of(li);
         // w: position inside a block
         if (clip != nullptr) {
             if (clip->wHi > 1) { v.extent.push_back(clip->wHi); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
         } else if (isP) {
-            const int64_t block = rs.lo / r.blockSize;
-            v.offset += (rs.lo - block * r.blockSize) * t.elemStride[i];
-            if (rs.hi - rs.lo > 1) { v.extent.push_back(rs.hi - rs.lo); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
+            const int64_t block = pLo / r.blockSize;
+            v.offset += (pLo - block * r.blockSize) * t.elemStride[i];
+            if (pHi - pLo > 1) { v.extent.push_back(pHi - pLo); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7); }
         } else if (r.blockSize > 1) {
             v.extent.push_back(r.blockSize); v.stride.push_back(t.elemStride[i]); v.modes.push_back(8 * li + 7);
         }
         // block-index digits
-        int64_t rest = isP ? rs.lo / r.blockSize : 0;
+        int64_t rest = isP ? pLo / r.blockSize : 0;
         int64_t gridStep = t.cellElems * t.cellStride[i], localStep = t.blockStride[i];
         for (int j = 0; j < (int)r.f.size(); ++j) {
             const bool grid = j < nGrid;
@@ -329,8 +336,8 @@ std::vector<int> cells_of(const MgTensor& t, const std::vector<int32_t>& labels,
         for (uint32_t i = 0; i < t.n && want; ++i) {
             const int li = find_label(universe, labels[i]);
             const int64_t coord = (c / t.cellStride[i]) % t.deviceCount[i];
-            if (li == rs.pLabel) {
-                want = coord == (rs.lo / radix[li].blockSize) % t.deviceCount[i];
+            if (rs.is_p(li)) {
+                want = coord == (rs.plo(li) / radix[li].blockSize) % t.deviceCount[i];
             } else if (li == rs.qLabel && rs.qDigit >= 0 && rs.qDigit < grid_digits(radix[li], t.deviceCount[i])) {
                 // q's cut digit is a grid digit of this tensor: its value inside the cell coordinate
                 int64_t below = 1;
@@ -675,29 +682,84 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     pl->qLabel = qLi >= 0 ? universe[qLi] : -1;
 
     // ---- pieces: one shard of p per device, cut at block boundaries, then runs of q's coordinate -------
-    struct Shard { int dev; int64_t lo, hi; };
+    // Shards of p start at multiples of 16 indices (64-byte aligned rows for the vector kernels).  When p is too short for one such
+    // shard per device (blog_post.cu on 8 devices: its largest free mode has 16 .. 96 indices at scaling 1 .. 12, :155-175) that rule
+    // alone leaves devices without work: p is then cut nP ways only (nP = the largest divisor of the device count whose 16-aligned
+    // shards are all non-empty) and a SECOND free
+    // mode p2 of C — the largest other one, preferably carried by the other operand so that both operands shrink per device — is cut
+    // n2 = devices / nP ways (plain ceil() shards: these modes are small, alignment is not the concern).  Device g works on
+    // (p shard g % nP, p2 shard g / nP).  The gather-ordering mode q is not used together with p2.
+    struct Shard { int dev; int64_t lo, hi, lo2, hi2; };
     std::vector<Shard> shards;
+    int p2C = -1, p2Li = -1;
     if (pC < 0) {
-        shards.push_back(Shard{0, 0, 0});
+        shards.push_back(Shard{0, 0, 0, 0, 0});
     } else {
         const int64_t E = d.C.extent[pC], bs = d.C.blockSize[pC];
-        int64_t per = (E + nDev - 1) / nDev;
+        int nP = nDev;
+        // c shards of ceil(E / c) rounded up to 16 indices: are all of them non-empty?
+        auto all_busy = [&](int c) { const int64_t per = ((E + c - 1) / c + 15) / 16 * 16; return per * (int64_t)(c - 1) < E; };
+        if (!all_busy(nDev) && !env_is("CUTENSORMG_AMD_SHARD2", "0")) {
+            nP = 1;
+            for (int c = 1; c <= nDev; ++c)
+                if (nDev % c == 0 && all_busy(c)) nP = c;
+            const bool pInA = find_label(d.mA, d.mC[pC]) >= 0;
+            const int n2w = nDev / nP;
+            // p2: a free mode with at least n2 indices whose n2 shards cross the FEWEST block boundaries (every crossing is another
+            // piece, i.e. another local contraction), the longer one on a tie
+            auto segments = [&](uint32_t i) {
+                const int64_t e = d.C.extent[i], b = d.C.blockSize[i], per2 = (e + n2w - 1) / n2w;
+                int64_t segs = 0;
+                for (int g2 = 0; g2 < n2w; ++g2) {
+                    const int64_t lo = (int64_t)g2 * per2, hi = std::min<int64_t>(e, lo + per2);
+                    if (lo < hi) segs += (hi - 1) / b - lo / b + 1;
+                }
+                return segs;
+            };
+            for (int pass = 0; pass < 2 && p2C < 0; ++pass)     // pass 0: free modes of the OTHER operand; pass 1: any other free mode
+                for (uint32_t i = 0; i < d.C.n; ++i) {
+                    if ((int)i == pC) continue;
+                    const bool inA = find_label(d.mA, d.mC[i]) >= 0, inB = find_label(d.mB, d.mC[i]) >= 0;
+                    if (inA == inB) continue;                   // batch modes are not sharded
+                    if (pass == 0 && inA == pInA) continue;
+                    if (d.C.extent[i] < (int64_t)n2w) continue;
+                    if (p2C < 0 || segments(i) < segments((uint32_t)p2C) ||
+                        (segments(i) == segments((uint32_t)p2C) && d.C.extent[i] > d.C.extent[p2C])) p2C = (int)i;
+                }
+            if (p2C < 0) nP = nDev;                             // nothing else to cut: the old rule (some devices stay idle)
+        }
+        const int n2 = (p2C >= 0) ? nDev / nP : 1;
+        if (p2C >= 0) { p2Li = find_label(universe, d.mC[p2C]); qLi = -1; qDigit = -1; qCount = 1; pl->qLabel = -1; }
+        int64_t per = (E + nP - 1) / nP;
         per = (per + 15) / 16 * 16;   // keep shard starts 64-byte aligned for the vector kernels
+        const int64_t E2 = p2C >= 0 ? d.C.extent[p2C] : 0, bs2 = p2C >= 0 ? d.C.blockSize[p2C] : 1;
+        const int64_t per2 = p2C >= 0 ? (E2 + n2 - 1) / n2 : 0;
         for (int g = 0; g < nDev; ++g) {
-            int64_t lo = (int64_t)g * per, hi = std::min<int64_t>(E, lo + per);
+            const int gp = g % nP, g2 = g / nP;
+            int64_t lo = (int64_t)gp * per, hi = std::min<int64_t>(E, lo + per);
             while (lo < hi) {
                 const int64_t cut = std::min<int64_t>(hi, (lo / bs + 1) * bs);
-                shards.push_back(Shard{g, lo, cut});
+                if (p2C < 0) shards.push_back(Shard{g, lo, cut, 0, 0});
+                else {
+                    int64_t lo2 = (int64_t)g2 * per2, hi2 = std::min<int64_t>(E2, lo2 + per2);
+                    while (lo2 < hi2) {
+                        const int64_t cut2 = std::min<int64_t>(hi2, (lo2 / bs2 + 1) * bs2);
+                        shards.push_back(Shard{g, lo, cut, lo2, cut2});
+                        lo2 = cut2;
+                    }
+                }
                 lo = cut;
             }
         }
     }
+    pl->p2Label = p2C >= 0 ? d.mC[p2C] : -1;
     double flopsAll = 2.0;
     for (size_t li = 0; li < universe.size(); ++li) flopsAll *= (double)(radix[li].blockSize * radix[li].numBlocks);
 
     auto restrict_of = [&](const Shard& s, int64_t c0, int64_t c1) {
         Restrict rs;
         if (pC >= 0) { rs.pLabel = pLi; rs.lo = s.lo; rs.hi = s.hi; }
+        if (p2Li >= 0 && s.hi2 > s.lo2) { rs.p2Label = p2Li; rs.lo2 = s.lo2; rs.hi2 = s.hi2; }
         if (qLi >= 0 && c1 > c0) { rs.qLabel = qLi; rs.qDigit = qDigit; rs.c0 = c0; rs.c1 = c1; }
         return rs;
     };
@@ -717,7 +779,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         for (const Shard& s : shards) {
             if (s.dev != g) continue;
             if (qLi < 0) {
-                Piece p; p.dev = g; p.lo = s.lo; p.hi = s.hi;
+                Piece p; p.dev = g; p.lo = s.lo; p.hi = s.hi; p.lo2 = s.lo2; p.hi2 = s.hi2;
                 mine.push_back(p);
                 continue;
             }
@@ -753,10 +815,11 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     std::map<std::pair<int, std::pair<int, int>>, int> have;   // (device, (tensor, cell)) -> transfer index
     bool staged[3] = {false, false, false};
     for (Piece& p : pieces) {
-        const Shard s{p.dev, p.lo, p.hi};
+        const Shard s{p.dev, p.lo, p.hi, p.lo2, p.hi2};
         const Restrict rs = restrict_of(s, p.q0, p.q1);
         p.flops = flopsAll;
         if (pC >= 0) p.flops *= (double)(p.hi - p.lo) / (double)d.C.extent[pC];
+        if (p2C >= 0 && p.hi2 > p.lo2) p.flops *= (double)(p.hi2 - p.lo2) / (double)d.C.extent[p2C];
         if (qLi >= 0) p.flops *= (double)(p.q1 - p.q0) / (double)qCount;
         for (int k = 0; k < 3; ++k) {
             OperandUse& u = p.use[k];
@@ -889,7 +952,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         if (st != CUTENSOR_STATUS_SUCCESS) break;
         if (handle->haveDevice) { (void)hipSetDevice(handle->devices[p.dev]); (void)hipGetLastError(); }
         cutensorHandle_t h = handle->handles[p.dev];
-        const Shard s{p.dev, p.lo, p.hi};
+        const Shard s{p.dev, p.lo, p.hi, p.lo2, p.hi2};
         Restrict rs = restrict_of(s, p.q0, p.q1);
         // work list of clip sets: the boxes of the contracted index space, each possibly split further ("peeled") below.  acc: an
         // earlier entry already writes this region of D — every box after the first (the boxes tile the CONTRACTED index space, all
@@ -956,7 +1019,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
                         c = &base.back();
                     }
                     const std::pair<int64_t, int64_t> range = c->digit[(size_t)dj];
-                    if (li != rs.pLabel && range.second - range.first >= 2) {
+                    if (!rs.is_p(li) && range.second - range.first >= 2) {
                         cutensorDestroyPlan(sub.plan);
                         const bool contractedDigit = find_label(d.mC, universe[(size_t)li]) < 0;
                         for (int64_t val = range.second - 1; val >= range.first; --val) {      // pushed in reverse: executed in ascending order
@@ -1454,14 +1517,15 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
         s += "]";
     }
     s += "],";
+    add("\"p2Label\":%d,", plan->p2Label);
     add("\"pLabel\":%d,\"qLabel\":%d,\"numWaves\":%d,\"useRccl\":%d,\"commStreams\":%d,\"contractionWs\":%llu,", plan->pLabel, plan->qLabel,
         plan->numWaves, (int)plan->useRccl, plan->commPerDevice, (unsigned long long)plan->contractionWs);
     add("\"stagingBytes\":[%lld,%lld,%lld],\"remoteBytes\":%lld,\"localCopyBytes\":%lld,\"pieces\":[", (long long)plan->stagingBytes[0],
         (long long)plan->stagingBytes[1], (long long)plan->stagingBytes[2], (long long)remote, (long long)local);
     for (size_t i = 0; i < plan->pieces.size(); ++i) {
         const Piece& p = plan->pieces[i];
-        add("%s{\"dev\":%d,\"lo\":%lld,\"hi\":%lld,\"q0\":%lld,\"q1\":%lld,\"stream\":%d,\"flops\":%.6g,\"use\":[", i ? "," : "", p.dev,
-            (long long)p.lo, (long long)p.hi, (long long)p.q0, (long long)p.q1, p.stream, p.flops);
+        add("%s{\"dev\":%d,\"lo\":%lld,\"hi\":%lld,\"lo2\":%lld,\"hi2\":%lld,\"q0\":%lld,\"q1\":%lld,\"stream\":%d,\"flops\":%.6g,\"use\":[", i ? "," : "", p.dev,
+            (long long)p.lo, (long long)p.hi, (long long)p.lo2, (long long)p.hi2, (long long)p.q0, (long long)p.q1, p.stream, p.flops);
         for (int k = 0; k < 3; ++k) {
             add("%s{\"direct\":%d,\"off\":%lld,\"cells\":[", k ? "," : "", (int)p.use[k].direct, (long long)p.use[k].off);
             for (size_t c = 0; c < p.use[k].cells.size(); ++c) add("%s%d", c ? "," : "", p.use[k].cells[c]);

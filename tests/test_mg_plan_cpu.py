@@ -218,6 +218,13 @@ def test_ragged_and_mixed_layouts_cover_c_once_and_gather_what_they_read(cm, see
                     rows = np.array(sorted(sum((_blocks_of(Ei, bi, di, c) for c in range(p["q0"], p["q1"])), [])), dtype=np.int64)
                 else:
                     rows = np.arange(Ei)
+            if p["hi2"] > p["lo2"]:      # the second sharded mode (p shorter than 16 x devices) cuts the other axis
+                cut = np.arange(p["lo2"], p["hi2"])
+                if d["p2Label"] == ord("i"):
+                    rows = np.intersect1d(rows, cut)
+                else:
+                    assert d["p2Label"] == ord("j")
+                    cols = np.intersect1d(cols, cut)
             if len(rows) and len(cols):
                 cov[np.ix_(rows, cols)] += 1
         assert (cov == 1).all(), (seed, n, extent, block, dcount, int(cov.min()), int(cov.max()))
@@ -315,6 +322,33 @@ def test_every_blog_post_configuration_plans(cm, n):
             # (by the single-GPU library — one tiled inner plan per index combination — or, where its budget refuses, by this plan)
             assert (d["peeled"] + d["libraryPeeled"] > 0) == ((n == 8 and s >= 2) or (n == 4 and s >= 9)), (n, s, d["peeled"], d["libraryPeeled"])
             assert d["modeTable"] == 0 and d["localContractions"] >= len(d["pieces"])
+
+
+@pytest.mark.parametrize("n,s", [(8, 1), (8, 2), (4, 1)])
+def test_short_first_mode_is_sharded_along_a_second_one(cm, n, s):
+    """blog_post.cu <n> <scaling> at small scalings (:155-175): the largest free mode of C has 16 indices — shorter than 16 x devices, so
+    the 16-index shard rule alone would leave all but one or two devices idle.  The plan cuts a second free mode (of the other
+    operand) as well: every device gets pieces, the pieces' flops add up to the problem, both operands shrink per device."""
+    modes, ext, block, dcount = _blog_post_shapes(n, s)
+    with cm.Contraction(list(range(n)), modes, ext, block, dcount) as con:
+        d = con.describe()
+        assert d["p2Label"] != -1 and d["p2Label"] != d["pLabel"] and d["qLabel"] == -1, d["p2Label"]
+        assert sorted({p["dev"] for p in d["pieces"]}) == list(range(n))
+        total = 2.0 * np.prod([float(v) for v in ext.values()])
+        assert abs(sum(p["flops"] for p in d["pieces"]) - total) < 1e-4 * total      # (flops are printed with six digits)
+        per_dev = [sum(p["flops"] for p in d["pieces"] if p["dev"] == g) for g in range(n)]
+        assert max(per_dev) <= 1.01 * total / n * (2 if n == 8 and s == 1 else 1.5), per_dev
+        in_a, in_b = chr(d["pLabel"]) in modes[0], chr(d["p2Label"]) in modes[0]
+        assert in_a != in_b        # one mode of each operand
+    # the old rule on request
+    import os
+    os.environ["CUTENSORMG_AMD_SHARD2"] = "0"
+    try:
+        with cm.Contraction(list(range(n)), modes, ext, block, dcount) as con:
+            d = con.describe()
+            assert d["p2Label"] == -1 and len({p["dev"] for p in d["pieces"]}) < n
+    finally:
+        del os.environ["CUTENSORMG_AMD_SHARD2"]
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])
