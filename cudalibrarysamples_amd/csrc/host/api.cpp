@@ -193,7 +193,7 @@ static void resolve_pending_measurements(cutensorHandle* handle) {
 // A finished plan that owns nothing becomes the prototype later plans of the same problem are cloned from; the least
 // recently used prototype makes room when the cache is full (capacity = cutensorHandleResizePlanCache's numEntries).
 static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash, const cutensorPlan& pl) {
-    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || !pl.wideTab.empty() || pl.bsp) return;
+    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || !pl.wideTab.empty() || pl.bsp) return;   // plans that own something are not prototypes
     std::shared_ptr<const cutensorPlan> proto(new (std::nothrow) cutensorPlan(pl));
     if (!proto) return;
     std::lock_guard<std::mutex> g(h->mtx);
@@ -281,6 +281,7 @@ cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
         h->device = dev;
+        h->haveDevice = true;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             h->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1150,6 +1151,23 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             // executed allocates nothing)
             pl->wideTab = tab;
             if (pl->wideTab.empty()) pl->wideTab.push_back(WideMode{make_fastdiv(1), 0, 0, 0, 0});
+            // The table goes to device memory HERE when the handle has a device — on the handle's device, outside any stream
+            // capture, so that cutensorContract neither allocates nor synchronises (it may be called while a graph is being
+            // captured).  Handles without a device (plan-only, the CPU tests) keep the host copy; a plan that one of those hands
+            // to a process with a GPU uploads at first execution.
+            if (handle->haveDevice) {
+                int prev = -1;
+                void* dev = nullptr;
+                const size_t bytes = pl->wideTab.size() * sizeof(WideMode);
+                const bool switched = hipGetDevice(&prev) == hipSuccess && prev != handle->device && hipSetDevice(handle->device) == hipSuccess;
+                if (hipMalloc(&dev, bytes) == hipSuccess && hipMemcpy(dev, pl->wideTab.data(), bytes, hipMemcpyHostToDevice) == hipSuccess)
+                    pl->wide.modes = static_cast<const WideMode*>(dev);
+                else {
+                    (void)hipGetLastError();
+                    if (dev) (void)hipFree(dev);
+                }
+                if (switched) (void)hipSetDevice(prev);
+            }
             pl->choice = ContractionChoice{};
             pl->choice.kernel = -2;
             pl->requiredWorkspace = 0;

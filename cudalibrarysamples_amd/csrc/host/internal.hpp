@@ -245,6 +245,7 @@ struct PlanMemoEntry {
 
 struct cutensorHandle {
     int device = 0;
+    bool haveDevice = false;            // a GPU was visible at cutensorCreate (false: descriptors and plans only)
     int numCUs = 256;
     int clockKHz = 2400000;
     std::mutex mtx;

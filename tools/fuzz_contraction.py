@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--aligned", action="store_true", help="extents that satisfy the 16-byte-lane / whole-K-tile conditions of the "
                                                            "streaming fp32 and the 16-bit MFMA kernels")
-    ap.add_argument("--all-types", action="store_true", help="also fp64, fp16 and complex<float> (the functional kernels)")
+    ap.add_argument("--all-types", action="store_true", help="also fp64, fp16, complex<float> and complex<double> (the general MFMA family)")
     ap.add_argument("--strided", action="store_true", help="give a third of the tensors padded (non-packed) strides")
     ap.add_argument("--many-modes", action="store_true", help="3-6 small modes per group: groups beyond the tiled kernels' four digits "
                                                               "(peeled into a host loop up to 64 launches, mode-table kernel beyond)")
@@ -28,7 +28,7 @@ def main():
     fails = 0
     kinds = {}
     for case in range(args.cases):
-        dtype = rnd.choice(["float32", "float32", "bfloat16"] + (["float64", "float16", "complex64"] if args.all_types else []))
+        dtype = rnd.choice(["float32", "float32", "bfloat16"] + (["float64", "float16", "complex64", "complex128"] if args.all_types else []))
         nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
         if args.many_modes:
             nM, nN, nK, nL = rnd.randint(2, 6), rnd.randint(1, 5), rnd.randint(1, 6), rnd.choice([0, 0, 1, 2])
@@ -78,7 +78,7 @@ def main():
         alpha, beta = rnd.choice([1.0, 0.5, -1.25]), rnd.choice([0.0, 0.0, 1.0, -0.5])
         limit = rnd.choice([0, 1 << 20, 1 << 28])
         try:
-            cdt = {"float32": ct.R_32F, "bfloat16": ct.R_16BF, "float64": ct.R_64F, "float16": ct.R_16F, "complex64": ct.C_32F}[dtype]
+            cdt = {"float32": ct.R_32F, "bfloat16": ct.R_16BF, "float64": ct.R_64F, "float16": ct.R_16F, "complex64": ct.C_32F, "complex128": ct.C_64F}[dtype]
             plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC,
                                         dtype=cdt, workspace_limit=limit, strideA=sA, strideB=sB, strideC=sC)
         except ct.CuTensorError as e:
@@ -97,7 +97,7 @@ def main():
         ktot = 1
         for c in K:
             ktot *= ext[c]
-        rel, absk = {"float32": (2e-5, 1e-5), "complex64": (4e-5, 2e-5), "float64": (1e-12, 1e-13), "float16": (2e-3, 1e-3),
+        rel, absk = {"float32": (2e-5, 1e-5), "complex64": (4e-5, 2e-5), "float64": (1e-12, 1e-13), "complex128": (2e-12, 2e-13), "float16": (2e-3, 1e-3),
                      "bfloat16": (1e-2, 4e-3)}[dtype]
         # sequential accumulation: ~eps * sqrt(K) steps, each relative to partial sums that themselves grow like sqrt(K)
         tol = rel * (1.0 + ref.abs()) + absk * ktot ** 0.5 + rel * 1e-3 * ktot
