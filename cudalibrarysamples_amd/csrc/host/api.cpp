@@ -784,6 +784,11 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
             if (pick_h16_choice(v, cap, handle->numCUs, hc) || pick_gen_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
             return CUTENSOR_STATUS_SUCCESS;
         }
+        if (!v.wide && (v.dtype == HIP_R_64F || v.dtype == HIP_C_32F || v.dtype == HIP_C_64F)) {   // split-K partials of the general MFMA family
+            ContractionChoice gc;
+            if (pick_gen_choice(v, cap, handle->numCUs, gc)) *workspaceSizeEstimate = gc.workspace;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
         if (v.wide) {    // a peeled contraction wants what its inner, tiled problem wants
             cutensorOperationDescriptor inner;
             std::vector<PeelMode> peel;
@@ -1510,7 +1515,9 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
             SplitKReduceParams r = plan->skr;
             r.partial = static_cast<float*>(workspace);
             r.C = p.C; r.D = D; r.alpha = p.alpha; r.beta = p.beta;
-            err = launch_splitk_reduce(r, stream);
+            r.alpha64 = a; r.beta64 = b; r.alphaIm = aIm; r.betaIm = bIm; r.conjC = p.conjC;
+            const int elem = plan->choice.family == 2 ? tab[plan->choice.kernel].elem : GEN_BF16;
+            err = (elem >= GEN_F64) ? launch_gen_splitk_reduce(r, elem, stream) : launch_splitk_reduce(r, stream);
         }
     } else {
         int count = 0;

@@ -586,17 +586,20 @@ bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     const GettKernelInfo& k = tab[c.kernel];
     const double tiles = tiles_of(c.kernel);
     const uint64_t kTiles = (v.totK + k.bk - 1) / k.bk;
+    // split-K when the output tiles alone leave most CUs idle: partial tiles [slice][L][M][N] in the accumulator type
+    // (fp32 for 16-bit data, double / float2 / double2 for fp64 / complex64 / complex128)
+    const uint64_t accBytes = (elem <= GEN_F16) ? 4ull : (elem == GEN_C64) ? 16ull : 8ull;
+    const uint64_t perSliceBytes = v.totL * v.totM * v.totN * accBytes;
     uint64_t split = 1;
-    if (elem <= GEN_F16 && tiles * 2.0 <= (double)numCUs && kTiles >= 8) {
+    if (tiles * 2.0 <= (double)numCUs && kTiles >= 8) {
         split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
-        const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
         while (split > 1 && split * perSliceBytes > wsLimit) --split;
         if (split < 2) split = 1;
     }
     const uint64_t tilesPerSlice = (kTiles + split - 1) / split;
     c.splitK = (uint32_t)((kTiles + tilesPerSlice - 1) / tilesPerSlice);
     c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
-    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * v.totL * v.totM * v.totN * 4ull : 0ull;
+    c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * perSliceBytes : 0ull;
     // rough time: the family's MFMA rate for the type at ~50 % utilisation (only used for logs / describe)
     const double flopPerClkCU = (elem <= GEN_F16) ? 4096.0 : (elem == GEN_C32) ? 256.0 : 128.0;
     const double flops = ((elem >= GEN_C32) ? 8.0 : 2.0) * k.bm * k.bn * (double)c.kPerSlice;

@@ -17,6 +17,66 @@ const GettKernelInfo* gett_gen_f64_kernels(int* count) {
 }  // namespace ctamd
 
 // ---------------------------------------------------------------------------------------------
+// Split-K fold of the fp64 / complex general kernels: one lane per output element (n fastest: the partial reads and, when D's
+// stride-1 mode is kernel-N, the stores are coalesced), slices summed in sequence, D = alpha * sum + beta * op(C) in the
+// accumulator precision.  R = float (complex64) or double; CPLX: elements are (re, im) pairs.
+// ---------------------------------------------------------------------------------------------
+namespace ctamd {
+template <typename R, bool CPLX>
+__global__ void __launch_bounds__(256) gen_splitk_reduce_kernel(const SplitKReduceParams p) {
+    constexpr int W = CPLX ? 2 : 1;
+    const uint32_t Mtot = p.gM.total, Ntot = p.gN.total;
+    const size_t plane = (size_t)Mtot * Ntot, total = plane * p.gL.total;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const R* src = reinterpret_cast<const R*>(p.partial) + e * W;
+    R re = 0, im = 0;
+    for (uint32_t s = 0; s < p.splitK; ++s) {
+        re += src[(size_t)s * total * W];
+        if constexpr (CPLX) im += src[(size_t)s * total * W + 1];
+    }
+    const uint32_t l = (uint32_t)(e / plane);
+    const size_t rem = e - (size_t)l * plane;
+    const uint32_t m = (uint32_t)(rem / Ntot), n = (uint32_t)(rem - (size_t)m * Ntot);
+    int64_t oDl, oCl, oDm, oCm, oDn, oCn;
+    group_offset2<2>(p.gL, p.cStrideL, l, oDl, oCl);
+    group_offset2<1>(p.gM, p.cStrideM, m, oDm, oCm);
+    group_offset2<1>(p.gN, p.cStrideN, n, oDn, oCn);
+    const int64_t oD = oDl + oDm + oDn, oC = oCl + oCm + oCn;
+    const R alRe = (R)p.alpha64, alIm = (R)p.alphaIm, beRe = (R)p.beta64, beIm = (R)p.betaIm;
+    if constexpr (!CPLX) {
+        R val = alRe * re;
+        if (beRe != (R)0) val += beRe * static_cast<const R*>(p.C)[oC];
+        static_cast<R*>(p.D)[oD] = val;
+    } else {
+        R oRe = alRe * re - alIm * im, oIm = alRe * im + alIm * re;
+        if (beRe != (R)0 || beIm != (R)0) {
+            const R* c = static_cast<const R*>(p.C) + 2 * oC;
+            const R cRe = c[0], cIm = p.conjC ? -c[1] : c[1];
+            oRe += beRe * cRe - beIm * cIm;
+            oIm += beRe * cIm + beIm * cRe;
+        }
+        R* d = static_cast<R*>(p.D) + 2 * oD;
+        d[0] = oRe;
+        d[1] = oIm;
+    }
+}
+
+hipError_t launch_gen_splitk_reduce(const SplitKReduceParams& p, int elem, hipStream_t stream) {
+    const size_t total = (size_t)p.gM.total * p.gN.total * p.gL.total;
+    if (total == 0) return hipSuccess;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (elem) {
+        case GEN_F64: hipLaunchKernelGGL((gen_splitk_reduce_kernel<double, false>), grid, block, 0, stream, p); break;
+        case GEN_C32: hipLaunchKernelGGL((gen_splitk_reduce_kernel<float, true>), grid, block, 0, stream, p); break;
+        case GEN_C64: hipLaunchKernelGGL((gen_splitk_reduce_kernel<double, true>), grid, block, 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+}  // namespace ctamd
+
+// ---------------------------------------------------------------------------------------------
 // What the chip sustains on nothing but v_mfma_f64_16x16x4_f64 (the fp64 general kernels' roofline; the microarchitecture guide
 // quotes no fp64 matrix figure, so it is measured): 256 threads per CU, eight independent accumulators per wave, operands held
 // in registers.  dataKind 0: zeros (issue rate at full clock), 1: U(-1, 1).  Returns TFLOP/s (2 * 16 * 16 * 4 flop per MFMA).

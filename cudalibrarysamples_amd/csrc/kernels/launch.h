@@ -50,6 +50,9 @@ const GettKernelInfo* gett_gen_kernels(int* count);
 const GettKernelInfo* gett_gen_h16_kernels(int* count);
 const GettKernelInfo* gett_gen_f64_kernels(int* count);
 const GettKernelInfo* gett_gen_cplx_kernels(int* count);
+// split-K fold of the general family's fp64 / complex kernels: D = alpha * sum_s partial[s] + beta * op(C); partials
+// [slice][L][M][N] in the accumulator type of `elem` (GEN_F64: double, GEN_C32: float2, GEN_C64: double2)
+hipError_t launch_gen_splitk_reduce(const SplitKReduceParams& p, int elem, hipStream_t stream);
 
 // simple one-thread-per-output contraction for every other dtype (and > kMaxGroupModes problems)
 hipError_t launch_gett_simple(const GettParams& p, int dtype /*hipDataType*/, bool accumulate64,

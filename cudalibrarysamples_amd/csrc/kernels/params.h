@@ -97,6 +97,10 @@ struct SplitKReduceParams {
     uint32_t     tilesM, tilesN;
     uint32_t     fragTM, fragTN;
     int32_t      outType;        // C / D element type of the row-major fold: 0 = fp32, 1 = bf16, 2 = fp16
+    // general MFMA family, fp64 / complex data (launch_gen_splitk_reduce): partials in the accumulator type (double, float2,
+    // double2), scalars at full width, conjugation of C
+    double       alpha64, beta64, alphaIm, betaIm;
+    int32_t      conjC;
 };
 
 // ---------------------------------------------------------------------------------------------

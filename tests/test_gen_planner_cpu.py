@@ -109,6 +109,19 @@ def test_split_k_of_16_bit_data_and_workspace_invariant(env):
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] == 1 and p.required_workspace == 0, d
     p.destroy()
+    # fp64 / complex: partials in the accumulator type (double, float2, double2)
+    for dtype, acc in ((ct.R_64F, 8), (ct.C_32F, 8), (ct.C_64F, 16)):
+        p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=dtype)
+        d = p.describe()
+        assert d["family"] == 2 and d["splitK"] > 1 and p.required_workspace == d["splitK"] * 64 * 48 * acc, d
+        assert p.required_workspace <= p.workspace_estimate
+        p.destroy()
+    # the headline einsum's shape with fp64 data: one 96 x 96 output, K = 262144 -> split over the chip, not one workgroup
+    e = dict(a=96, b=64, c=64, d=64, e=96)
+    p = ops.contraction_plan(h, [e[c] for c in "dcba"], "dcba", [e[c] for c in "ebcd"], "ebcd", [96, 96], "ea", dtype=ct.R_64F)
+    d = p.describe()
+    assert d["family"] == 2 and d["splitK"] >= 64 and d["blocks"] >= 128, d
+    p.destroy()
 
 
 def test_many_mode_complex_keeps_the_mode_table_kernel(env):

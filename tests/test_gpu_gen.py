@@ -171,6 +171,22 @@ def test_split_k_of_16_bit_data(env, dtype):
     assert d["splitK"] == 1, d
 
 
+@pytest.mark.parametrize("dtype", ["float64", "complex64", "complex128"])
+def test_split_k_of_fp64_and_complex_data(env, dtype):
+    """Few output tiles and a long K: the slices write partial tiles in the accumulator type (double / float2 / double2) and
+    gen_splitk_reduce_kernel folds them with alpha / beta (complex: conj(C) too); the headline einsum's mode structure as well."""
+    cplx = dtype != "float64"
+    d = run(env, dict(m=64, n=48, k=4000), "km", "kn", "mn", dtype, alpha=(0.5 - 0.25j) if cplx else 0.5, beta=(1.5 + 0.5j) if cplx else 1.5,
+            seed=31, opC=cplx)
+    assert d["splitK"] > 1, d
+    d = run(env, dict(m=51, n=49, k=2001, l=2), "mkl", "nkl", "mnl", dtype, seed=32)
+    assert d["splitK"] > 1, d
+    d = run(env, dict(a=48, b=6, c=10, d=32, e=40), "dcba", "ebcd", "ea", dtype, alpha=1.25, seed=33)
+    assert d["splitK"] > 1, d
+    d = run(env, dict(m=64, n=48, k=4000), "km", "kn", "mn", dtype, seed=34, ws_limit=0)
+    assert d["splitK"] == 1, d
+
+
 def test_fp64_matches_the_oracle_bit_for_bit_on_exact_data(env):
     """Small integers: every product and partial sum is exact in fp64, so the MFMA result must EQUAL the oracle's."""
     import oracle

@@ -57,8 +57,9 @@ def gemm(name, M, N, K, tdt, cdt, mA="km", mB="kn", flop_per_mac=2.0, reps=10, p
 
 def einsum_case(equation, a_size, b_size, tdt, reps=50):
     from cudalibrarysamples_amd import torch_einsum
-    a = torch.randn(*a_size, device="cuda").to(tdt)
-    b = torch.randn(*b_size, device="cuda").to(tdt)
+    mk = (lambda sz: torch.randn(*sz, device="cuda").to(tdt)) if not tdt.is_complex else \
+        (lambda sz: torch.complex(torch.randn(*sz, device="cuda"), torch.randn(*sz, device="cuda")).to(tdt))
+    a, b = mk(a_size), mk(b_size)
     out = torch_einsum.einsum(equation, a, b)
     torch.cuda.synchronize()
     p = torch_einsum._plans[(equation, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
@@ -74,10 +75,11 @@ def einsum_case(equation, a_size, b_size, tdt, reps=50):
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / n)
-    ref = torch.einsum(equation, a.double(), b.double())
-    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    wide = torch.complex128 if tdt.is_complex else torch.float64
+    ref = torch.einsum(equation, a.to(wide), b.to(wide))
+    err = float((out.to(wide) - ref).abs().max() / ref.abs().max())
     print(json.dumps({"shape": "einsum " + equation, "a": list(a_size), "b": list(b_size), "dtype": str(tdt), "us_per_call": round(best * 1e3, 2),
-                      "kname": d["kname"], "tile": [d["bm"], d["bn"], d["bk"]], "vec": d.get("vec"), "blocks": d["blocks"],
+                      "kname": d["kname"], "tile": [d["bm"], d["bn"], d["bk"]], "vec": d.get("vec"), "blocks": d["blocks"], "splitK": d["splitK"],
                       "max_err_over_max_ref": err}), flush=True)
 
 
@@ -114,6 +116,10 @@ def main():
         einsum_case("ik,kj->ij", (50, 50), (50, 50), torch.float16)
         einsum_case("lik,lkj->lij", (50, 50, 50), (50, 50, 50), torch.complex128)
         einsum_case("mlik,lkjm", (2, 5, 50, 2), (5, 2, 50, 2), torch.float64)
+        # the headline equation with other element types: one 96 x 96 output tile, K = 262144 -> split-K of the general family
+        einsum_case("abcd,dcbe->ae", (96, 64, 64, 64), (64, 64, 64, 96), torch.float64, reps=5)
+        einsum_case("abcd,dcbe->ae", (96, 64, 64, 64), (64, 64, 64, 96), torch.complex64, reps=5)
+        einsum_case("abcd,dcbe->ae", (96, 64, 64, 64), (64, 64, 64, 96), torch.bfloat16, reps=20)
 
 
 if __name__ == "__main__":
