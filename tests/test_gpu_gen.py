@@ -200,7 +200,8 @@ def test_fp64_matches_the_oracle_bit_for_bit_on_exact_data(env):
     dA, dB, dC = dev(A), dev(B), dev(C)
     plan = ops.contraction_plan(h, [ext["k"], ext["m"]], "km", [ext["k"], ext["n"]], "kn", [ext["m"], ext["n"]], "mn", dtype=ct.R_64F)
     assert plan.describe()["family"] == 2
-    plan.contract(2.0, dA.data_ptr(), dB.data_ptr(), -3.0, dC.data_ptr(), dC.data_ptr())
+    ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    plan.contract(2.0, dA.data_ptr(), dB.data_ptr(), -3.0, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), plan.required_workspace)
     torch.cuda.synchronize()
     want = C.copy(order="F")
     oracle.contract(A, "km", B, "kn", want, "mn", alpha=2.0, beta=-3.0, C=C)
