@@ -1524,6 +1524,10 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         const GettKernelInfo* tab = gett_f32_kernels(&count);
         g_launchCounts[2].fetch_add(1, std::memory_order_relaxed);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
+        {
+            static const int policy = [] { const char* e = std::getenv("CUTENSOR_AMD_PARTIAL_STORE"); return e ? (e[0] == 'p' ? 1 : e[0] == 'n' ? 2 : 0) : 0; }();
+            p.partialPolicy = policy;
+        }
         if (plan->fusedFold) {
             uint32_t slot;
             {

@@ -73,6 +73,14 @@ __device__ __forceinline__ void store_wt_16(f32x4 v, BufRsrc rsrc, uint32_t byte
     (void)v; (void)rsrc; (void)byteOff;
 #endif
 }
+template <int AUX>   // measurement: the same store with another cache policy (0 = plain / write-back, 2 = nontemporal)
+__device__ __forceinline__ void store_policy_16(f32x4 v, BufRsrc rsrc, uint32_t byteOff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)byteOff, 0, AUX);
+#else
+    (void)v; (void)rsrc; (void)byteOff;
+#endif
+}
 template <int AUX = 0>   // AUX = 2: nontemporal ("nt") — streamed once, not worth a line of the Infinity Cache
 __device__ __forceinline__ void lds_dma_16(BufRsrc rsrc, uint32_t laneBytes, uint32_t tileBytes, float* dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -488,10 +496,20 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         // so the kernel boundary in front of the fold kernel has no dirty partials left to flush
         f32x4* P = reinterpret_cast<f32x4*>(p.partial) + (tileIdx * 4 + wave) * (size_t)(TM * TN * 64);
         const BufRsrc rP = make_rsrc(reinterpret_cast<const float*>(P));
+        if (__builtin_expect(p.partialPolicy != 0, 0)) {      // measurement switch (wave-uniform): plain or nontemporal stores
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (p.partialPolicy == 1) store_policy_16<0>(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + laneE) * 16));
+                    else store_policy_16<2>(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + laneE) * 16));
+                }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) store_wt_16(acc[i][j], rP, (uint32_t)(((i * TN + j) * 64 + laneE) * 16));
+        }
         stamp(4);
         if (p.sync == nullptr) {   // the fold runs as its own kernel
             stamp(6);

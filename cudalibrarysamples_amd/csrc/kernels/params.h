@@ -55,6 +55,10 @@ struct GettParams {
     // conjugation of kernel-A / kernel-B / C
     double      alphaIm, betaIm;
     int32_t     conjA, conjB, conjC;
+    // measurement switch (CUTENSOR_AMD_PARTIAL_STORE): cache policy of the streaming fp32 kernels' split-K partial stores —
+    // 0 = write-through (sc1, the default), 1 = plain (write-back: the lines stay dirty in the XCD's L2 until the kernel ends),
+    // 2 = nontemporal
+    int32_t     partialPolicy;
 };
 
 // ---------------------------------------------------------------------------------------------
