@@ -606,6 +606,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two live rocprofv3 --pmc passes for roofline.traffic (the committed "
                                                           "figure of the latest profile is reported instead)")
+    ap.add_argument("--cold-only", action="store_true",
+                    help="profiling runs: only the HBM-cold variant of the headline (four rotating operand pairs, >= 500 steps), one small JSON line")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--mg-timeout", type=int, default=300, help="seconds per attempt of the multi-device child process")
     ap.add_argument("--einsum-only", action="store_true", help=argparse.SUPPRESS)   # ranks spawned by a plain `--gpus N` launch
@@ -711,6 +713,23 @@ def main():
         if world > 1:
             dist.barrier(group=cpu_group)
         torch.cuda.synchronize()
+
+    if args.cold_only:
+        # rocprofv3 --pmc passes of the cold rotation alone (tools/gpu_profile_all.sh): every launch of this process reads operands
+        # that are not in the Infinity Cache
+        pairs = [(a, b)] + [(torch.rand(a.shape, generator=g, device="cuda"), torch.rand(b.shape, generator=g, device="cuda")) for _ in range(3)]
+        n_cold = max(args.steps, 500)
+        for i in range(100):
+            contract(*pairs[i % 4], outs[i % nbuf])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_cold):
+            contract(*pairs[i % 4], outs[i % nbuf])
+        torch.cuda.synchronize()
+        cold_s = (time.perf_counter() - t1) / n_cold
+        print(json.dumps({"cold_only": True, "steps": n_cold, "ms_per_step": cold_s * 1e3, "value": FLOP / cold_s / 1e9, "unit": "GFLOP/s",
+                          "frac_of_nominal_f32_mfma_peak": FLOP / cold_s / 1e12 / PEAK_TFLOPS_F32_MFMA, "operand_bytes_rotated": 4 * BYTES}))
+        return
 
     # ---- device clock ramp (untimed, not a step count: wall-clock bounded) -----------------------------
     # A cold MI355X runs the first ~12-20 ms of a kernel stream ~10 % slower than its steady state (GETT kernel

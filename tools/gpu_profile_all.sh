@@ -15,6 +15,35 @@ summ() {   # summ <dir> <name>
 cd $ROOT && bash tools/gpu_profile.sh $TAG/einsum > $OUT/einsum_profile.log 2>&1
 for d in trace pmc_sq pmc_fetch pmc_write; do cp $OUT/einsum/$d.summary.txt $OUT/einsum_$d.summary.txt 2>/dev/null; done
 cp $OUT/einsum/pmc_traffic_einsum.json $OUT/pmc_traffic_einsum.json 2>/dev/null
+# ---- 1b. the same headline with HBM-cold operands only (four rotating pairs): trace + PMC of the cold launches alone -------
+cd /tmp
+COLD="python $ROOT/bench.py --cold-only --steps 500"
+rocprofv3 --kernel-trace --stats -d $OUT/cold_trace -o r -- $COLD > $OUT/cold_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $OUT/cold_sq -o r -- $COLD > $OUT/cold_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/cold_fetch -o r -- $COLD > $OUT/cold_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/cold_write -o r -- $COLD > $OUT/cold_write.log 2>&1
+for p in trace sq fetch write; do summ cold_$p einsum_cold_$p; done
+(cd $ROOT && for i in 1 2 3; do python bench.py --cold-only --steps 2000 2>/dev/null | tail -1; done > $OUT/einsum_cold_unprofiled.jsonl)
+# ---- 1c. the general MFMA family (round 4): fp64 4096^3 and complex64 2048^3: trace, SQ, FETCH, WRITE ---------------------------
+cd /tmp
+for W in f64 c64; do
+  G="python $ROOT/tools/bench_gen.py $W"
+  rocprofv3 --kernel-trace --stats -d $OUT/gen_${W}_trace -o r -- $G > $OUT/gen_${W}_trace.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/gen_${W}_sq -o r -- $G > $OUT/gen_${W}_sq.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $OUT/gen_${W}_fetch -o r -- $G > $OUT/gen_${W}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $OUT/gen_${W}_write -o r -- $G > $OUT/gen_${W}_write.log 2>&1
+  for p in trace sq fetch write; do summ gen_${W}_$p gen_${W}_$p; done
+done
+(cd $ROOT && python tools/bench_gen.py > $OUT/bench_gen.jsonl 2>/dev/null; CUTENSOR_AMD_GEN=0 python tools/bench_gen.py einsum f64 > $OUT/bench_gen_before.jsonl 2>/dev/null)
+# ---- 1d. the mid-size 16-bit kernel (round 4): bf16 2048^3 on gett_h16w4m4_kernel: trace, SQ, FETCH, WRITE -----------------------
+cd /tmp
+M="python $ROOT/tools/h16_shape_sweep.py --only 2048,2048,2048 --reps 200"
+rocprofv3 --kernel-trace --stats -d $OUT/h16m_trace -o r -- $M > $OUT/h16m_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/h16m_sq -o r -- $M > $OUT/h16m_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/h16m_fetch -o r -- $M > $OUT/h16m_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/h16m_write -o r -- $M > $OUT/h16m_write.log 2>&1
+for p in trace sq fetch write; do summ h16m_$p h16_mid_2048_$p; done
+(cd $ROOT && for L in mk,kn km,kn mk,nk; do python tools/h16_shape_sweep.py --layout $L 2>/dev/null; done > $OUT/h16_shape_sweep.jsonl)
 # ---- 2. bf16 8192^3, default kernel, two layouts: trace, SQ, FETCH, WRITE ---------------------------------------------
 cd /tmp
 for L in mk,kn km,kn; do
