@@ -1407,14 +1407,14 @@ static const GettKernelInfo g_h16_table[] = {
 // 128 x 128 mid-size sibling of that (two workgroups per CU); same order
 const GettKernelInfo* gett_h16_kernels(int* count) {
     constexpr int nHere = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
-    struct All { GettKernelInfo e[nHere + 32]; int n; };
+    struct All { GettKernelInfo e[nHere + 40]; int n; };
     static const All all = [] {
         All a{};
         for (int i = 0; i < nHere; ++i) a.e[i] = g_h16_table[i];
         int nv = 0;
         const GettKernelInfo* v = gett_h16v_kernels(&nv);
         a.n = nHere;
-        for (int i = 0; i < nv && i < 32; ++i) a.e[a.n++] = v[i];
+        for (int i = 0; i < nv && i < 40; ++i) a.e[a.n++] = v[i];
         return a;
     }();
     *count = all.n;

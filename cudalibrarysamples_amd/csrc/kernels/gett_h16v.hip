@@ -15,6 +15,8 @@
 //     and ONE countdown covers both rare events (carry past the second K digit, end of the K range: steps become zero);
 //     ~14 scalar instructions per K-tile spread over three MFMA pairs — instead of ~60 in one block behind a branch.
 // Roofline and algorithmic bytes as in gett_h16.hip.
+#include <type_traits>
+
 #include "gett_h16_common.h"
 
 namespace ctamd {
@@ -825,6 +827,236 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     }
 }
 
+
+// =====================================================================================================
+// gett_h16w8m_kernel (CUTENSOR_AMD_H16_WAVES=8m): the 128 x 128 x 64 tile with DEDICATED data-moving waves.
+// tools/ubench/ldsdma_rate.hip measures what a CU pulls into LDS through buffer_load ... lds when it does nothing else: ~60 B/clk
+// (130 GB/s per CU, 33-35 TB/s chip-wide) from L2 — yet every four-wave 16-bit kernel here ends up at 28-36 B/clk/CU
+// (profiles/r04f_h16_shape_sweep.txt).  The difference is not bandwidth but ISSUE: an LDS-DMA instruction holds its wave's issue
+// port for 60-180 cycles (tools/ubench/dma_issue.hip), and a wave that owns a SIMD's matrix pipe cannot queue MFMAs meanwhile —
+// eight pieces per K-tile are 500-800 cycles on top of the 512 cycles of MFMA issue of a 64 x 64 wave tile.  So, as in the fp32
+// streaming kernel (gett_f32_stream.hip): eight waves, waves 0-3 multiply (one per SIMD: the compute stream of gett_h16w4m_kernel
+// WITHOUT its LDS-DMA pieces, odometer and vmcnt waits), waves 4-7 only move data (one per SIMD: staging tables, K odometer, eight
+// pieces per K-tile each) — a piece's issue time now overlaps the OTHER wave's MFMAs.  Four K-tiles of 32 KiB in LDS (128 KiB), one
+// workgroup per CU, ONE barrier per K-tile for all eight waves:
+//   barrier #0      : tile 0 has landed
+//   barrier #(t+1)  : tile t + 1 has landed (every mover waited for its own pieces: vmcnt(16), tiles t + 2 and t + 3 stay in flight)
+//                     and every multiplying wave holds the last fragments of tile t in registers -> buffer t % 4 is refilled with
+//                     tile t + 4
+// Same LDS images, swizzles, fragment addressing and epilogues as gett_h16w4m_kernel.
+// =====================================================================================================
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p) {
+    constexpr int R = 4;
+    __shared__ __attribute__((aligned(16))) char lds[R * 2 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3;
+    const bool mover = wave8 >= 4;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, p.nBlocks);
+    const uint32_t tilesMN = p.tilesM * p.tilesN;
+    const uint32_t tilesAll = tilesMN * p.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * p.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kMTile, n0 = nt * kMTile;
+    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const bool splitK = p.partial != nullptr;
+
+    if (mover) {
+        // =========================== data movers ======================================================
+        HOperand<LA, 4, false, 1, 1> oa;
+        HOperand<LB, 4, false, 1, 1> ob;
+        oa.init(p.gM, p.gK.stride[0][0], m0, wave, lane);
+        ob.init(p.gN, p.gK.stride[1][0], n0, wave, lane);
+        const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
+        const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
+        VOdometer odo;
+        odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+        const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+        // the eight pieces of the K-tile the odometer describes into the buffer at LDS byte offset BUFOFF (wave-uniform), then on to
+        // the next K-tile (beyond the K range the odometer stays where it is: the last tile is staged again and never read)
+#define CTAMD_W_ISSUE(BUFOFF, PAD)                                                                                   \
+        {                                                                                                          \
+            const uint32_t wl_ = VOdometer::sgpr(waveLds + (BUFOFF));                                              \
+            v_dma16<0 * 4096, PAD>(v_rsrc(odo.addrA), oa.src[0][0], wl_);                                          \
+            v_dma16<1 * 4096, PAD>(v_rsrc(odo.addrA), oa.src[0][1], wl_);                                          \
+            v_dma16<2 * 4096, PAD>(v_rsrc(odo.addrA), oa.src[0][2], wl_);                                          \
+            v_dma16<3 * 4096, PAD>(v_rsrc(odo.addrA), oa.src[0][3], wl_);                                          \
+            v_dma16<(uint32_t)kHalfBytes + 0 * 4096, PAD>(v_rsrc(odo.addrB), ob.src[0][0], wl_);                   \
+            v_dma16<(uint32_t)kHalfBytes + 1 * 4096, PAD>(v_rsrc(odo.addrB), ob.src[0][1], wl_);                   \
+            v_dma16<(uint32_t)kHalfBytes + 2 * 4096, PAD>(v_rsrc(odo.addrB), ob.src[0][2], wl_);                   \
+            v_dma16<(uint32_t)kHalfBytes + 3 * 4096, PAD>(v_rsrc(odo.addrB), ob.src[0][3], wl_);                   \
+            odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);                                             \
+        }
+        constexpr uint32_t kBuf = 2u * (uint32_t)kHalfBytes;
+        CTAMD_W_ISSUE(0u * kBuf, true)
+        CTAMD_W_ISSUE(1u * kBuf, true)
+        CTAMD_H_VMCNT(8);                              // progressive start: the multipliers go as soon as tile 0 is there
+        __builtin_amdgcn_s_barrier();                  // #0
+        CTAMD_W_ISSUE(2u * kBuf, true)
+        CTAMD_W_ISSUE(3u * kBuf, true)
+        uint32_t bufOff = 0;
+        for (int t = 0; t < nTiles; ++t) {
+            CTAMD_H_VMCNT(16);                         // tile t + 1 has landed; tiles t + 2, t + 3 stay in flight
+            __builtin_amdgcn_s_barrier();              // #(t + 1): buffer t % 4 is free
+            CTAMD_W_ISSUE(bufOff, false)               // tile t + 4
+            bufOff = (bufOff + kBuf == (uint32_t)R * kBuf) ? 0u : bufOff + kBuf;
+        }
+        CTAMD_H_VMCNT(0);                              // no LDS-DMA may outlive the workgroup (or land in the epilogue's scratch)
+        if (!splitK) __builtin_amdgcn_s_barrier();     // the epilogue's barrier: every piece has landed, every fragment is read
+        return;
+    }
+
+    // =============================== multipliers ======================================================
+    __builtin_amdgcn_s_setprio(2);
+    constexpr int nRdA = (LA == LAY_K) ? 2 : 4, nRdB = (LB == LAY_K) ? 2 : 4;
+    uint32_t rdA[R][nRdA], rdB[R][nRdB];
+#pragma unroll
+    for (int P = 0; P < R; ++P) {
+#pragma unroll
+        for (int x = 0; x < nRdA; ++x) {
+            rdA[P][x] = ldsBase + (uint32_t)((2 * P) * kHalfBytes) + (LA == LAY_K ? (uint32_t)(8192 * wr) + x_offK(lane, x) : x_offF(lane, 4 * wr + x));
+            asm volatile("" : "+v"(rdA[P][x]));
+        }
+#pragma unroll
+        for (int x = 0; x < nRdB; ++x) {
+            rdB[P][x] = ldsBase + (uint32_t)((2 * P + 1) * kHalfBytes) + (LB == LAY_K ? (uint32_t)(8192 * wc) + x_offK(lane, x) : x_offF(lane, 4 * wc + x));
+            asm volatile("" : "+v"(rdB[P][x]));
+        }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[2][4], b[2][4];                       // two register sets: k-step s uses set s
+
+#define CTAMD_W_READ(P, S, Q)                                                                                       \
+    {                                                                                                              \
+        if constexpr ((Q) < 4) {                                                                                   \
+            if constexpr (LB == LAY_K) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][(S) % nRdB]);                    \
+            else b[S][Q] = v_read<LAY_F, 8192 * (S)>(rdB[P][(Q) % nRdB]);                                          \
+        } else {                                                                                                   \
+            if constexpr (LA == LAY_K) a[S][(Q) - 4] = v_read<LAY_K, 2048 * ((Q) - 4)>(rdA[P][(S) % nRdA]);        \
+            else a[S][(Q) - 4] = v_read<LAY_F, 8192 * (S)>(rdA[P][((Q) - 4) % nRdA]);                              \
+        }                                                                                                          \
+    }
+#define CTAMD_W_MFMA(S, M) x_mfma<BF>(acc[(M) >> 2][(M) & 3], a[S][(M) >> 2], b[S][(M) & 3]);
+    // k-step 0, group Q: one read of k-step 1 (same buffer), two MFMAs;  k-step 1 (behind the barrier): one read of the next tile's
+    // k-step 0 (next buffer), two MFMAs
+#define CTAMD_W_G0(P, Q)                                                                                            \
+    CTAMD_W_READ(P, 1, Q)                                                                                          \
+    CTAMD_W_MFMA(0, 2 * (Q)) CTAMD_W_MFMA(0, 2 * (Q) + 1)                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_W_G1(P, Q)                                                                                            \
+    CTAMD_W_READ(((P) + 1) % R, 0, Q)                                                                              \
+    CTAMD_W_MFMA(1, 2 * (Q)) CTAMD_W_MFMA(1, 2 * (Q) + 1)                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_W_TILE(P)                                                                                             \
+    CTAMD_W_G0(P, 0) CTAMD_W_G0(P, 1) CTAMD_W_G0(P, 2) CTAMD_W_G0(P, 3)                                            \
+    CTAMD_W_G0(P, 4) CTAMD_W_G0(P, 5) CTAMD_W_G0(P, 6) CTAMD_W_G0(P, 7)                                            \
+    CTAMD_H_LGKM0();                                                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_W_G1(P, 0) CTAMD_W_G1(P, 1) CTAMD_W_G1(P, 2) CTAMD_W_G1(P, 3)                                            \
+    CTAMD_W_G1(P, 4) CTAMD_W_G1(P, 5) CTAMD_W_G1(P, 6) CTAMD_W_G1(P, 7)
+
+    __builtin_amdgcn_s_barrier();                 // #0: tile 0 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    CTAMD_W_READ(0, 0, 0) CTAMD_W_READ(0, 0, 1) CTAMD_W_READ(0, 0, 2) CTAMD_W_READ(0, 0, 3)
+    CTAMD_W_READ(0, 0, 4) CTAMD_W_READ(0, 0, 5) CTAMD_W_READ(0, 0, 6) CTAMD_W_READ(0, 0, 7)
+    int t = 0;
+    for (; t + 3 < nTiles; t += 4) { CTAMD_W_TILE(0) CTAMD_W_TILE(1) CTAMD_W_TILE(2) CTAMD_W_TILE(3) }
+    if (t < nTiles) { CTAMD_W_TILE(0) }
+    if (t + 1 < nTiles) { CTAMD_W_TILE(1) }
+    if (t + 2 < nTiles) { CTAMD_W_TILE(2) }
+    CTAMD_H_LGKM0();                              // the (unused) fragments of the tile behind the last one
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    __builtin_amdgcn_s_setprio(0);
+    const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+
+    const uint32_t mW = m0 + 64 * wr, nW = n0 + 64 * wc;      // this wave's quadrant
+    if (splitK) {                                 // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
+        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
+                if (m < Mt) {
+                    float* row = P + (size_t)m * Nt;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t n = nW + 16 * j + (laneE & 15);
+                        if (n < Nt) row[n] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                 // every wave has finished reading the ring, every piece has landed (the movers' last barrier)
+    HEpilogue ep;
+    ep.init(p, l, lds, wave);                     // 16 KiB of the (dead) ring per multiplying wave
+    if (ep.vecD && ep.beta == 0.f) {
+        uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
+        constexpr int kPitch = 72;                // 16-bit elements per image row (gett_h16w4m_kernel's 16-bit epilogue)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4& c = acc[2 * i + a2][j];
+                    uint16_t* st = stage + (16 * a2 + 4 * (laneE >> 4)) * kPitch + 16 * j + (laneE & 15);
+                    st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                    st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+                }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + laneE, row = q >> 3, cc = q & 7;
+                const s16x8 v = *reinterpret_cast<const s16x8*>(stage + row * kPitch + 8 * cc);
+                const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
+                if (m < ep.Mtot && n < ep.Ntot) {
+                    int64_t offD, offC;
+                    ep.offsets(p, m, n, offD, offC);
+                    __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int F = 0; F < 4; ++F)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);
+                const f32x4& c = acc[2 * (F >> 1) + (h >> 1)][2 * (F & 1) + (h & 1)];
+                st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
+            }
+        ep.template flush<BF>(p, mW, 32u, 0u, nW, 0u, 32u, laneE);
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w8m(const GettParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <bool BF, int LA, int LB, int R>
 static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB, R>), dim3(p.nBlocks), dim3(256), 0, stream, p);
@@ -846,6 +1078,8 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
     {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 8, 1, 0, &launch_h16w4m<bf, la, lb, 2>, 0},
 #define CTAMD_H16W4M4_ENTRY(bf, la, lb) \
     {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 9, 1, 0, &launch_h16w4m<bf, la, lb, 4>, 0},
+#define CTAMD_H16W8M_ENTRY(bf, la, lb) \
+    {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 512, 10, 1, 0, &launch_h16w8m<bf, la, lb>, 0},
 static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
@@ -865,7 +1099,12 @@ static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4M4_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4M4_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4M4_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4M4_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W4M4_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4M4_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4M4_ENTRY(false, LAY_F, LAY_F)
+    // entries 32..39 (72..79 of the family): 128 x 128, four multiplying + four data-moving waves, four-deep ring
+    CTAMD_H16W8M_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W8M_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W8M_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W8M_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W8M_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W8M_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16v_kernels(int* count) {
     *count = (int)(sizeof(g_h16v_table) / sizeof(g_h16v_table[0]));
