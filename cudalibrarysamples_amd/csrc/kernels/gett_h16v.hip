@@ -712,7 +712,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     // k-step 0, group Q: one read of k-step 1 (same buffer) and two MFMAs; three of the groups carry the odometer
     // (R = 4: the groups also carry pieces 4..7 of tile t + 3 into the buffer behind this one, then the odometer moves on)
 #define CTAMD_M_G0(P, Q)                                                                                            \
-    CTAMD_M_READ(P, 1, Q)                                                                                          \
+    if constexpr ((Q) < 4) { CTAMD_M_READ(P, 1, 2 * (Q)) CTAMD_M_READ(P, 1, 2 * (Q) + 1) }   /* reads early: see gett_h16w8m_kernel */ \
     CTAMD_M_MFMA(0, 2 * (Q))                                                                                       \
     if constexpr (R == 2) {                                                                                        \
         if constexpr ((Q) == 1) odo.advance_a();                                                                   \
@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into this
     // buffer, two MFMAs
 #define CTAMD_M_G1(P, Q)                                                                                            \
-    CTAMD_M_READ(((P) + 1) % R, 0, Q)                                                                              \
+    if constexpr ((Q) < 4) { CTAMD_M_READ(((P) + 1) % R, 0, 2 * (Q)) CTAMD_M_READ(((P) + 1) % R, 0, 2 * (Q) + 1) } \
     CTAMD_M_MFMA(1, 2 * (Q))                                                                                       \
     if constexpr (R == 2) CTAMD_M_DMA(P, Q, false)                                                                 \
     else if constexpr ((Q) % 2 == 0) CTAMD_M_DMA(P, (Q) / 2, false)         /* pieces 0..3 of tile t + 4 */          \
@@ -958,12 +958,14 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
 #define CTAMD_W_MFMA(S, M) x_mfma<BF>(acc[(M) >> 2][(M) & 3], a[S][(M) >> 2], b[S][(M) & 3]);
     // k-step 0, group Q: one read of k-step 1 (same buffer), two MFMAs;  k-step 1 (behind the barrier): one read of the next tile's
     // k-step 0 (next buffer), two MFMAs
+    // (the eight reads of a k-step go out in its FIRST four groups, two per group: at the tile barrier's lgkmcnt(0) the youngest read
+    // is then 128 MFMA cycles old instead of 32 — with 512 cycles of MFMAs per K-tile an LDS latency per tile is a quarter of the loop)
 #define CTAMD_W_G0(P, Q)                                                                                            \
-    CTAMD_W_READ(P, 1, Q)                                                                                          \
+    if constexpr ((Q) < 4) { CTAMD_W_READ(P, 1, 2 * (Q)) CTAMD_W_READ(P, 1, 2 * (Q) + 1) }                         \
     CTAMD_W_MFMA(0, 2 * (Q)) CTAMD_W_MFMA(0, 2 * (Q) + 1)                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_W_G1(P, Q)                                                                                            \
-    CTAMD_W_READ(((P) + 1) % R, 0, Q)                                                                              \
+    if constexpr ((Q) < 4) { CTAMD_W_READ(((P) + 1) % R, 0, 2 * (Q)) CTAMD_W_READ(((P) + 1) % R, 0, 2 * (Q) + 1) } \
     CTAMD_W_MFMA(1, 2 * (Q)) CTAMD_W_MFMA(1, 2 * (Q) + 1)                                                          \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_W_TILE(P)                                                                                             \
