@@ -840,14 +840,18 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
 // pieces per K-tile each) — a piece's issue time now overlaps the OTHER wave's MFMAs.  Four K-tiles of 32 KiB in LDS (128 KiB), one
 // workgroup per CU, ONE barrier per K-tile for all eight waves:
 //   barrier #0      : tile 0 has landed
-//   barrier #(t+1)  : tile t + 1 has landed (every mover waited for its own pieces: vmcnt(16), tiles t + 2 and t + 3 stay in flight)
-//                     and every multiplying wave holds the last fragments of tile t in registers -> buffer t % 4 is refilled with
-//                     tile t + 4
+//   barrier #(t+1)  : tile t + 1 has landed (every mover waited for its own pieces: vmcnt(8 (R - 2)), the tiles behind it stay in
+//                     flight) and every multiplying wave holds the last fragments of tile t in registers -> buffer t % R is
+//                     refilled with tile t + R
+// R = 5 (all 160 KiB of LDS): what bounds a 128 x 128 tile is neither the LDS-DMA issue nor its bandwidth but LATENCY x bytes in
+// flight — the landing buffers ARE the in-flight bytes, and at ~1 us of loaded LDS-DMA latency three tiles (96 KiB) sustain
+// ~80 GB/s per CU = a K-tile every 0.42 us where its MFMAs take 0.27 (every schedule of the four-deep ring measured that, NOTES.md);
+// four tiles in flight: ~110 GB/s.
 // Same LDS images, swizzles, fragment addressing and epilogues as gett_h16w4m_kernel.
 // =====================================================================================================
-template <bool BF, int LA, int LB>
+template <bool BF, int LA, int LB, int R = 5>
 __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p) {
-    constexpr int R = 4;
+    static_assert(R == 4 || R == 5, "ring of four or five K-tiles (128 / 160 KiB)");
     __shared__ __attribute__((aligned(16))) char lds[R * 2 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
@@ -909,11 +913,12 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
         __builtin_amdgcn_s_barrier();                  // #0
         CTAMD_W_ISSUE(2u * kBuf, true)
         CTAMD_W_ISSUE(3u * kBuf, true)
+        if constexpr (R == 5) CTAMD_W_ISSUE(4u * kBuf, true)
         uint32_t bufOff = 0;
         for (int t = 0; t < nTiles; ++t) {
-            CTAMD_H_VMCNT(16);                         // tile t + 1 has landed; tiles t + 2, t + 3 stay in flight
+            CTAMD_H_VMCNT(8 * (R - 2));                // tile t + 1 has landed; tiles t + 2 .. t + R - 1 stay in flight
             __builtin_amdgcn_s_barrier();              // #(t + 1): buffer t % 4 is free
-            CTAMD_W_ISSUE(bufOff, false)               // tile t + 4
+            CTAMD_W_ISSUE(bufOff, false)               // tile t + R
             bufOff = (bufOff + kBuf == (uint32_t)R * kBuf) ? 0u : bufOff + kBuf;
         }
         CTAMD_H_VMCNT(0);                              // no LDS-DMA may outlive the workgroup (or land in the epilogue's scratch)
@@ -982,10 +987,15 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
     CTAMD_W_READ(0, 0, 0) CTAMD_W_READ(0, 0, 1) CTAMD_W_READ(0, 0, 2) CTAMD_W_READ(0, 0, 3)
     CTAMD_W_READ(0, 0, 4) CTAMD_W_READ(0, 0, 5) CTAMD_W_READ(0, 0, 6) CTAMD_W_READ(0, 0, 7)
     int t = 0;
-    for (; t + 3 < nTiles; t += 4) { CTAMD_W_TILE(0) CTAMD_W_TILE(1) CTAMD_W_TILE(2) CTAMD_W_TILE(3) }
+    if constexpr (R == 4) {
+        for (; t + 3 < nTiles; t += 4) { CTAMD_W_TILE(0) CTAMD_W_TILE(1) CTAMD_W_TILE(2) CTAMD_W_TILE(3) }
+    } else {
+        for (; t + 4 < nTiles; t += 5) { CTAMD_W_TILE(0) CTAMD_W_TILE(1) CTAMD_W_TILE(2) CTAMD_W_TILE(3) CTAMD_W_TILE(4) }
+    }
     if (t < nTiles) { CTAMD_W_TILE(0) }
     if (t + 1 < nTiles) { CTAMD_W_TILE(1) }
     if (t + 2 < nTiles) { CTAMD_W_TILE(2) }
+    if constexpr (R == 5) { if (t + 3 < nTiles) { CTAMD_W_TILE(3) } }
     CTAMD_H_LGKM0();                              // the (unused) fragments of the tile behind the last one
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
     __builtin_amdgcn_s_setprio(0);
@@ -1055,7 +1065,9 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w8m(const GettParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    static const bool ring4 = [] { const char* e = getenv("CUTENSOR_AMD_H16_RING"); return e && e[0] == '4'; }();   // measurement: the four-deep ring
+    if (ring4) hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
