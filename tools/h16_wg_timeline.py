@@ -28,6 +28,16 @@ ct.lib.ctamdSetTimingBuffer(h.h, tbuf.data_ptr())
 plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
 torch.cuda.synchronize()
 ct.lib.ctamdSetTimingBuffer(h.h, None)
+# the measurement instantiations (CUTENSOR_AMD_H16_XST) must still compute the product: 256 rows against torch, and the rate of 20 calls
+ref = (A[:256].float() @ B.float())
+err = float((D[:256].float() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) if not zeros else float(D.float().abs().max())
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
+e1.record()
+torch.cuda.synchronize()
+tflops = 2.0 * n ** 3 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e12
 t = tbuf.cpu().numpy()[64:].reshape(nwg, 8).astype(np.float64)
 pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 w0 = t[:, 4].min()
@@ -36,7 +46,8 @@ dur = end - start
 clk = (t[:, 3] - t[:, 0]) / (dur * 1e3)                               # GHz
 order = np.argsort(start)
 rounds = [order[i * 256:(i + 1) * 256] for i in range(4)]
-out = {"zeros": zeros, "cycles_mean": {"prologue": pro.mean(), "main_loop": loop.mean(), "epilogue": epi.mean()},
+out = {"zeros": zeros, "xst": os.environ.get("CUTENSOR_AMD_H16_XST", "0"), "rel_err_256_rows": err, "tflops_20_calls": tflops,
+       "cycles_mean": {"prologue": pro.mean(), "main_loop": loop.mean(), "epilogue": epi.mean()},
        "cycles_per_k_tile": loop.mean() / 128, "clock_ghz_mean": clk.mean(), "kernel_span_us": float(end.max()),
        "rounds": [{"start_us": [float(start[r].min()), float(start[r].max())], "end_us": [float(end[r].min()), float(end[r].max())],
                    "dur_us_mean": float(dur[r].mean())} for r in rounds],
