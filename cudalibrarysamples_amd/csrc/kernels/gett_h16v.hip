@@ -350,11 +350,20 @@ __device__ __forceinline__ uint32_t x_offF(int lane, int f) {
 // TIMED (measurement-only instantiation, CUTENSOR_AMD_H16_TIMED=1 with the planner's default kernel, layout mk,kn): wave 0 of every
 // workgroup records shader cycles at entry / first MFMA / end of the main loop / exit and the wall clock at entry / exit into
 // p.timing (the layout tools/h16_wg_timeline.py reads).  XST (measurement, CUTENSOR_AMD_H16_XST, with TIMED only): 0 the default,
-// 1 plain instead of nontemporal stores in the epilogue, 3 always the fp32 LDS image (the general path) instead of the 16-bit one.
+// 1 plain instead of nontemporal stores in the epilogue, 3 always the fp32 LDS image (the general path) instead of the 16-bit one,
+// 4 the fragment reads of a k-step issued in its first eight groups (main loop 2280 -> 2415 cycles per K-tile), 5 first-round
+// workgroups start staggered (epilogue 16.4k -> 15.8k cycles, rate unchanged) — profiles/r04n_w4x_variants.jsonl.
 template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     unsigned long long wgStamp[6] = {0, 0, 0, 0, 0, 0};
+    constexpr bool kEarly = (XST == 4);          // measurement: the 16 fragment reads of a k-step in its first 8 groups
+    if constexpr (XST == 5) {                    // measurement: first-round workgroups start up to 15 x 1024 cycles apart
+        if (blockIdx.x < 256u) {
+            const uint32_t steps = (blockIdx.x * 37u) & 15u;
+            for (uint32_t i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     if constexpr (TIMED) { wgStamp[0] = __builtin_readcyclecounter(); wgStamp[4] = wall_clock64(); }
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
@@ -447,7 +456,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 #define CTAMD_X_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
     // k-step 0, group Q: one read of k-step 1 (same buffer) and four MFMAs; three of the groups carry the odometer
 #define CTAMD_X_G0(P, Q)                                                                                            \
-    CTAMD_X_READ(P, 1, Q)                                                                                          \
+    if constexpr (!kEarly) CTAMD_X_READ(P, 1, Q)                                                                   \
+    if constexpr (kEarly && (Q) < 8) { CTAMD_X_READ(P, 1, 2 * ((Q) & 7)) CTAMD_X_READ(P, 1, 2 * ((Q) & 7) + 1) }   \
     CTAMD_X_MFMA(0, 4 * (Q)) CTAMD_X_MFMA(0, 4 * (Q) + 1)                                                          \
     if constexpr ((Q) == 2) odo.advance_a();                                                                       \
     if constexpr ((Q) == 5) odo.advance_b();                                                                       \
@@ -457,7 +467,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into
     // this buffer, four MFMAs
 #define CTAMD_X_G1(P, Q)                                                                                            \
-    CTAMD_X_READ((P) ^ 1, 0, Q)                                                                                    \
+    if constexpr (!kEarly) CTAMD_X_READ((P) ^ 1, 0, Q)                                                             \
+    if constexpr (kEarly && (Q) < 8) { CTAMD_X_READ((P) ^ 1, 0, 2 * ((Q) & 7)) CTAMD_X_READ((P) ^ 1, 0, 2 * ((Q) & 7) + 1) } \
     CTAMD_X_MFMA(1, 4 * (Q)) CTAMD_X_MFMA(1, 4 * (Q) + 1)                                                          \
     CTAMD_X_DMA(P, Q, false)                                                                                       \
     CTAMD_X_MFMA(1, 4 * (Q) + 2) CTAMD_X_MFMA(1, 4 * (Q) + 3)                                                      \
@@ -577,6 +588,8 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         static const int xst = [] { const char* e = getenv("CUTENSOR_AMD_H16_XST"); return e ? atoi(e) : 0; }();
         if (timed && xst == 1) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 1>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed && xst == 3) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 3>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 4) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 5) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
@@ -831,22 +844,22 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
 // =====================================================================================================
 // gett_h16w8m_kernel (CUTENSOR_AMD_H16_WAVES=8m): the 128 x 128 x 64 tile with DEDICATED data-moving waves.
 // tools/ubench/ldsdma_rate.hip measures what a CU pulls into LDS through buffer_load ... lds when it does nothing else: ~60 B/clk
-// (130 GB/s per CU, 33-35 TB/s chip-wide) from L2 — yet every four-wave 16-bit kernel here ends up at 28-36 B/clk/CU
-// (profiles/r04f_h16_shape_sweep.txt).  The difference is not bandwidth but ISSUE: an LDS-DMA instruction holds its wave's issue
-// port for 60-180 cycles (tools/ubench/dma_issue.hip), and a wave that owns a SIMD's matrix pipe cannot queue MFMAs meanwhile —
-// eight pieces per K-tile are 500-800 cycles on top of the 512 cycles of MFMA issue of a 64 x 64 wave tile.  So, as in the fp32
+// (130 GB/s per CU, 33-35 TB/s chip-wide) from L2, with or without LDS readers beside it — yet every four-wave 16-bit kernel here
+// ends up at 28-36 B/clk/CU (profiles/r04f_h16_shape_sweep.txt), and a 128 x 128 x 64 tile needs 64 B/clk to keep its MFMAs fed.
+// This kernel tests the ISSUE hypothesis: an LDS-DMA instruction holds its wave's issue port for 60-180 cycles
+// (tools/ubench/dma_issue.hip), and a wave that owns a SIMD's matrix pipe cannot queue MFMAs meanwhile.  So, as in the fp32
 // streaming kernel (gett_f32_stream.hip): eight waves, waves 0-3 multiply (one per SIMD: the compute stream of gett_h16w4m_kernel
 // WITHOUT its LDS-DMA pieces, odometer and vmcnt waits), waves 4-7 only move data (one per SIMD: staging tables, K odometer, eight
-// pieces per K-tile each) — a piece's issue time now overlaps the OTHER wave's MFMAs.  Four K-tiles of 32 KiB in LDS (128 KiB), one
-// workgroup per CU, ONE barrier per K-tile for all eight waves:
+// pieces per K-tile each) — a piece's issue time now overlaps the OTHER wave's MFMAs.  R K-tiles of 32 KiB in LDS, one workgroup
+// per CU, ONE barrier per K-tile for all eight waves:
 //   barrier #0      : tile 0 has landed
 //   barrier #(t+1)  : tile t + 1 has landed (every mover waited for its own pieces: vmcnt(8 (R - 2)), the tiles behind it stay in
 //                     flight) and every multiplying wave holds the last fragments of tile t in registers -> buffer t % R is
 //                     refilled with tile t + R
-// R = 5 (all 160 KiB of LDS): what bounds a 128 x 128 tile is neither the LDS-DMA issue nor its bandwidth but LATENCY x bytes in
-// flight — the landing buffers ARE the in-flight bytes, and at ~1 us of loaded LDS-DMA latency three tiles (96 KiB) sustain
-// ~80 GB/s per CU = a K-tile every 0.42 us where its MFMAs take 0.27 (every schedule of the four-deep ring measured that, NOTES.md);
-// four tiles in flight: ~110 GB/s.
+// Measured (profiles/r04k..r04m): +3 % over the four-wave ring-4 form on 2048^3-class shapes, +10-20 % at 1024^3 (shorter prologue:
+// the movers start while the multiplying waves set up), and R = 5 (all 160 KiB) = R = 4 — neither the issue port nor latency x bytes
+// in flight is what holds these kernels at ~0.42 us per K-tile (NOTES.md, round 4, "what was ruled out").  An autotuning candidate
+// and CUTENSOR_AMD_H16_WAVES=8m; not ranked by the planner.
 // Same LDS images, swizzles, fragment addressing and epilogues as gett_h16w4m_kernel.
 // =====================================================================================================
 template <bool BF, int LA, int LB, int R = 5>

@@ -29,7 +29,8 @@ plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
 torch.cuda.synchronize()
 ct.lib.ctamdSetTimingBuffer(h.h, None)
 # the measurement instantiations (CUTENSOR_AMD_H16_XST) must still compute the product: 256 rows against torch, and the rate of 20 calls
-ref = (A[:256].float() @ B.float())
+# (modes "mk" / "kn" / "mn" name the FASTEST mode first: the torch tensors are [k][m], [n][k] and [n][m])
+ref = (B[:256].float() @ A.float())
 err = float((D[:256].float() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) if not zeros else float(D.float().abs().max())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
