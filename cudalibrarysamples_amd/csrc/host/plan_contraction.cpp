@@ -406,6 +406,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4' && e[1] == 'v') return 40;
         if (e && e[0] == '4' && e[1] == 'x') return 48;
+        if (e && e[0] == '4' && e[1] == 'q') return 80;
         if (e && e[0] == '8' && e[1] == 'm') return 72;
         if (e && e[0] == '4' && e[1] == 'm' && e[2] == '4') return 64;
         if (e && e[0] == '4' && e[1] == 'm') return 56;
@@ -423,7 +424,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         return std::ceil((double)v.totM / k.bm) * std::ceil((double)v.totN / k.bn) * (double)v.totL;
     };
     // workgroup slots of the chip: the 128 x 128 kernel on the two-deep ring (variant 56) runs two workgroups per CU
-    auto slots_of = [&](int var) { return (double)numCUs * (var == 56 ? 2.0 : 1.0); };
+    auto slots_of = [&](int var) { return (double)numCUs * ((var == 56 || var == 80) ? 2.0 : 1.0); };
     // split-K when the output tiles alone leave most CUs idle: slices of >= 4 K-tiles, fp32 partials [slice][L][M][N]
     auto auto_split = [&](int var) -> uint64_t {
         const double tiles = tiles_of(var), slots = slots_of(var);
@@ -440,12 +441,15 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     //   256 x 256, four waves (48):  11 us fixed, 1.00 us per K-tile      256 x 256, eight waves (0): 10 us fixed, 1.13 us per K-tile
     //   128 x 128, ring 2 (56), two workgroups per CU: 5 us fixed, 0.92 us per K-tile (0.68 with the CU to itself)
     //   128 x 128, ring 4 (64), one workgroup per CU:  4.5 us fixed, 0.46 us per K-tile
+    //   64 x 64 (80), two workgroups per CU: 4.6 us fixed, 0.31 us per K-tile (4.4 / 0.223 while every workgroup has a CU to itself;
+    //   profiles/r04w_sweep_4q_*: 1024^3 7.6-7.9 us, 4096^3 195-202 us)
     //   fold (splitk_reduce_wide_kernel): 3 us + partial bytes written and read back at ~5 TB/s
     auto model_us = [&](int var, uint64_t split) {
         const double wgs = tiles_of(var) * (double)split, slots = slots_of(var);
         const double kt = std::ceil((double)kTiles / (double)split);
         double fix, per;
         if (var == 64) { fix = 4.5; per = 0.46; }
+        else if (var == 80) { fix = wgs <= (double)numCUs ? 4.4 : 4.6; per = wgs <= (double)numCUs ? 0.223 : 0.31; }
         else if (var == 56) { fix = 5.0; per = wgs <= (double)numCUs ? 0.68 : 0.92; }
         else if (kt <= 16) { fix = 10.0; per = 1.13; }
         else { fix = 11.0; per = 1.0; }
@@ -459,10 +463,10 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (layoutIdx + var >= count) return false;
         split = auto_split(var);
     } else {
-        // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below) and
-        // the 128 x 128 mid-size family, each without split-K and at its automatic split
+        // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below), the
+        // 128 x 128 mid-size family and the 64 x 64 tile, each without split-K and at its automatic split
         double best = 1e30;
-        for (int cand : {48, 64, 56}) {
+        for (int cand : {48, 64, 56, 80}) {
             if (layoutIdx + cand >= count) continue;
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {
@@ -498,7 +502,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 48, 56, 64, 72, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
+    for (int other : {0, 48, 56, 64, 72, 80, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

@@ -41,13 +41,26 @@ __device__ __forceinline__ HRsrc h_make_rsrc(uint64_t addr) {
     r[3] = 0x00020000;
     return r;
 }
+// Minimum over the 64 lanes of a wave (all active) of byte offsets that lie within 2^31 of each other (the planner admits the
+// 16-bit kernels only when ONE tile spans less than 2^31 bytes): the 32-bit differences to the first lane's value are reduced with
+// four DPP steps inside each row of 16 lanes and four v_readlane — ~50 cycles.  (As six __shfl_xor rounds on 64-bit values this was
+// 24 dependent ds_bpermute per kernel start, ~2.5k cycles of every workgroup's prologue: tools/h16_small_timeline.py.)
 __device__ __forceinline__ int64_t h_wave_min(int64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int64_t w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int64_t ref = (int64_t)h_uniform64((uint64_t)v);
+    int d = (int)(v - ref);
+    int t;
+    t = __builtin_amdgcn_update_dpp(d, d, 0xB1, 0xF, 0xF, false);  d = t < d ? t : d;     // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_update_dpp(d, d, 0x4E, 0xF, 0xF, false);  d = t < d ? t : d;     // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_update_dpp(d, d, 0x141, 0xF, 0xF, false); d = t < d ? t : d;     // row_half_mirror
+    t = __builtin_amdgcn_update_dpp(d, d, 0x140, 0xF, 0xF, false); d = t < d ? t : d;     // row_mirror: every lane holds its row's minimum
+    const int r0 = __builtin_amdgcn_readlane(d, 0), r1 = __builtin_amdgcn_readlane(d, 16);
+    const int r2 = __builtin_amdgcn_readlane(d, 32), r3 = __builtin_amdgcn_readlane(d, 48);
+    const int m01 = r0 < r1 ? r0 : r1, m23 = r2 < r3 ? r2 : r3;
+    return ref + (int64_t)(m01 < m23 ? m01 : m23);
+#else
     return v;
+#endif
 }
 
 // 64 lanes x 16 B -> the 1-KiB LDS piece at byte address ldsByte (wave-uniform).  Hidden from the
@@ -229,11 +242,12 @@ struct HEpilogue {
     // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a scratch allocation is paid for at
     // every dispatch)
     // ST (measurement): 0 = nontemporal stores, 1 = plain, 2 = write-through (sc1)
-    template <bool BF, int ST = 0>
+    // NF: fragments parked (4; 1: fragment 0 only — the 64 x 64 kernel's one fragment per wave)
+    template <bool BF, int ST = 0, int NF = 4>
     __device__ __forceinline__ void flush(const GettParams& p, uint32_t mB0, uint32_t mHi, uint32_t mLo, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane) const {
         if (vecD) {
 #pragma unroll 2
-            for (int it = 0; it < 8; ++it) {              // fragment it >> 1, chunks (it & 1) * 64 + lane of its 128
+            for (int it = 0; it < 2 * NF; ++it) {         // fragment it >> 1, chunks (it & 1) * 64 + lane of its 128
                 const int f = it >> 1;
                 const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
                 const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
@@ -271,7 +285,7 @@ struct HEpilogue {
         }
         // element-wise form (any strides): lane = column, one row per iteration
 #pragma unroll 1
-        for (int it = 0; it < 4 * 32; ++it) {
+        for (int it = 0; it < NF * 32; ++it) {
             const int f = it >> 5, row = it & 31;
             const uint32_t mB = mB0 + mHi * (uint32_t)(f >> 1) + mLo * (uint32_t)(f & 1);
             const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);

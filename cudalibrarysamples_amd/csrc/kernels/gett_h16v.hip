@@ -774,10 +774,12 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
     const uint32_t mW = m0 + 64 * wr, nW = n0 + 64 * wc;      // this wave's quadrant
+    GettParams pe;                                // the epilogue's arguments in one burst of scalar loads (gett_h16w4q_kernel)
+    h_reload_params(pe);
     // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
-    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
-        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
-        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+    if (pe.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
+        float* P = pe.partial + ((size_t)slice * pe.gL.total + l) * (size_t)Mt * Nt;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -796,7 +798,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     }
     __syncthreads();                              // every wave has finished reading the operand ring
     HEpilogue ep;
-    ep.init(p, l, lds, wave);                     // 16 KiB of the (dead) ring per wave
+    ep.init(pe, l, lds, wave);                     // 16 KiB of the (dead) ring per wave
     if (ep.vecD && ep.beta == 0.f) {
         // beta == 0 and 16-byte lanes in D: rounded once on the way into a 16-bit image of 32 rows x 64 columns (144-byte rows: the
         // 2-byte writes of a 16-lane group and the 16-byte reads of a row both spread over the banks), out as 16-byte reads +
@@ -821,7 +823,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
                 const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
                 if (m < ep.Mtot && n < ep.Ntot) {
                     int64_t offD, offC;
-                    ep.offsets(p, m, n, offD, offC);
+                    ep.offsets(pe, m, n, offD, offC);
                     __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
                 }
             }
@@ -836,7 +838,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
                 const f32x4& c = acc[2 * (F >> 1) + (h >> 1)][2 * (F & 1) + (h & 1)];
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
-        ep.template flush<BF>(p, mW, 32u, 0u, nW, 0u, 32u, laneE);
+        ep.template flush<BF>(pe, mW, 32u, 0u, nW, 0u, 32u, laneE);
     }
 }
 
@@ -1015,9 +1017,11 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
     const uint32_t mW = m0 + 64 * wr, nW = n0 + 64 * wc;      // this wave's quadrant
+    GettParams pe;                                // the epilogue's arguments in one burst of scalar loads (gett_h16w4q_kernel)
+    h_reload_params(pe);
     if (splitK) {                                 // split-K: fp32 partial tile, row-major [slice][l][m][n]
-        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
-        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+        const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
+        float* P = pe.partial + ((size_t)slice * pe.gL.total + l) * (size_t)Mt * Nt;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1036,7 +1040,7 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
     }
     __builtin_amdgcn_s_barrier();                 // every wave has finished reading the ring, every piece has landed (the movers' last barrier)
     HEpilogue ep;
-    ep.init(p, l, lds, wave);                     // 16 KiB of the (dead) ring per multiplying wave
+    ep.init(pe, l, lds, wave);                     // 16 KiB of the (dead) ring per multiplying wave
     if (ep.vecD && ep.beta == 0.f) {
         uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
         constexpr int kPitch = 72;                // 16-bit elements per image row (gett_h16w4m_kernel's 16-bit epilogue)
@@ -1058,7 +1062,7 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
                 const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
                 if (m < ep.Mtot && n < ep.Ntot) {
                     int64_t offD, offC;
-                    ep.offsets(p, m, n, offD, offC);
+                    ep.offsets(pe, m, n, offD, offC);
                     __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
                 }
             }
@@ -1072,8 +1076,287 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
                 const f32x4& c = acc[2 * (F >> 1) + (h >> 1)][2 * (F & 1) + (h & 1)];
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
-        ep.template flush<BF>(p, mW, 32u, 0u, nW, 0u, 32u, laneE);
+        ep.template flush<BF>(pe, mW, 32u, 0u, nW, 0u, 32u, laneE);
     }
+}
+
+// =====================================================================================================
+// gett_h16w4q_kernel (CUTENSOR_AMD_H16_WAVES=4q): the 64 x 64 x 64 tile for SMALL 16-bit problems (1024^3: 64 tiles of 128 x 128
+// leave three quarters of the CUs idle for 16 K-tiles; split-K pays a second launch and a round trip of fp32 partials).
+// Same instruction (v_mfma_f32_16x16x32 from inline asm), K odometer, LDS-DMA staging and source-side swizzles; per K-tile an
+// operand is 64 rows x 64 k = 8 KiB = two 1-KiB pieces per wave:
+//   K-contiguous operand: the first 64 rows of the 128-row half-tile image ([row][64 k], unit u of row r at u ^ ((r >> 1) & 7));
+//   free-contiguous operand: image [64 k][64 rows] with 128-byte k-rows, unit p of k-row k holds row-unit p ^ 2 (k & 3): the
+//   4 k x 16 rows block a 16-lane group of a transposing read fetches (32 bytes in each of four k-rows) covers all 32 banks.
+// 4 waves as 2 x 2, a 32 x 32 quadrant each = 2 x 2 accumulator fragments (16 AGPRs); per K-tile and wave 8 MFMAs, 8 fragment reads
+// (tile t + 1 into the other of two register sets while tile t multiplies), 4 LDS-DMA pieces (tile t + 4: ring of four 16-KiB
+// K-tiles = 64 KiB, two workgroups per CU), ONE barrier:
+//   barrier #(t+1): every wave's pieces of tile t + 1 have landed (vmcnt(8): tiles t + 2, t + 3 stay in flight) and every wave holds
+//   tile t's fragments in registers -> buffer t % 4 is refilled with tile t + 4.
+// The tile is bound by its staging stream (16 KiB per 128 cycles of MFMA issue), like its 128 x 128 sibling; what it buys is 4 x
+// the workgroups.  Epilogue: ONE 64 x 64 16-bit image per workgroup (beta = 0, 16-byte lanes in D: whole 128-byte row segments
+// leave), else a 32 x 32 fp32 fragment per wave through HEpilogue::flush.
+// =====================================================================================================
+constexpr int kQTile = 64;
+constexpr int kQBuf = 16384;                      // one K-tile: A 8 KiB + B 8 KiB
+
+template <int LAY>
+struct QOperand {
+    uint32_t src[2];                              // byte offset of this lane's 16-byte unit, piece i of this wave, relative to `base`
+    uint64_t base;
+    __device__ __forceinline__ void init(const ModeGroup& gFree, int64_t strideK0, uint32_t row0, int wave, int lane) {
+        int64_t off[2];
+        int64_t mn = INT64_MAX;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = wave + 4 * i;           // 1-KiB piece 0..7
+            if constexpr (LAY == LAY_K) {
+                const int r = 8 * c + (lane >> 3), pp = lane & 7;
+                const int u = pp ^ ((r >> 1) & 7);
+                uint32_t row = row0 + (uint32_t)r;
+                if (row >= gFree.total) row = gFree.total - 1;        // clamped rows feed outputs that are never stored
+                off[i] = (group_offset<0>(gFree, row) + 8 * u) * 2;
+            } else {
+                const int kk = 8 * c + (lane >> 3), pp = lane & 7;
+                const int u = pp ^ (2 * (kk & 3));
+                uint32_t row = row0 + 8u * (uint32_t)u;
+                if (row >= gFree.total) row = gFree.total - 8;        // extent % 8 == 0: a unit is all in or all out
+                off[i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
+            }
+            mn = off[i] < mn ? off[i] : mn;
+        }
+        const int64_t mnW = (int64_t)h_uniform64((uint64_t)h_wave_min(mn));
+        base = (uint64_t)mnW;
+        src[0] = (uint32_t)(off[0] - mnW);
+        src[1] = (uint32_t)(off[1] - mnW);
+    }
+};
+
+// byte offset of this lane's 8 bytes of fragment f (rows 16 f) inside the free-contiguous 8-KiB image, first transposing read (k-rows
+// 8 g + [0,4) of k-step 0; + 512: k + 4; + 4096: k-step 1)
+__device__ __forceinline__ uint32_t q_offF(int lane, int f) {
+    const int g = lane >> 4, i = lane & 15;
+    const int unit = (2 * f + ((i >> 1) & 1)) ^ (2 * ((i >> 2) & 3));
+    return (uint32_t)((8 * g + (i >> 2)) * 128 + (unit << 4) + 8 * (i & 1));
+}
+template <int LAY, int IMM>
+__device__ __forceinline__ s16x8 q_read(uint32_t base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LAY == LAY_K) {
+        return *(VLdsVec8)(uintptr_t)(base + (uint32_t)IMM);
+    } else {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM + 512u));
+        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#else
+    (void)base; return s16x8{};
+#endif
+}
+
+// TIMED (measurement, CUTENSOR_AMD_H16_TIMED=1, bf16 mk,kn only): wave 0 records shader cycles at entry / first piece issued / tile 0
+// landed / end of the main loop / stores issued and the wall clock at entry / exit (tools/h16_small_timeline.py)
+// (An eight-deep ring, 128 KiB and one workgroup per CU, measured the same 460 cycles per K-tile at 1024^3 as this four-deep one and
+// a later first tile: a lone workgroup is not latency-bound either.  profiles/r04v_small_timeline.jsonl)
+template <bool BF, int LA, int LB, bool TIMED = false>
+__global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p) {
+    constexpr int R = 4;
+    __shared__ __attribute__((aligned(16))) char lds[R * kQBuf];
+    unsigned long long qs[7] = {0, 0, 0, 0, 0, 0, 0};
+    if constexpr (TIMED) { qs[0] = __builtin_readcyclecounter(); qs[5] = wall_clock64(); }
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    // the arguments the setup reads, in ONE burst of scalar loads (through `p` they arrive one dependent round at a time)
+    GettParams ps;
+    h_reload_params(ps);
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    uint32_t id = xcd_remap(blockIdx.x, ps.nBlocks);
+    const uint32_t tilesMN = ps.tilesM * ps.tilesN;
+    const uint32_t tilesAll = tilesMN * ps.gL.total;
+    const uint32_t slice = id / tilesAll;
+    id -= slice * tilesAll;
+    const uint32_t l = id / tilesMN;
+    id -= l * tilesMN;
+    const uint32_t perGroup = 8u * ps.tilesN;
+    const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
+    const uint32_t first = grp * 8u;
+    const uint32_t gsz = (ps.tilesM - first < 8u) ? (ps.tilesM - first) : 8u;
+    const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
+    const uint32_t m0 = mt * kQTile, n0 = nt * kQTile;
+    const uint32_t kTilesAll = ps.gK.total / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
+    const uint32_t tile0 = slice * tilesPerSlice;
+    const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+
+    QOperand<LA> oa;
+    QOperand<LB> ob;
+    oa.init(ps.gM, ps.gK.stride[0][0], m0, wave, lane);
+    ob.init(ps.gN, ps.gK.stride[1][0], n0, wave, lane);
+    const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.A) + group_offset<0>(ps.gL, l)) + oa.base);
+    const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.B) + group_offset<1>(ps.gL, l)) + ob.base);
+    VOdometer odo;
+    odo.init(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+    // fragment-read address registers: this wave's fragments are f = 2 wr + i (A) / 2 wc + j (B).  K-contiguous operand: one register
+    // per k-step (fragment 2048 i and buffer in the immediate); free-contiguous: one per fragment (k-step 4096 s and buffer in the
+    // immediate)
+    uint32_t rdA[2], rdB[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        rdA[x] = ldsBase + (LA == LAY_K ? (uint32_t)(4096 * wr) + x_offK(lane, x) : q_offF(lane, 2 * wr + x));
+        rdB[x] = ldsBase + 8192u + (LB == LAY_K ? (uint32_t)(4096 * wc) + x_offK(lane, x) : q_offF(lane, 2 * wc + x));
+        asm volatile("" : "+v"(rdA[x]));
+        asm volatile("" : "+v"(rdB[x]));
+    }
+
+    // piece N = 0..3 of the K-tile the odometer describes into buffer P: operand N >> 1 (A, B), piece N & 1 of this wave
+#define CTAMD_Q_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr uint32_t imm_ = (uint32_t)((P) * kQBuf + ((N) >> 1) * 8192 + ((N) & 1) * 4096);                  \
+        if constexpr (((N) >> 1) == 0) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[(N) & 1], waveLds);            \
+        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[(N) & 1], waveLds);                                      \
+    }
+#define CTAMD_Q_DMA4(P, PAD) CTAMD_Q_DMA(P, 0, PAD) CTAMD_Q_DMA(P, 1, PAD) CTAMD_Q_DMA(P, 2, PAD) CTAMD_Q_DMA(P, 3, PAD)
+#define CTAMD_Q_NEXT() { odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK); }
+
+    // ---- prologue: K-tiles 0 .. R - 1; the odometer stays on tile R - 1 ----------------------------------------------------
+    if constexpr (TIMED) qs[1] = __builtin_readcyclecounter();
+    CTAMD_Q_DMA4(0, true)
+    CTAMD_Q_NEXT() CTAMD_Q_DMA4(1, true)
+    CTAMD_Q_NEXT() CTAMD_Q_DMA4(2, true)
+    CTAMD_Q_NEXT() CTAMD_Q_DMA4(3, true)
+    CTAMD_H_VMCNT(4 * (R - 1));                   // this wave's pieces of tile 0
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TIMED) qs[2] = __builtin_readcyclecounter();
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[2][2][2], b[2][2][2];                 // [register set][k-step][fragment]
+
+    // the eight fragments of the K-tile in buffer P into register set S
+#define CTAMD_Q_RD(P, S, KS, F)                                                                                     \
+    if constexpr (LA == LAY_K) a[S][KS][F] = q_read<LAY_K, (P) * kQBuf + 2048 * (F)>(rdA[KS]);                     \
+    else a[S][KS][F] = q_read<LAY_F, (P) * kQBuf + 4096 * (KS)>(rdA[F]);                                           \
+    if constexpr (LB == LAY_K) b[S][KS][F] = q_read<LAY_K, (P) * kQBuf + 2048 * (F)>(rdB[KS]);                     \
+    else b[S][KS][F] = q_read<LAY_F, (P) * kQBuf + 4096 * (KS)>(rdB[F]);
+#define CTAMD_Q_READ8(P, S) CTAMD_Q_RD(P, S, 0, 0) CTAMD_Q_RD(P, S, 0, 1) CTAMD_Q_RD(P, S, 1, 0) CTAMD_Q_RD(P, S, 1, 1)
+#define CTAMD_Q_MFMA2(S, KS, I) x_mfma<BF>(acc[I][0], a[S][KS][I], b[S][KS][0]); x_mfma<BF>(acc[I][1], a[S][KS][I], b[S][KS][1]);
+    // tile t in buffer P / register set P & 1
+#define CTAMD_Q_TILE(P)                                                                                             \
+    CTAMD_H_VMCNT(4 * (R - 2));       /* tile t + 1 has landed; the pieces of tiles t + 2 .. t + R - 1 stay in flight */ \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_Q_READ8(((P) + 1) % R, ((P) + 1) & 1)                                                                    \
+    CTAMD_Q_NEXT()                                                                                                 \
+    CTAMD_Q_DMA(P, 0, false) CTAMD_Q_MFMA2((P) & 1, 0, 0)                                                          \
+    CTAMD_Q_DMA(P, 1, false) CTAMD_Q_MFMA2((P) & 1, 0, 1)                                                          \
+    CTAMD_Q_DMA(P, 2, false) CTAMD_Q_MFMA2((P) & 1, 1, 0)                                                          \
+    CTAMD_Q_DMA(P, 3, false) CTAMD_Q_MFMA2((P) & 1, 1, 1)                                                          \
+    CTAMD_H_LGKM0();                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+
+    CTAMD_Q_READ8(0, 0)
+    CTAMD_H_LGKM0();
+    int t = 0;
+    for (; t + 3 < nTiles; t += 4) { CTAMD_Q_TILE(0) CTAMD_Q_TILE(1) CTAMD_Q_TILE(2) CTAMD_Q_TILE(3) }
+    if (t < nTiles) { CTAMD_Q_TILE(0) }
+    if (t + 1 < nTiles) { CTAMD_Q_TILE(1) }
+    if (t + 2 < nTiles) { CTAMD_Q_TILE(2) }
+    CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    if constexpr (TIMED) qs[3] = __builtin_readcyclecounter();
+    const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+
+    const uint32_t mW = m0 + 32 * wr, nW = n0 + 32 * wc;      // this wave's quadrant
+    // a fresh copy of the arguments for the epilogue, loaded in ONE burst (only the fields used): read through `p` the compiler fetches
+    // them one dependent s_load round at a time (~20 rounds, most of a 64 x 64 tile's epilogue: tools/h16_small_timeline.py)
+    GettParams pe;
+    h_reload_params(pe);
+    // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
+    if (pe.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
+        float* P = pe.partial + ((size_t)slice * pe.gL.total + l) * (size_t)Mt * Nt;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
+                if (m < Mt) {
+                    float* row = P + (size_t)m * Nt;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const uint32_t n = nW + 16 * j + (laneE & 15);
+                        if (n < Nt) row[n] = acc[i][j][r];
+                    }
+                }
+            }
+        return;
+    }
+    __syncthreads();                              // every wave has finished reading the operand ring, no piece is in flight
+    HEpilogue ep;
+    ep.init(pe, l, lds + 16384, wave, 4096);       // fp32 path: 4 KiB per wave behind the 16-bit image's 9 KiB
+    if (ep.vecD && ep.beta == 0.f) {
+        // ONE 16-bit image of the workgroup's 64 x 64 tile (144-byte rows: the 2-byte writes of a 16-lane group and the 16-byte reads
+        // of a row both spread over the banks); out as 16-byte reads + nontemporal stores of whole 128-byte row segments
+        uint16_t* stage = reinterpret_cast<uint16_t*>(lds);
+        constexpr int kPitch = 72;                // 16-bit elements per image row
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4& c = acc[i][j];
+                uint16_t* st = stage + (32 * wr + 16 * i + 4 * (laneE >> 4)) * kPitch + 32 * wc + 16 * j + (laneE & 15);
+                st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+            }
+        __syncthreads();
+        const int tidE = wave * 64 + laneE;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = it * 256 + tidE, row = q >> 3, cc = q & 7;
+            const s16x8 v = *reinterpret_cast<const s16x8*>(stage + row * kPitch + 8 * cc);
+            const uint32_t m = m0 + (uint32_t)row, n = n0 + 8u * (uint32_t)cc;
+            if (m < ep.Mtot && n < ep.Ntot) {
+                int64_t offD, offC;
+                ep.offsets(pe, m, n, offD, offC);
+                __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+            }
+        }
+    } else {
+        // the wave's 32 x 32 quadrant as one fp32 fragment
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {             // 16 x 16 quarter (h >> 1, h & 1)
+            float* st = ep.scratch + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);
+            const f32x4& c = acc[h >> 1][h & 1];
+            st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
+        }
+        ep.template flush<BF, 0, 1>(pe, mW, 0u, 0u, nW, 0u, 0u, laneE);
+    }
+    if constexpr (TIMED) {
+        if (p.timing != nullptr && wave == 0 && laneE == 0) {
+            qs[4] = __builtin_readcyclecounter();                 // the stores are issued, not waited for
+            qs[6] = wall_clock64();
+#pragma unroll
+            for (int i = 0; i < 7; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = qs[i];
+        }
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4q(const GettParams& p, hipStream_t stream) {
+    if constexpr (BF && LA == LAY_K && LB == LAY_F) {
+        static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
+        if (timed) { hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+    }
+    hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 template <bool BF, int LA, int LB>
@@ -1107,6 +1390,8 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
     {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 256, 9, 1, 0, &launch_h16w4m<bf, la, lb, 4>, 0},
 #define CTAMD_H16W8M_ENTRY(bf, la, lb) \
     {kMTile, kMTile, kHBK, 2, 2, 1, la, lb, 512, 10, 1, 0, &launch_h16w8m<bf, la, lb>, 0},
+#define CTAMD_H16W4Q_ENTRY(bf, la, lb) \
+    {kQTile, kQTile, kHBK, 2, 2, 1, la, lb, 256, 11, 1, 0, &launch_h16w4q<bf, la, lb>, 0},
 static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4V_ENTRY(true, LAY_F, LAY_F)
@@ -1131,7 +1416,12 @@ static const GettKernelInfo g_h16v_table[] = {
     CTAMD_H16W8M_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W8M_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16W8M_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W8M_ENTRY(true, LAY_F, LAY_F)
     CTAMD_H16W8M_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W8M_ENTRY(false, LAY_K, LAY_F)
-    CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_F)};
+    CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W8M_ENTRY(false, LAY_F, LAY_F)
+    // entries 40..47 (80..87 of the family): 64 x 64, four waves, four-deep ring of 16-KiB K-tiles, two workgroups per CU
+    CTAMD_H16W4Q_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4Q_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4Q_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4Q_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4Q_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4Q_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4Q_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4Q_ENTRY(false, LAY_F, LAY_F)};
 
 const GettKernelInfo* gett_h16v_kernels(int* count) {
     *count = (int)(sizeof(g_h16v_table) / sizeof(g_h16v_table[0]));

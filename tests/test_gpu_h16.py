@@ -178,11 +178,11 @@ def test_headline_einsum_shape_in_bf16(env):
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.25)
 
 
-@pytest.mark.parametrize("variant", ["4", "s", "p", "4s", "4r", "4v", "4x", "4m", "4m4", "8m"])
+@pytest.mark.parametrize("variant", ["4", "s", "p", "4s", "4r", "4v", "4x", "4m", "4m4", "8m", "4q"])
 def test_kernel_variant_parity(built, variant):
     """The other 16-bit kernel variants (CUTENSOR_AMD_H16_WAVES=4: gett_h16w4_kernel, one wave per SIMD, 128 x 128 per
     wave; =s: gett_h16s_kernel, eight free-running waves, K-tile of 32, five-deep LDS ring, one barrier per K-tile; =p: gett_h16_kernel, two wave rows
-    alternated by barriers; =4m: gett_h16w4m_kernel, the 128 x 128 mid-size sibling of the default kernel, two workgroups per CU; =4m4: the same on a four-deep K-tile ring, one workgroup per CU; =4s: gett_h16w4s_kernel, four waves with 128 x 128 wave tiles on the K-tile-32 ring; =4r: gett_h16w4r_kernel, four waves register-staged; =4v: gett_h16w4v_kernel, the four-wave kernel with the lean instruction stream of gett_h16v.hip) must give the same answers: the GEMM-like, multi-mode and split-K cases of this file in a
+    alternated by barriers; =4m: gett_h16w4m_kernel, the 128 x 128 mid-size sibling of the default kernel, two workgroups per CU; =4m4: the same on a four-deep K-tile ring, one workgroup per CU; =8m: that tile with four data-moving waves; =4q: gett_h16w4q_kernel, the 64 x 64 tile for small problems; =4s: gett_h16w4s_kernel, four waves with 128 x 128 wave tiles on the K-tile-32 ring; =4r: gett_h16w4r_kernel, four waves register-staged; =4v: gett_h16w4v_kernel, the four-wave kernel with the lean instruction stream of gett_h16v.hip) must give the same answers: the GEMM-like, multi-mode and split-K cases of this file in a
     child process that plans with the variant (the planner reads the switch once per process)."""
     import os
     import subprocess
@@ -212,7 +212,7 @@ def test_bf16_operand_larger_than_4_gib(built, mA):
     p = ops.contraction_plan(h, [K, M] if mA == "km" else [M, K], mA, [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF,
                              workspace_limit=1 << 30)
     d = p.describe()
-    assert d["kname"] in ("gett_h16_kernel", "gett_h16w4_kernel", "gett_h16s_kernel", "gett_h16w4s_kernel", "gett_h16w4r_kernel", "gett_h16w4v_kernel", "gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel"), d
+    assert d["kname"] in ("gett_h16_kernel", "gett_h16w4_kernel", "gett_h16s_kernel", "gett_h16w4s_kernel", "gett_h16w4r_kernel", "gett_h16w4v_kernel", "gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel"), d
     ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
     p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), p.required_workspace)
     torch.cuda.synchronize()

@@ -57,22 +57,23 @@ def test_short_k_ranges_stay_on_the_eight_wave_kernel(env):
 def test_mid_size_problems_run_the_128_tile_family(env):
     """Problems whose 256 x 256 tiles leave most CUs idle (round 3: split-K over the 256 x 256 kernels + a fold: 2048^3 at 0.41 PFLOP/s,
     1024^3 at 0.08): at most one 128 x 128 tile per CU -> the four-deep-ring kernel, one workgroup per CU, no split unless the tiles
-    are very few; up to two per CU -> the two-deep-ring kernel, two workgroups per CU; a full chip of 256 x 256 tiles -> as before."""
+    are very few; up to two per CU -> the two-deep-ring kernel, two workgroups per CU; a full chip of 256 x 256 tiles -> as before;
+    and problems whose 128 x 128 tiles still leave three quarters of the CUs idle (1024^3) -> the 64 x 64 kernel."""
     ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
     for (M, N, K, want, split, blocks) in [(2048, 2048, 2048, "gett_h16w4m4_kernel", 1, 256),
-                                           (1024, 1024, 1024, "gett_h16w4m4_kernel", 1, 64),
+                                           (1024, 1024, 1024, "gett_h16w4q_kernel", 1, 256),
                                            (4096, 1024, 4096, "gett_h16w4m4_kernel", 1, 256),
-                                           (1000, 1000, 1024, "gett_h16w4m4_kernel", 1, 64),
+                                           (1000, 1000, 1024, "gett_h16w4q_kernel", 1, 256),
                                            (512, 512, 65536, "gett_h16w4m4_kernel", 16, 256),
                                            (2048, 4096, 4096, "gett_h16w4m_kernel", 1, 512),
                                            (4096, 4096, 4096, "gett_h16w4x_kernel", 1, 256)]:
         p = _plan(ct, ops, h, M, N, K)
         d = p.describe()
         assert (d["kname"], d["splitK"], d["blocks"]) == (want, split, blocks), (M, N, K, d)
-        assert (d["bm"], d["bn"]) == ((128, 128) if "w4m" in want else (256, 256)), d
+        assert (d["bm"], d["bn"]) == ((128, 128) if "w4m" in want else (64, 64) if "w4q" in want else (256, 256)), d
         p.destroy()
 
 
@@ -82,18 +83,18 @@ def test_every_variant_stays_an_autotuning_candidate(env):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
     names = []
-    for r in range(10):
+    for r in range(11):
         p = _plan(ct, ops, h, 8192, 8192, 8192, algo=r, cache_mode=ct.CACHE_MODE_NONE)
         names.append(p.describe()["kname"])
         p.destroy()
     assert names[0] == "gett_h16w4x_kernel", names
     assert set(names) == {"gett_h16w4x_kernel", "gett_h16_kernel", "gett_h16w4v_kernel", "gett_h16w4r_kernel", "gett_h16s_kernel",
-                          "gett_h16w4s_kernel", "gett_h16w4_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel"}, names
+                          "gett_h16w4s_kernel", "gett_h16w4_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel"}, names
 
 
 @pytest.mark.parametrize("waves,want", [("8", "gett_h16_kernel"), ("4", "gett_h16w4_kernel"), ("4v", "gett_h16w4v_kernel"),
                                         ("4x", "gett_h16w4x_kernel"), ("s", "gett_h16s_kernel"), ("4m", "gett_h16w4m_kernel"),
-                                        ("4m4", "gett_h16w4m4_kernel"), ("8m", "gett_h16w8m_kernel")])
+                                        ("4m4", "gett_h16w4m4_kernel"), ("8m", "gett_h16w8m_kernel"), ("4q", "gett_h16w4q_kernel")])
 def test_the_switch_overrides_the_planner(built, waves, want):
     code = ("import json, sys; sys.path.insert(0, %r); from cudalibrarysamples_amd import cutensor as ct, ops; h = ops.Handle(); "
             "out = []\n"

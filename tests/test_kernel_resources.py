@@ -74,28 +74,38 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     two = {n: v for n, v in mid.items() if n.endswith("Li2EEEvNS_10GettParamsE")}
     assert len(two) == 8 and all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in two.values()), mid
     assert all(v.get("group_segment_fixed_size") == 131072 for n, v in mid.items() if n not in two), mid
+    # the 64 x 64 kernel for small problems: no scratch, four K-tiles of 16 KiB, registers for two workgroups per CU
+    small = {n: v for n, v in k.items() if "gett_h16w4q_kernel" in n}
+    assert len(small) >= 8, sorted(k)
+    assert not {n: v for n, v in small.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}, small
+    assert all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in small.values()), small
 
 
 def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tmp_path):
-    """gett_h16w4x_kernel issues its MFMAs from inline asm (the compiler's hazard recognizer pads independent 4-pass MFMAs to 27
-    cycles), so the compiler does not know that the accumulators are written late: in every instantiation the two `s_nop 15` of the
-    kernel must lie between the last MFMA and the first instruction that reads an accumulator register, and no accumulator may be
-    spilled (a spill store right behind an asm MFMA would read the register before the matrix pipe has written it)."""
+    """The 16x16x32 kernels issue their MFMAs from inline asm (the compiler's hazard recognizer pads independent 4-pass MFMAs to 27
+    cycles), so the compiler does not know that the accumulators are written late: in every instantiation every instruction that
+    reads an accumulator register must have the kernel's two `s_nop 15` — not an MFMA — as its nearest predecessor of the two kinds in
+    the instruction stream, and no accumulator may be spilled (a spill store right behind an asm MFMA would read the register before
+    the matrix pipe has written it)."""
     co = _code_object(tmp_path, "gett_h16v")
     k = _kernel_notes(co)
-    names = [n for n in k if "gett_h16w4x_kernel" in n or "gett_h16w4m_kernel" in n]
-    assert len(names) >= 24, sorted(k)
+    names = [n for n in k if any(x in n for x in ("gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4q_kernel", "gett_h16w8m_kernel"))]
+    assert len(names) >= 48, sorted(k)
     for name in names:
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
                              capture_output=True, text=True).stdout.splitlines()
         ins = [l.split("//")[0].strip() for l in dis if l.startswith("\t")]
         mfma = [i for i, l in enumerate(ins) if l.startswith("v_mfma_f32_16x16x32")]
-        assert len(mfma) >= (3 * 128 if "w4x" in name else 3 * 32), (name, len(mfma))      # two unrolled K-tiles and the tail
-        reads = [i for i, l in enumerate(ins) if i > mfma[-1] and (l.startswith("v_accvgpr_read") or l.startswith("v_accvgpr_mov")
-                                                                   or re.search(r"(store|write)\S* .*\ba\[?\d", l))]
+        assert len(mfma) >= (3 * 128 if "w4x" in name else 7 * 8 if "w4q" in name else 3 * 32), (name, len(mfma))      # the unrolled K-tiles and the tail
+        # (v_accvgpr_mov a, a only spreads the zero the accumulators start from)
+        reads = [i for i, l in enumerate(ins) if l.startswith("v_accvgpr_read")
+                 or re.match(r"(ds_write|ds_store|global_store|buffer_store|flat_store|scratch_store)\S* .*\ba\[?\d", l)]
         assert reads, name
-        between = ins[mfma[-1] + 1:reads[0]]
-        assert sum(1 for l in between if l.startswith("s_nop 15")) >= 2, (name, between)
+        for i in reads:
+            j = i - 1
+            while j >= 0 and not ins[j].startswith("v_mfma") and not ins[j].startswith("s_nop 15"):
+                j -= 1
+            assert j >= 1 and ins[j].startswith("s_nop 15") and ins[j - 1].startswith("s_nop 15"), (name, i, ins[max(j - 2, 0):i + 1][:12])
         assert not any(l.startswith("scratch_") for l in ins), name
 
 
