@@ -474,6 +474,33 @@ def secondary_single_gpu(torch, ct, ops, h, stream):
         del A, B, D
     except Exception as ex:   # noqa: BLE001
         out.append({"workload": "contraction bf16 8192^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- bf16 mid-size and small shapes (the size class of blog_post.cu's per-device pieces and of contraction.cu retyped): the 128 x 128
+    #      and 64 x 64 tile kernels of round 4, whatever the planner picks -----------------------------------------------------------
+    for (M, N, K) in ((2048, 2048, 2048), (4096, 1024, 4096), (1024, 1024, 1024)):
+        try:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(2)
+            A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)      # modes "mk": m fastest
+            B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)      # "kn"
+            D = torch.empty((N, M), device="cuda", dtype=torch.bfloat16)
+            p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF, workspace_limit=1 << 30)
+            ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+            fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)   # noqa: E731
+            for _ in range(200):
+                fn()
+            ms = min(timed_batch(torch, fn, reps=200), timed_batch(torch, fn, reps=200))
+            flop = 2.0 * M * N * K
+            tf = flop / (ms * 1e-3) / 1e12
+            d = p.describe()
+            out.append({"workload": "contraction bf16 C[m,n]=A[m,k]B[k,n] M=%d N=%d K=%d, U(-1,1) data (mid-size class)" % (M, N, K), "dtype": "bf16",
+                        "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms, "kernel": d["kname"], "splitK": d["splitK"],
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS_BF16_MFMA,
+                                     "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * (M * K + K * N + M * N),
+                                     "note": "bound in practice by the LDS-DMA staging stream of the tile and the fixed cost of a launch (DESIGN.md section 3)"}})
+            p.destroy()
+            del A, B, D, ws
+        except Exception as ex:   # noqa: BLE001
+            out.append({"workload": "contraction bf16 %dx%dx%d" % (M, N, K), "error": "%s: %s" % (type(ex).__name__, ex)})
     # ---- 2048^3 fp32 permute abc->cab and reduce abc->ac (configs[2]); tensors generated on the device ----------------
     try:
         n = 2048
