@@ -44,6 +44,14 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/h16m_fetch -o r -- $M > $OUT/h16m_fetch.log 2
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/h16m_write -o r -- $M > $OUT/h16m_write.log 2>&1
 for p in trace sq fetch write; do summ h16m_$p h16_mid_2048_$p; done
 (cd $ROOT && for L in mk,kn km,kn mk,nk; do python tools/h16_shape_sweep.py --layout $L 2>/dev/null; done > $OUT/h16_shape_sweep.jsonl)
+# ---- 1e. the small-problem 16-bit kernel (round 4): bf16 1024^3 on gett_h16w4q_kernel: trace, SQ, FETCH; in-kernel timeline ----------
+cd /tmp
+S="python $ROOT/tools/h16_shape_sweep.py --only 1024,1024,1024 --reps 400"
+rocprofv3 --kernel-trace --stats -d $OUT/h16q_trace -o r -- $S > $OUT/h16q_trace.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/h16q_sq -o r -- $S > $OUT/h16q_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/h16q_fetch -o r -- $S > $OUT/h16q_fetch.log 2>&1
+for p in trace sq fetch; do summ h16q_$p h16_small_1024_$p; done
+(cd $ROOT && for s in "1024 1024 1024" "1024 1024 4096" "2048 2048 2048"; do python tools/h16_small_timeline.py $s 2>/dev/null; done > $OUT/h16_small_timeline.jsonl)
 # ---- 2. bf16 8192^3, default kernel, two layouts: trace, SQ, FETCH, WRITE ---------------------------------------------
 cd /tmp
 for L in mk,kn km,kn; do
