@@ -329,6 +329,21 @@ __device__ __forceinline__ void x_mfma(f32x4& c, const s16x8& a, const s16x8& b)
     (void)c; (void)a; (void)b;
 #endif
 }
+// The accumulators as the epilogue may read them: every fragment passes through an (empty) asm statement placed BEHIND the two
+// s_nop 15 that wait out the last MFMAs — volatile asm statements keep their order, and every later read of an accumulator depends
+// on this one.  Without it nothing ties the epilogue's v_accvgpr_read copies to the s_nops: the compiler has hoisted them in front
+// of the wait (tests/test_kernel_resources.py checks the order in every instantiation).
+template <int FI, int FJ>
+__device__ __forceinline__ void x_acc_ready(f32x4 (&acc)[FI][FJ]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+#endif
+}
+
 // byte offset of this lane's 16 bytes of a 16-row fragment, k-step s (0, 1), inside a K-contiguous half-tile (rows 16 f: + 2048 f)
 __device__ __forceinline__ uint32_t x_offK(int lane, int s) {
     const int row = lane & 15, unit = (lane >> 4) + 4 * s;
@@ -495,17 +510,19 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     for (; t + 1 < nTiles; t += 2) { CTAMD_X_TILE(0) CTAMD_X_TILE(1) }
     if (t < nTiles) { CTAMD_X_TILE(0) }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    x_acc_ready(acc);
     if constexpr (TIMED) wgStamp[2] = __builtin_readcyclecounter();
     // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake (one
     // spilled register = a scratch allocation at every dispatch)
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
     const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant
+    GettParams pe;                                // the epilogue's arguments in one burst of scalar loads (gett_h16w4q_kernel)
+    h_reload_params(pe);
     // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
-    if (p.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
-        const uint32_t Mt = p.gM.total, Nt = p.gN.total;
-        float* P = p.partial + ((size_t)slice * p.gL.total + l) * (size_t)Mt * Nt;
+    if (pe.partial != nullptr) {                   // split-K: fp32 partial tile, row-major [slice][l][m][n]
+        const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
+        float* P = pe.partial + ((size_t)slice * pe.gL.total + l) * (size_t)Mt * Nt;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -524,7 +541,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     }
     __syncthreads();                              // every wave has finished reading the operand ring
     HEpilogue ep;
-    ep.init(p, l, lds, wave);
+    ep.init(pe, l, lds, wave);
+    unsigned long long tInit = 0, tWrite = 0;     // XST = 7 (measurement): cycles in HEpilogue::init and in the LDS-write phases
+    if constexpr (TIMED && XST == 7) tInit = __builtin_readcyclecounter() - wgStamp[2];
     if (XST != 3 && ep.vecD && ep.beta == 0.f) {
         // beta == 0 and 16-byte lanes in D: the accumulators are rounded ONCE on their way into LDS (alpha * acc -> 16 bit), a pass of
         // 32 rows x 128 columns is an image of 272-byte rows (16 bytes of padding: the 2-byte writes of a 16-lane group and the
@@ -534,6 +553,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
         constexpr int kPitch = 136;               // 16-bit elements per image row
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            unsigned long long tw0 = 0;
+            if constexpr (TIMED && XST == 7) tw0 = __builtin_readcyclecounter();
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
@@ -543,6 +564,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                     st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
                     st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
                 }
+            if constexpr (TIMED && XST == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tWrite += __builtin_readcyclecounter() - tw0; }
 #pragma unroll 4
             for (int it = 0; it < 8; ++it) {
                 const int q = it * 64 + laneE, row = q >> 4, cc = q & 15;
@@ -550,7 +572,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                 const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
                 if (m < ep.Mtot && n < ep.Ntot) {
                     int64_t offD, offC;
-                    ep.offsets(p, m, n, offD, offC);
+                    ep.offsets(pe, m, n, offD, offC);
                     if constexpr (XST == 1) *reinterpret_cast<s16x8*>(ep.D + offD) = v;
                     else __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
                 }
@@ -568,7 +590,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                 st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
             }
         const uint32_t mB = mW + 32 * i;
-        ep.template flush<BF, (XST == 1 ? 1 : 0)>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
+        ep.template flush<BF, (XST == 1 ? 1 : 0)>(pe, mB, 0u, 0u, nW, 64u, 32u, laneE);
     }
     if constexpr (TIMED) {
         if (p.timing != nullptr && wave == 0 && laneE == 0) {
@@ -577,6 +599,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 #pragma unroll
             for (int i = 0; i < 6; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
             p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+            if constexpr (XST == 7) { p.timing[64 + 8 * (size_t)blockIdx.x + 1] = tInit; p.timing[64 + 8 * (size_t)blockIdx.x + 7] = tWrite; }
         }
     }
 }
@@ -590,6 +613,7 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed && xst == 3) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 3>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed && xst == 4) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed && xst == 5) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 7) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 7>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
@@ -770,7 +794,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
         if (t + 2 < nTiles) { CTAMD_M_TILE(2) }
     }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    x_acc_ready(acc);
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
     const uint32_t mW = m0 + 64 * wr, nW = n0 + 64 * wc;      // this wave's quadrant
@@ -1012,7 +1036,7 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
     if (t + 2 < nTiles) { CTAMD_W_TILE(2) }
     if constexpr (R == 5) { if (t + 3 < nTiles) { CTAMD_W_TILE(3) } }
     CTAMD_H_LGKM0();                              // the (unused) fragments of the tile behind the last one
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    x_acc_ready(acc);
     __builtin_amdgcn_s_setprio(0);
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 
@@ -1270,7 +1294,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     if (t + 1 < nTiles) { CTAMD_Q_TILE(1) }
     if (t + 2 < nTiles) { CTAMD_Q_TILE(2) }
     CTAMD_H_VMCNT(0);                             // the re-staged tail: no LDS-DMA may outlive the workgroup
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
+    x_acc_ready(acc);
     if constexpr (TIMED) qs[3] = __builtin_readcyclecounter();
     const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 

@@ -47,7 +47,11 @@ dur = end - start
 clk = (t[:, 3] - t[:, 0]) / (dur * 1e3)                               # GHz
 order = np.argsort(start)
 rounds = [order[i * 256:(i + 1) * 256] for i in range(4)]
-out = {"zeros": zeros, "xst": os.environ.get("CUTENSOR_AMD_H16_XST", "0"), "rel_err_256_rows": err, "tflops_20_calls": tflops,
+extra = {}
+if os.environ.get("CUTENSOR_AMD_H16_XST") == "7":      # slot 1 = cycles in HEpilogue::init, slot 7 = cycles in the epilogue's LDS-write phases
+    extra = {"epilogue_init_cycles": float(t[:, 1].mean()), "epilogue_lds_write_phase_cycles": float(t[:, 7].mean())}
+    pro = pro * 0
+out = {"zeros": zeros, **extra, "xst": os.environ.get("CUTENSOR_AMD_H16_XST", "0"), "rel_err_256_rows": err, "tflops_20_calls": tflops,
        "cycles_mean": {"prologue": pro.mean(), "main_loop": loop.mean(), "epilogue": epi.mean()},
        "cycles_per_k_tile": loop.mean() / 128, "clock_ghz_mean": clk.mean(), "kernel_span_us": float(end.max()),
        "rounds": [{"start_us": [float(start[r].min()), float(start[r].max())], "end_us": [float(end[r].min()), float(end[r].max())],
