@@ -438,7 +438,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     };
     // Time model (us) of a variant at a split, from the shape sweeps of round 4 (profiles/r04*_h16_shape_sweep*: 8192^3 .. 256^2 x 16384 on
     // all variants): rounds x (fixed cost per workgroup + K-tiles x time per K-tile) + the fold.  Only has to ORDER the candidates.
-    //   256 x 256, four waves (48):  11 us fixed, 1.00 us per K-tile      256 x 256, eight waves (0): 10 us fixed, 1.13 us per K-tile
+    //   256 x 256, four waves (48):  10 us fixed, 1.00 us per K-tile      (256 x 256, eight waves (0): 10 us fixed, 1.13 us per K-tile)
     //   128 x 128, ring 2 (56), two workgroups per CU: 5 us fixed, 0.92 us per K-tile (0.68 with the CU to itself)
     //   128 x 128, ring 4 (64), one workgroup per CU:  4.5 us fixed, 0.46 us per K-tile
     //   64 x 64 (80), two workgroups per CU: 4.6 us fixed, 0.31 us per K-tile (4.4 / 0.223 while every workgroup has a CU to itself;
@@ -451,8 +451,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (var == 64) { fix = 4.5; per = 0.46; }
         else if (var == 80) { fix = wgs <= (double)numCUs ? 4.4 : 4.6; per = wgs <= (double)numCUs ? 0.223 : 0.31; }
         else if (var == 56) { fix = 5.0; per = wgs <= (double)numCUs ? 0.68 : 0.92; }
-        else if (kt <= 16) { fix = 10.0; per = 1.13; }
-        else { fix = 11.0; per = 1.0; }
+        else { fix = 10.0; per = 1.0; }
         double t = std::ceil(wgs / slots) * (fix + kt * per);
         if (split > 1) t += 3.0 + 2.0 * (double)split * (double)perSliceBytes / 5.0e6;
         return t;
@@ -487,10 +486,9 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c.kPerSlice = (uint32_t)(tilesPerSlice * 64);
     c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * perSliceBytes : 0ull;
     c.estimateUs = model_us(var, c.splitK);
-    // short K ranges: a workgroup of the four-wave kernels spends ~14 us outside its main loop (prologue + a 256 x 256 epilogue on
-    // four waves) against ~10 us for the eight-wave kernel, and wins ~0.13 us per K-tile inside it (tools/h16_shape_sweep.py:
-    // K = 512 -> 0.088 ms with eight waves, 0.102 ms with four; K = 4096 the other way round) — the planner's own choice only
-    if (var == 48 && !forced && tilesPerSlice <= 16) c.kernel -= 48;
+    // (Rounds 2-3 sent K ranges of at most 16 K-tiles to the eight-wave kernel, whose fixed cost per workgroup was ~4 us lower; with the
+    // shorter prologue and the pipelined epilogue of round 4 the four-wave kernel is ahead there too: 8192^2 x 256 / 512 / 1024
+    // 71.6 / 96.4 / 148 us against 72.7 / 101 / 157, profiles/r04z_short_k_4x_vs_8.txt.)
     return true;
 }
 

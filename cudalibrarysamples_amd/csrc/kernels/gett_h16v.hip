@@ -551,6 +551,44 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
         // whole 256-byte row segments, no conversion behind the LDS.  Half the instructions of the fp32 image below.
         uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
         constexpr int kPitch = 136;               // 16-bit elements per image row
+        const bool interior = ep.flat && mW + 128u <= ep.Mtot && nW + 128u <= ep.Ntot;
+        const int64_t stepI = 4 * pe.gM.stride[1][0];                  // four rows on (vecD: the N mode's stride is 1)
+        uint16_t* dstI = ep.D + (int64_t)(mW + (uint32_t)(laneE >> 4)) * pe.gM.stride[1][0] + (int64_t)(nW + 8u * (uint32_t)(laneE & 15));
+        if (interior) {
+            // The whole quadrant inside D and one M / one N mode (wave-uniform).  Software pipeline over the four passes of 32 rows: the
+            // eight 16-byte chunks of pass i - 1 (read out of the image into registers) are stored one per eight accumulator elements
+            // of pass i on their way into the image — the conversions + 2-byte LDS writes of a pass (1.55k cycles of VALU issue) and its
+            // stores (1.65k cycles when all 256 CUs store at once) overlap instead of adding up; no bounds test, addresses one
+            // addition apart.  (profiles/r04z_w4x_epilogue_breakdown.jsonl: 16.6k cycles before.)
+            s16x8 v[2][8];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {         // group g: fragments (a2 = g >> 2, j = 2 (g & 3) + {0, 1}) of pass i, chunk g of pass i - 1
+                    if (i < 4) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int a2 = g >> 2, j = 2 * (g & 3) + jj;
+                            const f32x4& c = acc[2 * (i < 4 ? i : 0) + a2][j];
+                            uint16_t* st = stage + (16 * a2 + 4 * (laneE >> 4)) * kPitch + 16 * j + (laneE & 15);
+                            st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                            st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+                        }
+                    }
+                    if (i > 0) {
+                        if constexpr (XST == 1) *reinterpret_cast<s16x8*>(dstI) = v[(i - 1) & 1][g];
+                        else __builtin_nontemporal_store(v[(i - 1) & 1][g], reinterpret_cast<s16x8*>(dstI));
+                        dstI += stepI;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i < 4) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it)
+                        v[i & 1][it] = *reinterpret_cast<const s16x8*>(stage + (4 * it + (laneE >> 4)) * kPitch + 8 * (laneE & 15));
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned long long tw0 = 0;
@@ -577,6 +615,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                     else __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
                 }
             }
+        }
         }
     } else
 #pragma unroll

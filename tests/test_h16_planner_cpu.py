@@ -39,13 +39,16 @@ def test_headline_16_bit_shape_runs_the_16x16x32_kernel(env, mA, mB, dtype):
     p.destroy()
 
 
-def test_short_k_ranges_stay_on_the_eight_wave_kernel(env):
+def test_short_k_ranges_run_the_default_kernel_too(env):
+    """Rounds 2-3 sent K ranges of at most 16 K-tiles per workgroup to the eight-wave kernel (lower fixed cost per workgroup); with the
+    shorter prologue and the pipelined epilogue of round 4 the four-wave 16x16x32 kernel is ahead there as well
+    (profiles/r04z_short_k_4x_vs_8.txt), so one rule is left: the planner's time model."""
     ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
-    for (M, N, K, want, split) in [(8192, 8192, 512, "gett_h16_kernel", 1),        # 8 K-tiles per workgroup
-                                   (8192, 8192, 1024, "gett_h16_kernel", 1),       # 16
+    for (M, N, K, want, split) in [(8192, 8192, 512, "gett_h16w4x_kernel", 1),        # 8 K-tiles per workgroup
+                                   (8192, 8192, 1024, "gett_h16w4x_kernel", 1),    # 16
                                    (8192, 8192, 1088, "gett_h16w4x_kernel", 1),    # 17
                                    (2048, 2048, 16384, "gett_h16w4x_kernel", 4)]:  # 64 per slice
         p = _plan(ct, ops, h, M, N, K)
