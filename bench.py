@@ -633,6 +633,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two live rocprofv3 --pmc passes for roofline.traffic (the committed "
                                                           "figure of the latest profile is reported instead)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the HBM-cold leg (profiling runs of the warm headline: tools/gpu_profile.sh; the cold "
+                                                           "leg has its own trace, tools/gpu_profile_all.sh 1b)")
     ap.add_argument("--cold-only", action="store_true",
                     help="profiling runs: only the HBM-cold variant of the headline (four rotating operand pairs, >= 500 steps), one small JSON line")
     ap.add_argument("--mg-child", type=int, default=0, help=argparse.SUPPRESS)
@@ -863,7 +865,7 @@ def main():
             roof["rocprof_trace"] = {"file": trace_file, "kernel_avg_us": k_avg, "kernel_min_us": k_min, "calls": k_calls,
                                      "frac_from_trace_avg": FLOP / (k_avg * 1e-6) / 1e12 / peak if peak else None,
                                      "fold_avg_us": trace_rows.get("splitk_reduce_frag_flat_kernel", (None,))[0],
-                                     "what": "rocprofv3 --kernel-trace --stats of this command on the round's profiling box (cold and gapped launches included)"}
+                                     "what": "rocprofv3 --kernel-trace --stats of this command with --no-cold --no-secondary on the round's profiling box (burn-in, warm-up and gapped launches included; the cold-operand leg has its own trace)"}
         # ---- the sample's own protocol (contraction.cu:252-270): device sync, GPUTimer (event pair) around ONE cutensorContract,
         #      event sync, minimum of 3 — every call starts on an idle, drained device ----------------------------------------------
         try:
@@ -887,6 +889,8 @@ def main():
         # ---- HBM-cold variant of the headline: four rotating (A, B) pairs = 805 MB of operands, beyond the 256-MiB
         #      Infinity Cache, so no step finds its inputs on-die ------------------------------------------------------------
         try:
+            if args.no_cold:
+                raise RuntimeError("skipped (--no-cold)")
             pairs = [(a, b)]
             for k in range(3):
                 pairs.append((torch.rand(a.shape, generator=g, device="cuda"), torch.rand(b.shape, generator=g, device="cuda")))

@@ -186,4 +186,21 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nBlocks) {
     return base + i;
 }
 
+// A fresh copy of the kernel's argument block (the kernel's only parameter, at offset 0 of the kernarg segment), read
+// through a laundered pointer so that the loads cannot be merged with earlier ones: only the fields used are loaded.
+__device__ __forceinline__ void reload_params(GettParams& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    typedef const __attribute__((address_space(4))) uint32_t* wptr;
+    wptr w = (wptr)kp;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(GettParams) / 4); ++i) d[i] = w[i];
+#else
+    (void)q;
+#endif
+}
+
+
 }  // namespace ctamd

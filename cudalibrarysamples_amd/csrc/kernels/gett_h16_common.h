@@ -396,21 +396,8 @@ __device__ __forceinline__ s16x8 h_read_frag(const char* slot, int rb, int s, co
     }
 }
 
-// A fresh copy of the kernel's argument block (the kernel's only parameter, at offset 0 of the kernarg segment), read
-// through a laundered pointer so that the loads cannot be merged with earlier ones: only the fields used are loaded.
-__device__ __forceinline__ void h_reload_params(GettParams& q) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    typedef const __attribute__((address_space(4))) uint32_t* wptr;
-    wptr w = (wptr)kp;
-    uint32_t* d = reinterpret_cast<uint32_t*>(&q);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(GettParams) / 4); ++i) d[i] = w[i];
-#else
-    (void)q;
-#endif
-}
+// (h_reload_params: gett_common.h reload_params)
+__device__ __forceinline__ void h_reload_params(GettParams& q) { reload_params(q); }
 
 // Wave-uniform walk over the K-tiles of the contraction: byte offsets of tile t in A and B.  Fast-K: the
 // fastest contracted digit's extent is a multiple of kHBK, so a tile never straddles a digit boundary.

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-secondary $*"
+BENCH="python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu --no-secondary --no-cold $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o r -- $BENCH > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o r -- $BENCH > $OUT/pmc_fetch.log 2>&1
