@@ -1273,7 +1273,7 @@ template <bool BF, int LA, int LB, bool TIMED = false>
 __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p) {
     constexpr int R = 4;
     __shared__ __attribute__((aligned(16))) char lds[R * kQBuf];
-    unsigned long long qs[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long qs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (TIMED) { qs[0] = __builtin_readcyclecounter(); qs[5] = wall_clock64(); }
     prefetch_kernarg<(int)sizeof(GettParams)>();
     // the arguments the setup reads, in ONE burst of scalar loads (through `p` they arrive one dependent round at a time)
@@ -1300,6 +1300,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint32_t kTilesAll = ps.gK.total / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
+    if constexpr (TIMED) { asm volatile("" :: "s"(nTiles), "s"(m0), "s"(n0)); qs[7] = __builtin_readcyclecounter(); }   // arguments fetched, tile located
 
     QOperand<LA> oa;
     QOperand<LB> ob;
@@ -1455,7 +1456,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
             qs[4] = __builtin_readcyclecounter();                 // the stores are issued, not waited for
             qs[6] = wall_clock64();
 #pragma unroll
-            for (int i = 0; i < 7; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = qs[i];
+            for (int i = 0; i < 8; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = qs[i];
         }
     }
 }

@@ -31,7 +31,7 @@ for _ in range(3):      # the last of three back-to-back launches is the one rec
 torch.cuda.synchronize()
 ct.lib.ctamdSetTimingBuffer(h.h, None)
 t = tbuf.cpu().numpy()[64:].reshape(nwg, 8).astype(np.float64)
-seg = {"setup(entry->first piece)": t[:, 1] - t[:, 0], "first tile lands": t[:, 2] - t[:, 1], "main loop": t[:, 3] - t[:, 2],
+seg = {"arguments fetched + tile located": t[:, 7] - t[:, 0], "setup(entry->first piece)": t[:, 1] - t[:, 0], "first tile lands": t[:, 2] - t[:, 1], "main loop": t[:, 3] - t[:, 2],
        "epilogue (stores issued)": t[:, 4] - t[:, 3]}
 w0 = t[:, 5].min()
 start, end = (t[:, 5] - w0) / 100.0, (t[:, 6] - w0) / 100.0          # wall clock: 100 MHz -> us
