@@ -6,6 +6,7 @@
 #include <new>
 
 #include "einsum.hpp"
+#include "../host/api_guard.hpp"
 
 namespace {
 constexpr int kMaxModes = 64;   // torch/einsum.cc:84
@@ -39,7 +40,7 @@ struct Impl : Base {
 
 extern "C" {
 
-void* ctamdEinsumCreate(const char* equation, const int64_t* shapeA, int nA, const int64_t* shapeB, int nB, int dtype) {
+void* ctamdEinsumCreate(const char* equation, const int64_t* shapeA, int nA, const int64_t* shapeB, int nB, int dtype) try {
     if (equation == nullptr || nA < 0 || nB < 0) return nullptr;
     std::vector<int64_t> a(shapeA, shapeA + nA), b(shapeB, shapeB + nB);
     switch (dtype) {
@@ -51,30 +52,30 @@ void* ctamdEinsumCreate(const char* equation, const int64_t* shapeA, int nA, con
         case HIP_C_64F:  return static_cast<Base*>(new (std::nothrow) Impl<std::complex<double>>(equation, a, b));
         default: return nullptr;
     }
-}
-void ctamdEinsumDestroy(void* e) { delete static_cast<Base*>(e); }
-void ctamdEinsumSetConjugate(void* e, int conjA, int conjB) { if (e) static_cast<Base*>(e)->conj(conjA != 0, conjB != 0); }
-int ctamdEinsumIsInitialized(void* e) { return e && static_cast<Base*>(e)->init() ? 1 : 0; }
-int ctamdEinsumOutputShape(void* e, int64_t* out, int cap) {
+} CTAMD_API_CATCH_NULL
+void ctamdEinsumDestroy(void* e) try { delete static_cast<Base*>(e); } CTAMD_API_CATCH_VOID
+void ctamdEinsumSetConjugate(void* e, int conjA, int conjB) try { if (e) static_cast<Base*>(e)->conj(conjA != 0, conjB != 0); } CTAMD_API_CATCH_VOID
+int ctamdEinsumIsInitialized(void* e) try { return e && static_cast<Base*>(e)->init() ? 1 : 0; } CTAMD_API_CATCH_INT
+int ctamdEinsumOutputShape(void* e, int64_t* out, int cap) try {
     if (!e) return -1;
     const std::vector<int64_t> s = static_cast<Base*>(e)->shape();
     for (size_t i = 0; i < s.size() && (int)i < cap; ++i) out[i] = s[i];
     return (int)s.size();
-}
-int ctamdEinsumPlan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) {
+} CTAMD_API_CATCH_INT
+int ctamdEinsumPlan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) try {
     if (!e || !static_cast<Base*>(e)->plan(h, limit)) return 0;
     if (required) *required = static_cast<Base*>(e)->required();
     return 1;
-}
+} CTAMD_API_CATCH_INT
 // einsum.cc:104-123: plan again under a smaller workspace limit (0 = CUTENSOR_WORKSPACE_MIN) after an allocation failure
-int ctamdEinsumReplan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) {
+int ctamdEinsumReplan(void* e, cutensorHandle_t h, uint64_t limit, uint64_t* required) try {
     if (!e || !static_cast<Base*>(e)->replan(h, limit)) return 0;
     if (required) *required = static_cast<Base*>(e)->required();
     return 1;
-}
-int ctamdEinsumExecute(void* e, cutensorHandle_t h, const void* A, const void* B, void* C, void* work, hipStream_t stream) {
+} CTAMD_API_CATCH_INT
+int ctamdEinsumExecute(void* e, cutensorHandle_t h, const void* A, const void* B, void* C, void* work, hipStream_t stream) try {
     return (e && static_cast<Base*>(e)->exec(h, A, B, C, work, stream)) ? 1 : 0;
-}
-cutensorPlan_t ctamdEinsumRawPlan(void* e) { return e ? static_cast<Base*>(e)->raw() : nullptr; }
+} CTAMD_API_CATCH_INT
+cutensorPlan_t ctamdEinsumRawPlan(void* e) try { return e ? static_cast<Base*>(e)->raw() : nullptr; } CTAMD_API_CATCH_NULL
 
 }  // extern "C"

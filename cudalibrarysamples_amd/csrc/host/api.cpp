@@ -274,7 +274,7 @@ static void peel_fix_alignment(cutensorOperationDescriptor& inner, const std::ve
 extern "C" {
 
 // ---- handle (contraction.cu:123-124) -----------------------------------------------------------
-cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
+cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) try {
     if (handle == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorHandle* h = new (std::nothrow) cutensorHandle();
     if (h == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
@@ -294,9 +294,9 @@ cutensorStatus_t cutensorCreate(cutensorHandle_t* handle) {
     }
     *handle = h;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) {
+cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) try {
     if (handle != nullptr) {
         for (auto& m : handle->pending) { (void)hipEventDestroy(m.e0); (void)hipEventDestroy(m.e1); }
         for (auto& ev : handle->prof.events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -304,20 +304,20 @@ cutensorStatus_t cutensorDestroy(cutensorHandle_t handle) {
     if (handle != nullptr && handle->syncPool != nullptr) (void)hipFree(handle->syncPool);
     delete handle;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // einsum.cu:445
-cutensorStatus_t cutensorHandleResizePlanCache(cutensorHandle_t handle, const uint32_t numEntries) {
+cutensorStatus_t cutensorHandleResizePlanCache(cutensorHandle_t handle, const uint32_t numEntries) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     std::lock_guard<std::mutex> g(handle->mtx);
     handle->planCacheCapacity = numEntries;
     while (handle->planCache.size() > numEntries) handle->planCache.erase(handle->planCache.begin());
     if (handle->planMemo.size() > numEntries) handle->planMemo.clear();
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_plan_cache.cu:324-337 — one line per cached problem: key \t kernel \t splitK
-cutensorStatus_t cutensorHandleWritePlanCacheToFile(const cutensorHandle_t handle, const char filename[]) {
+cutensorStatus_t cutensorHandleWritePlanCacheToFile(const cutensorHandle_t handle, const char filename[]) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     resolve_pending_measurements(handle);
@@ -333,11 +333,11 @@ cutensorStatus_t cutensorHandleWritePlanCacheToFile(const cutensorHandle_t handl
     }
     std::fclose(f);
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_plan_cache.cu:132-148
 cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, const char filename[],
-                                                     uint32_t* numCachelinesRead) {
+                                                     uint32_t* numCachelinesRead) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (numCachelinesRead) *numCachelinesRead = 0;
@@ -379,13 +379,13 @@ cutensorStatus_t cutensorHandleReadPlanCacheFromFile(cutensorHandle_t handle, co
     std::fclose(f);
     if (numCachelinesRead) *numCachelinesRead = n;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // ---- tensor descriptor (contraction.cu:131-137) ------------------------------------------------
 cutensorStatus_t cutensorCreateTensorDescriptor(const cutensorHandle_t handle, cutensorTensorDescriptor_t* desc,
                                                 const uint32_t numModes, const int64_t extent[],
                                                 const int64_t stride[], cutensorDataType_t dataType,
-                                                uint32_t alignmentRequirement) {
+                                                uint32_t alignmentRequirement) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || (numModes > 0 && extent == nullptr)) return CUTENSOR_STATUS_INVALID_VALUE;
     if (numModes > 64) return CUTENSOR_STATUS_NOT_SUPPORTED;
@@ -412,12 +412,12 @@ cutensorStatus_t cutensorCreateTensorDescriptor(const cutensorHandle_t handle, c
     }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorDestroyTensorDescriptor(cutensorTensorDescriptor_t desc) {
+cutensorStatus_t cutensorDestroyTensorDescriptor(cutensorTensorDescriptor_t desc) try {
     delete desc;   // NULL tolerated (python/einsum.h:302,396)
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // ---- operation descriptors ----------------------------------------------------------------------
 static cutensorStatus_t new_op(cutensorOperationDescriptor_t* out, cutensorOperationDescriptor& tmp) {
@@ -433,7 +433,7 @@ cutensorStatus_t cutensorCreateContraction(const cutensorHandle_t handle, cutens
                                            const cutensorTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
                                            const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                            const cutensorTensorDescriptor_t descD, const int32_t modeD[],
-                                           const cutensorComputeDescriptor_t descCompute) {
+                                           const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorOperationDescriptor op{};
@@ -454,7 +454,7 @@ cutensorStatus_t cutensorCreateContraction(const cutensorHandle_t handle, cutens
     const double es = (double)dtype_size(op.A.desc.dtype);
     op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.B.desc) + num_elements(op.D.desc));
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
 // contraction_trinary.cu:191-198: E = alpha * A * B * C + beta * D, executed as two pairwise contractions through a
 // packed intermediate T.  The pair contracted first is the one that minimises flops(first) + flops(second)
@@ -466,7 +466,7 @@ cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle,
                                                   const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                                   const cutensorTensorDescriptor_t descD, const int32_t modeD[], cutensorOperator_t opD,
                                                   const cutensorTensorDescriptor_t descE, const int32_t modeE[],
-                                                  const cutensorComputeDescriptor_t descCompute) {
+                                                  const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorOperationDescriptor op{};
@@ -542,14 +542,14 @@ cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle,
     const double es = (double)dtype_size(op.A.desc.dtype);
     op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.B.desc) + num_elements(op.C.desc) + num_elements(op.E.desc));
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
 // reduction.cu:141-146
 cutensorStatus_t cutensorCreateReduction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
                                          const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
                                          const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                          const cutensorTensorDescriptor_t descD, const int32_t modeD[],
-                                         cutensorOperator_t opReduce, const cutensorComputeDescriptor_t descCompute) {
+                                         cutensorOperator_t opReduce, const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorOperationDescriptor op{};
@@ -569,13 +569,13 @@ cutensorStatus_t cutensorCreateReduction(const cutensorHandle_t handle, cutensor
     op.flops = num_elements(op.A.desc);
     op.movedBytes = es * (num_elements(op.A.desc) + num_elements(op.D.desc));   // reduction.cu:229-231
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
 // elementwise_permute.cu:142-149
 cutensorStatus_t cutensorCreatePermutation(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
                                            const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
                                            const cutensorTensorDescriptor_t descB, const int32_t modeB[],
-                                           const cutensorComputeDescriptor_t descCompute) {
+                                           const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorOperationDescriptor op{};
@@ -591,14 +591,14 @@ cutensorStatus_t cutensorCreatePermutation(const cutensorHandle_t handle, cutens
     if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreatePermutation: %s", why.c_str()); return st; }
     op.movedBytes = 2.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);   // elementwise_permute.cu:208
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
 // elementwise_binary.cu:149-153 — only opAC = ADD is implemented
 cutensorStatus_t cutensorCreateElementwiseBinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
                                                  const cutensorTensorDescriptor_t descA, const int32_t modeA[], cutensorOperator_t opA,
                                                  const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                                  const cutensorTensorDescriptor_t descD, const int32_t modeD[],
-                                                 cutensorOperator_t opAC, const cutensorComputeDescriptor_t descCompute) {
+                                                 cutensorOperator_t opAC, const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     if (opAC != CUTENSOR_OP_ADD && opAC != CUTENSOR_OP_MUL && opAC != CUTENSOR_OP_MAX && opAC != CUTENSOR_OP_MIN) return CUTENSOR_STATUS_NOT_SUPPORTED;
@@ -617,7 +617,7 @@ cutensorStatus_t cutensorCreateElementwiseBinary(const cutensorHandle_t handle, 
     if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateElementwiseBinary: %s", why.c_str()); return st; }
     op.movedBytes = 3.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
 // elementwise_trinary.cu:174-182
 cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
@@ -626,7 +626,7 @@ cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle,
                                                   const cutensorTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                                   const cutensorTensorDescriptor_t descD, const int32_t modeD[],
                                                   cutensorOperator_t opAB, cutensorOperator_t opABC,
-                                                  const cutensorComputeDescriptor_t descCompute) {
+                                                  const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || !valid_compute(descCompute)) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorOperationDescriptor op{};
@@ -646,17 +646,17 @@ cutensorStatus_t cutensorCreateElementwiseTrinary(const cutensorHandle_t handle,
     if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateElementwiseTrinary: %s", why.c_str()); return st; }
     op.movedBytes = 4.0 * (double)dtype_size(op.D.desc.dtype) * num_elements(op.D.desc);   // elementwise_trinary.cu:234-238
     return new_op(desc, op);
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorDestroyOperationDescriptor(cutensorOperationDescriptor_t desc) {
+cutensorStatus_t cutensorDestroyOperationDescriptor(cutensorOperationDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction.cu:176-180, contraction_jit.cu:379-383
 cutensorStatus_t cutensorOperationDescriptorGetAttribute(const cutensorHandle_t handle, cutensorOperationDescriptor_t desc,
                                                          cutensorOperationDescriptorAttribute_t attr, void* buf,
-                                                         size_t sizeInBytes) {
+                                                         size_t sizeInBytes) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     switch (attr) {
@@ -679,11 +679,11 @@ cutensorStatus_t cutensorOperationDescriptorGetAttribute(const cutensorHandle_t 
         default:
             return CUTENSOR_STATUS_NOT_SUPPORTED;
     }
-}
+} CTAMD_API_CATCH
 
 cutensorStatus_t cutensorOperationDescriptorSetAttribute(const cutensorHandle_t handle, cutensorOperationDescriptor_t desc,
                                                          cutensorOperationDescriptorAttribute_t attr, const void* buf,
-                                                         size_t sizeInBytes) {
+                                                         size_t sizeInBytes) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (attr == CUTENSOR_OPERATION_DESCRIPTOR_TAG && sizeInBytes == sizeof(int32_t)) {
@@ -715,11 +715,11 @@ cutensorStatus_t cutensorOperationDescriptorSetAttribute(const cutensorHandle_t 
         return CUTENSOR_STATUS_SUCCESS;
     }
     return CUTENSOR_STATUS_NOT_SUPPORTED;
-}
+} CTAMD_API_CATCH
 
 // ---- plan preference (contraction.cu:194-198) ----------------------------------------------------
 cutensorStatus_t cutensorCreatePlanPreference(const cutensorHandle_t handle, cutensorPlanPreference_t* pref,
-                                              cutensorAlgo_t algo, cutensorJitMode_t jitMode) {
+                                              cutensorAlgo_t algo, cutensorJitMode_t jitMode) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (pref == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorPlanPreference* p = new (std::nothrow) cutensorPlanPreference();
@@ -728,17 +728,17 @@ cutensorStatus_t cutensorCreatePlanPreference(const cutensorHandle_t handle, cut
     p->jit = jitMode;   // accepted and ignored: every kernel is ahead-of-time compiled for gfx950
     *pref = p;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorDestroyPlanPreference(cutensorPlanPreference_t pref) {
+cutensorStatus_t cutensorDestroyPlanPreference(cutensorPlanPreference_t pref) try {
     delete pref;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_plan_cache.cu:215-237
 cutensorStatus_t cutensorPlanPreferenceSetAttribute(const cutensorHandle_t handle, cutensorPlanPreference_t pref,
                                                     cutensorPlanPreferenceAttribute_t attr, const void* buf,
-                                                    size_t sizeInBytes) {
+                                                    size_t sizeInBytes) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (pref == nullptr || buf == nullptr || sizeInBytes != 4) return CUTENSOR_STATUS_INVALID_VALUE;
     const int32_t v = *static_cast<const int32_t*>(buf);
@@ -752,13 +752,13 @@ cutensorStatus_t cutensorPlanPreferenceSetAttribute(const cutensorHandle_t handl
         default: return CUTENSOR_STATUS_INVALID_VALUE;
     }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction.cu:207-211
 cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc,
                                                const cutensorPlanPreference_t planPref,
                                                const cutensorWorksizePreference_t workspacePref,
-                                               uint64_t* workspaceSizeEstimate) {
+                                               uint64_t* workspaceSizeEstimate) try {
     (void)planPref;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || workspaceSizeEstimate == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -811,14 +811,17 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         *workspaceSizeEstimate = rp.workspace;
     }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // ---- measured selection for CUTENSOR_ALGO_DEFAULT_PATIENT -------------------------------------
 // Times the best-ranked candidates on scratch tensors of the problem's own shape; plan creation is
 // outside every timed region of the samples (contraction.cu:218-222 vs :253-270).
 static int autotune_contraction(cutensorHandle_t handle, const cutensorOperationDescriptor& op,
                                 const ContractionView& v, const std::vector<ContractionChoice>& ch) {
-    const int family = ch.empty() ? 0 : ch[0].family;
+    if (ch.size() < 2) return 0;                 // nothing to choose between (the general MFMA family ranks ONE candidate)
+    const int family = ch[0].family;             // 0 fp32 GETT, 1 aligned 16-bit (LDS-DMA), 2 general MFMA family — one table each
+    for (const ContractionChoice& c : ch)
+        if (c.family != family) return 0;        // mixed lists are not timed: a kernel index means nothing outside its own table
     const size_t es = dtype_size(op.A.desc.dtype);
     auto span = [&](const cutensorTensorDescriptor& d) {
         int64_t n = 1;
@@ -841,7 +844,7 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
     (void)hipMemset(B, 0x3c, span(op.B.desc));
     {
         int count = 0;
-        const GettKernelInfo* tab = family == 1 ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
+        const GettKernelInfo* tab = family == 2 ? gett_gen_kernels(&count) : family == 1 ? gett_h16_kernels(&count) : gett_f32_kernels(&count);
         float bestMs = 1e30f;
         for (size_t i = 0; i < nTry; ++i) {
             GettParams gp;
@@ -856,11 +859,16 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
             auto once = [&]() -> bool {
                 if (tab[ch[i].kernel].launch(gp, nullptr) != hipSuccess) return false;
                 if (ch[i].splitK > 1) {
-                    const hipError_t e = tab[ch[i].kernel].fragPartials ? launch_splitk_reduce_frag(rp, nullptr) : launch_splitk_reduce(rp, nullptr);
+                    // the fold that matches the kernel's partials: accumulator-register order (fp32 stream kernels), row-major fp32, or —
+                    // general family with 8- / 16-byte elements — row-major partials in the accumulator type
+                    const int elem = family == 2 ? tab[ch[i].kernel].elem : GEN_BF16;
+                    const hipError_t e = (family == 2 && elem >= GEN_F64) ? launch_gen_splitk_reduce(rp, elem, nullptr)
+                                       : tab[ch[i].kernel].fragPartials ? launch_splitk_reduce_frag(rp, nullptr) : launch_splitk_reduce(rp, nullptr);
                     if (e != hipSuccess) return false;
                 }
                 return true;
             };
+            if (ch[i].kernel < 0 || ch[i].kernel >= count) continue;
             float ms = 1e30f;
             bool ok = once() && hipDeviceSynchronize() == hipSuccess;
             if (ok && i == 0) {
@@ -1009,7 +1017,7 @@ static unsigned long long calibrate_xcd_split(cutensorHandle_t handle, const cut
 // contraction.cu:218-222, elementwise_permute.cu:183-187 (limit 0), einsum.cu:324-329 (limit 1 GiB)
 cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_t* plan,
                                     const cutensorOperationDescriptor_t desc, const cutensorPlanPreference_t pref,
-                                    uint64_t workspaceSizeLimit) {
+                                    uint64_t workspaceSizeLimit) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || desc == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorPlanPreference defaults;
@@ -1371,7 +1379,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     if (memoable) memo_insert(handle, mkey, mhash, *pl);
     *plan = pl;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 cutensorPlan::~cutensorPlan() {
     delete sub1;
@@ -1379,14 +1387,14 @@ cutensorPlan::~cutensorPlan() {
     if (wide.modes != nullptr) (void)hipFree(const_cast<ctamd::WideMode*>(wide.modes));
 }
 
-cutensorStatus_t cutensorDestroyPlan(cutensorPlan_t plan) {
+cutensorStatus_t cutensorDestroyPlan(cutensorPlan_t plan) try {
     delete plan;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction.cu:231-235
 cutensorStatus_t cutensorPlanGetAttribute(const cutensorHandle_t handle, const cutensorPlan_t plan,
-                                          cutensorPlanAttribute_t attr, void* buf, size_t sizeInBytes) {
+                                          cutensorPlanAttribute_t attr, void* buf, size_t sizeInBytes) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || buf == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (attr == CUTENSOR_PLAN_REQUIRED_WORKSPACE && sizeInBytes == sizeof(uint64_t)) {
@@ -1394,13 +1402,13 @@ cutensorStatus_t cutensorPlanGetAttribute(const cutensorHandle_t handle, const c
         return CUTENSOR_STATUS_SUCCESS;
     }
     return CUTENSOR_STATUS_INVALID_VALUE;
-}
+} CTAMD_API_CATCH
 
 // ---- execution -----------------------------------------------------------------------------------
 // contraction.cu:261-265, einsum.cu:334-338
 cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
                                   const void* A, const void* B, const void* beta, const void* C, void* D,
-                                  void* workspace, uint64_t workspaceSize, cudaStream_t stream) {
+                                  void* workspace, uint64_t workspaceSize, cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::Contraction) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1565,7 +1573,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     }
     if (err != hipSuccess) { CT_LOG("cutensorContract: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 static hipError_t run_elementwise(const EwPlan& ew, hipDataType dtype, double a, const void* A, double g,
                                   const void* C, void* D, hipStream_t stream, const void* E = nullptr, double d = 0.0) {
@@ -1583,7 +1591,7 @@ static hipError_t run_elementwise(const EwPlan& ew, hipDataType dtype, double a,
 // reduction.cu:219-222, einsum.cu:369-372
 cutensorStatus_t cutensorReduce(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
                                 const void* A, const void* beta, const void* C, void* D, void* workspace,
-                                uint64_t workspaceSize, cudaStream_t stream) {
+                                uint64_t workspaceSize, cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::Reduction) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1607,11 +1615,11 @@ cutensorStatus_t cutensorReduce(const cutensorHandle_t handle, const cutensorPla
     }
     if (err != hipSuccess) { CT_LOG("cutensorReduce: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // elementwise_permute.cu:198-200
 cutensorStatus_t cutensorPermute(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
-                                 const void* A, void* B, const cudaStream_t stream) {
+                                 const void* A, void* B, const cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::Permutation) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || A == nullptr || B == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1626,12 +1634,12 @@ cutensorStatus_t cutensorPermute(const cutensorHandle_t handle, const cutensorPl
     if (err == hipSuccess) err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, out, stream);
     if (err != hipSuccess) { CT_LOG("cutensorPermute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // elementwise_binary.cu:202-205
 cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
                                                   const void* alpha, const void* A, const void* gamma,
-                                                  const void* C, void* D, cudaStream_t stream) {
+                                                  const void* C, void* D, cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::ElementwiseBinary) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || gamma == nullptr || A == nullptr || C == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1640,12 +1648,12 @@ cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle,
     hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, g, C, D, stream);
     if (err != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // elementwise_trinary.cu:223-227
 cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle, const cutensorPlan_t plan,
                                                    const void* alpha, const void* A, const void* beta, const void* B,
-                                                   const void* gamma, const void* C, void* D, cudaStream_t stream) {
+                                                   const void* gamma, const void* C, void* D, cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::ElementwiseTrinary) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || gamma == nullptr || A == nullptr || B == nullptr || C == nullptr || D == nullptr)
@@ -1672,12 +1680,12 @@ cutensorStatus_t cutensorElementwiseTrinaryExecute(const cutensorHandle_t handle
     }
     if (err != hipSuccess) { CT_LOG("cutensorElementwiseTrinaryExecute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_trinary.cu:290-294
 cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
                                          const void* A, const void* B, const void* C, const void* beta, const void* D, void* E,
-                                         void* workspace, uint64_t workspaceSize, cudaStream_t stream) {
+                                         void* workspace, uint64_t workspaceSize, cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::ContractionTrinary || plan->sub1 == nullptr || plan->sub2 == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || C == nullptr || E == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1697,12 +1705,12 @@ cutensorStatus_t cutensorContractTrinary(const cutensorHandle_t handle, const cu
     cutensorStatus_t st = cutensorContract(handle, plan->sub1, one, X, Y, zero, T, T, ws, workspaceSize - tOff, stream);
     if (st != CUTENSOR_STATUS_SUCCESS) return st;
     return cutensorContract(handle, plan->sub2, alpha, T, Z, beta, D, E, ws, workspaceSize - tOff, stream);
-}
+} CTAMD_API_CATCH
 
 // contraction_jit.cu:134,398 — the engine has no run-time code generation (every kernel is compiled ahead of
 // time for gfx950), so its "kernel cache" holds nothing: writing produces a small tagged file, reading checks
 // the tag and reports IO_ERROR for a missing file exactly as the sample expects on its first run.
-cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]) {
+cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, const char filename[]) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     FILE* f = std::fopen(filename, "w");
@@ -1710,8 +1718,8 @@ cutensorStatus_t cutensorWriteKernelCacheToFile(const cutensorHandle_t handle, c
     std::fprintf(f, "cutensor-amd-kernelcache 1 gfx950 0\n");
     std::fclose(f);
     return CUTENSOR_STATUS_SUCCESS;
-}
-cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]) {
+} CTAMD_API_CATCH
+cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const char filename[]) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (filename == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     FILE* f = std::fopen(filename, "r");
@@ -1720,7 +1728,7 @@ cutensorStatus_t cutensorReadKernelCacheFromFile(cutensorHandle_t handle, const 
     const bool ok = std::fscanf(f, "%63s", tag) == 1 && std::strcmp(tag, "cutensor-amd-kernelcache") == 0;
     std::fclose(f);
     return ok ? CUTENSOR_STATUS_SUCCESS : CUTENSOR_STATUS_IO_ERROR;
-}
+} CTAMD_API_CATCH
 
 // utils.cuh:38
 const char* cutensorGetErrorString(const cutensorStatus_t error) {
@@ -1751,7 +1759,7 @@ size_t cutensorGetVersion(void) { return CUTENSOR_VERSION; }
 // argument block describes: its canonical modes as (group 0 = L, 1 = M, 2 = N, 3 = K; caller's label; extent), at most maxOut of
 // them; returns how many there are, 0 for every other plan.  cuTENSORMg uses it to peel one digit of an oversized group into a
 // host loop (mg.cpp) instead of running the functional kernel.
-int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut) {
+int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut) try {
     if (plan == nullptr || plan->kind != OpKind::Contraction || plan->choice.kernel != -2) return 0;
     if (plan->view.dtype == HIP_C_32F || plan->view.dtype == HIP_C_64F) return 0;     // complex data: not a matter of mode counts
     int n = 0;
@@ -1765,32 +1773,32 @@ int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t*
             ++n;
         }
     return n;
-}
+} CTAMD_API_CATCH_INT
 
 // Launches of the inner plan a peeled contraction plan makes per call (peel_wide_contraction); 0 for every other plan.
-int ctamdPlanPeelLaunches(const cutensorPlan_t plan) {
+int ctamdPlanPeelLaunches(const cutensorPlan_t plan) try {
     if (plan == nullptr || plan->kind != OpKind::Contraction || plan->choice.kernel != -3) return 0;
     long long n = 1;
     for (const PeelMode& pm : plan->peel) n *= pm.extent;
     return (int)n;
-}
+} CTAMD_API_CATCH_INT
 
 // cutensorContract launches by kernel kind since the library was loaded: out[0] gett_simple_kernel (scalar FMA fallback), [1]
 // gett_wide_kernel (mode table), [2] fp32 MFMA families, [3] aligned 16-bit MFMA family, [4] general MFMA family.  Lets a test that
 // drives the library through someone else's binding (the reference's own einsum.cc) assert which kernels its cases ran on.
-void ctamdLaunchCounts(uint64_t out[5]) {
+void ctamdLaunchCounts(uint64_t out[5]) try {
     for (int i = 0; i < 5; ++i) out[i] = g_launchCounts[i].load(std::memory_order_relaxed);
-}
+} CTAMD_API_CATCH_VOID
 
 // Plan-memo counters of this handle: plans answered by cloning a prototype / plans that went through the planner.
-void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) {
+void ctamdPlanMemoStats(const cutensorHandle_t handle, uint64_t* hits, uint64_t* misses, uint32_t* entries) try {
     if (handle == nullptr) return;
     if (hits) *hits = handle->memoHits.load(std::memory_order_relaxed);
     if (misses) *misses = handle->memoMisses.load(std::memory_order_relaxed);
     if (entries) { std::lock_guard<std::mutex> g(handle->mtx); *entries = (uint32_t)handle->planMemo.size(); }
-}
+} CTAMD_API_CATCH_VOID
 // Writes a one-line JSON description of the plan's kernel choice into buf.
-int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
+int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
     if (plan == nullptr || buf == nullptr || len == 0) return -1;
     int n = 0;
     if (plan->kind == OpKind::Contraction && plan->choice.kernel == -3 && plan->sub1 != nullptr) {
@@ -1840,30 +1848,30 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) {
                           e.variant, e.p.E0, e.p.E1, e.p.rest.total, e.p.nBlocks, e.p.tile0, e.p.order);
     }
     return n;
-}
+} CTAMD_API_CATCH_INT
 
 // Diagnostics, all per handle.  Device buffer of 8 x uint64 per workgroup that the GETT kernel fills with phase
 // timestamps (shader clock and wall clock); nullptr switches it off.
-void ctamdSetTimingBuffer(cutensorHandle_t handle, void* deviceBuffer) {
+void ctamdSetTimingBuffer(cutensorHandle_t handle, void* deviceBuffer) try {
     if (handle != nullptr) handle->timingBuffer.store(static_cast<unsigned long long*>(deviceBuffer), std::memory_order_relaxed);
-}
+} CTAMD_API_CATCH_VOID
 
 // enabled = 0 makes cutensorContract on this handle launch the GETT kernel only (the split-K partials stay unfolded, D is
 // not written) so that a stream of back-to-back GETT launches can be timed with one event pair — per-launch event
 // pairs put a ~6 us idle gap after every kernel and the chip leaves its steady clock state.  Never used by the samples.
-void ctamdSetSplitKFold(cutensorHandle_t handle, int enabled) {
+void ctamdSetSplitKFold(cutensorHandle_t handle, int enabled) try {
     if (handle != nullptr) handle->skipFold.store(enabled == 0, std::memory_order_relaxed);
-}
+} CTAMD_API_CATCH_VOID
 
 // Per-kernel timing of the GETT kernel inside cutensorContract on this handle: Begin() arms it, End() synchronises the
 // recorded event pairs and returns the number of launches and their mean / min duration in ms.
-void ctamdProfileBegin(cutensorHandle_t handle) {
+void ctamdProfileBegin(cutensorHandle_t handle) try {
     if (handle == nullptr) return;
     std::lock_guard<std::mutex> g(handle->prof.mtx);
     handle->prof.events.clear();
     handle->prof.enabled.store(true, std::memory_order_relaxed);
-}
-int ctamdProfileEnd(cutensorHandle_t handle, float* meanMs, float* minMs) {
+} CTAMD_API_CATCH_VOID
+int ctamdProfileEnd(cutensorHandle_t handle, float* meanMs, float* minMs) try {
     if (handle == nullptr) return 0;
     std::lock_guard<std::mutex> g(handle->prof.mtx);
     handle->prof.enabled.store(false, std::memory_order_relaxed);
@@ -1884,29 +1892,29 @@ int ctamdProfileEnd(cutensorHandle_t handle, float* meanMs, float* minMs) {
     if (meanMs) *meanMs = n ? (float)(sum / n) : 0.f;
     if (minMs) *minMs = n ? mn : 0.f;
     return n;
-}
+} CTAMD_API_CATCH_INT
 
 // Instantiated fp32 GETT kernels (test coverage bookkeeping): table size, and whether entry i is a
 // measurement-only ablation variant (never planned unless CUTENSOR_AMD_ABLATION is set).
-int ctamdKernelCount(void) {
+int ctamdKernelCount(void) try {
     int count = 0;
     (void)gett_f32_kernels(&count);
     return count;
-}
-int ctamdKernelIsAblation(int i) {
+} CTAMD_API_CATCH_INT
+int ctamdKernelIsAblation(int i) try {
     int count = 0;
     const GettKernelInfo* tab = gett_f32_kernels(&count);
     return (i >= 0 && i < count && tab[i].ablation) ? 1 : 0;
-}
+} CTAMD_API_CATCH_INT
 
 // Number of ranked candidates for a contraction descriptor under a workspace limit (so that a
 // caller can sweep CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK / algo >= 0 exhaustively).
-int ctamdCountCandidates(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc, uint64_t wsLimit) {
+int ctamdCountCandidates(const cutensorHandle_t handle, const cutensorOperationDescriptor_t desc, uint64_t wsLimit) try {
     if (handle == nullptr || desc == nullptr || desc->kind != OpKind::Contraction) return -1;
     ContractionView v;
     if (build_contraction_view(*desc, v, nullptr) != CUTENSOR_STATUS_SUCCESS) return -1;
     if (v.dtype != HIP_R_32F || v.wide) return 0;
     return (int)rank_contraction_choices(v, wsLimit, handle->numCUs).size();
-}
+} CTAMD_API_CATCH_INT
 
 }  // extern "C"

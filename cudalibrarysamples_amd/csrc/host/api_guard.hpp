@@ -1,0 +1,19 @@
+// api_guard.hpp — the exception barrier of the C ABI.
+// The host side is C++17 with std::vector / std::map / std::string / std::shared_ptr behind every entry point; the callers are C
+// programs, ctypes and the reference's samples (utils.cuh:35-46 turns a STATUS into an exception on ITS side).  No exception may
+// cross the boundary: every `extern "C"` function of libcutensor.so / libcutensorMg.so /
+// libcutensorMp.so is a function-try-block that ends in one of these handlers.  An allocation failure becomes
+// CUTENSOR_STATUS_ALLOC_FAILED, anything else CUTENSOR_STATUS_INTERNAL_ERROR; diagnostics that return int / size_t / pointers
+// answer -1 / 0 / nullptr.  tests/test_abi.py::test_allocation_failure_* drives the entry points with a throwing operator new.
+#pragma once
+#include <new>
+
+#include <cutensor.h>
+
+#define CTAMD_API_CATCH                                                          \
+    catch (const std::bad_alloc&) { return CUTENSOR_STATUS_ALLOC_FAILED; }       \
+    catch (...) { return CUTENSOR_STATUS_INTERNAL_ERROR; }
+#define CTAMD_API_CATCH_INT  catch (...) { return -1; }
+#define CTAMD_API_CATCH_ZERO catch (...) { return 0; }
+#define CTAMD_API_CATCH_NULL catch (...) { return nullptr; }
+#define CTAMD_API_CATCH_VOID catch (...) { }

@@ -216,7 +216,7 @@ cutensorStatus_t cutensorCreateBlockSparseTensorDescriptor(cutensorHandle_t hand
                                                            const uint32_t numModes, const uint64_t numNonZeroBlocks,
                                                            const uint32_t numSectionsPerMode[], const int64_t extent[],
                                                            const int32_t nonZeroCoordinates[], const int64_t stride[],
-                                                           cudaDataType_t dataType) {
+                                                           cudaDataType_t dataType) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || numModes == 0 || numSectionsPerMode == nullptr || extent == nullptr || (numNonZeroBlocks && nonZeroCoordinates == nullptr))
         return CUTENSOR_STATUS_INVALID_VALUE;
@@ -241,12 +241,12 @@ cutensorStatus_t cutensorCreateBlockSparseTensorDescriptor(cutensorHandle_t hand
     if (stride != nullptr) d->strides.assign(stride, stride + numNonZeroBlocks * numModes);
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorDestroyBlockSparseTensorDescriptor(cutensorBlockSparseTensorDescriptor_t desc) {
+cutensorStatus_t cutensorDestroyBlockSparseTensorDescriptor(cutensorBlockSparseTensorDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // blocksparse.cu:177-182
 cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t handle, cutensorOperationDescriptor_t* desc,
@@ -254,7 +254,7 @@ cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t han
                                                       const cutensorBlockSparseTensorDescriptor_t descB, const int32_t modeB[], cutensorOperator_t opB,
                                                       const cutensorBlockSparseTensorDescriptor_t descC, const int32_t modeC[], cutensorOperator_t opC,
                                                       const cutensorBlockSparseTensorDescriptor_t descD, const int32_t modeD[],
-                                                      const cutensorComputeDescriptor_t descCompute) {
+                                                      const cutensorComputeDescriptor_t descCompute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || descA == nullptr || descB == nullptr || descC == nullptr || descD == nullptr || descCompute == nullptr)
         return CUTENSOR_STATUS_INVALID_VALUE;
@@ -284,13 +284,13 @@ cutensorStatus_t cutensorCreateBlockSparseContraction(const cutensorHandle_t han
     if (st != CUTENSOR_STATUS_SUCCESS) { delete op; return st; }
     *desc = op;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // blocksparse.cu:206-209
 cutensorStatus_t cutensorBlockSparseContract(const cutensorHandle_t handle, const cutensorPlan_t plan, const void* alpha,
                                              const void* const A[], const void* const B[], const void* beta,
                                              const void* const C[], void* const D[], void* workspace, uint64_t workspaceSize,
-                                             cudaStream_t stream) {
+                                             cudaStream_t stream) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || plan->kind != OpKind::BlockSparseContraction || !plan->bsp) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -317,6 +317,6 @@ cutensorStatus_t cutensorBlockSparseContract(const cutensorHandle_t handle, cons
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
     }
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 }  // extern "C"

@@ -11,6 +11,7 @@
 
 #include <cutensor.h>
 
+#include "api_guard.hpp"
 #include "../kernels/launch.h"
 #include "../kernels/params.h"
 

@@ -513,8 +513,9 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
 // General MFMA family (kernels/gett_gen.inc): bf16 / fp16 shapes the aligned kernels refuse, fp64, complex64 / complex128.
 // Per operand: the orientation of its staged units (along k when the fastest contracted mode is its stride-1 mode, along rows
 // when the fastest free mode is) and the widest unit V its extents, strides and pointer alignment admit; the kernel runs both
-// operands at the smaller V.  Tile: the large one when it still fills the chip.  Split-K (16-bit data only: fp32 partials through
-// the existing fold) when the output tiles alone leave most CUs idle.
+// operands at the smaller V.  Tile: the large one when it still fills the chip.  Split-K for every element type when the output
+// tiles alone leave most CUs idle: partials in the accumulator type — fp32 for 16-bit data (folded by launch_splitk_reduce with one
+// rounding), double / float2 / double2 otherwise (launch_gen_splitk_reduce).
 // ---------------------------------------------------------------------------------------------
 static int gen_elem_of(hipDataType t) {
     switch (t) {
@@ -663,7 +664,9 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
     r.splitK = c.splitK;
     r.tilesM = p.tilesM; r.tilesN = p.tilesN;
     r.fragTM = (uint32_t)bm / 32u; r.fragTN = (uint32_t)bn / 32u;
-    r.outType = (c.family == 1 || c.family == 2) ? (v.dtype == HIP_R_16BF ? 1 : 2) : 0;   // family 2 splits K for 16-bit data only
+    // output type of launch_splitk_reduce (0 fp32, 1 bf16, 2 fp16): set for 16-bit data only — fp64 / complex partials of the general
+    // family are folded by launch_gen_splitk_reduce, which takes the element type from the kernel table and never reads this field
+    r.outType = (v.dtype == HIP_R_16BF) ? 1 : (v.dtype == HIP_R_16F) ? 2 : 0;
 }
 
 }  // namespace ctamd

@@ -44,6 +44,8 @@
 #include <cutensor.h>
 #include <cutensorMg.h>
 
+#include "../host/api_guard.hpp"
+
 extern "C" int ctamdPlanPeelLaunches(const cutensorPlan_t plan);
 extern "C" int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut);   // libcutensor.so diagnostic
 
@@ -398,7 +400,7 @@ bool env_is(const char* name, const char* value) {
 extern "C" {
 
 // contraction_multi_gpu.cu:151
-cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevices, const int32_t devices[]) {
+cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevices, const int32_t devices[]) try {
     if (handle == nullptr || numDevices == 0 || devices == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     DeviceGuard guard;
     int count = 0;
@@ -426,10 +428,10 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
     }
     *handle = h;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_multi_gpu.cu:383
-cutensorStatus_t cutensorMgDestroy(cutensorMgHandle_t handle) {
+cutensorStatus_t cutensorMgDestroy(cutensorMgHandle_t handle) try {
     if (handle == nullptr) return CUTENSOR_STATUS_SUCCESS;
     DeviceGuard guard;
     for (size_t g = 0; g < handle->commStreams.size(); ++g) {
@@ -441,14 +443,14 @@ cutensorStatus_t cutensorMgDestroy(cutensorMgHandle_t handle) {
     for (cutensorHandle_t h : handle->handles) cutensorDestroy(h);
     delete handle;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_multi_gpu.cu:195-197
 cutensorStatus_t cutensorMgCreateTensorDescriptor(const cutensorMgHandle_t handle, cutensorMgTensorDescriptor_t* desc,
                                                   uint32_t numModes, const int64_t extent[], const int64_t elementStride[],
                                                   const int64_t blockSize[], const int64_t blockStride[],
                                                   const int32_t deviceCount[], uint32_t numDevices, const int32_t devices[],
-                                                  cudaDataType_t type) {
+                                                  cudaDataType_t type) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || (numModes > 0 && extent == nullptr) || devices == nullptr || numDevices == 0) return CUTENSOR_STATUS_INVALID_VALUE;
     if (numModes > 20 || elem_size(type) == 0) return CUTENSOR_STATUS_NOT_SUPPORTED;
@@ -492,12 +494,12 @@ cutensorStatus_t cutensorMgCreateTensorDescriptor(const cutensorMgHandle_t handl
     t.cellElems = span;
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMgDestroyTensorDescriptor(cutensorMgTensorDescriptor_t desc) {
+cutensorStatus_t cutensorMgDestroyTensorDescriptor(cutensorMgTensorDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_multi_gpu.cu:228-233
 cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t handle, cutensorMgContractionDescriptor_t* desc,
@@ -505,7 +507,7 @@ cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t 
                                                        const cutensorMgTensorDescriptor_t descB, const int32_t modesB[],
                                                        const cutensorMgTensorDescriptor_t descC, const int32_t modesC[],
                                                        const cutensorMgTensorDescriptor_t descD, const int32_t modesD[],
-                                                       cutensorComputeType_t compute) {
+                                                       cutensorComputeType_t compute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || descA == nullptr || descB == nullptr || descC == nullptr || descD == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorMgContractionDescriptor* d = new (std::nothrow) cutensorMgContractionDescriptor();
@@ -545,16 +547,16 @@ cutensorStatus_t cutensorMgCreateContractionDescriptor(const cutensorMgHandle_t 
     if (st != CUTENSOR_STATUS_SUCCESS) { delete d; return st; }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMgDestroyContractionDescriptor(cutensorMgContractionDescriptor_t desc) {
+cutensorStatus_t cutensorMgDestroyContractionDescriptor(cutensorMgContractionDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_multi_gpu.cu:236-237
 cutensorStatus_t cutensorMgCreateContractionFind(const cutensorMgHandle_t handle, cutensorMgContractionFind_t* find,
-                                                 const cutensorMgAlgo_t algo) {
+                                                 const cutensorMgAlgo_t algo) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (find == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorMgContractionFind* f = new (std::nothrow) cutensorMgContractionFind();
@@ -562,12 +564,12 @@ cutensorStatus_t cutensorMgCreateContractionFind(const cutensorMgHandle_t handle
     f->algo = algo;
     *find = f;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMgDestroyContractionFind(cutensorMgContractionFind_t find) {
+cutensorStatus_t cutensorMgDestroyContractionFind(cutensorMgContractionFind_t find) try {
     delete find;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 static const uint64_t kLocalContractionWs = 128ull << 20;   // split-K scratch offered to every local plan (per compute stream)
 
@@ -584,7 +586,7 @@ static void staging_sizes(const cutensorMgContractionDescriptor& d, int64_t out[
 // contraction_multi_gpu.cu:241-242
 cutensorStatus_t cutensorMgContractionGetWorkspace(const cutensorMgHandle_t handle, const cutensorMgContractionDescriptor_t desc,
                                                    const cutensorMgContractionFind_t find, cutensorWorksizePreference_t preference,
-                                                   int64_t deviceWorkspaceSize[], int64_t* hostWorkspaceSize) {
+                                                   int64_t deviceWorkspaceSize[], int64_t* hostWorkspaceSize) try {
     (void)find; (void)preference;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || deviceWorkspaceSize == nullptr || hostWorkspaceSize == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -594,12 +596,12 @@ cutensorStatus_t cutensorMgContractionGetWorkspace(const cutensorMgHandle_t hand
         deviceWorkspaceSize[i] = s[0] + s[1] + s[2] + (int64_t)(kComputeStreams * kLocalContractionWs);
     *hostWorkspaceSize = 0;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // contraction_multi_gpu.cu:249-250
 cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle, cutensorMgContractionPlan_t* plan,
                                                  const cutensorMgContractionDescriptor_t desc, const cutensorMgContractionFind_t find,
-                                                 const int64_t deviceWorkspaceSize[], int64_t hostWorkspaceSize) {
+                                                 const int64_t deviceWorkspaceSize[], int64_t hostWorkspaceSize) try {
     (void)find; (void)hostWorkspaceSize;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || desc == nullptr || deviceWorkspaceSize == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -895,7 +897,6 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             }
         }
         p.waitEvents.assign(ev.begin(), ev.end());
-        if (env_is("CUTENSORMG_AMD_TEST_DROP_WAITS", "1")) p.waitEvents.clear();   // fault injection: tests/test_mg_replay_cpu.py proves its ordering check live
     }
     for (int k = 0; k < 3; ++k)
         if (!staged[k]) pl->stagingBytes[k] = 0;
@@ -1072,9 +1073,9 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     pl->pieces.swap(pieces);
     *plan = pl;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMgDestroyContractionPlan(cutensorMgContractionPlan_t plan) {
+cutensorStatus_t cutensorMgDestroyContractionPlan(cutensorMgContractionPlan_t plan) try {
     if (plan == nullptr) return CUTENSOR_STATUS_SUCCESS;
     destroy_pieces(plan->pieces);
     if (plan->owner != nullptr && plan->owner->haveDevice && plan->trialEv[0] != nullptr) {
@@ -1093,7 +1094,7 @@ cutensorStatus_t cutensorMgDestroyContractionPlan(cutensorMgContractionPlan_t pl
     }
     delete plan;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // Streams and events of the execution engine (created on first use; the Mg model is one host thread).
 static bool ensure_runtime(cutensorMgHandle* h, cutensorMgContractionPlan* pl) {
@@ -1123,7 +1124,7 @@ static bool ensure_runtime(cutensorMgHandle* h, cutensorMgContractionPlan* pl) {
 cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cutensorMgContractionPlan_t plan,
                                        const void* alpha, const void* A[], const void* B[], const void* beta,
                                        const void* C[], void* D[], void* workspaceDevice[], void* workspaceHost,
-                                       cudaStream_t streams[]) {
+                                       cudaStream_t streams[]) try {
     (void)workspaceHost;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr ||
@@ -1343,12 +1344,12 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
     }
 #undef MG_HIP
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // ---- diagnostics (not part of the cuTENSORMg ABI; used by the tests and the bench) -------------------------------
 // The boxes kbox_list() cuts the valid part [0, extent) of a padded index space into (block size, digit extents least
 // significant first), as JSON: [{"wHi":..,"digits":[[lo,hi],...]},...].
-int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const int64_t* f, char* buf, size_t len) {
+int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const int64_t* f, char* buf, size_t len) try {
     if (buf == nullptr || len == 0 || blockSize <= 0 || extent <= 0 || nDigits < 0 || (nDigits > 0 && f == nullptr)) return -1;
     Radix r;
     r.blockSize = blockSize;
@@ -1371,7 +1372,7 @@ int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const 
     if (s.size() + 1 > len) return -(int)(s.size() + 1);
     std::memcpy(buf, s.c_str(), s.size() + 1);
     return (int)s.size();
-}
+} CTAMD_API_CATCH_INT
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1391,7 +1392,7 @@ typedef int (*ctamdMgHostContractFn)(void* user, int dtype, const ctamdMgHostVie
                                      const ctamdMgHostView* C, const void* c, void* d, double alpha, double beta);
 
 int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, const void* const A[], const void* const B[], double beta,
-                        const void* const C[], void* const D[], ctamdMgHostContractFn contract, void* user, char* err, size_t errLen) {
+                        const void* const C[], void* const D[], ctamdMgHostContractFn contract, void* user, char* err, size_t errLen) try {
     auto fail = [&](int code, const std::string& msg) {
         if (err != nullptr && errLen > 0) { std::snprintf(err, errLen, "%s", msg.c_str()); }
         return code;
@@ -1420,11 +1421,15 @@ int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, co
     }
     // ---- 2. pieces in execution order ---------------------------------------------------------------------------------------------
     std::vector<std::set<int>> waited((size_t)(nDev * kComputeStreams));
+    const bool dropWaits = env_is("CUTENSORMG_AMD_TEST_DROP_WAITS", "1");
     for (size_t pi = 0; pi < pl->pieces.size(); ++pi) {
         const Piece& p = pl->pieces[pi];
         const int g = p.dev;
         std::set<int>& w = waited[(size_t)(g * kComputeStreams + p.stream)];
-        for (int e : p.waitEvents) w.insert(e);
+        // fault injection lives HERE, in the checker, never in the plan a device would execute: with CUTENSORMG_AMD_TEST_DROP_WAITS=1 the
+        // replay pretends the pieces wait for nothing (tests/test_mg_replay_cpu.py proves the ordering check live with it)
+        if (!dropWaits)
+            for (int e : p.waitEvents) w.insert(e);
         for (int k = 0; k < 3; ++k) {
             if (p.use[k].direct || (k == 2 && beta == 0.0)) continue;
             for (int c : p.use[k].cells) {
@@ -1474,11 +1479,11 @@ int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, co
         }
     }
     return 0;
-}
+} CTAMD_API_CATCH_INT
 
 // One JSON object describing the plan: which mode is sharded, the pieces in execution order with the grid cells they
 // read in place / from the staging image and the events they wait for, and every cell transfer.
-int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_t len) {
+int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_t len) try {
     if (plan == nullptr || buf == nullptr || len == 0) return -1;
     std::string s;
     char tmp[256];
@@ -1547,6 +1552,6 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
     if (s.size() + 1 > len) return -(int)(s.size() + 1);
     std::memcpy(buf, s.c_str(), s.size() + 1);
     return (int)s.size();
-}
+} CTAMD_API_CATCH_INT
 
 }  // extern "C"

@@ -42,6 +42,8 @@
 #include <cutensor.h>
 #include <cutensorMp.h>
 
+#include "../host/api_guard.hpp"
+
 namespace {
 
 size_t elem_size(hipDataType t) {
@@ -740,7 +742,7 @@ static cutensorStatus_t finish_handle(cutensorMpHandle* h, int localDevice, hipS
 }
 
 // cutensorMp_contraction.cu:470-471
-cutensorStatus_t cutensorMpCreate(cutensorMpHandle_t* handle, ncclComm_t comm, int localDevice, cudaStream_t stream) {
+cutensorStatus_t cutensorMpCreate(cutensorMpHandle_t* handle, ncclComm_t comm, int localDevice, cudaStream_t stream) try {
     if (handle == nullptr || comm == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     int rank = 0, n = 0;
     if (ncclCommUserRank(comm, &rank) != ncclSuccess || ncclCommCount(comm, &n) != ncclSuccess || n <= 0)
@@ -750,25 +752,25 @@ cutensorStatus_t cutensorMpCreate(cutensorMpHandle_t* handle, ncclComm_t comm, i
     h->transport = new (std::nothrow) RcclTransport(comm, rank, n);
     if (h->transport == nullptr) { delete h; return CUTENSOR_STATUS_ALLOC_FAILED; }
     return finish_handle(h, localDevice, stream, handle);
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMpDestroy(cutensorMpHandle_t handle) {
+cutensorStatus_t cutensorMpDestroy(cutensorMpHandle_t handle) try {
     delete handle;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t ctamdMpLocalWorldCreate(void** world, int nranks) {
+cutensorStatus_t ctamdMpLocalWorldCreate(void** world, int nranks) try {
     if (world == nullptr || nranks <= 0) return CUTENSOR_STATUS_INVALID_VALUE;
     LocalWorld* w = new (std::nothrow) LocalWorld(nranks);
     if (w == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
     *world = w;
     return CUTENSOR_STATUS_SUCCESS;
-}
-cutensorStatus_t ctamdMpLocalWorldDestroy(void* world) {
+} CTAMD_API_CATCH
+cutensorStatus_t ctamdMpLocalWorldDestroy(void* world) try {
     delete static_cast<LocalWorld*>(world);
     return CUTENSOR_STATUS_SUCCESS;
-}
-cutensorStatus_t ctamdMpCreateOnLocalWorld(cutensorMpHandle_t* handle, void* world, int rank, int localDevice, cudaStream_t stream) {
+} CTAMD_API_CATCH
+cutensorStatus_t ctamdMpCreateOnLocalWorld(cutensorMpHandle_t* handle, void* world, int rank, int localDevice, cudaStream_t stream) try {
     LocalWorld* w = static_cast<LocalWorld*>(world);
     if (handle == nullptr || w == nullptr || rank < 0 || rank >= w->nranks) return CUTENSOR_STATUS_INVALID_VALUE;
     cutensorMpHandle* h = new (std::nothrow) cutensorMpHandle();
@@ -779,14 +781,14 @@ cutensorStatus_t ctamdMpCreateOnLocalWorld(cutensorMpHandle_t* handle, void* wor
     cutensorStatus_t st = finish_handle(h, localDevice, stream, handle);
     if (st == CUTENSOR_STATUS_SUCCESS) lt->set_engine((*handle)->h);
     return st;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:474-483
 cutensorStatus_t cutensorMpCreateTensorDescriptor(const cutensorMpHandle_t handle, cutensorMpTensorDescriptor_t* desc,
                                                   uint32_t numModes, const int64_t extent[], const int64_t elementStride[],
                                                   const int64_t blockSize[], const int64_t blockStride[],
                                                   const int64_t nranksPerMode[], uint32_t nranks, const int32_t ranks[],
-                                                  cutensorDataType_t type) {
+                                                  cutensorDataType_t type) try {
     (void)blockStride;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || (numModes > 0 && extent == nullptr)) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -826,12 +828,12 @@ cutensorStatus_t cutensorMpCreateTensorDescriptor(const cutensorMpHandle_t handl
     }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMpDestroyTensorDescriptor(cutensorMpTensorDescriptor_t desc) {
+cutensorStatus_t cutensorMpDestroyTensorDescriptor(cutensorMpTensorDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:485-488
 cutensorStatus_t cutensorMpCreateContraction(const cutensorMpHandle_t handle, cutensorMpOperationDescriptor_t* desc,
@@ -839,7 +841,7 @@ cutensorStatus_t cutensorMpCreateContraction(const cutensorMpHandle_t handle, cu
                                              const cutensorMpTensorDescriptor_t descB, const int32_t modesB[], cutensorOperator_t opB,
                                              const cutensorMpTensorDescriptor_t descC, const int32_t modesC[], cutensorOperator_t opC,
                                              const cutensorMpTensorDescriptor_t descD, const int32_t modesD[],
-                                             const cutensorComputeDescriptor_t compute) {
+                                             const cutensorComputeDescriptor_t compute) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (desc == nullptr || descA == nullptr || descB == nullptr || descC == nullptr || descD == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if ((descA->t.n && !modesA) || (descB->t.n && !modesB) || (descC->t.n && (!modesC || !modesD))) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -871,17 +873,17 @@ cutensorStatus_t cutensorMpCreateContraction(const cutensorMpHandle_t handle, cu
         if (find_label(d->mA, l) < 0 && find_label(d->mB, l) < 0) { delete d; return CUTENSOR_STATUS_INVALID_VALUE; }
     *desc = d;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMpDestroyOperationDescriptor(cutensorMpOperationDescriptor_t desc) {
+cutensorStatus_t cutensorMpDestroyOperationDescriptor(cutensorMpOperationDescriptor_t desc) try {
     delete desc;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:490-500
 cutensorStatus_t cutensorMpCreatePlanPreference(const cutensorMpHandle_t handle, cutensorMpPlanPreference_t* pref,
                                                 cutensorMpAlgo_t algo, uint64_t workspaceSizeDeviceLimit,
-                                                uint64_t workspaceSizeHostLimit) {
+                                                uint64_t workspaceSizeHostLimit) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (pref == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (algo != CUTENSORMP_ALGO_DEFAULT) return CUTENSOR_STATUS_NOT_SUPPORTED;
@@ -889,16 +891,16 @@ cutensorStatus_t cutensorMpCreatePlanPreference(const cutensorMpHandle_t handle,
     if (p == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
     *pref = p;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMpDestroyPlanPreference(cutensorMpPlanPreference_t pref) {
+cutensorStatus_t cutensorMpDestroyPlanPreference(cutensorMpPlanPreference_t pref) try {
     delete pref;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:502-503
 cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorMpPlan_t* plan,
-                                      const cutensorMpOperationDescriptor_t desc, const cutensorMpPlanPreference_t pref) {
+                                      const cutensorMpOperationDescriptor_t desc, const cutensorMpPlanPreference_t pref) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || desc == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     const uint64_t devLimit = pref ? pref->devLimit : (1ull << 62);
@@ -1061,11 +1063,11 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
     pl->requiredDevice = fixed + (uint64_t)round_up((int64_t)pl->contractionWs, 256);
     *plan = pl;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:506-509
 cutensorStatus_t cutensorMpPlanGetAttribute(const cutensorMpHandle_t handle, const cutensorMpPlan_t plan,
-                                            cutensorMpPlanAttribute_t attr, void* buf, size_t sizeInBytes) {
+                                            cutensorMpPlanAttribute_t attr, void* buf, size_t sizeInBytes) try {
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || buf == nullptr || sizeInBytes < sizeof(uint64_t)) return CUTENSOR_STATUS_INVALID_VALUE;
     switch (attr) {
@@ -1073,17 +1075,17 @@ cutensorStatus_t cutensorMpPlanGetAttribute(const cutensorMpHandle_t handle, con
         case CUTENSORMP_PLAN_REQUIRED_WORKSPACE_HOST: *static_cast<uint64_t*>(buf) = 0; return CUTENSOR_STATUS_SUCCESS;
     }
     return CUTENSOR_STATUS_INVALID_VALUE;
-}
+} CTAMD_API_CATCH
 
-cutensorStatus_t cutensorMpDestroyPlan(cutensorMpPlan_t plan) {
+cutensorStatus_t cutensorMpDestroyPlan(cutensorMpPlan_t plan) try {
     delete plan;
     return CUTENSOR_STATUS_SUCCESS;
-}
+} CTAMD_API_CATCH
 
 // cutensorMp_contraction.cu:537-538
 cutensorStatus_t cutensorMpContract(const cutensorMpHandle_t handle, const cutensorMpPlan_t plan, const void* alpha,
                                     const void* A, const void* B, const void* beta, const void* C, void* D,
-                                    void* workspaceDevice, void* workspaceHost) {
+                                    void* workspaceDevice, void* workspaceHost) try {
     (void)workspaceHost;
     if (handle == nullptr) return CUTENSOR_STATUS_NOT_INITIALIZED;
     if (plan == nullptr || alpha == nullptr || beta == nullptr || A == nullptr || B == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
@@ -1151,9 +1153,9 @@ cutensorStatus_t cutensorMpContract(const cutensorMpHandle_t handle, const cuten
                            : static_cast<const void*>(static_cast<const char*>(user[k]) + o.viewOff * es);
     }
     return cutensorContract(h, plan->contraction, alpha, opnd[0], opnd[1], beta, C ? C : D, D, ctrWs, plan->contractionWs, s);
-}
+} CTAMD_API_CATCH
 
-size_t ctamdMpDescribePlan(const cutensorMpPlan_t plan, char* buf, size_t bufSize) {
+size_t ctamdMpDescribePlan(const cutensorMpPlan_t plan, char* buf, size_t bufSize) try {
     if (plan == nullptr) return 0;
     std::string j = "{";
     char tmp[256];
@@ -1187,6 +1189,6 @@ size_t ctamdMpDescribePlan(const cutensorMpPlan_t plan, char* buf, size_t bufSiz
         buf[n] = 0;
     }
     return j.size() + 1;
-}
+} CTAMD_API_CATCH_ZERO
 
 }  // extern "C"

@@ -298,3 +298,44 @@ def test_reference_torch_binding_loads_without_gpu(built):
                          capture_output=True, text=True).stdout
     have = {ln.split()[-1] for ln in lib.splitlines()}
     assert not [s for s in wanted if s not in have], [s for s in wanted if s not in have]
+
+
+def test_allocation_failure_inside_an_entry_point_becomes_a_status(built, tmp_path):
+    """No exception crosses the C ABI (csrc/host/api_guard.hpp): tests/harness/alloc_fail_harness.cpp replaces operator new, lets the
+    k-th allocation of the contraction.cu:123-235 call sequence (and of the contraction_multi_gpu.cu:151-250 planning sequence on two
+    device ids) throw std::bad_alloc for every k, and every entry point must answer CUTENSOR_STATUS_ALLOC_FAILED — an exception
+    that unwound into the harness's C-style frames would end the process in std::terminate."""
+    import subprocess
+    exe = str(tmp_path / "alloc_fail_harness")
+    lib = os.path.join(ROOT, "cudalibrarysamples_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "harness", "alloc_fail_harness.cpp"), "-o", exe,
+                           "-L", lib, "-lcutensorMg", "-lcutensor", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe, "mg"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cutensor: alloc guard ok" in r.stdout and "cutensorMg: alloc guard ok" in r.stdout, r.stdout
+
+
+def test_every_extern_c_entry_point_is_a_function_try_block():
+    """Static twin of the test above: every function the libraries define inside an `extern "C"` block opens a function-try-block
+    (`) try {`, closed by a CTAMD_API_CATCH* handler) — a new entry point without one fails here, not in a caller's process."""
+    csrc = os.path.join(ROOT, "cudalibrarysamples_amd", "csrc")
+    missing, seen = [], 0
+    for rel in ("host/api.cpp", "host/blocksparse.cpp", "mg/mg.cpp", "mp/mp.cpp", "einsum/einsum_c.cpp"):
+        lines = open(os.path.join(csrc, rel)).read().split("\n")
+        inside = False
+        for i, line in enumerate(lines):
+            if line.startswith('extern "C" {'):
+                inside = True
+            elif line.startswith('}  // extern "C"'):
+                inside = False
+            m = inside and re.match(r"^(?:cutensorStatus_t|int|size_t|void\*?|cutensorPlan_t) ((?:cutensor|ctamd)\w+)\(", line)
+            if not m or m.group(1) == "cutensorGetVersion":
+                continue
+            j = i
+            while not re.search(r"\)\s*(?:try\s*)?\{", lines[j]):      # the line that closes the parameter list and opens the body
+                j += 1
+            seen += 1
+            if not re.search(r"\) try \{", lines[j]):
+                missing.append((rel, m.group(1)))
+    assert seen >= 80 and not missing, (seen, missing)

@@ -44,7 +44,7 @@ def _tensor(rng, ext, pad, np_dt):
 
 
 def run(env, ext, mA, mB, mC, dtype, alpha=1.0, beta=0.0, seed=0, padA=None, padB=None, padC=None, opA=False, opB=False, opC=False,
-        ws_limit=1 << 28, alignment=128, expect=None):
+        ws_limit=1 << 28, alignment=128, expect=None, algo=None):
     torch, ct, ops, h = env
     np_dt, cname, tname, rtol = DT[dtype]
     tdt = getattr(torch, tname)
@@ -63,7 +63,7 @@ def run(env, ext, mA, mB, mC, dtype, alpha=1.0, beta=0.0, seed=0, padA=None, pad
     plan = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=getattr(ct, cname), strideA=strides(A), strideB=strides(B),
                                 strideC=strides(C), workspace_limit=ws_limit, alignment=alignment,
                                 opA=ct.OP_CONJ if opA else ct.OP_IDENTITY, opB=ct.OP_CONJ if opB else ct.OP_IDENTITY,
-                                opC=ct.OP_CONJ if opC else ct.OP_IDENTITY)
+                                opC=ct.OP_CONJ if opC else ct.OP_IDENTITY, **({} if algo is None else dict(algo=algo)))
     d = plan.describe()
     assert d["family"] == 2 and d["kname"] == "gett_gen_kernel", d
     if expect:
@@ -237,3 +237,14 @@ def test_peeled_contracted_mode_with_different_c_and_d_layouts(env, dtype):
     got = dD.cpu().numpy().reshape(PD.shape, order="F")
     np.testing.assert_allclose(got, ref, rtol=1e-5 if dtype == "float32" else 1e-12, atol=(1e-5 if dtype == "float32" else 1e-12) * float(np.abs(ref).max()))
     plan.destroy()
+
+
+@pytest.mark.parametrize("dtype,ext", [("float64", dict(m=200, n=136, k=104)), ("float16", dict(m=201, n=135, k=103)),
+                                        ("complex64", dict(m=96, n=80, k=6000)), ("bfloat16", dict(m=72, n=64, k=12001))])
+def test_patient_autotuning_of_a_general_family_problem(env, dtype, ext):
+    """CUTENSOR_ALGO_DEFAULT_PATIENT on problems that only the general MFMA family serves (fp64, complex, unaligned 16-bit; the last
+    two split K): cutensorCreatePlan must time general-family candidates against the general-family kernel table (an index into it
+    means nothing in the fp32 table: the round-4 advisor's finding) — or not time at all when there is one candidate — and the plan
+    it returns computes the right result."""
+    _, ct, _, _ = env
+    run(env, ext, "mk", "kn", "mn", dtype, alpha=1.25, beta=0.5, seed=11, algo=ct.ALGO_DEFAULT_PATIENT)

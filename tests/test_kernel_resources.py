@@ -134,3 +134,16 @@ def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, 
     burst = {int(off, 16): reg for reg, off in loads if int(off, 16) % 64 == 0 and int(off, 16) < 896}
     assert sorted(burst) == [64 * i for i in range(14)], loads[:20]
     assert len(set(burst.values())) == 14, burst          # fourteen lines, fourteen different destination registers
+
+
+@pytest.mark.parametrize("obj", ["gett_gen_h16", "gett_gen_f64", "gett_gen_cplx"])
+def test_general_mfma_family_uses_no_scratch(built, tmp_path, obj):
+    """gett_gen_kernel is compiled with __launch_bounds__(256, 2) = 256 registers per lane; the fp64 128 x 128 x 16 tile (128
+    accumulator + 64 fragment + 32 staging registers) and the three-accumulator complex tiles are the tight ones.  A spill would be a
+    scratch allocation at every dispatch (and lost occupancy): every instantiation must come out with no private segment."""
+    k = _kernel_notes(_code_object(tmp_path, obj))
+    gen = {n: v for n, v in k.items() if "gett_gen_kernel" in n}
+    assert len(gen) >= 8, sorted(k)
+    bad = {n: v for n, v in gen.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+    assert all(v.get("vgpr_count", 999) <= 256 for v in gen.values()), gen      # two workgroups per CU

@@ -188,8 +188,8 @@ def test_blog_post_on_eight_devices_executes(cm, s):
 
 
 def test_a_missing_wait_is_detected(cm, monkeypatch):
-    """The ordering check is live: with the events stripped from the pieces (CUTENSORMG_AMD_TEST_DROP_WAITS, a fault-injection
-    switch of the plan builder), the replay refuses the first piece that reads a gathered cell."""
+    """The ordering check is live: with the pieces' waits ignored (CUTENSORMG_AMD_TEST_DROP_WAITS, a fault-injection
+    switch of the REPLAY CHECKER — the plan itself, which a device would execute, is never altered), the replay refuses the first piece that reads a gathered cell."""
     monkeypatch.setenv("CUTENSORMG_AMD_TEST_DROP_WAITS", "1")
     n = 4
     with cm.Contraction(list(range(n)), *free_mode_layout(n, 16 * n)) as con:
