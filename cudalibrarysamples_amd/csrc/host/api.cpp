@@ -44,8 +44,8 @@ int log_level() {
 #define CT_LOG(...) do { if (log_level() > 0) { std::fprintf(stderr, "[cutensor-amd] " __VA_ARGS__); std::fputc('\n', stderr); } } while (0)
 
 bool supported_dtype(hipDataType t) {
-    // complex data is accepted for contractions only (mode-table kernel); the element-wise / reduction planners
-    // answer NOT_SUPPORTED for it
+    // complex data: contractions (general MFMA family / mode-table kernel), reductions, permutations and the binary element-wise
+    // form (ADD / MUL); the trinary element-wise planner answers NOT_SUPPORTED for it
     return t == HIP_R_32F || t == HIP_R_64F || t == HIP_R_16F || t == HIP_R_16BF || t == HIP_C_32F || t == HIP_C_64F;
 }
 
@@ -1576,14 +1576,16 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
 } CTAMD_API_CATCH
 
 static hipError_t run_elementwise(const EwPlan& ew, hipDataType dtype, double a, const void* A, double g,
-                                  const void* C, void* D, hipStream_t stream, const void* E = nullptr, double d = 0.0) {
+                                  const void* C, void* D, hipStream_t stream, const void* E = nullptr, double d = 0.0,
+                                  double aIm = 0.0, double gIm = 0.0) {   // aIm / gIm: imaginary parts of alpha / gamma (complex data)
     Ew2DParams p = ew.p;
     p.A = A;
     // a zero gamma drops the C term only for ADD (alpha perm(A) + 0): MUL / MAX / MIN still need it
-    p.C = (ew.usesC && (g != 0.0 || (p.opAC != 0 && p.opAC != CUTENSOR_OP_ADD))) ? C : nullptr;
+    p.C = (ew.usesC && (g != 0.0 || gIm != 0.0 || (p.opAC != 0 && p.opAC != CUTENSOR_OP_ADD))) ? C : nullptr;
     p.D = D;
     p.E = E;
     p.alpha = (float)a; p.gamma = (float)g; p.alpha64 = a; p.gamma64 = g;
+    p.alphaIm = aIm; p.gammaIm = gIm;
     p.delta = (float)d; p.delta64 = d;
     return launch_elementwise(p, ew.variant, (int)dtype, stream);
 }
@@ -1596,18 +1598,21 @@ cutensorStatus_t cutensorReduce(const cutensorHandle_t handle, const cutensorPla
     if (plan == nullptr || plan->kind != OpKind::Reduction) return CUTENSOR_STATUS_INVALID_VALUE;
     if (alpha == nullptr || beta == nullptr || A == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     const double a = scalar_as_double(alpha, plan->scalarType), b = scalar_as_double(beta, plan->scalarType);
-    if (b != 0.0 && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
-    if (misaligned(A, plan->alignA) || misaligned(D, plan->alignD) || (b != 0.0 && misaligned(C, plan->alignC)))
+    const double aIm = scalar_imag(alpha, plan->scalarType), bIm = scalar_imag(beta, plan->scalarType);   // complex data: complex scalars
+    const bool betaSet = b != 0.0 || bIm != 0.0;
+    if (betaSet && C == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+    if (misaligned(A, plan->alignA) || misaligned(D, plan->alignD) || (betaSet && misaligned(C, plan->alignC)))
         return CUTENSOR_STATUS_INVALID_VALUE;
     hipError_t err;
     if (plan->red.isPermutation) {
-        err = run_elementwise(plan->red.perm, plan->dtype, a, A, b, C, D, stream);
+        err = run_elementwise(plan->red.perm, plan->dtype, a, A, b, C, D, stream, nullptr, 0.0, aIm, bIm);
     } else {
         if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
             return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
         ReduceParams p = plan->red.p;
-        p.A = A; p.C = (b != 0.0) ? C : D; p.D = D;
+        p.A = A; p.C = betaSet ? C : D; p.D = D;
         p.alpha = (float)a; p.beta = (float)b; p.alpha64 = a; p.beta64 = b;
+        p.alphaIm = aIm; p.betaIm = bIm;
         p.partial = (p.splitR > 1) ? workspace : nullptr;
         const bool acc64 = plan->accumulate64 || plan->dtype == HIP_R_64F;
         err = launch_reduce(p, plan->red.variant, (int)plan->dtype, acc64, stream);
@@ -1631,7 +1636,7 @@ cutensorStatus_t cutensorPermute(const cutensorHandle_t handle, const cutensorPl
         err = launch_fill(B, plan->padFillElems, (int)plan->dtype, plan->padValue, stream);
         out = static_cast<char*>(B) + plan->padOffsetElems * (int64_t)dtype_size(plan->dtype);
     }
-    if (err == hipSuccess) err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, out, stream);
+    if (err == hipSuccess) err = run_elementwise(plan->ew, plan->dtype, a, A, 0.0, nullptr, out, stream, nullptr, 0.0, scalar_imag(alpha, plan->scalarType));
     if (err != hipSuccess) { CT_LOG("cutensorPermute: %s", hipGetErrorString(err)); return CUTENSOR_STATUS_EXECUTION_FAILED; }
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH
@@ -1645,7 +1650,8 @@ cutensorStatus_t cutensorElementwiseBinaryExecute(const cutensorHandle_t handle,
     if (alpha == nullptr || gamma == nullptr || A == nullptr || C == nullptr || D == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
     if (misaligned(A, plan->alignA) || misaligned(C, plan->alignC) || misaligned(D, plan->alignD)) return CUTENSOR_STATUS_INVALID_VALUE;
     const double a = scalar_as_double(alpha, plan->scalarType), g = scalar_as_double(gamma, plan->scalarType);
-    hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, g, C, D, stream);
+    hipError_t err = run_elementwise(plan->ew, plan->dtype, a, A, g, C, D, stream, nullptr, 0.0, scalar_imag(alpha, plan->scalarType),
+                                     scalar_imag(gamma, plan->scalarType));
     if (err != hipSuccess) return CUTENSOR_STATUS_EXECUTION_FAILED;
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH

@@ -81,13 +81,20 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     // second permuted operand: only the trinary planner passes a descriptor of kind ElementwiseBinary with B present
     const bool usesX = op.kind == OpKind::ElementwiseBinary && op.B.present;
     if (usesX && (op.B.desc.dtype != D.desc.dtype || dup_labels(op.B.modes))) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "second permuted operand");
-    if (D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex element-wise operations");
+    // complex data (python/einsum.h:326-343 routes a unary einsum on complex tensors here through cutensorCreateReduction):
+    // one permuted operand, combiner ADD or MUL, conjugation of A / C — the (re, im)-pair form of the generic kernel
+    const bool cplx = D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F;
+    if (cplx && usesX) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex element-wise trinary operations");
+    if (cplx && op.kind == OpKind::ElementwiseBinary && op.opReduce != CUTENSOR_OP_ADD && op.opReduce != CUTENSOR_OP_MUL)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "MAX / MIN are not defined on complex data");
     if (dup_labels(A.modes) || dup_labels(D.modes) || (usesC && dup_labels(C.modes)))
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
     if (A.desc.dtype != D.desc.dtype || (usesC && C.desc.dtype != D.desc.dtype))
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mixed data types");
-    if (A.op != CUTENSOR_OP_IDENTITY || (usesC && C.op != CUTENSOR_OP_IDENTITY))
-        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    // unary operators: IDENTITY, and CONJ (a no-op on real data)
+    auto unary_ok = [](cutensorOperator_t o) { return o == CUTENSOR_OP_IDENTITY || o == CUTENSOR_OP_CONJ; };
+    if (!unary_ok(A.op) || (usesC && !unary_ok(C.op)) || (usesX && op.B.op != CUTENSOR_OP_IDENTITY))
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity and conjugation operators are implemented");
     for (int32_t l : A.modes)
         if (find_label(D.modes, l) < 0 && A.desc.extent[find_label(A.modes, l)] != 1)
             return fail(CUTENSOR_STATUS_INVALID_VALUE, "mode of A missing from the output");
@@ -133,6 +140,8 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     std::memset(&p, 0, sizeof(p));
     p.E0 = p.E1 = 1;
     if (op.kind == OpKind::ElementwiseBinary) p.opAC = (int32_t)op.opReduce;   // ADD / MUL / MAX / MIN; every other caller adds
+    p.conjA = (cplx && A.op == CUTENSOR_OP_CONJ) ? 1 : 0;
+    p.conjC = (cplx && usesC && C.op == CUTENSOR_OP_CONJ) ? 1 : 0;
     std::vector<EwMode> rest;
     int i1 = -1;
     if (!modes.empty()) {
@@ -232,6 +241,8 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
     if (!ok_op(op.opAB) || !ok_op(op.opReduce)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "binary operator");
     if (op.A.op != CUTENSOR_OP_IDENTITY || op.B.op != CUTENSOR_OP_IDENTITY || op.C.op != CUTENSOR_OP_IDENTITY)
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    if (op.D.desc.dtype == HIP_C_32F || op.D.desc.dtype == HIP_C_64F)
+        return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex element-wise trinary operations");
     auto same_layout = [&](const TensorUse& X) {
         if (X.modes.size() != op.D.modes.size() || X.desc.dtype != op.D.desc.dtype) return false;
         for (size_t i = 0; i < op.D.modes.size(); ++i) {
@@ -291,15 +302,17 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
         return st;
     };
     const TensorUse &A = op.A, &C = op.C, &D = op.D;
-    if (D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "complex reductions");
+    const bool cplx = D.desc.dtype == HIP_C_32F || D.desc.dtype == HIP_C_64F;   // python/einsum.h:326-343 (unary einsum on complex tensors)
     if (dup_labels(A.modes) || dup_labels(D.modes)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "repeated mode label inside one tensor");
     if (C.modes != D.modes) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "modes of C and D differ");
     if (C.desc.extent != D.desc.extent) return fail(CUTENSOR_STATUS_INVALID_VALUE, "extents of C and D differ");
     if (A.desc.dtype != D.desc.dtype || C.desc.dtype != D.desc.dtype) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mixed data types");
-    if (A.op != CUTENSOR_OP_IDENTITY || C.op != CUTENSOR_OP_IDENTITY) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity operator is implemented");
+    auto unary_ok = [](cutensorOperator_t o) { return o == CUTENSOR_OP_IDENTITY || o == CUTENSOR_OP_CONJ; };   // CONJ: a no-op on real data
+    if (!unary_ok(A.op) || !unary_ok(C.op)) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "only the identity and conjugation operators are implemented");
     const int rop = (int)op.opReduce;
     if (rop != CUTENSOR_OP_ADD && rop != CUTENSOR_OP_MUL && rop != CUTENSOR_OP_MAX && rop != CUTENSOR_OP_MIN)
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "reduction operator");
+    if (cplx && rop != CUTENSOR_OP_ADD && rop != CUTENSOR_OP_MUL) return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "MAX / MIN are not defined on complex data");
     for (size_t i = 0; i < D.modes.size(); ++i) {
         const int ia = find_label(A.modes, D.modes[i]);
         if (ia < 0 && D.desc.extent[i] != 1) return fail(CUTENSOR_STATUS_INVALID_VALUE, "output mode missing from A");
@@ -353,6 +366,8 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
     if (!fill_rest(p.kept, kept) || !fill_rest(p.red, red))
         return fail(CUTENSOR_STATUS_NOT_SUPPORTED, "mode group too large");
     p.op = rop;
+    p.conjA = (cplx && A.op == CUTENSOR_OP_CONJ) ? 1 : 0;
+    p.conjC = (cplx && C.op == CUTENSOR_OP_CONJ) ? 1 : 0;
 
     const bool f32 = A.desc.dtype == HIP_R_32F;
     const bool acc64 = (op.compute != nullptr && op.compute->id == 5 /*64F*/) || A.desc.dtype == HIP_R_64F;
@@ -378,7 +393,8 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
     if (items < wantItems) split = (wantItems + items - 1) / std::max<uint64_t>(items, 1);
     split = std::min<uint64_t>(split, std::max<uint64_t>(redTot / minRedPerSplit, 1));
     split = std::min<uint64_t>(split, 4096);
-    const uint64_t accBytes = (acc64 ? 8 : 4);
+    // bytes of one partial: the accumulator type (float / double; (re, im) pairs in the data's precision for complex tensors)
+    const uint64_t accBytes = A.desc.dtype == HIP_C_64F ? 16 : A.desc.dtype == HIP_C_32F ? 8 : (acc64 ? 8 : 4);
     while (split > 1 && split * keptTot * accBytes > wsLimit) split /= 2;
     uint64_t per = (redTot + split - 1) / split;
     per = ((per + gran - 1) / gran) * gran;

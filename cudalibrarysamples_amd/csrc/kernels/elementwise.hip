@@ -558,6 +558,47 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EW_GENERIC for complex data (HIP_C_32F / HIP_C_64F): what the reference's binding runs for a unary einsum on complex tensors
+// (python/einsum.h:326-343,430-441: cutensorCreateReduction + cutensorReduce with no reduced mode = a permutation;
+// torch/einsum.cc:83 dispatches the complex types) and cutensorPermute / cutensorElementwiseBinaryExecute on complex tensors.
+//   D = opAC(alpha * op(perm(A)), gamma * op(perm(C)))      alpha, gamma complex; op in {IDENTITY, CONJ}; opAC in {ADD, MUL}
+// One (re, im) pair per lane: 8- / 16-byte loads and stores, 512 B / 1 KiB per wave along D's fastest mode.  Same tile
+// decomposition as ew_generic_kernel (64 dim0 elements x 4 dim1 rows).  HBM-bound: 2 |D| bytes (+ |C|).
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct EwCx { R re, im; };
+template <typename R> __device__ __forceinline__ EwCx<R> cx_mul(EwCx<R> a, EwCx<R> b) { return EwCx<R>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <typename R> __device__ __forceinline__ EwCx<R> cx_comb(int op, EwCx<R> x, EwCx<R> y) {
+    return op == 5 ? cx_mul(x, y) : EwCx<R>{x.re + y.re, x.im + y.im};     // CUTENSOR_OP_MUL, else ADD (the planner admits nothing else)
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) ew_generic_cplx_kernel(const Ew2DParams p) {
+    typedef EwCx<R> T;
+    const T* A = static_cast<const T*>(p.A);
+    const T* C = static_cast<const T*>(p.C);
+    T*       D = static_cast<T*>(p.D);
+    const T alpha = {(R)p.alpha64, (R)p.alphaIm}, gamma = {(R)p.gamma64, (R)p.gammaIm};
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * GN_T0 + (tid & 63);
+        const uint32_t r1 = t.t1 * GN_T1 + (tid >> 6);
+        if (c0 >= p.E0 || r1 >= p.E1) continue;
+        T a = A[oA + (int64_t)c0 * p.sA0 + (int64_t)r1 * p.sA1];
+        if (p.conjA) a.im = -a.im;
+        T v = cx_mul(alpha, a);
+        if (C != nullptr) {
+            T c = C[oC + (int64_t)c0 * p.sC0 + (int64_t)r1 * p.sC1];
+            if (p.conjC) c.im = -c.im;
+            v = cx_comb(p.opAC, v, cx_mul(gamma, c));
+        }
+        D[oD + (int64_t)c0 * p.sD0 + (int64_t)r1 * p.sD1] = v;
+    }
+}
+
 // Contiguous fill with 16-byte stores (HBM-bound: n * sizeof(T) bytes written).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct FillPattern { uint32_t w[4]; };
@@ -593,6 +634,9 @@ hipError_t launch_fill(void* D, uint64_t n, int dtype, double value, hipStream_t
         case HIP_R_64F: { uint64_t u; std::memcpy(&u, &value, 8); pat = FillPattern{{(uint32_t)u, (uint32_t)(u >> 32), (uint32_t)u, (uint32_t)(u >> 32)}}; es = 8; break; }
         case HIP_R_16F: { const uint32_t u = fill_f32_to_f16((float)value), w = u | (u << 16); pat = FillPattern{{w, w, w, w}}; es = 2; break; }
         case HIP_R_16BF: { const uint32_t u = fill_f32_to_bf16((float)value), w = u | (u << 16); pat = FillPattern{{w, w, w, w}}; es = 2; break; }
+        // complex: the padding value is real (CUTENSOR_OPERATION_DESCRIPTOR_PADDING_VALUE is read as one scalar), imaginary part 0
+        case HIP_C_32F: { const float v = (float)value; uint32_t u; std::memcpy(&u, &v, 4); pat = FillPattern{{u, 0u, u, 0u}}; es = 8; break; }
+        case HIP_C_64F: { uint64_t u; std::memcpy(&u, &value, 8); pat = FillPattern{{(uint32_t)u, (uint32_t)(u >> 32), 0u, 0u}}; es = 16; break; }
         default: return hipErrorInvalidValue;
     }
     if ((reinterpret_cast<uintptr_t>(D) & 15) != 0) return hipErrorInvalidValue;   // descriptors carry >= 16-byte alignment here
@@ -645,6 +689,10 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
             case HIP_R_64F:  hipLaunchKernelGGL(ew_generic_kernel<double>, dim3(grid), dim3(256), 0, stream, p); break;
             case HIP_R_16F:  hipLaunchKernelGGL(ew_generic_kernel<__half>, dim3(grid), dim3(256), 0, stream, p); break;
             case HIP_R_16BF: hipLaunchKernelGGL(ew_generic_kernel<__hip_bfloat16>, dim3(grid), dim3(256), 0, stream, p); break;
+            case HIP_C_32F:  if (p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;
+                             hipLaunchKernelGGL(ew_generic_cplx_kernel<float>, dim3(grid), dim3(256), 0, stream, p); break;
+            case HIP_C_64F:  if (p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;
+                             hipLaunchKernelGGL(ew_generic_cplx_kernel<double>, dim3(grid), dim3(256), 0, stream, p); break;
             default: return hipErrorInvalidValue;
         }
     } else {

@@ -148,6 +148,10 @@ struct Ew2DParams {
     int64_t     restX[kMaxGroupModes];
     float       xi;
     double      xi64;
+    // complex data (HIP_C_32F / HIP_C_64F, ew_generic_cplx_kernel): imaginary parts of alpha / gamma (alpha64 / gamma64 hold the
+    // real parts) and conjugation of the permuted operand A / of C
+    double      alphaIm, gammaIm;
+    int32_t     conjA, conjC;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -165,6 +169,9 @@ struct ReduceParams {
     int32_t     op;                // cutensorOperator_t: ADD / MUL / MIN / MAX
     float       alpha, beta;
     double      alpha64, beta64;
+    // complex data (reduce_generic_cplx_kernel): imaginary parts of the scalars, conjugation of A / C; partials are (re, im) pairs
+    double      alphaIm, betaIm;
+    int32_t     conjA, conjC;
 };
 
 }  // namespace ctamd

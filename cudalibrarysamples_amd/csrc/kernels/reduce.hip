@@ -220,6 +220,64 @@ __global__ void __launch_bounds__(256) reduce_finalize_kernel(const ReduceParams
     rg_store<T>(static_cast<T*>(p.D) + rd_offset<1>(p.kept, k), (double)val);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Complex reductions (HIP_C_32F / HIP_C_64F; python/einsum.h:326-343,430-441 runs a unary einsum on complex tensors through
+// cutensorCreateReduction(OP_ADD) + cutensorReduce; einsum.cu:346-372): RED_GENERIC's structure on (re, im) pairs — one lane per
+// (kept element, split), complex alpha / beta, conjugation of A / C, ADD and MUL.  Accumulation in the data's own precision
+// (like the real kernels: float for complex64, double for complex128); partials are [splitR][kept] pairs.
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct RdCx { R re, im; };
+template <typename R> __device__ __forceinline__ RdCx<R> rc_mul(RdCx<R> a, RdCx<R> b) { return RdCx<R>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <typename R> __device__ __forceinline__ RdCx<R> rc_apply(int op, RdCx<R> a, RdCx<R> b) {
+    return op == OP_MUL ? rc_mul(a, b) : RdCx<R>{a.re + b.re, a.im + b.im};
+}
+template <typename R> __device__ __forceinline__ void rc_finish(const ReduceParams& p, uint32_t k, RdCx<R> acc) {
+    const RdCx<R> alpha = {(R)p.alpha64, (R)p.alphaIm}, beta = {(R)p.beta64, (R)p.betaIm};
+    RdCx<R> val = rc_mul(alpha, acc);
+    if (beta.re != (R)0 || beta.im != (R)0) {
+        RdCx<R> c = static_cast<const RdCx<R>*>(p.C)[rd_offset<2>(p.kept, k)];
+        if (p.conjC) c.im = -c.im;
+        const RdCx<R> bc = rc_mul(beta, c);
+        val.re += bc.re; val.im += bc.im;
+    }
+    static_cast<RdCx<R>*>(p.D)[rd_offset<1>(p.kept, k)] = val;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) reduce_generic_cplx_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= p.kept.total) return;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const RdCx<R>* A = static_cast<const RdCx<R>*>(p.A) + rd_offset<0>(p.kept, k);
+    RdCx<R> acc = {op == OP_MUL ? (R)1 : (R)0, (R)0};
+    const R sgn = p.conjA ? (R)-1 : (R)1;
+    for (uint32_t r = rBegin; r < rEnd; ++r) {
+        RdCx<R> x = A[rd_offset<0>(p.red, r)];
+        x.im *= sgn;
+        acc = rc_apply<R>(op, acc, x);
+    }
+    if (p.partial != nullptr) {
+        static_cast<RdCx<R>*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
+        return;
+    }
+    rc_finish<R>(p, k, acc);
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) reduce_finalize_cplx_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= p.kept.total) return;
+    const int op = p.op;
+    const RdCx<R>* P = static_cast<const RdCx<R>*>(p.partial) + k;
+    RdCx<R> acc = {op == OP_MUL ? (R)1 : (R)0, (R)0};
+    for (uint32_t s = 0; s < p.splitR; ++s) acc = rc_apply<R>(op, acc, P[(size_t)s * p.kept.total]);
+    rc_finish<R>(p, k, acc);
+}
+
 template <typename T, typename S>
 static void launch_generic_t(const ReduceParams& p, hipStream_t stream) {
     const dim3 grid((p.kept.total + 255u) / 256u, p.splitR);
@@ -244,6 +302,8 @@ hipError_t launch_reduce(const ReduceParams& p, int variant, int dtype, bool acc
             case HIP_R_64F:  launch_generic_t<double, double>(p, stream); break;
             case HIP_R_16F:  launch_generic_t<__half, float>(p, stream); break;
             case HIP_R_16BF: launch_generic_t<__hip_bfloat16, float>(p, stream); break;
+            case HIP_C_32F:  hipLaunchKernelGGL(reduce_generic_cplx_kernel<float>, dim3((p.kept.total + 255u) / 256u, p.splitR), dim3(256), 0, stream, p); break;
+            case HIP_C_64F:  hipLaunchKernelGGL(reduce_generic_cplx_kernel<double>, dim3((p.kept.total + 255u) / 256u, p.splitR), dim3(256), 0, stream, p); break;
             default: return hipErrorInvalidValue;
         }
     } else {
@@ -259,6 +319,8 @@ hipError_t launch_reduce_finalize(const ReduceParams& p, int dtype, bool acc64, 
         case HIP_R_64F:  launch_finalize_t<double, double>(p, stream); break;
         case HIP_R_16F:  launch_finalize_t<__half, float>(p, stream); break;
         case HIP_R_16BF: launch_finalize_t<__hip_bfloat16, float>(p, stream); break;
+        case HIP_C_32F:  hipLaunchKernelGGL(reduce_finalize_cplx_kernel<float>, dim3((p.kept.total + 255u) / 256u), dim3(256), 0, stream, p); break;
+        case HIP_C_64F:  hipLaunchKernelGGL(reduce_finalize_cplx_kernel<double>, dim3((p.kept.total + 255u) / 256u), dim3(256), 0, stream, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -140,11 +140,11 @@ def contraction_plan(handle, extA, modesA, extB, modesB, extC, modesC, dtype=ct.
 
 
 def reduction_plan(handle, extA, modesA, extC, modesC, dtype=ct.R_32F, strideA=None, strideC=None,
-                   op_reduce=ct.OP_ADD, compute=None, alignment=128, **plan_kw):
+                   op_reduce=ct.OP_ADD, compute=None, alignment=128, opA=ct.OP_IDENTITY, opC=ct.OP_IDENTITY, **plan_kw):
     dA, dC = _desc3(handle, [(extA, strideA), (extC, strideC)], dtype, alignment)
     op = ctypes.c_void_p()
-    st = ct.cutensorCreateReduction(handle.h, ctypes.byref(op), dA, ct.i32(modesA), ct.OP_IDENTITY, dC, ct.i32(modesC),
-                                    ct.OP_IDENTITY, dC, ct.i32(modesC), op_reduce,
+    st = ct.cutensorCreateReduction(handle.h, ctypes.byref(op), dA, ct.i32(modesA), opA, dC, ct.i32(modesC),
+                                    opC, dC, ct.i32(modesC), op_reduce,
                                     ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
     ct.cutensorDestroyTensorDescriptor(dA)
     ct.cutensorDestroyTensorDescriptor(dC)
@@ -153,12 +153,12 @@ def reduction_plan(handle, extA, modesA, extC, modesC, dtype=ct.R_32F, strideA=N
 
 
 def permutation_plan(handle, extA, modesA, extB, modesB, dtype=ct.R_32F, strideA=None, strideB=None,
-                     compute=None, alignment=128, padding=None, **plan_kw):
+                     compute=None, alignment=128, padding=None, opA=ct.OP_IDENTITY, **plan_kw):
     """padding = (left[], right[], value): CUTENSOR_OPERATION_DESCRIPTOR_PADDING_* per output mode
     (elementwise_permute_padding.cu:178-195); the output buffer then holds extB + left + right per mode."""
     dA, dB = _desc3(handle, [(extA, strideA), (extB, strideB)], dtype, alignment)
     op = ctypes.c_void_p()
-    st = ct.cutensorCreatePermutation(handle.h, ctypes.byref(op), dA, ct.i32(modesA), ct.OP_IDENTITY, dB, ct.i32(modesB),
+    st = ct.cutensorCreatePermutation(handle.h, ctypes.byref(op), dA, ct.i32(modesA), opA, dB, ct.i32(modesB),
                                       ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
     ct.cutensorDestroyTensorDescriptor(dA)
     ct.cutensorDestroyTensorDescriptor(dB)
@@ -176,12 +176,13 @@ def permutation_plan(handle, extA, modesA, extB, modesB, dtype=ct.R_32F, strideA
     return Plan(handle, op, "permutation", dtype, **plan_kw)
 
 
-def binary_plan(handle, extA, modesA, extC, modesC, op="ADD", dtype=ct.R_32F, compute=None, alignment=128, **plan_kw):
+def binary_plan(handle, extA, modesA, extC, modesC, op="ADD", dtype=ct.R_32F, compute=None, alignment=128, opA=ct.OP_IDENTITY,
+                opC=ct.OP_IDENTITY, **plan_kw):
     """D = op(alpha * perm(A), gamma * C) — cutensorCreateElementwiseBinary (elementwise_binary.cu:149-153)."""
     dA, dC = _desc3(handle, [(extA, None), (extC, None)], dtype, alignment)
     opd = ctypes.c_void_p()
-    st = ct.cutensorCreateElementwiseBinary(handle.h, ctypes.byref(opd), dA, ct.i32(modesA), ct.OP_IDENTITY, dC, ct.i32(modesC),
-                                            ct.OP_IDENTITY, dC, ct.i32(modesC), _OPS[op],
+    st = ct.cutensorCreateElementwiseBinary(handle.h, ctypes.byref(opd), dA, ct.i32(modesA), opA, dC, ct.i32(modesC),
+                                            opC, dC, ct.i32(modesC), _OPS[op],
                                             ct.compute_desc(compute or _DTYPE_COMPUTE[dtype]))
     ct.cutensorDestroyTensorDescriptor(dA)
     ct.cutensorDestroyTensorDescriptor(dC)

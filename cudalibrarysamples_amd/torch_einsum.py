@@ -11,7 +11,7 @@ import torch
 from . import cutensor as ct
 
 _TORCH2CT = {torch.float32: ct.R_32F, torch.float64: ct.R_64F, torch.float16: ct.R_16F, torch.bfloat16: ct.R_16BF,
-             torch.complex64: ct.C_32F, torch.complex128: ct.C_64F}   # complex: binary contractions only
+             torch.complex64: ct.C_32F, torch.complex128: ct.C_64F}   # complex: contractions, and unary equations (reduce / permute)
 
 _handle = None
 

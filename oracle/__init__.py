@@ -110,23 +110,32 @@ def contract(A, modesA, B, modesB, D, modesD, alpha=1.0, beta=0.0, C=None, acc64
 OP_ADD, OP_MUL, OP_MAX, OP_MIN = 3, 5, 6, 7
 
 
-def reduce(A, modesA, D, modesD, alpha=1.0, beta=0.0, C=None, op=OP_ADD):
+def reduce(A, modesA, D, modesD, alpha=1.0, beta=0.0, C=None, op=OP_ADD, conjA=False, conjC=False):
+    """D[modesD] = alpha * reduce_op over the modes of A missing from D + beta * C.  Complex tensors (complex64 / complex128:
+    what python/einsum.h:326-343 hands to cutensorCreateReduction for a unary equation) take complex alpha / beta and the
+    conjugation flags; op is ADD or MUL there."""
     if C is None:
         C = D
-    fn = {np.dtype(np.float32): lib().oracle_reduce_f32, np.dtype(np.float64): lib().oracle_reduce_f64}[A.dtype]
     nA, mA, eA, sA = _desc(A, modesA)
     nC, mC, eC, sC = _desc(C, modesD)
     _, _, _, sD = _desc(D, modesD)
-    fn.restype = ctypes.c_int
-    rc = fn(nA, mA, eA, sA, _ptr(A), nC, mC, eC, sC, _ptr(C), sD, _ptr(D), ctypes.c_double(alpha),
-            ctypes.c_double(beta), int(op))
+    if np.issubdtype(A.dtype, np.complexfloating):
+        fn = {np.dtype(np.complex64): lib().oracle_reduce_c32, np.dtype(np.complex128): lib().oracle_reduce_c64}[A.dtype]
+        fn.restype = ctypes.c_int
+        a, b = complex(alpha), complex(beta)
+        rc = fn(nA, mA, eA, sA, _ptr(A), int(bool(conjA)), nC, mC, eC, sC, _ptr(C), int(bool(conjC)), sD, _ptr(D),
+                ctypes.c_double(a.real), ctypes.c_double(a.imag), ctypes.c_double(b.real), ctypes.c_double(b.imag), int(op))
+    else:
+        fn = {np.dtype(np.float32): lib().oracle_reduce_f32, np.dtype(np.float64): lib().oracle_reduce_f64}[A.dtype]
+        fn.restype = ctypes.c_int
+        rc = fn(nA, mA, eA, sA, _ptr(A), nC, mC, eC, sC, _ptr(C), sD, _ptr(D), ctypes.c_double(alpha),
+                ctypes.c_double(beta), int(op))
     if rc != 0:
         raise RuntimeError("oracle_reduce failed: %d" % rc)
     return D
 
 
-def permute(A, modesA, B, modesB, alpha=1.0, C=None, gamma=0.0):
-    fn = {np.dtype(np.float32): lib().oracle_permute_f32, np.dtype(np.float64): lib().oracle_permute_f64}[A.dtype]
+def permute(A, modesA, B, modesB, alpha=1.0, C=None, gamma=0.0, conjA=False):
     nA, mA, eA, sA = _desc(A, modesA)
     nB, mB, eB, sB = _desc(B, modesB)
     if C is not None:
@@ -134,9 +143,17 @@ def permute(A, modesA, B, modesB, alpha=1.0, C=None, gamma=0.0):
         cp = _ptr(C)
     else:
         sC, cp = None, None
-    fn.restype = ctypes.c_int
-    rc = fn(nA, mA, eA, sA, _ptr(A), nB, mB, eB, sB, _ptr(B), ctypes.c_double(alpha), cp, sC,
-            ctypes.c_double(gamma))
+    if np.issubdtype(A.dtype, np.complexfloating):
+        fn = {np.dtype(np.complex64): lib().oracle_permute_c32, np.dtype(np.complex128): lib().oracle_permute_c64}[A.dtype]
+        fn.restype = ctypes.c_int
+        a, g = complex(alpha), complex(gamma)
+        rc = fn(nA, mA, eA, sA, _ptr(A), int(bool(conjA)), nB, mB, eB, sB, _ptr(B), ctypes.c_double(a.real), ctypes.c_double(a.imag),
+                cp, sC, ctypes.c_double(g.real), ctypes.c_double(g.imag))
+    else:
+        fn = {np.dtype(np.float32): lib().oracle_permute_f32, np.dtype(np.float64): lib().oracle_permute_f64}[A.dtype]
+        fn.restype = ctypes.c_int
+        rc = fn(nA, mA, eA, sA, _ptr(A), nB, mB, eB, sB, _ptr(B), ctypes.c_double(alpha), cp, sC,
+                ctypes.c_double(gamma))
     if rc != 0:
         raise RuntimeError("oracle_permute failed: %d" % rc)
     return B

@@ -233,9 +233,11 @@ def test_many_mode_and_complex_contractions_are_accepted(ct, ops):
     ct.check(ct.cutensorEstimateWorkspaceSize(h.h, op, None, ct.WORKSPACE_DEFAULT, ctypes.byref(est)))
     assert est.value == 0                           # the mode-table kernel needs no workspace
     ct.cutensorDestroyOperationDescriptor(op)
-    # complex element-wise operations are not served
+    # complex element-wise operations are served since round 5 (test_complex_reductions_and_permutations_plan); 25 identically
+    # ordered extent-2 modes fuse into one
     p = ctypes.c_void_p()
-    assert ct.cutensorCreatePermutation(h.h, ctypes.byref(p), dA, ct.i32(mA), ct.OP_IDENTITY, dA, ct.i32(mA), ct.compute_desc("32F")) == 15
+    assert ct.cutensorCreatePermutation(h.h, ctypes.byref(p), dA, ct.i32(mA), ct.OP_IDENTITY, dA, ct.i32(mA), ct.compute_desc("32F")) == 0
+    ct.cutensorDestroyOperationDescriptor(p)
 
 
 def test_blocksparse_descriptor_validation(ct, ops):
@@ -339,3 +341,28 @@ def test_every_extern_c_entry_point_is_a_function_try_block():
             if not re.search(r"\) try \{", lines[j]):
                 missing.append((rel, m.group(1)))
     assert seen >= 80 and not missing, (seen, missing)
+
+
+def test_complex_reductions_and_permutations_plan(ct, ops):
+    """Planning only (no GPU): complex64 / complex128 reductions, permutations and the binary element-wise form are accepted (round 5:
+    python/einsum.h:326-343 routes a unary einsum on complex tensors to cutensorCreateReduction), the scalar type is the data type,
+    split-reduction partials are (re, im) pairs in the data's precision, MAX / MIN and the trinary form stay NOT_SUPPORTED."""
+    h = ops.Handle()
+    for dt, es in ((ct.C_32F, 8), (ct.C_64F, 16)):
+        p = ops.permutation_plan(h, [50, 64], "ij", [64, 50], "ji", dtype=dt)
+        assert p.scalar_type == dt and p.describe()["variant"] == 2          # EW_GENERIC: one (re, im) pair per lane
+        p.destroy()
+        r = ops.reduction_plan(h, [4096, 6], "ab", [6], "b", dtype=dt, opA=ct.OP_CONJ)
+        assert r.scalar_type == dt and r.required_workspace % (6 * es) == 0 and r.required_workspace > 0   # [splitR][kept] pairs
+        assert r.required_workspace <= r.workspace_estimate
+        r.destroy()
+        r = ops.reduction_plan(h, [20, 50, 30], "kji", [30, 20], "ik", dtype=dt)           # the binding's "ijk->ik" after reversal
+        r.destroy()
+        with pytest.raises(RuntimeError):
+            ops.reduction_plan(h, [8, 8], "ab", [8], "a", dtype=dt, op_reduce=ct.OP_MAX)
+        with pytest.raises(RuntimeError):
+            ops.binary_plan(h, [8, 8], "ab", [8, 8], "ba", op="MIN", dtype=dt)
+        b = ops.binary_plan(h, [8, 8], "ab", [8, 8], "ba", op="MUL", dtype=dt)
+        b.destroy()
+    # CONJ on real data is the identity, not an error
+    ops.reduction_plan(h, [64, 8], "ab", [8], "b", opA=ct.OP_CONJ).destroy()

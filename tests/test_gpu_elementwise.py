@@ -285,3 +285,126 @@ def test_bandwidth_config_at_true_size_2048_cubed(env):
     p.destroy()
     del A, At, R, ref, got
     torch.cuda.empty_cache()
+
+
+# ---- complex reductions / permutations (round 5) -------------------------------------------------------------------------------
+# What the reference's binding runs for a unary einsum on complex tensors: python/einsum.h:326-343 (cutensorCreateReduction, OP_ADD),
+# :430-441 (cutensorReduce); torch/einsum.cc:83 dispatches the complex types; einsum.cu:346-372.  Against the oracle's complex entry
+# points (pinned to numpy in tests/test_oracle.py).  complex64 rtol 2e-5 of the magnitude sum, complex128 1e-12.
+def _cplx(ext, seed, np_dt):
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(ext)) if len(ext) else 1
+    flat = ((rng.random(n) * 2 - 1) + 1j * (rng.random(n) * 2 - 1)).astype(np_dt)
+    return np.reshape(flat, tuple(ext), order="F") if len(ext) else flat.reshape(())
+
+
+def _cdev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr.ravel(order="F")).copy()).cuda()
+
+
+CPLX = {"complex64": (np.complex64, "C_32F", 2e-5), "complex128": (np.complex128, "C_64F", 1e-12)}
+
+
+@pytest.mark.parametrize("dtype", sorted(CPLX))
+@pytest.mark.parametrize("case", [
+    (dict(a=33, b=17, c=5), "abc", "cab"),
+    (dict(a=128, b=20, c=68), "abc", "cba"),
+    (dict(i=50, j=64), "ij", "ji"),                # the unary einsum "ji->ij" of the reference's binding
+    (dict(a=257), "a", "a"),
+])
+def test_complex_permutation(env, dtype, case):
+    ct, ops, h, torch = env
+    np_dt, cname, rtol = CPLX[dtype]
+    ext, mA, mB = case
+    eA, eB = [ext[c] for c in mA], [ext[c] for c in mB]
+    A = _cplx(eA, 61, np_dt)
+    dA = _cdev(torch, A)
+    for alpha, conj in ((1.0, False), (0.75 - 1.5j, False), (1j, True)):
+        p = ops.permutation_plan(h, eA, mA, eB, mB, dtype=getattr(ct, cname), opA=ct.OP_CONJ if conj else ct.OP_IDENTITY)
+        dB = torch.zeros(int(np.prod(eB)), dtype=dA.dtype, device="cuda")
+        p.permute(alpha, dA.data_ptr(), dB.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ref = np.zeros(eB, dtype=np_dt, order="F")
+        oracle.permute(A, mA, ref, mB, alpha=alpha, conjA=conj)
+        got = np.reshape(dB.cpu().numpy(), eB, order="F")
+        if alpha == 1.0:
+            assert np.array_equal(got, ref), (mA, mB)          # pure data movement: bit-exact
+        else:
+            np.testing.assert_allclose(got, ref, rtol=rtol * 4, atol=rtol * 4)
+        p.destroy()
+
+
+@pytest.mark.parametrize("dtype", sorted(CPLX))
+@pytest.mark.parametrize("case", [
+    (dict(m=40, h=16, k=8, v=12), "mhkv", "mv"),
+    (dict(a=64, b=40, c=24), "abc", "ac"),         # the unary einsum "cba->ca" of the reference's binding
+    (dict(a=64, b=40, c=24), "abc", "c"),
+    (dict(a=4096, b=6), "ab", "b"),                # few kept elements: the reduced range is split over workgroups + finalize
+    (dict(a=64, b=48), "ab", ""),                  # full reduction to a scalar
+])
+def test_complex_reduction(env, dtype, case):
+    ct, ops, h, torch = env
+    np_dt, cname, rtol = CPLX[dtype]
+    ext, mA, mC = case
+    eA, eC = [ext[c] for c in mA], [ext[c] for c in mC]
+    A, C = _cplx(eA, 71, np_dt), _cplx(eC, 72, np_dt)
+    dA, dC = _cdev(torch, A), _cdev(torch, C)
+    for alpha, beta, cA, cC in ((1.0, 0.0, False, False), (1.1 - 0.3j, 0.5j, False, False), (-1j, 2.0, True, True)):
+        p = ops.reduction_plan(h, eA, mA, eC, mC, dtype=getattr(ct, cname), opA=ct.OP_CONJ if cA else ct.OP_IDENTITY,
+                               opC=ct.OP_CONJ if cC else ct.OP_IDENTITY)
+        assert p.required_workspace <= p.workspace_estimate
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        dD = dC.clone()
+        p.reduce(alpha, dA.data_ptr(), beta, dD.data_ptr(), dD.data_ptr(), ws.data_ptr(), p.required_workspace, 0)
+        torch.cuda.synchronize()
+        ref = np.zeros_like(C)
+        oracle.reduce(A, mA, ref, mC, alpha=alpha, beta=beta, C=C, conjA=cA, conjC=cC)
+        got = np.reshape(dD.cpu().numpy(), eC, order="F") if len(eC) else dD.cpu().numpy().reshape(())
+        mag = abs(alpha) * np.abs(A).sum() / max(C.size, 1) + abs(beta) * np.abs(C).max() + 1.0
+        np.testing.assert_allclose(got, ref, rtol=0, atol=rtol * mag * 4)
+        p.destroy()
+
+
+def test_complex_product_reduction_and_binary_forms(env):
+    """OP_MUL over a short reduced mode, and cutensorElementwiseBinaryExecute D = alpha conj(perm(A)) (+ | *) gamma C on complex data;
+    MAX / MIN are refused (not defined on complex numbers), the trinary element-wise form stays NOT_SUPPORTED."""
+    ct, ops, h, torch = env
+    np_dt = np.complex128
+    A = _cplx([6, 5, 7], 81, np_dt)
+    dA = _cdev(torch, A)
+    p = ops.reduction_plan(h, [6, 5, 7], "abc", [6, 7], "ac", dtype=ct.C_64F, op_reduce=ct.OP_MUL)
+    dD = torch.zeros(42, dtype=torch.complex128, device="cuda")
+    p.reduce(1.0, dA.data_ptr(), 0.0, dD.data_ptr(), dD.data_ptr(), 0, 0, 0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(np.reshape(dD.cpu().numpy(), [6, 7], order="F"), A.prod(axis=1), rtol=1e-12, atol=1e-12)
+    C = _cplx([7, 6, 5], 82, np_dt)
+    for op, fn in (("ADD", lambda x, y: x + y), ("MUL", lambda x, y: x * y)):
+        b = ops.binary_plan(h, [6, 5, 7], "abc", [7, 6, 5], "cab", op=op, dtype=ct.C_64F, opA=ct.OP_CONJ)
+        dC = _cdev(torch, C)
+        b.binary(0.5 + 1j, dA.data_ptr(), -2j, dC.data_ptr(), dC.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ref = fn((0.5 + 1j) * np.conj(np.transpose(A, (2, 0, 1))), -2j * C)
+        np.testing.assert_allclose(np.reshape(dC.cpu().numpy(), [7, 6, 5], order="F"), ref, rtol=1e-12, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        ops.reduction_plan(h, [6, 5, 7], "abc", [6, 7], "ac", dtype=ct.C_64F, op_reduce=ct.OP_MAX)
+    with pytest.raises(RuntimeError):
+        ops.binary_plan(h, [6, 5, 7], "abc", [7, 6, 5], "cab", op="MAX", dtype=ct.C_32F)
+
+
+def test_complex_unary_einsum_through_the_torch_front_end(env):
+    """cudalibrarysamples_amd.torch_einsum on complex tensors with ONE operand: permutation and reduction, forward and (for the
+    permutation) backward, against torch.einsum at the reference's tolerance (einsum_test.py:35-42)."""
+    ct, ops, h, torch = env
+    from cudalibrarysamples_amd import torch_einsum as te
+    torch.manual_seed(0)
+    for dt in (torch.complex64, torch.complex128):
+        z = torch.randn(12, 50, 20, dtype=dt, device="cuda", requires_grad=True)
+        for eq in ("ijk->kji", "ijk->ik", "ijk->", "ijk->j"):
+            got = te.einsum(eq, z.detach())
+            torch.testing.assert_close(got, torch.einsum(eq, z.detach()), rtol=5e-3, atol=6e-3)
+        out = te.EinsumFunction.apply("ijk->kij", z)
+        g = torch.randn_like(out)
+        out.backward(g)
+        zr = z.detach().clone().requires_grad_(True)
+        torch.einsum("ijk->kij", zr).backward(g)
+        torch.testing.assert_close(z.grad, zr.grad, rtol=5e-3, atol=6e-3)

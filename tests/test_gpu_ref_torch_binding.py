@@ -137,3 +137,31 @@ def test_reference_binding_bf16(ref_test_module):
     ref = torch.einsum("mlik,lkjm->lij", a.double(), b.double())
     # K = 20*50 terms of N(0,1) products: |ref| ~ 32; bf16 output rounding 2^-8 relative
     torch.testing.assert_close(got.double(), ref, rtol=1e-2, atol=0.25)
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_reference_binding_complex_unary_equations(ref_test_module, dtype):
+    """Unary equations on complex tensors THROUGH THE REFERENCE'S UNMODIFIED BINDING: torch/einsum.cc:83 dispatches the complex types
+    for every form, python/einsum.h:326-343 turns a one-operand equation into cutensorCreateReduction(OP_ADD) and :430-441 into
+    cutensorReduce (einsum.cu:346-372) — a permutation ("ij->ji"), a reduction ("ijk->ik"), a full reduction, and EinsumGeneral with
+    its unary step (einsum.py:139-150).  Against torch.einsum at the reference's own tolerance (einsum_test.py:35-42); the
+    permutation also backward (its gradient is the inverse permutation; a reduction's gradient is a broadcast, which the
+    reference's unary path does not express either)."""
+    import torch
+    import cutensor.torch as ct
+    tdt = getattr(torch, dtype)
+    torch.manual_seed(0)
+    z2 = torch.randn(50, 64, dtype=tdt, device="cuda", requires_grad=True)
+    z3 = torch.randn(20, 50, 30, dtype=tdt, device="cuda")
+    tol = dict(rtol=5e-3, atol=6e-3)
+    out = ct.EinsumFunction.apply("ij->ji", z2)
+    torch.testing.assert_close(out, torch.einsum("ij->ji", z2.detach()), **tol)
+    g = torch.randn_like(out)
+    out.backward(g)
+    torch.testing.assert_close(z2.grad, g.t().contiguous(), **tol)
+    for eq in ("ijk->ik", "ijk->kji", "ijk->", "ijk->j"):
+        torch.testing.assert_close(ct.EinsumFunction.apply(eq, z3), torch.einsum(eq, z3), **tol)
+    torch.testing.assert_close(ct.EinsumGeneral("ijk->ki", z3), torch.einsum("ijk->ki", z3), **tol)
+    # a binary step followed by nothing unary, for completeness of the N-ary path on complex data
+    w = torch.randn(30, 8, dtype=tdt, device="cuda")
+    torch.testing.assert_close(ct.EinsumGeneral("ijk,kl->il", z3, w), torch.einsum("ijk,kl->il", z3, w), **tol)

@@ -148,6 +148,36 @@ def test_complex_contraction_with_conjugation():
     np.testing.assert_allclose(D, ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
+def test_complex_reduction_and_permutation(dt):
+    """What the reference's binding runs for a unary equation on complex tensors (python/einsum.h:326-343,430-441: cutensorCreateReduction
+    with OP_ADD + cutensorReduce; torch/einsum.cc:83 dispatches the complex types): the oracle's complex entry points against numpy."""
+    rng = np.random.default_rng(5)
+    def cplx(shape):
+        return np.asfortranarray((rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt))
+    tol = dict(rtol=2e-5, atol=2e-5) if dt is np.complex64 else dict(rtol=1e-12, atol=1e-12)
+    A, C = cplx((7, 5, 3, 4)), cplx((7, 4))
+    D = np.zeros_like(C)
+    oracle.reduce(A, "mhkv", D, "mv", alpha=1.1 - 0.3j, beta=0.5j, C=C)
+    np.testing.assert_allclose(D, (1.1 - 0.3j) * A.astype(np.complex128).sum(axis=(1, 2)) + 0.5j * C, **tol)
+    oracle.reduce(A, "mhkv", D, "mv", conjA=True, beta=2.0, C=C, conjC=True)
+    np.testing.assert_allclose(D, np.conj(A.astype(np.complex128)).sum(axis=(1, 2)) + 2.0 * np.conj(C), **tol)
+    Dm = np.zeros_like(C)
+    oracle.reduce(A[:, :2, :2, :], "mhkv", Dm, "mv", op=oracle.OP_MUL)
+    np.testing.assert_allclose(Dm, A[:, :2, :2, :].astype(np.complex128).prod(axis=(1, 2)), **tol)
+    P = np.zeros((3, 7, 5, 4), dtype=dt, order="F")
+    oracle.permute(A, "whcn", P, "cwhn", alpha=1.5 + 2j)
+    np.testing.assert_allclose(P, (1.5 + 2j) * np.transpose(A, (2, 0, 1, 3)), **tol)
+    Q = cplx((3, 7, 5, 4))
+    Q0 = Q.copy()
+    oracle.permute(A, "whcn", Q, "cwhn", alpha=1j, C=Q, gamma=-1.0, conjA=True)
+    np.testing.assert_allclose(Q, 1j * np.conj(np.transpose(A, (2, 0, 1, 3))) - Q0, **tol)
+    # the framework-level helper: unary equations go to the reduction entry point (einsum.cu:346-372)
+    z = (rng.standard_normal((4, 6, 5)) + 1j * rng.standard_normal((4, 6, 5))).astype(dt)
+    np.testing.assert_allclose(oracle.einsum("ijk->ik", z), np.einsum("ijk->ik", z.astype(np.complex128)), **tol)
+    np.testing.assert_allclose(oracle.einsum("ij->ji", z[0]), z[0].T, **tol)
+
+
 def test_naive_fp32_loop_is_the_literal_triple_loop():
     """oracle_contract_f32_naive is the loop BASELINE.json names (fp32 accumulation in loop order): identical to a Python
     restatement of that loop on a tiny case, and within fp32 round-off of the fp64-accumulating oracle."""
