@@ -404,6 +404,8 @@ __device__ __forceinline__ void x_store_interior16(f32x4 (&acc)[FI][FJ], uint16_
 // 1 plain instead of nontemporal stores in the epilogue, 3 always the fp32 LDS image (the general path) instead of the 16-bit one,
 // 4 the fragment reads of a k-step issued in its first eight groups (main loop 2280 -> 2415 cycles per K-tile), 5 first-round
 // workgroups start staggered (epilogue 16.4k -> 15.8k cycles, rate unchanged) — profiles/r04n_w4x_variants.jsonl.
+// XST = 8 / 9 / 10 (round 5, ZERO-FILLED operands only: the results are wrong on any other data — the tile barrier loses its
+// vmcnt(0) / its s_barrier / both): what of the 2280 - 2048 cycles per K-tile is data latency and what is wave skew.
 template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
@@ -529,8 +531,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     CTAMD_X_G0(P, 6) CTAMD_X_G0(P, 7) CTAMD_X_G0(P, 8) CTAMD_X_G0(P, 9) CTAMD_X_G0(P, 10) CTAMD_X_G0(P, 11)        \
     CTAMD_X_G0(P, 12) CTAMD_X_G0(P, 13) CTAMD_X_G0(P, 14) CTAMD_X_G0(P, 15)                                        \
     CTAMD_H_LGKM0();                                                                                               \
-    CTAMD_H_VMCNT(0);                                                                                              \
-    __builtin_amdgcn_s_barrier();                                                                                  \
+    if constexpr (XST != 8 && XST != 10) CTAMD_H_VMCNT(0);                                                         \
+    if constexpr (XST != 9 && XST != 10) __builtin_amdgcn_s_barrier();                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     CTAMD_X_G1(P, 0) CTAMD_X_G1(P, 1) CTAMD_X_G1(P, 2) CTAMD_X_G1(P, 3) CTAMD_X_G1(P, 4) CTAMD_X_G1(P, 5)          \
     CTAMD_X_G1(P, 6) CTAMD_X_G1(P, 7) CTAMD_X_G1(P, 8) CTAMD_X_G1(P, 9) CTAMD_X_G1(P, 10) CTAMD_X_G1(P, 11)        \
@@ -689,6 +691,9 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed && xst == 4) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 4>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed && xst == 5) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 5>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed && xst == 7) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 7>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 8) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 8>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 9) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 9>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && xst == 10) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 10>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
