@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layout", default="mk,kn")
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--only", default="", help="M,N,K: this shape only")
+    ap.add_argument("--only", default="", help="M,N,K[;M,N,K...]: these shapes only")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -26,7 +26,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda")
     g.manual_seed(1)
-    shapes = [tuple(int(x) for x in args.only.split(","))] if args.only else SHAPES
+    shapes = [tuple(int(x) for x in sh.split(",")) for sh in args.only.split(";")] if args.only else SHAPES
     for (M, N, K) in shapes:
         A = (torch.rand((M * K,), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
         B = (torch.rand((K * N,), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)

@@ -17,9 +17,7 @@ SH="2048,2048,2048;1024,1024,1024;4096,1024,4096;8192,8192,512;4096,4096,4096;20
 timeout 300 python tools/ubench/vendor_gemm_bf16.py --shapes "$SH" --reps 50 > $OUT/h16_mid_vendor.jsonl 2>/dev/null
 : > $OUT/h16_mid_engine.jsonl
 for L in mk,kn km,kn mk,nk; do
-  for S in 2048,2048,2048 1024,1024,1024 4096,1024,4096 8192,8192,512 4096,4096,4096 2048,2048,16384; do
-    timeout 120 python tools/h16_shape_sweep.py --layout $L --only $S --reps 50 2>/dev/null | tail -1 >> $OUT/h16_mid_engine.jsonl
-  done
+  timeout 300 python tools/h16_shape_sweep.py --layout $L --only "$SH" --reps 50 2>/dev/null >> $OUT/h16_mid_engine.jsonl
 done
 tail -3 $OUT/pytest_gpu.log
 cat $OUT/w4x_barrier_decomposition.jsonl | cut -c1-400
