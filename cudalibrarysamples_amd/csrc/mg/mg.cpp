@@ -129,6 +129,12 @@ struct cutensorMgHandle {
     std::vector<int32_t> devices;
     std::vector<cutensorHandle_t> handles;
     bool distinct = true;
+    // CUTENSORMG_AMD_FORCE_GATHER=1 at cutensorMgCreate (round 5): the operands are ALWAYS staged through the communication path — cells
+    // the computing device already holds travel to its own staging image by RCCL (one-rank ncclAllGather, or ncclSend / ncclRecv to
+    // itself) on the communication stream, the pieces read the staged image behind the wave event.  A communicator is created for
+    // ONE device too.  This is how the all-gather / event-graph code of contraction_multi_gpu.cu:286-345's path executes on a
+    // one-GPU box (tests/test_gpu_mg.py, bench.py's forced-gather line); no effect on results.
+    bool forceGather = false;
     bool haveDevice = false;         // false: no GPU visible — descriptors and plans only (CPU tests)
     std::vector<ncclComm_t> comms;   // one per handle device when distinct and > 1
     // execution resources, created on first use: [device][k]
@@ -154,6 +160,7 @@ struct cutensorMgContractionPlan {
     int numBoxes = 1;                          // local contractions per piece (> 1: a contracted mode is ragged)
     int peeled = 0;                            // how many times a digit of an oversized mode group was peeled into a host loop
     bool useRccl = false;
+    bool forceGather = false;     // handle created under CUTENSORMG_AMD_FORCE_GATHER=1: operands always staged through the communication path
     // events (created on first execution): per device {start, localReady, auxDone, commDone[k]...}, then one per (device, wave)
     std::vector<hipEvent_t> events;
     int evPerDevice = 0;
@@ -411,6 +418,7 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
     h->devices.assign(devices, devices + numDevices);
     std::set<int32_t> uniq(h->devices.begin(), h->devices.end());
     h->distinct = uniq.size() == h->devices.size();
+    h->forceGather = env_is("CUTENSORMG_AMD_FORCE_GATHER", "1");
     for (int32_t d : h->devices) {
         if (d < 0 || (count > 0 && d >= count)) { cutensorMgDestroy(h); return CUTENSOR_STATUS_INVALID_VALUE; }
         if (count > 0) (void)hipSetDevice(d);
@@ -421,7 +429,7 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
             for (int32_t o : uniq)
                 if (o != d) { (void)hipDeviceEnablePeerAccess(o, 0); (void)hipGetLastError(); }   // xGMI peer mapping
     }
-    if (count > 0 && h->distinct && numDevices > 1 && !env_is("CUTENSORMG_AMD_TRANSPORT", "peer")) {
+    if (count > 0 && h->distinct && (numDevices > 1 || h->forceGather) && !env_is("CUTENSORMG_AMD_TRANSPORT", "peer")) {
         h->comms.resize(numDevices);
         std::vector<int> devs(h->devices.begin(), h->devices.end());
         if (ncclCommInitAll(h->comms.data(), (int)numDevices, devs.data()) != ncclSuccess) h->comms.clear();
@@ -621,9 +629,10 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         ctrWs = std::min<uint64_t>(ctrWs, (uint64_t)(deviceWorkspaceSize[g] - fixed) / kComputeStreams / 256 * 256);
     }
     pl->contractionWs = ctrWs;
+    pl->forceGather = handle->forceGather;
     pl->useRccl = !handle->comms.empty() ||
                   // plan-only handles (no GPU visible): CPU tests of the RCCL event wiring and transport choice
-                  (!handle->haveDevice && handle->distinct && nDev > 1 && env_is("CUTENSORMG_AMD_ASSUME_RCCL", "1"));
+                  (!handle->haveDevice && handle->distinct && (nDev > 1 || handle->forceGather) && env_is("CUTENSORMG_AMD_ASSUME_RCCL", "1"));
 
     // ---- label universe, block-index digits per label ----------------------------------------------
     const MgTensor* T[3] = {&d.A, &d.B, &d.C};
@@ -827,7 +836,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             OperandUse& u = p.use[k];
             u.cells = cells_of(*T[k], *M[k], universe, radix, rs);
             u.direct = u.cells.size() == 1 && T[k]->devices[u.cells[0]] == handle->devices[p.dev] &&
-                       !env_is("CUTENSORMG_AMD_DIRECT", "0");
+                       !env_is("CUTENSORMG_AMD_DIRECT", "0") && !(handle->forceGather && k < 2);
             if (u.direct) { u.cell = u.cells[0]; continue; }
             staged[k] = true;
             for (int c : u.cells) {
@@ -837,7 +846,9 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
                 t.tensor = k; t.cell = c; t.dst = p.dev;
                 t.ownerDevice = T[k]->devices[c];
                 t.src = device_rank(handle, t.ownerDevice);
-                t.local = t.ownerDevice == handle->devices[p.dev];
+                // forced gather: an own cell of an operand is NOT a device copy on the caller's stream — it goes the remote way (RCCL
+                // to itself / a peer copy onto the same device) on the communication stream, with its wave event
+                t.local = t.ownerDevice == handle->devices[p.dev] && !(handle->forceGather && k < 2);
                 t.bytes = T[k]->cellElems * (int64_t)es;
                 have[key] = (int)pl->transfers.size();
                 pl->transfers.push_back(t);
@@ -902,12 +913,13 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         if (!staged[k]) pl->stagingBytes[k] = 0;
     // all-gather eligibility per tensor (a property of the layout; whether RCCL is there is a property of the handle)
     for (int k = 0; k < 2; ++k) {   // operands only: C is gathered only for beta != 0 and scattered back, never all-gathered
-        bool ok = handle->distinct && nDev > 1 && T[k]->numCells == nDev;
+        bool ok = handle->distinct && (nDev > 1 || handle->forceGather) && T[k]->numCells == nDev;
         for (int c = 0; ok && c < nDev; ++c) ok = T[k]->devices[(size_t)c] == handle->devices[(size_t)c];
         std::vector<int> remote((size_t)nDev, 0);
         for (const Transfer& t : pl->transfers)
             if (t.tensor == k && !t.local) { ++remote[(size_t)t.dst]; ok = ok && t.wave == 0; }
-        for (int g = 0; ok && g < nDev; ++g) ok = remote[(size_t)g] == nDev - 1;
+        // every device receives every cell it does not hold (forced gather: its own one too — the collective delivers all nDev anyway)
+        for (int g = 0; ok && g < nDev; ++g) ok = remote[(size_t)g] == (handle->forceGather ? nDev : nDev - 1);
         pl->allGatherEligible[k] = ok;
     }
     pl->transport = env_is("CUTENSORMG_AMD_TRANSPORT", "allgather") ? 1 : env_is("CUTENSORMG_AMD_TRANSPORT", "sendrecv") ? 2 : 0;
@@ -1522,7 +1534,7 @@ int ctamdMgDescribePlan(const cutensorMgContractionPlan_t plan, char* buf, size_
         s += "]";
     }
     s += "],";
-    add("\"p2Label\":%d,", plan->p2Label);
+    add("\"p2Label\":%d,\"forceGather\":%d,", plan->p2Label, (int)plan->forceGather);
     add("\"pLabel\":%d,\"qLabel\":%d,\"numWaves\":%d,\"useRccl\":%d,\"commStreams\":%d,\"contractionWs\":%llu,", plan->pLabel, plan->qLabel,
         plan->numWaves, (int)plan->useRccl, plan->commPerDevice, (unsigned long long)plan->contractionWs);
     add("\"stagingBytes\":[%lld,%lld,%lld],\"remoteBytes\":%lld,\"localCopyBytes\":%lld,\"pieces\":[", (long long)plan->stagingBytes[0],

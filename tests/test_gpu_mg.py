@@ -304,3 +304,50 @@ def test_mg_ragged_contracted_mode(mg, handle_devices, Ek, bs, dc):
         got = _gather_cells([t.cpu().numpy() for t in cellsC], (Ei, padj), (bi, bi), (dci, dci), np.float32)[:Ei, :Ej]
         assert np.isfinite(got).all()
         np.testing.assert_allclose(got, A.astype(np.float64) @ B.astype(np.float64) + beta * C, rtol=1e-4)
+
+
+@pytest.mark.parametrize("transport", ["allgather", "sendrecv", "peer", ""])
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+def test_mg_forced_gather_runs_rccl_and_the_event_graph_on_one_device(mg, monkeypatch, transport, beta):
+    """CUTENSORMG_AMD_FORCE_GATHER=1 on the ONE GPU of the box (round 5): cutensorMgCreate builds a one-rank RCCL communicator
+    (ncclCommInitAll), cutensorMgContraction runs the one-rank ncclAllGather / the ncclSend + ncclRecv pair to itself (or the
+    peer copy) on the communication stream into the staging image, records the wave event, the local contraction waits for it and
+    reads the STAGED operands, the caller's stream joins the communication stream at the end — the transport and event-graph code
+    of contraction_multi_gpu.cu:286-345's path, executed for real; the result must not change.  Three calls: the first two of the
+    automatic mode are its timed trials (all-gather, then send/recv), the third uses the winner."""
+    cm, torch = mg
+    monkeypatch.setenv("CUTENSORMG_AMD_FORCE_GATHER", "1")
+    if transport:
+        monkeypatch.setenv("CUTENSORMG_AMD_TRANSPORT", transport)
+    E = 512
+    rng = np.random.default_rng(23)
+    A = rng.random((E, E), dtype=np.float32)
+    B = rng.random((E, E), dtype=np.float32)
+    C = rng.random((E, E), dtype=np.float32)
+    modes = ["ik", "kj", "ij"]
+    with cm.Contraction([0], modes, dict(i=E, j=E, k=E), [dict(), dict(), dict()], [dict(), dict(), dict()]) as con:
+        d = con.describe()
+        assert d["forceGather"] == 1 and d["remoteBytes"] >= 2 * E * E * 4 and d["localCopyBytes"] == 0, d
+        assert d["useRccl"] == (0 if transport == "peer" else 1), d
+        assert all(not t["local"] and t["src"] == 0 and t["dst"] == 0 for t in d["transfers"] if t["tensor"] < 2)
+        assert all(p["wait"] and not p["use"][0]["direct"] and not p["use"][1]["direct"] for p in d["pieces"]), d["pieces"]
+        dev = [torch.from_numpy(np.ascontiguousarray(G.ravel(order="F"))).cuda() for G in (A, B, C)]
+        ws = [torch.empty(int(con.ws_sizes[0]), dtype=torch.uint8, device="cuda")]
+        ws[0].fill_(0xff)                                       # NaN patterns in the staging images: stale reads would show
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            dev[2].copy_(torch.from_numpy(np.ascontiguousarray(C.ravel(order="F"))))
+            if rep == 2:                                        # new operand values: the staging image must be refreshed by the gather
+                A = A[::-1].copy()
+                dev[0].copy_(torch.from_numpy(np.ascontiguousarray(A.ravel(order="F"))))
+            torch.cuda.synchronize()
+            cm.check(con.run(1.0, [dev[0].data_ptr()], [dev[1].data_ptr()], beta, [dev[2].data_ptr()], [dev[2].data_ptr()],
+                             [ws[0].data_ptr()], [stream.cuda_stream]))
+            stream.synchronize()                                # ONLY the caller's stream: the join must have put everything behind it
+            got = np.reshape(dev[2].cpu().numpy(), (E, E), order="F")
+            ref = A.astype(np.float64) @ B.astype(np.float64) + beta * C
+            np.testing.assert_allclose(got, ref, rtol=1e-4, err_msg="call %d, %s" % (rep, str(con.describe())[:300]))
+        d = con.describe()
+        if transport == "":
+            assert d["chosen"] in (0, 1, 2) and d["transport"].startswith("auto"), d

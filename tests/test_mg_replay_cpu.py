@@ -197,3 +197,29 @@ def test_a_missing_wait_is_detected(cm, monkeypatch):
         addr = [b.ctypes.data for b in z]
         rc, msg = cm.replay_on_host(con.plan, 1.0, addr, addr, 0.0, None, addr, lambda *a: 0)
         assert rc == -4 and "without having waited" in msg, (rc, msg)
+
+
+@pytest.mark.parametrize("n", [1, 2, 4])
+@pytest.mark.parametrize("transport", ["", "allgather", "sendrecv"])
+def test_forced_gather_stages_every_operand_cell_through_the_communication_path(cm, n, transport, monkeypatch):
+    """CUTENSORMG_AMD_FORCE_GATHER=1 (round 5: the mode that lets the RCCL all-gather and the wave-event graph of
+    contraction_multi_gpu.cu:286-345's path execute on a ONE-GPU box): no operand is read in place, cells the computing device holds
+    itself travel as remote transfers (source = destination rank) with a wave event the pieces wait for, a one-device plan is
+    all-gather eligible, and the result is unchanged (executed here by the host replay, ordering check included)."""
+    monkeypatch.setenv("CUTENSORMG_AMD_FORCE_GATHER", "1")
+    monkeypatch.setenv("CUTENSORMG_AMD_ASSUME_RCCL", "1")
+    if transport:
+        monkeypatch.setenv("CUTENSORMG_AMD_TRANSPORT", transport)
+    E = 32 * n
+    d, _ = run_case(cm, n, *free_mode_layout(n, E), beta=0.5 if n == 2 else 0.0, seed=70 + n)
+    assert d["forceGather"] == 1 and d["useRccl"] == 1
+    ops = [t for t in d["transfers"] if t["tensor"] < 2]
+    assert ops and all(not t["local"] and t["event"] >= 0 for t in ops)
+    assert any(t["src"] == t["dst"] for t in ops)                       # own cells go the remote way
+    assert all(not p["use"][0]["direct"] and not p["use"][1]["direct"] for p in d["pieces"])
+    assert all(p["wait"] for p in d["pieces"]), d["pieces"][0]
+    cell = E * (E // n) * 4
+    assert d["remoteBytes"] >= n * n * cell                            # all of B on every device (+ the A slabs)
+    assert d["allGatherEligible"][1] == 1
+    if n == 1:
+        assert d["allGatherEligible"] == [1, 1] and d["numWaves"] == 1
