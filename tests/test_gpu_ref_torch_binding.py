@@ -164,4 +164,4 @@ def test_reference_binding_complex_unary_equations(ref_test_module, dtype):
     torch.testing.assert_close(ct.EinsumGeneral("ijk->ki", z3), torch.einsum("ijk->ki", z3), **tol)
     # a binary step followed by nothing unary, for completeness of the N-ary path on complex data
     w = torch.randn(30, 8, dtype=tdt, device="cuda")
-    torch.testing.assert_close(ct.EinsumGeneral("ijk,kl->il", z3, w), torch.einsum("ijk,kl->il", z3, w), **tol)
+    torch.testing.assert_close(ct.EinsumGeneral("ijk,kl->ijl", z3, w), torch.einsum("ijk,kl->ijl", z3, w), **tol)
