@@ -1835,7 +1835,7 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
                           plan->gett.splitK, plan->gett.kPerSlice, plan->gett.nBlocks,
                           (unsigned long long)plan->requiredWorkspace, plan->choice.estimateUs, (int)plan->fusedFold,
                           (unsigned long long)plan->gett.xcdTiles,
-                          k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 2 ? "gett_gen_kernel" : plan->choice.family == 1 ? (tab[k].threads == 256 || tab[k].pf == 10 ? (tab[k].bk == 32 ? "gett_h16w4s_kernel" : tab[k].pf == 3 ? "gett_h16w4r_kernel" : tab[k].pf == 6 ? "gett_h16w4v_kernel" : tab[k].pf == 7 ? "gett_h16w4x_kernel" : tab[k].pf == 8 ? "gett_h16w4m_kernel" : tab[k].pf == 9 ? "gett_h16w4m4_kernel" : tab[k].pf == 10 ? "gett_h16w8m_kernel" : tab[k].pf == 11 ? "gett_h16w4q_kernel" : "gett_h16w4_kernel") : tab[k].pf == 4 ? "gett_h16s_kernel" : "gett_h16_kernel") : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
+                          k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 2 ? "gett_gen_kernel" : plan->choice.family == 1 ? (tab[k].threads == 256 || tab[k].pf == 10 ? (tab[k].bk == 32 ? "gett_h16w4s_kernel" : tab[k].pf == 3 ? "gett_h16w4r_kernel" : tab[k].pf == 6 ? "gett_h16w4v_kernel" : tab[k].pf == 7 ? "gett_h16w4x_kernel" : tab[k].pf == 8 ? "gett_h16w4m_kernel" : tab[k].pf == 9 ? "gett_h16w4m4_kernel" : tab[k].pf == 10 ? "gett_h16w8m_kernel" : tab[k].pf == 11 ? "gett_h16w4q_kernel" : tab[k].pf == 12 ? "gett_h16w4p_kernel" : "gett_h16w4_kernel") : tab[k].pf == 4 ? "gett_h16s_kernel" : "gett_h16_kernel") : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
         if (n > 0 && (size_t)n < len && plan->choice.family == 2 && k >= 0)
             n += std::snprintf(buf + n, len - n, ",\"orientA\":%d,\"orientB\":%d,\"vec\":%d,\"elem\":%d", tab[k].layA, tab[k].layB, tab[k].vec, tab[k].elem);

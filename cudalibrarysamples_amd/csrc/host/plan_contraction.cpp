@@ -406,6 +406,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4' && e[1] == 'v') return 40;
         if (e && e[0] == '4' && e[1] == 'x') return 48;
+        if (e && e[0] == '4' && e[1] == 'p') return 88;
         if (e && e[0] == '4' && e[1] == 'q') return 80;
         if (e && e[0] == '8' && e[1] == 'm') return 72;
         if (e && e[0] == '4' && e[1] == 'm' && e[2] == '4') return 64;
@@ -500,7 +501,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     int count = 0;
     (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
-    for (int other : {0, 48, 56, 64, 72, 80, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
+    for (int other : {0, 48, 88, 56, 64, 72, 80, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;

@@ -1405,10 +1405,10 @@ static const GettKernelInfo g_h16_table[] = {
 
 // entries 40..47: the four-wave kernel with the lean instruction stream (gett_h16v.hip), 48..55: its 16x16x32 form, 56..63: the
 // 128 x 128 mid-size sibling of that (two workgroups per CU), 64..71 / 72..79: that tile on a four-deep ring / with dedicated
-// data-moving waves, 80..87: the 64 x 64 tile; same order
+// data-moving waves, 80..87: the 64 x 64 tile, 88..95: the persistent 256 x 256 kernel (gett_h16p.hip, round 5); same order
 const GettKernelInfo* gett_h16_kernels(int* count) {
     constexpr int nHere = (int)(sizeof(g_h16_table) / sizeof(g_h16_table[0]));
-    struct All { GettKernelInfo e[nHere + 56]; int n; };
+    struct All { GettKernelInfo e[nHere + 56 + 8]; int n; };
     static const All all = [] {
         All a{};
         for (int i = 0; i < nHere; ++i) a.e[i] = g_h16_table[i];
@@ -1416,6 +1416,8 @@ const GettKernelInfo* gett_h16_kernels(int* count) {
         const GettKernelInfo* v = gett_h16v_kernels(&nv);
         a.n = nHere;
         for (int i = 0; i < nv && i < 56; ++i) a.e[a.n++] = v[i];
+        const GettKernelInfo* pk = gett_h16p_kernels(&nv);     // 88..95: the persistent 256 x 256 kernel (gett_h16p.hip)
+        for (int i = 0; i < nv && i < 8; ++i) a.e[a.n++] = pk[i];
         return a;
     }();
     *count = all.n;

@@ -1,0 +1,388 @@
+// gett_h16p.hip — gett_h16w4p_kernel (round 5): the PERSISTENT form of gett_h16w4x_kernel (gett_h16v.hip).
+//
+// Same tile (256 x 256 x 64), four waves (one per SIMD, a 128 x 128 quadrant = 8 x 8 accumulator fragments of
+// v_mfma_f32_16x16x32_{bf16,f16} from inline asm), LDS images, source-side swizzles, LDS-DMA staging, K odometer and main loop.
+// What changes is everything OUTSIDE the main loop — the 6.6 % of a workgroup's 313k cycles at 8192^3 (prologue 7.8k, epilogue
+// 12-13.7k; profiles/r05a_w4x_barrier_decomposition.jsonl) and more than half of them at 8192^2 x 512 — which the power-limited
+// clock gives back in full (MI355X guide, "DVFS give-back": an epilogue saving returns as throughput, a main-loop saving half):
+//   * one workgroup per CU walks the tiles (grid = min(tiles, CUs); tile ids in the XCD-grouped order of the one-tile kernel:
+//     workgroup w takes the ids w, w + grid, w + 2 grid, ... of xcd_remap's sequence, so an XCD keeps its 8 x 4 block of concurrent
+//     tiles).  For a tile that lies inside D (one M and one N mode, 16-byte lanes, beta = 0) the NEXT tile's setup (tile
+//     coordinates, staging tables, odometer) and the LDS-DMA of its first two K-tiles are issued BEFORE the epilogue of the current
+//     one: the 4.8k cycles a first K-tile takes to arrive behind a chip-wide burst, and the 3k of setup, run under the stores;
+//   * that epilogue does not use the operand ring (it is being refilled): a wave owns two 4-KiB images in the 32 KiB of LDS
+//     beyond the 128-KiB ring — 160 KiB in all — and works in eight passes of 16 rows;
+//   * the image is TRANSPOSED: an accumulator fragment holds, per lane, four consecutive ROWS of one column, so after two packed
+//     conversions (v_cvt_pk_bf16_f32) the lane's four values are 8 contiguous bytes of a column-major image [128 columns][16 rows]
+//     — ONE ds_write_b64 per fragment instead of four 2-byte writes — and the way out is ds_read_b64_tr_b16, the transposing read
+//     the main loop uses for free-contiguous operands: a 16-lane group fetches a [4 columns][16 rows] block and every lane receives
+//     four consecutive columns of its row; two reads = 16 bytes of a row of D = one nontemporal 16-byte store.  Per accumulator
+//     element: 1 accumulator read + 1/2 multiply + 1/2 conversion + 1/4 LDS write + 1/4 LDS read + 1/8 store = 2.6 instructions
+//     (gett_h16w4x_kernel: 4.25).  Image row of column c at 32 R(c) bytes, R(c) = c ^ 4 ((c >> 3) & 1); the 8-byte slot of rows
+//     4 s .. 4 s + 3 inside it at s ^ ((R >> 2) & 3): the ds_write_b64 of a 16-lane group and the transposing read of a 32-lane half
+//     both touch every bank once (replayed on the CPU: tests/test_h16p_epilogue_layout_cpu.py).
+// Every other tile (edges, beta != 0, strided D, split-K partials) takes the epilogues of gett_h16w4x_kernel, in the ring, and
+// stages the next tile afterwards.  Roofline and algorithmic bytes as in gett_h16.hip (MFMA bf16; 2 M N K flop).
+#include <type_traits>
+
+#include "gett_h16x_common.h"
+#include "gett_h16p_layout.h"
+
+namespace ctamd {
+
+constexpr int kPRingBytes  = 8 * kHalfBytes;   // two K-tiles of 64 KiB
+constexpr int kPImageBytes = kPImgBytes;       // one pass of a wave: 128 columns x 16 rows x 2 B (gett_h16p_layout.h)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// four consecutive rows of one column (an accumulator fragment's four registers, times alpha) -> four 16-bit values
+template <bool BF>
+__device__ __forceinline__ s16x4 p_round4(const f32x4& c, float alpha) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BF) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 lo = __builtin_convertvector(f32x2{alpha * c[0], alpha * c[1]}, bf16x2);
+        const bf16x2 hi = __builtin_convertvector(f32x2{alpha * c[2], alpha * c[3]}, bf16x2);
+        const uint32_t l = __builtin_bit_cast(uint32_t, lo), h = __builtin_bit_cast(uint32_t, hi);
+        return __builtin_bit_cast(s16x4, (unsigned long long)l | ((unsigned long long)h << 32));
+    } else {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const f16x2 lo = __builtin_convertvector(f32x2{alpha * c[0], alpha * c[1]}, f16x2);
+        const f16x2 hi = __builtin_convertvector(f32x2{alpha * c[2], alpha * c[3]}, f16x2);
+        const uint32_t l = __builtin_bit_cast(uint32_t, lo), h = __builtin_bit_cast(uint32_t, hi);
+        return __builtin_bit_cast(s16x4, (unsigned long long)l | ((unsigned long long)h << 32));
+    }
+#else
+    (void)c; (void)alpha; return s16x4{};
+#endif
+}
+
+template <bool BF, int LA, int LB>
+__global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[kPRingBytes + 8 * kPImageBytes];     // 160 KiB: the ring + two pass images per wave
+    prefetch_kernarg<(int)sizeof(GettParams)>();
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
+    constexpr int nRdA = (LA == LAY_K) ? 2 : 8, nRdB = (LB == LAY_K) ? 2 : 8;
+    uint32_t rdA[2][nRdA], rdB[2][nRdB];
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+        for (int x = 0; x < nRdA; ++x) {
+            rdA[P][x] = ldsBase + (uint32_t)((P * 4 + wr) * kHalfBytes) + (LA == LAY_K ? x_offK(lane, x) : x_offF(lane, x));
+            asm volatile("" : "+v"(rdA[P][x]));
+        }
+#pragma unroll
+        for (int x = 0; x < nRdB; ++x) {
+            rdB[P][x] = ldsBase + (uint32_t)((P * 4 + 2 + wc) * kHalfBytes) + (LB == LAY_K ? x_offK(lane, x) : x_offF(lane, x));
+            asm volatile("" : "+v"(rdB[P][x]));
+        }
+    }
+
+    // ---- the tile in flight ------------------------------------------------------------------------------------------------
+    HOperand<LA, 4, false, 1> oa;
+    HOperand<LB, 4, false, 1> ob;
+    VOdometer odo;
+    uint32_t m0 = 0, n0 = 0, slice = 0, l = 0;
+    int nTiles = 0;
+    // tile of virtual workgroup id VB_ (the one-tile kernel's blockIdx.x): coordinates, staging tables, K odometer.  The arguments come
+    // from a FRESH copy of the argument block and the lane index from the hardware, behind an opaque asm: nothing this block needs
+    // may stay live across the main loop (kept in registers "because it is used again" it would be ~150 SGPRs of mode tables and a
+    // dozen lane-derived VGPRs — spilled, and reloaded by v_readlane between the MFMAs)
+#define CTAMD_P_SETUP(VB_)                                                                                          \
+    {                                                                                                              \
+        GettParams ps_;                                                                                            \
+        h_reload_params(ps_);                                                                                      \
+        int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));                       \
+        asm volatile("" : "+v"(lane_));                                                                            \
+        const uint32_t tilesMN_ = ps_.tilesM * ps_.tilesN;                                                         \
+        const uint32_t tilesAll_ = tilesMN_ * ps_.gL.total;                                                        \
+        const uint32_t kTilesAll_ = ps_.gK.total / kHBK, tilesPerSlice_ = ps_.kPerSlice / kHBK;                    \
+        uint32_t id_ = xcd_remap((VB_), ps_.nBlocks);                                                              \
+        slice = VOdometer::sgpr(id_ / tilesAll_);                                                                  \
+        id_ -= slice * tilesAll_;                                                                                  \
+        l = VOdometer::sgpr(id_ / tilesMN_);                                                                       \
+        id_ -= l * tilesMN_;                                                                                       \
+        const uint32_t perGroup_ = 8u * ps_.tilesN;                                                                \
+        const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;                                    \
+        const uint32_t first_ = grp_ * 8u;                                                                         \
+        const uint32_t gsz_ = (ps_.tilesM - first_ < 8u) ? (ps_.tilesM - first_) : 8u;                             \
+        m0 = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);                                                   \
+        n0 = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                                            \
+        const uint32_t tile0_ = slice * tilesPerSlice_;                                                            \
+        nTiles = (int)VOdometer::sgpr((tile0_ + tilesPerSlice_ <= kTilesAll_) ? tilesPerSlice_ : (kTilesAll_ - tile0_)); \
+        oa.init(ps_.gM, ps_.gK.stride[0][0], m0, wave, lane_);                                                     \
+        ob.init(ps_.gN, ps_.gK.stride[1][0], n0, wave, lane_);                                                     \
+        const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.A) + group_offset<0>(ps_.gL, l)) + oa.base); \
+        const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.B) + group_offset<1>(ps_.gL, l)) + ob.base); \
+        odo.init(ps_.gK, tile0_ * kHBK, (uint32_t)nTiles, bA_, bB_);                                               \
+    }
+#define CTAMD_P_DMA(P, N, PAD)                                                                                      \
+    {                                                                                                              \
+        constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
+        constexpr uint32_t imm_ = (uint32_t)(((P) * 4 + q_) * kHalfBytes + i_ * 4096);                             \
+        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[q_][i_], waveLds);                      \
+        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[q_ - 2][i_], waveLds);                                   \
+    }
+#define CTAMD_P_DMA8(P, N0, PAD)                                                                                    \
+    CTAMD_P_DMA(P, (N0) + 0, PAD) CTAMD_P_DMA(P, (N0) + 1, PAD) CTAMD_P_DMA(P, (N0) + 2, PAD) CTAMD_P_DMA(P, (N0) + 3, PAD) \
+    CTAMD_P_DMA(P, (N0) + 4, PAD) CTAMD_P_DMA(P, (N0) + 5, PAD) CTAMD_P_DMA(P, (N0) + 6, PAD) CTAMD_P_DMA(P, (N0) + 7, PAD)
+    // K-tiles 0 and 1 of the tile just set up; the odometer stays on tile 1 (k-step 0 of tile t moves it to tile t + 2)
+#define CTAMD_P_ISSUE2()                                                                                            \
+    {                                                                                                              \
+        CTAMD_P_DMA8(0, 0, true) CTAMD_P_DMA8(0, 8, true)                                                          \
+        odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);                                                 \
+        CTAMD_P_DMA8(1, 0, true) CTAMD_P_DMA8(1, 8, true)                                                          \
+    }
+
+    f32x4 acc[8][8];
+    s16x8 a[2][8], b[2][8];                       // two register sets: k-step s uses set s
+#define CTAMD_P_READ(P, S, Q)                                                                                       \
+    {                                                                                                              \
+        if constexpr ((Q) < 8) {                                                                                   \
+            if constexpr (LB == LAY_K) b[S][Q] = v_read<LAY_K, 2048 * (Q)>(rdB[P][(S) % nRdB]);                    \
+            else b[S][Q] = v_read<LAY_F, 8192 * (S)>(rdB[P][(Q) % nRdB]);                                          \
+        } else {                                                                                                   \
+            if constexpr (LA == LAY_K) a[S][(Q) - 8] = v_read<LAY_K, 2048 * ((Q) - 8)>(rdA[P][(S) % nRdA]);        \
+            else a[S][(Q) - 8] = v_read<LAY_F, 8192 * (S)>(rdA[P][((Q) - 8) % nRdA]);                              \
+        }                                                                                                          \
+    }
+#define CTAMD_P_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
+    // k-step 0, group Q: one read of k-step 1 (same buffer) and four MFMAs; three of the groups carry the odometer
+#define CTAMD_P_G0(P, Q)                                                                                            \
+    CTAMD_P_READ(P, 1, Q)                                                                                          \
+    CTAMD_P_MFMA(0, 4 * (Q)) CTAMD_P_MFMA(0, 4 * (Q) + 1)                                                          \
+    if constexpr ((Q) == 2) odo.advance_a();                                                                       \
+    if constexpr ((Q) == 5) odo.advance_b();                                                                       \
+    if constexpr ((Q) == 8) odo.advance_event(p.gK);                                                               \
+    CTAMD_P_MFMA(0, 4 * (Q) + 2) CTAMD_P_MFMA(0, 4 * (Q) + 3)                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into
+    // this buffer, four MFMAs
+#define CTAMD_P_G1(P, Q)                                                                                            \
+    CTAMD_P_READ((P) ^ 1, 0, Q)                                                                                    \
+    CTAMD_P_MFMA(1, 4 * (Q)) CTAMD_P_MFMA(1, 4 * (Q) + 1)                                                          \
+    CTAMD_P_DMA(P, Q, false)                                                                                       \
+    CTAMD_P_MFMA(1, 4 * (Q) + 2) CTAMD_P_MFMA(1, 4 * (Q) + 3)                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define CTAMD_P_TILE(P)                                                                                             \
+    CTAMD_P_G0(P, 0) CTAMD_P_G0(P, 1) CTAMD_P_G0(P, 2) CTAMD_P_G0(P, 3) CTAMD_P_G0(P, 4) CTAMD_P_G0(P, 5)          \
+    CTAMD_P_G0(P, 6) CTAMD_P_G0(P, 7) CTAMD_P_G0(P, 8) CTAMD_P_G0(P, 9) CTAMD_P_G0(P, 10) CTAMD_P_G0(P, 11)        \
+    CTAMD_P_G0(P, 12) CTAMD_P_G0(P, 13) CTAMD_P_G0(P, 14) CTAMD_P_G0(P, 15)                                        \
+    CTAMD_H_LGKM0();                                                                                               \
+    CTAMD_H_VMCNT(0);                                                                                              \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_P_G1(P, 0) CTAMD_P_G1(P, 1) CTAMD_P_G1(P, 2) CTAMD_P_G1(P, 3) CTAMD_P_G1(P, 4) CTAMD_P_G1(P, 5)          \
+    CTAMD_P_G1(P, 6) CTAMD_P_G1(P, 7) CTAMD_P_G1(P, 8) CTAMD_P_G1(P, 9) CTAMD_P_G1(P, 10) CTAMD_P_G1(P, 11)        \
+    CTAMD_P_G1(P, 12) CTAMD_P_G1(P, 13) CTAMD_P_G1(P, 14) CTAMD_P_G1(P, 15)
+
+    uint32_t vb = blockIdx.x;                     // virtual workgroup id of the tile in flight
+    bool staged = false;                          // its first two K-tiles are already on their way (issued under the previous epilogue)
+    for (;;) {
+        if (!staged) {
+            CTAMD_P_SETUP(vb)
+            CTAMD_P_ISSUE2()
+        }
+        const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant of the tile about to be multiplied
+        const uint32_t tM0 = m0, tN0 = n0, curL = l, curSlice = slice;
+        const int curTiles = nTiles;
+        // K-tile 0 has landed: loads complete in issue order, so "at most 16 memory operations outstanding" leaves at most the 16
+        // pieces of K-tile 1 (and, from the second tile on, waits out the previous epilogue's stores, which were issued later)
+        CTAMD_H_VMCNT(16);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        CTAMD_P_READ(0, 0, 0) CTAMD_P_READ(0, 0, 1) CTAMD_P_READ(0, 0, 2) CTAMD_P_READ(0, 0, 3)
+        CTAMD_P_READ(0, 0, 4) CTAMD_P_READ(0, 0, 5) CTAMD_P_READ(0, 0, 6) CTAMD_P_READ(0, 0, 7)
+        CTAMD_P_READ(0, 0, 8) CTAMD_P_READ(0, 0, 9) CTAMD_P_READ(0, 0, 10) CTAMD_P_READ(0, 0, 11)
+        CTAMD_P_READ(0, 0, 12) CTAMD_P_READ(0, 0, 13) CTAMD_P_READ(0, 0, 14) CTAMD_P_READ(0, 0, 15)
+        int t = 0;
+        for (; t + 1 < curTiles; t += 2) { CTAMD_P_TILE(0) CTAMD_P_TILE(1) }
+        if (t < curTiles) { CTAMD_P_TILE(0) }
+        CTAMD_H_VMCNT(0);                         // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
+        x_acc_ready(acc);
+        // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake
+        const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const uint32_t nextVb = vb + gridDim.x;
+        GettParams pe;                            // the epilogue's arguments in one burst of scalar loads
+        h_reload_params(pe);
+        // (values read through the laundered argument pointer count as divergent for the compiler: what steers control flow is made
+        // wave-uniform again explicitly, or the K loop's scalar state would be given vector registers)
+        const bool more = VOdometer::sgpr(nextVb < pe.nBlocks ? 1u : 0u) != 0u;
+        // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
+        if (VOdometer::sgpr(pe.partial != nullptr ? 1u : 0u) != 0u) {   // split-K: fp32 partial tile, row-major [slice][l][m][n]; no LDS involved
+            const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
+            float* P = pe.partial + ((size_t)curSlice * pe.gL.total + curL) * (size_t)Mt * Nt;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
+                    if (m < Mt) {
+                        float* row = P + (size_t)m * Nt;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t n = nW + 16 * j + (laneE & 15);
+                            if (n < Nt) row[n] = acc[i][j][r];
+                        }
+                    }
+                }
+            if (!more) break;
+            __syncthreads();                      // every wave has finished reading the operand ring
+            vb = nextVb;
+            staged = false;
+            continue;
+        }
+        __syncthreads();                          // every wave has finished reading the operand ring
+        HEpilogue ep;
+        ep.init(pe, curL, lds, wave);
+        // workgroup-uniform: the whole tile inside D, one M and one N mode, 16-byte lanes, nothing to add
+        const bool fast = VOdometer::sgpr((ep.vecD && ep.beta == 0.f && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
+        if (fast) {
+            const int64_t sM = pe.gM.stride[1][0];
+            uint16_t* dst = ep.D + (int64_t)(mW + (uint32_t)(laneE & 15)) * sM + (int64_t)(nW + 8u * (uint32_t)(laneE >> 4));
+            const float alpha = ep.alpha;
+            if (more) {                           // the next tile's first two K-tiles arrive under this epilogue
+                vb = nextVb;
+                CTAMD_P_SETUP(vb)
+                CTAMD_P_ISSUE2()
+            }
+            // image offsets: gett_h16p_layout.h (replayed on the CPU by tests/harness/h16p_layout_harness.cpp)
+            char* const img = lds + kPRingBytes + wave * (2 * kPImageBytes);
+            char* const wPtr = img + p_img_write_off(laneE, 0);                 // fragment j: + 512 j
+            const char* const rPtr0 = img + p_img_read_off(laneE, 0, 0);        // iteration it: + 1024 it
+            const char* const rPtr1 = img + p_img_read_off(laneE, 0, 1);
+            typedef s16x8 __attribute__((address_space(1))) * PGlb8;            // D is device memory: global, not flat, stores
+            typedef s16x4 __attribute__((address_space(3))) * PLds4;
+            s16x8 v[2][4];
+#define CTAMD_P_FRAG(I, J)                                                                                          \
+            *reinterpret_cast<s16x4*>(wPtr + ((I) & 1) * kPImageBytes + 512 * (J)) = p_round4<BF>(acc[(I) < 8 ? (I) : 0][J], alpha);
+#define CTAMD_P_STORE(I, IT)                                                                                        \
+            __builtin_nontemporal_store(v[((I) - 1) & 1][IT], (PGlb8)(uintptr_t)(dst + 32 * (IT)));
+#define CTAMD_P_LOAD(I, IT)                                                                                         \
+            {                                                                                                      \
+                const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr0 + ((I) & 1) * kPImageBytes + 1024 * (IT))); \
+                const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr1 + ((I) & 1) * kPImageBytes + 1024 * (IT))); \
+                v[(I) & 1][IT] = s16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};             \
+            }
+            // pass I: the eight fragments of rows 16 I + [0, 16) go into image I & 1 while the four chunks of pass I - 1 (read out of
+            // the other image at the end of that pass) are stored, one per two fragments; then the chunks of pass I are read
+#define CTAMD_P_PASS(I)                                                                                             \
+            {                                                                                                      \
+                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 0) CTAMD_P_FRAG(I, 1) }                                   \
+                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 0) }                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 2) CTAMD_P_FRAG(I, 3) }                                   \
+                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 1) }                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 4) CTAMD_P_FRAG(I, 5) }                                   \
+                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 2) }                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 6) CTAMD_P_FRAG(I, 7) }                                   \
+                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 3) dst += 16 * sM; }                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                if constexpr ((I) < 8) { CTAMD_P_LOAD(I, 0) CTAMD_P_LOAD(I, 1) CTAMD_P_LOAD(I, 2) CTAMD_P_LOAD(I, 3) } \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }
+            CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
+            CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
+#undef CTAMD_P_PASS
+#undef CTAMD_P_LOAD
+#undef CTAMD_P_STORE
+#undef CTAMD_P_FRAG
+            if (!more) break;
+            staged = true;
+            continue;
+        }
+        // ---- every other tile: the epilogues of gett_h16w4x_kernel, in the (dead) ring ---------------------------------------------
+        if (ep.vecD && ep.beta == 0.f) {
+            // beta == 0 and 16-byte lanes in D: a pass of 32 rows x 128 columns is a 16-bit image of 272-byte rows, rounded once
+            uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
+            constexpr int kPitch = 136;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4& c = acc[2 * i + a2][j];
+                        uint16_t* st = stage + (16 * a2 + 4 * (laneE >> 4)) * kPitch + 16 * j + (laneE & 15);
+                        st[0] = h_round16<BF>(ep.alpha * c[0]); st[kPitch] = h_round16<BF>(ep.alpha * c[1]);
+                        st[2 * kPitch] = h_round16<BF>(ep.alpha * c[2]); st[3 * kPitch] = h_round16<BF>(ep.alpha * c[3]);
+                    }
+#pragma unroll 4
+                for (int it = 0; it < 8; ++it) {
+                    const int q = it * 64 + laneE, row = q >> 4, cc = q & 15;
+                    const s16x8 v = *reinterpret_cast<const s16x8*>(stage + row * kPitch + 8 * cc);
+                    const uint32_t m = mW + 32 * i + row, n = nW + 8 * cc;
+                    if (m < ep.Mtot && n < ep.Ntot) {
+                        int64_t offD, offC;
+                        ep.offsets(pe, m, n, offD, offC);
+                        __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {             // four passes of 32 rows: the epilogue's image is four 32 x 32 fp32 fragments
+#pragma unroll
+                for (int F = 0; F < 4; ++F)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {     // 16 x 16 quarter (h >> 1, h & 1) of 32 x 32 fragment F
+                        float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);
+                        const f32x4& c = acc[2 * i + (h >> 1)][2 * F + (h & 1)];
+                        st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];
+                    }
+                const uint32_t mB = mW + 32 * i;
+                ep.template flush<BF, 0>(pe, mB, 0u, 0u, nW, 64u, 32u, laneE);
+            }
+        }
+        if (!more) break;
+        __syncthreads();                          // the epilogue's images in the ring are dead in every wave
+        vb = nextVb;
+        staged = false;
+    }
+}
+
+template <bool BF, int LA, int LB>
+static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
+    // one workgroup per CU (160 KiB of LDS, 512 registers per lane), each walking tiles blockIdx.x, + grid, + 2 grid, ...
+    static const int numCUs = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        return n;
+    }();
+    static const int cap = [] { const char* e = getenv("CUTENSOR_AMD_H16P_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    uint32_t grid = (uint32_t)(cap > 0 ? cap : numCUs);
+    grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
+    if (grid == 0) grid = 8;
+    if (grid > p.nBlocks) grid = p.nBlocks;
+    hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+#define CTAMD_H16W4P_ENTRY(bf, la, lb) \
+    {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 12, 1, 0, &launch_h16w4p<bf, la, lb>, 0},
+static const GettKernelInfo g_h16p_table[] = {
+    CTAMD_H16W4P_ENTRY(true, LAY_K, LAY_K) CTAMD_H16W4P_ENTRY(true, LAY_K, LAY_F)
+    CTAMD_H16W4P_ENTRY(true, LAY_F, LAY_K) CTAMD_H16W4P_ENTRY(true, LAY_F, LAY_F)
+    CTAMD_H16W4P_ENTRY(false, LAY_K, LAY_K) CTAMD_H16W4P_ENTRY(false, LAY_K, LAY_F)
+    CTAMD_H16W4P_ENTRY(false, LAY_F, LAY_K) CTAMD_H16W4P_ENTRY(false, LAY_F, LAY_F)};
+
+const GettKernelInfo* gett_h16p_kernels(int* count) {
+    *count = (int)(sizeof(g_h16p_table) / sizeof(g_h16p_table[0]));
+    return g_h16p_table;
+}
+
+}  // namespace ctamd

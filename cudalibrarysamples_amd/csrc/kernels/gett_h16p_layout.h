@@ -1,0 +1,38 @@
+// gett_h16p_layout.h — index arithmetic of gett_h16w4p_kernel's transposed epilogue image (gett_h16p.hip), plain C++ so that the
+// kernel and tests/harness/h16p_layout_harness.cpp compile the SAME functions (the harness replays a pass on the CPU: every element
+// of the 16 x 128 pass reaches the lane and register that stores it, and no LDS access of the pass has a bank conflict).
+//
+// A pass = rows 16 i + [0, 16) of a wave's 128 x 128 quadrant = the eight accumulator fragments acc[i][0..7]; fragment j holds, in
+// lane (g = lane >> 4, cl = lane & 15), rows 4 g + [0, 4) of column 16 j + cl.  Image: [128 columns][16 rows] of 16-bit values,
+// 32 bytes per column: column c lives at image row R(c) = c ^ 4 ((c >> 3) & 1), and inside it rows 4 s + [0, 4) (8 bytes) at slot
+// s ^ ((R(c) >> 2) & 3).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CTAMD_HD __host__ __device__ inline
+#else
+#define CTAMD_HD inline
+#endif
+
+namespace ctamd {
+
+constexpr int kPImgBytes = 4096;          // one pass of one wave
+
+// byte offset of the 8 bytes lane writes for fragment j (ds_write_b64; fragments j and j + 1 are 512 bytes apart)
+CTAMD_HD uint32_t p_img_write_off(int lane, int j) {
+    const int g = lane >> 4, cl = lane & 15;
+    const int rw = cl ^ (((cl >> 3) & 1) << 2);                       // R(16 j + cl) = 16 j + rw
+    return (uint32_t)(512 * j + rw * 32 + ((g ^ ((rw >> 2) & 3)) << 3));
+}
+// byte offset of the 8 bytes lane supplies to the transposing read (ds_read_b64_tr_b16) of chunk q = 4 it + (lane >> 4) — columns
+// 8 q + [0, 8) of the pass's 16 rows — half h (columns 8 q + 4 h + [0, 4)): the lane addresses column 8 q + 4 h + (cl >> 2), rows
+// 4 (cl & 3) + [0, 4); after the read it holds columns 8 q + 4 h + [0, 4) of row cl
+CTAMD_HD uint32_t p_img_read_off(int lane, int it, int h) {
+    const int g = lane >> 4, cl = lane & 15, ge = g & 1;
+    const int row = (4 * (h ^ ge) + (cl >> 2));                      // R(8 q + 4 h + (cl >> 2)) - 8 q: bit 3 of the column is q & 1 = g & 1
+    const int slot = (cl & 3) ^ ((2 * ge + (h ^ ge)) & 3);           // ((R >> 2) & 3) = (2 q + (h ^ ge)) & 3, 2 q = 2 g (mod 4) = 2 ge (mod 4)
+    return (uint32_t)(1024 * it + 256 * g + row * 32 + (slot << 3));
+}
+
+}  // namespace ctamd

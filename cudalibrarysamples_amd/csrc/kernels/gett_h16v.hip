@@ -17,126 +17,9 @@
 // Roofline and algorithmic bytes as in gett_h16.hip.
 #include <type_traits>
 
-#include "gett_h16_common.h"
+#include "gett_h16x_common.h"
 
 namespace ctamd {
-
-typedef __attribute__((address_space(3))) const s16x8* VLdsVec8;
-typedef s16x4 __attribute__((address_space(3))) * VLdsVec4;
-
-// 64 lanes x 16 B -> the 1-KiB LDS piece at byte address waveLds + IMM (waveLds wave-uniform).  PAD: the SGPR operands may come
-// straight from a v_readfirstlane (VALU-write -> VMEM-read hazard).  Completion is counted by hand (CTAMD_H_VMCNT).
-template <uint32_t IMM, bool PAD>
-__device__ __forceinline__ void v_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t waveLds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (PAD)
-        asm volatile("s_nop 4\n\ts_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(waveLds), "v"(laneBytes), "s"(rsrc), "i"(IMM) : "memory", "scc");
-    else
-        asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                     :: "s"(waveLds), "v"(laneBytes), "s"(rsrc), "i"(IMM) : "memory", "scc");
-#else
-    (void)rsrc; (void)laneBytes; (void)waveLds;
-#endif
-}
-
-__device__ __forceinline__ HRsrc v_rsrc(uint64_t addr) {      // addr is a valid device address: bits 48..63 are zero
-    HRsrc r;
-    r[0] = (int)(uint32_t)addr;
-    r[1] = (int)(uint32_t)(addr >> 32);
-    r[2] = -1;
-    r[3] = 0x00020000;
-    return r;
-}
-
-// One fragment (32 rows x 16 k) from LDS byte address base + IMM.  LAY_K: one ds_read_b128; LAY_F: two transposing reads.
-template <int LAY, int IMM>
-__device__ __forceinline__ s16x8 v_read(uint32_t base) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (LAY == LAY_K) {
-        return *(VLdsVec8)(uintptr_t)(base + (uint32_t)IMM);
-    } else {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLdsVec4)(uintptr_t)(base + (uint32_t)IMM + 1024u));
-        return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-#else
-    (void)base; return s16x8{};
-#endif
-}
-
-// K odometer over the descriptor bases (bytes).  K index = j0 * 64 + E0 * (j1 + e1 * hi) as in HOdometer; here digit 0 is a
-// countdown and `untilEvent` counts the advances up to the next rare event.  Exactly nTiles - 1 advances move the bases
-// (K-tiles 1 .. nTiles - 1 of this workgroup's slice); any further call leaves them where they are (the last tile is re-staged,
-// never read).
-struct VOdometer {
-    uint64_t addrA, addrB, stepA, stepB, wrapA, wrapB;     // hot
-    uint32_t untilWrap, n0, untilEvent;                    // hot
-    uint32_t left, carryLen, hi, e1, carryPending;         // cold (event path)
-    uint64_t baseA, baseB;                                 // cold: descriptor bases at K index 0
-
-    __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-    __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0, uint32_t nTiles, uint64_t bA, uint64_t bB) {
-        const uint32_t E0 = gK.div[0].d;
-        n0 = sgpr(E0 / kHBK);
-        e1 = sgpr(gK.div[1].d);
-        const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
-        const uint32_t j0 = (k0 - q0 * E0) / kHBK;
-        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
-        const uint32_t j1 = q0 - hi * e1;
-        baseA = bA;
-        baseB = bB;
-        addrA = h_uniform64(bA + (uint64_t)(group_offset<0>(gK, k0) * 2));
-        addrB = h_uniform64(bB + (uint64_t)(group_offset<1>(gK, k0) * 2));
-        stepA = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[0][0] * 2));
-        stepB = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[1][0] * 2));
-        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
-        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
-        untilWrap = sgpr(n0 - j0);
-        carryLen = sgpr(n0 * e1);
-        const uint32_t untilCarry = (e1 - j1) * n0 - j0;
-        left = sgpr(nTiles - 1u);
-        carryPending = 0;
-        untilEvent = 1;
-        next_segment(untilCarry);
-    }
-    // the valid advances that are left are cut into segments that end at a carry past digit 1 or at the end of the K range
-    __device__ __forceinline__ void next_segment(uint32_t toCarry) {
-        if (left == 0u) {
-            stepA = stepB = wrapA = wrapB = 0;
-            untilEvent = 0x7fffffffu;
-            carryPending = 0;
-        } else {
-            const uint32_t seg = toCarry < left ? toCarry : left;
-            left = sgpr(left - seg);
-            carryPending = sgpr(seg == toCarry ? 1u : 0u);
-            untilEvent = sgpr(seg);
-        }
-    }
-    __device__ __forceinline__ void advance_a() {          // digit 0 and the A base
-        untilWrap -= 1u;
-        addrA += (untilWrap == 0u) ? wrapA : stepA;
-    }
-    __device__ __forceinline__ void advance_b() {          // the B base, digit 0 reloaded
-        addrB += (untilWrap == 0u) ? wrapB : stepB;
-        untilWrap = (untilWrap == 0u) ? n0 : untilWrap;
-    }
-    __device__ __forceinline__ void advance_event(const ModeGroup& gK) {
-        untilEvent -= 1u;
-        if (__builtin_expect(untilEvent == 0u, 0)) {
-            if (carryPending != 0u) {                      // the advance just made wrapped digit 1: bases from the full index
-                hi += 1u;
-                const uint32_t k = hi * e1 * gK.div[0].d;
-                if (k < gK.total) {
-                    addrA = h_uniform64(baseA + (uint64_t)(group_offset<0>(gK, k) * 2));
-                    addrB = h_uniform64(baseB + (uint64_t)(group_offset<1>(gK, k) * 2));
-                }
-            }
-            next_segment(carryLen);
-        }
-    }
-};
 
 template <bool BF, int LA, int LB>
 __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p) {
@@ -320,48 +203,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
 // one per four MFMAs).  Same LDS images as every 16-bit kernel: a 16-row fragment of the K-contiguous image is rows x 4 units
 // (lane & 15 = row, lane >> 4 = k-unit, one ds_read_b128); of the free-contiguous image two transposing reads (x_offF).
 // =====================================================================================================
-template <bool BF>
-__device__ __forceinline__ void x_mfma(f32x4& c, const s16x8& a, const s16x8& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else              asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#else
-    (void)c; (void)a; (void)b;
-#endif
-}
-// The accumulators as the epilogue may read them: every fragment passes through an (empty) asm statement placed BEHIND the two
-// s_nop 15 that wait out the last MFMAs — volatile asm statements keep their order, and every later read of an accumulator depends
-// on this one.  Without it nothing ties the epilogue's v_accvgpr_read copies to the s_nops: the compiler has hoisted them in front
-// of the wait (tests/test_kernel_resources.py checks the order in every instantiation).
-template <int FI, int FJ>
-__device__ __forceinline__ void x_acc_ready(f32x4 (&acc)[FI][FJ]) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have written their accumulators
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) asm volatile("" : "+a"(acc[i][j]));
-#endif
-}
-
-// byte offset of this lane's 16 bytes of a 16-row fragment, k-step s (0, 1), inside a K-contiguous half-tile (rows 16 f: + 2048 f)
-__device__ __forceinline__ uint32_t x_offK(int lane, int s) {
-    const int row = lane & 15, unit = (lane >> 4) + 4 * s;
-    return (uint32_t)(row * 128 + (((unit ^ (row >> 1)) & 7) << 4));
-}
-
-// the same for a free-contiguous half-tile (image [64 k][128 rows], 256-byte k-rows, HOperand's SWZ = 1 form: unit p of k-row k holds
-// row-unit p ^ 4 (k & 3) ^ 2 ((k >> 3) & 1)): a 16-lane group g fetches the 4 k x 16 rows block (k = 8 g + [0,4), rows of fragment f)
-// that ds_read_b64_tr_b16 turns into "lane = row, four k"; the second read (+ 1024 B) brings k + 4.  The block is 32 contiguous
-// bytes in each of its four k-rows: quarter (f >> 1) ^ (k & 3) of the row, half (f & 1) ^ (g & 1) of the quarter — the groups g and
-// g + 1 that one read serves together never share a bank.  Both f >> 1 and f & 1 sit inside the swizzle: one address register per
-// (f >> 1, f & 1), k-step and + 4 as immediates (8192 s, 1024).
-__device__ __forceinline__ uint32_t x_offF(int lane, int f) {
-    const int g = lane >> 4, i = lane & 15, q = (i >> 2) & 3, b = (i >> 1) & 1;
-    const int unit = b | ((((f & 1) ^ (g & 1)) & 1) << 1) | ((((f >> 1) ^ q) & 3) << 2);
-    return (uint32_t)((8 * g + (i >> 2)) * 256 + (unit << 4) + 8 * (i & 1));
-}
-
 // The 16-bit epilogue of a quadrant that lies inside D with one M and one N mode (wave-uniform test by the caller), as a software
 // pipeline over its passes of 32 rows x 16 FJ columns: the 16-byte chunks of pass i - 1 wait in registers and are stored one per two
 // accumulator fragments of pass i on their way into the image (pitch kPitch 16-bit elements), addresses one addition apart, no bounds

@@ -41,7 +41,8 @@ const GettKernelInfo* gett_f32_stream_kernels(int* count);
 
 // bf16 / fp16 data, fp32 accumulation (v_mfma_f32_32x32x16_{bf16,f16}), gett_h16.hip
 const GettKernelInfo* gett_h16_kernels(int* count);
-const GettKernelInfo* gett_h16v_kernels(int* count);   // gett_h16v.hip: appended to the table above as entries 40..47
+const GettKernelInfo* gett_h16v_kernels(int* count);   // gett_h16v.hip: appended to the table above as entries 40..87
+const GettKernelInfo* gett_h16p_kernels(int* count);   // gett_h16p.hip (persistent 256 x 256 kernel): entries 88..95
 
 // general MFMA family: bf16 / fp16 shapes the aligned kernels above refuse (no 16-byte lanes, K not in whole 64-deep tiles), fp64,
 // complex64 / complex128 — register-staged, any strides and extents (gett_gen.inc; the table is the concatenation of the three

@@ -1,0 +1,72 @@
+// h16p_layout_harness.cpp — CPU replay of one epilogue pass of gett_h16w4p_kernel (csrc/kernels/gett_h16p_layout.h, the functions the
+// kernel itself compiles): 64 lanes write the eight fragments of a 16 x 128 pass into the transposed 4-KiB image, read it back with
+// the transposing read's semantics and must end up with, per lane and chunk, eight consecutive columns of ONE row — what a 16-byte
+// store to D needs.  Also: every byte of the image written exactly once, and no bank conflict in the ds_write_b64 of a 16-lane group
+// (bank = (address / 4) mod 32) nor in the ds_read_b64_tr_b16 of a 32-lane half (bank = (address / 4) mod 64) — MI355X guide, LDS table.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <set>
+
+#include "gett_h16p_layout.h"
+
+using namespace ctamd;
+
+int main() {
+    uint16_t img[kPImgBytes / 2];
+    int writes[kPImgBytes];
+    std::memset(writes, 0, sizeof(writes));
+    std::memset(img, 0xff, sizeof(img));
+    auto code = [](int row, int col) { return (uint16_t)(row * 128 + col); };
+    // ---- write side: fragment j, lane (g, cl): rows 4 g + r, column 16 j + cl
+    for (int j = 0; j < 8; ++j) {
+        for (int grp = 0; grp < 4; ++grp) {                  // ds_write_b64: lane groups of 16 contiguous lanes
+            std::set<int> banks;
+            for (int lane = 16 * grp; lane < 16 * grp + 16; ++lane) {
+                const uint32_t off = p_img_write_off(lane, j);
+                if (off % 8 != 0 || off + 8 > (uint32_t)kPImgBytes) { std::printf("write offset out of range / misaligned\n"); return 1; }
+                for (int r = 0; r < 4; ++r) img[off / 2 + r] = code(4 * (lane >> 4) + r, 16 * j + (lane & 15));
+                for (int b = 0; b < 8; ++b) ++writes[off + b];
+                banks.insert((off / 4) % 32);
+                banks.insert((off / 4 + 1) % 32);
+            }
+            if (banks.size() != 32) { std::printf("ds_write_b64 bank conflict: fragment %d lane group %d touches %zu banks\n", j, grp, banks.size()); return 2; }
+        }
+    }
+    for (int b = 0; b < kPImgBytes; ++b)
+        if (writes[b] != 1) { std::printf("image byte %d written %d times\n", b, writes[b]); return 3; }
+    // ---- read side: iteration it, half h; within a 16-lane group the block M[kk][r] = what lane 4 kk + (r >> 2) loaded, element r & 3;
+    //      output lane i = {M[0][i], M[1][i], M[2][i], M[3][i]}
+    for (int it = 0; it < 4; ++it) {
+        uint16_t out[64][8];
+        for (int h = 0; h < 2; ++h) {
+            for (int half = 0; half < 2; ++half) {           // ds_read_b64_tr_b16: 2 x 32 lanes
+                std::set<int> banks;
+                for (int lane = 32 * half; lane < 32 * half + 32; ++lane) {
+                    const uint32_t off = p_img_read_off(lane, it, h);
+                    if (off % 8 != 0 || off + 8 > (uint32_t)kPImgBytes) { std::printf("read offset out of range / misaligned\n"); return 4; }
+                    banks.insert((off / 4) % 64);
+                    banks.insert((off / 4 + 1) % 64);
+                }
+                if (banks.size() != 64) { std::printf("ds_read_b64_tr_b16 bank conflict: it %d half %d lanes %d.. touch %zu banks\n", it, h, 32 * half, banks.size()); return 5; }
+            }
+            for (int grp = 0; grp < 4; ++grp)
+                for (int i = 0; i < 16; ++i)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int src = 16 * grp + 4 * kk + (i >> 2);
+                        out[16 * grp + i][4 * h + kk] = img[p_img_read_off(src, it, h) / 2 + (i & 3)];
+                    }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, q = 4 * it + (lane >> 4);
+            for (int e = 0; e < 8; ++e)
+                if (out[lane][e] != code(row, 8 * q + e)) {
+                    std::printf("lane %d it %d element %d: got (row %d, col %d), want (row %d, col %d)\n", lane, it, e, out[lane][e] / 128,
+                                out[lane][e] % 128, row, 8 * q + e);
+                    return 6;
+                }
+        }
+    }
+    std::printf("h16p layout ok\n");
+    return 0;
+}

@@ -29,3 +29,13 @@ def test_the_harness_covers_every_instantiated_shape():
     src = open(os.path.join(ROOT, "tests", "harness", "gen_layout_harness.cpp")).read()
     have = {tuple(int(x) for x in m.groups()) for m in re.finditer(r"REPLAY\((\d+), (\d+), (\d+), (\d+)\)", src)}
     assert want and want <= have, sorted(want - have)
+
+
+def test_persistent_kernel_epilogue_image_replay(tmp_path):
+    """gett_h16w4p_kernel's transposed epilogue image (csrc/kernels/gett_h16p_layout.h, compiled into the kernel): a pass replayed on
+    the CPU — every element reaches the lane / register that stores it, every image byte is written once, no bank conflicts."""
+    exe = str(tmp_path / "h16p_layout_harness")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "cudalibrarysamples_amd", "csrc", "kernels"),
+                           os.path.join(ROOT, "tests", "harness", "h16p_layout_harness.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "h16p layout ok" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,116 @@
+"""GPU parity of the PERSISTENT 16-bit kernel (csrc/kernels/gett_h16p.hip: gett_h16w4p_kernel, round 5) through the C ABI against
+torch in fp64 on inputs already rounded to the 16-bit type (tolerances of tests/test_gpu_h16.py: bf16 rtol 8e-3, fp16 2e-3).
+
+What is special about this kernel is what happens BETWEEN tiles, so the cases run in a child process whose grid is capped at eight
+workgroups (CUTENSOR_AMD_H16P_GRID=8): every workgroup then walks several tiles — interior tiles whose epilogue (transposed 16-bit
+image + ds_read_b64_tr_b16, in the LDS beyond the ring) runs while the next tile's first K-tiles are already landing in the ring;
+edge tiles, beta != 0 and strided outputs, which take the ring-resident epilogues and stage the next tile afterwards; mixtures of both
+in one workgroup's sequence; split-K partials; one, two, three and many K-tiles per tile; batch modes; all four operand layouts; fp16.
+A second child runs the same list with the default grid (one workgroup per CU)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # (extents, modes A, modes B, modes C, dtype, alpha, beta, note)
+    (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "12 interior tiles, 4 K-tiles"),
+    (dict(m=1024, n=768, k=256), "km", "kn", "mn", "bfloat16", 1.0, 0.0, "both K-contiguous"),
+    (dict(m=1024, n=768, k=256), "mk", "nk", "mn", "bfloat16", 0.5, 0.0, "both free-contiguous, alpha"),
+    (dict(m=1024, n=768, k=256), "km", "nk", "mn", "bfloat16", 1.0, 0.0, "K-contiguous A, free-contiguous B"),
+    (dict(m=768, n=1280, k=64), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "one K-tile per tile"),
+    (dict(m=768, n=1280, k=128), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "two K-tiles"),
+    (dict(m=768, n=1280, k=192), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "three K-tiles (odd: the tail body)"),
+    (dict(m=1000, n=712, k=320), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "ragged M and N: interior and edge tiles in one sequence"),
+    (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "bfloat16", 1.25, -0.5, "beta != 0: the fp32 image in the ring"),
+    (dict(m=1024, n=512, k=256), "mk", "kn", "nm", "bfloat16", 1.0, 0.0, "D with n fastest (orientation swap)"),
+    (dict(m=512, n=512, k=128, l=5), "mkl", "knl", "mnl", "bfloat16", 1.0, 0.0, "batch mode: 20 tiles over 5 batches"),
+    (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "float16", 1.0, 0.0, "fp16"),
+    (dict(m=1000, n=712, k=192), "km", "nk", "mn", "float16", 0.75, 0.25, "fp16, ragged, beta"),
+    (dict(m=512, n=256, k=8192), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "split-K partials (two tiles, long K)"),
+    (dict(a=96, b=16, c=16, d=64, e=96), "dcba", "ebcd", "ea", "bfloat16", 1.0, 0.0, "the headline equation's view: one tile, split-K"),
+]
+
+
+def _child():
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    h = ops.Handle()
+    g = torch.Generator(device="cuda")
+    for idx, (ext, mA, mB, mC, dt, alpha, beta, note) in enumerate(CASES):
+        tdt = getattr(torch, dt)
+        cdt = ct.R_16BF if dt == "bfloat16" else ct.R_16F
+        g.manual_seed(100 + idx)
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        B = (torch.rand(eB[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        C = (torch.rand(eC[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        D = C.clone()
+        plan = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=cdt, workspace_limit=1 << 28)
+        d = plan.describe()
+        assert d["kname"] == "gett_h16w4p_kernel", (note, d)
+        ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        for rep in range(2):       # twice: a second launch finds the LDS as the first one left it
+            D.copy_(C)
+            plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
+        torch.cuda.synchronize()
+        ref = alpha * torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.double(), B.double()) + beta * C.double()
+        rtol = 8e-3 if dt == "bfloat16" else 2e-3
+        err = (D.double() - ref).abs()
+        tol = rtol * ref.abs() + (0.25 if dt == "bfloat16" else 0.03) * (1.0 if ext.get("k", 4096) > 2048 or "a" in ext else 0.2)
+        bad = int((err > tol).sum())
+        assert bad == 0, "%s: %d / %d elements off, worst %g (plan %s)" % (note, bad, err.numel(), float((err - tol).max()), d)
+        print("ok  %-70s splitK %d" % (note, d["splitK"]), flush=True)
+        plan.destroy()
+    print("H16P_CHILD_OK")
+
+
+@pytest.mark.parametrize("grid", ["8", ""])
+def test_persistent_kernel_parity(built, grid):
+    env = dict(os.environ, CUTENSOR_AMD_H16_WAVES="4p")
+    if grid:
+        env["CUTENSOR_AMD_H16P_GRID"] = grid
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "H16P_CHILD_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_many_rounds_at_full_grid(built):
+    """More tiles than CUs without the grid cap: 4352 x 4352 x 128 = 289 tiles on 256 workgroups (33 of them walk two tiles), checked by
+    sampled fp64 dot products; and the size class of the bench line at reduced K (8192 x 8192 x 256: 1024 tiles, four rounds)."""
+    env = dict(os.environ, CUTENSOR_AMD_H16_WAVES="4p")
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from cudalibrarysamples_amd import cutensor as ct, ops
+h = ops.Handle()
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+for (M, N, K) in ((4352, 4352, 128), (8192, 8192, 256)):
+    A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "mk": m fastest
+    B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "kn"
+    D = torch.empty((N, M), device="cuda", dtype=torch.bfloat16)
+    p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF)
+    assert p.describe()["kname"] == "gett_h16w4p_kernel", p.describe()
+    p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())
+    torch.cuda.synchronize()
+    rows = torch.tensor([0, 255, 256, 1000, 2047, 2048, 4095, 4096, M - 257, M - 256, M - 1], device="cuda")
+    ref = B.double() @ A.double()[:, rows]                      # [N][len(rows)]
+    err = float((D[:, rows].double() - ref).abs().max() / ref.abs().max())
+    assert err < 8e-3, (M, N, K, err)
+    cols = torch.tensor([0, 255, 256, 3000, N - 256, N - 1], device="cuda")
+    ref = B.double()[cols] @ A.double()
+    err = float((D[cols].double() - ref).abs().max() / ref.abs().max())
+    assert err < 8e-3, (M, N, K, err)
+print("MANY_ROUNDS_OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "MANY_ROUNDS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+if __name__ == "__main__":
+    _child()

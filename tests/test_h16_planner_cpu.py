@@ -86,18 +86,20 @@ def test_every_variant_stays_an_autotuning_candidate(env):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
     names = []
-    for r in range(11):
+    for r in range(12):
         p = _plan(ct, ops, h, 8192, 8192, 8192, algo=r, cache_mode=ct.CACHE_MODE_NONE)
         names.append(p.describe()["kname"])
         p.destroy()
     assert names[0] == "gett_h16w4x_kernel", names
     assert set(names) == {"gett_h16w4x_kernel", "gett_h16_kernel", "gett_h16w4v_kernel", "gett_h16w4r_kernel", "gett_h16s_kernel",
-                          "gett_h16w4s_kernel", "gett_h16w4_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel"}, names
+                          "gett_h16w4s_kernel", "gett_h16w4_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel",
+                          "gett_h16w4p_kernel"}, names
 
 
 @pytest.mark.parametrize("waves,want", [("8", "gett_h16_kernel"), ("4", "gett_h16w4_kernel"), ("4v", "gett_h16w4v_kernel"),
                                         ("4x", "gett_h16w4x_kernel"), ("s", "gett_h16s_kernel"), ("4m", "gett_h16w4m_kernel"),
-                                        ("4m4", "gett_h16w4m4_kernel"), ("8m", "gett_h16w8m_kernel"), ("4q", "gett_h16w4q_kernel")])
+                                        ("4m4", "gett_h16w4m4_kernel"), ("8m", "gett_h16w8m_kernel"), ("4q", "gett_h16w4q_kernel"),
+                                        ("4p", "gett_h16w4p_kernel")])
 def test_the_switch_overrides_the_planner(built, waves, want):
     code = ("import json, sys; sys.path.insert(0, %r); from cudalibrarysamples_amd import cutensor as ct, ops; h = ops.Handle(); "
             "out = []\n"

@@ -147,3 +147,33 @@ def test_general_mfma_family_uses_no_scratch(built, tmp_path, obj):
     bad = {n: v for n, v in gen.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     assert all(v.get("vgpr_count", 999) <= 256 for v in gen.values()), gen      # two workgroups per CU
+
+
+def test_persistent_16_bit_kernel_uses_no_scratch_and_all_of_the_lds(built, tmp_path):
+    """gett_h16p.hip (round 5): the persistent 256 x 256 kernel keeps the next tile's staging tables and odometer alive during its
+    epilogue — still no private segment, no spilled vector register, 256 accumulator registers, and exactly 160 KiB of LDS (the 128-KiB
+    ring + two 4-KiB epilogue images per wave); its accumulator reads wait behind the two s_nop 15 like every inline-asm MFMA kernel."""
+    co = _code_object(tmp_path, "gett_h16p")
+    k = _kernel_notes(co)
+    hot = {n: v for n, v in k.items() if "gett_h16w4p_kernel" in n}
+    assert len(hot) == 8, sorted(k)
+    bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
+    assert all(v.get("group_segment_fixed_size") == 163840 and v.get("agpr_count") == 256 for v in hot.values()), hot
+    for name in hot:
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
+                             capture_output=True, text=True).stdout.splitlines()
+        ins = [l.split("//")[0].strip() for l in dis if l.startswith("\t")]
+        assert sum(1 for l in ins if l.startswith("v_mfma_f32_16x16x32")) >= 3 * 128, name
+        reads = [i for i, l in enumerate(ins) if l.startswith("v_accvgpr_read")
+                 or re.match(r"(ds_write|ds_store|global_store|buffer_store|flat_store|scratch_store)\S* .*\ba\[?\d", l)]
+        assert reads, name
+        for i in reads:
+            j = i - 1
+            while j >= 0 and not ins[j].startswith("v_mfma") and not ins[j].startswith("s_nop 15"):
+                j -= 1
+            assert j >= 1 and ins[j].startswith("s_nop 15") and ins[j - 1].startswith("s_nop 15"), (name, i, ins[max(j - 2, 0):i + 1][:12])
+        assert not any(l.startswith("scratch_") for l in ins), name
+        # the transposed epilogue: transposing reads outside the main loop's count, 8-byte LDS writes, global (not flat) 16-byte stores
+        assert any(l.startswith("ds_write2st64_b64") or l.startswith("ds_write_b64") for l in ins), name
+        assert sum(1 for l in ins if l.startswith("global_store_dwordx4")) >= 32, name
