@@ -158,7 +158,8 @@ def mg_measure(ndev, extent, steps, warmup, sample_reps=3, check=True, virtual=F
                 "sample_protocol_gflops": flop / best / 1e9, "flop": flop, "elapsed_s": elapsed,
                 "gather_bytes_per_call": d["remoteBytes"], "local_copy_bytes_per_call": d["localCopyBytes"],
                 "pieces": len(d["pieces"]), "gather_waves": d["numWaves"],
-                "transport": (d2["transport"] if n > 1 else "none"), "rccl": bool(d["useRccl"]),
+                "transport": (d2["transport"] if (n > 1 or d.get("forceGather")) else "none"), "rccl": bool(d["useRccl"]),
+                "forced_gather": bool(d.get("forceGather")), "rccl_ranks_seen": (len(set(devs)) if d["useRccl"] else 0),
                 "all_gather_eligible": d2.get("allGatherEligible"), "transport_trial_ms": d2.get("trialMs"),
                 "transport_chosen": {0: "undecided", 1: "allgather", 2: "sendrecv"}.get(d2.get("chosen", 0)),
                 "max_rel_err_sampled": err}
@@ -341,6 +342,62 @@ def live_pmc_traffic_of(cmd, kernel_like, timeout_s=240):
                 "launches": min(vals["FETCH_SIZE"]["launches"], vals["WRITE_SIZE"]["launches"]), "kernel": vals["FETCH_SIZE"]["kernel"]}
     except (subprocess.TimeoutExpired, OSError, sqlite3.Error, KeyError):
         return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_profile_of(cmd, kernel_like, timeout_s=240):
+    """What rocprofv3 says about the kernels matching `kernel_like` (SQL LIKE) in a child command, measured IN THIS RUN by two separate
+    passes (never combined: counters never ride with tracing):
+      * `--kernel-trace --stats`: launches, average / minimum duration [us];
+      * `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY`: matrix-pipe busy % = MFMA-busy cycles / SIMDs over the
+        GPU-active cycles per XCD (GRBM_GUI_ACTIVE is summed over the 8 XCDs, the busy counter over the 4 x CUs SIMDs), and the sustained
+        clock = active cycles per XCD / the kernel's duration in that same pass.
+    Returns a dict or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_prof_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    out = {}
+    try:
+        import torch
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        for tag, flags in (("trace", ["--kernel-trace", "--stats"]),
+                           ("pmc", ["--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])):
+            d = os.path.join(tmp, tag)
+            r = subprocess.run([exe] + flags + ["-d", d, "-o", "r", "--"] + cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return out or None
+            c = sqlite3.connect(dbs[0])
+            rows = list(c.execute("select name, count(*), avg(duration), min(duration) from kernels where name like ? group by name "
+                                  "order by sum(duration) desc", (kernel_like,)))
+            if not rows:
+                c.close()
+                return out or None
+            name, calls, avg_ns, min_ns = rows[0]
+            if tag == "trace":
+                out.update({"kernel": name[:100], "launches": calls, "kernel_avg_us": avg_ns / 1e3, "kernel_min_us": min_ns / 1e3})
+            else:
+                cnt = dict(c.execute("select counter_name, avg(value) from counters_collection where kernel_name like ? group by counter_name",
+                                     (kernel_like,)).fetchall())
+                busy, active = cnt.get("SQ_VALU_MFMA_BUSY_CYCLES"), cnt.get("GRBM_GUI_ACTIVE")
+                if busy and active:
+                    per_xcd = active / 8.0
+                    out.update({"mfma_busy_pct": 100.0 * (busy / (4.0 * cus)) / per_xcd, "sustained_clock_ghz": per_xcd / avg_ns,
+                                "kernel_avg_us_under_pmc": avg_ns / 1e3,
+                                "wait_any_pct_of_wave_cycles": (100.0 * cnt["SQ_WAIT_ANY"] / cnt["SQ_WAVE_CYCLES"]) if cnt.get("SQ_WAVE_CYCLES") and cnt.get("SQ_WAIT_ANY") else None,
+                                "pmc_raw": {k: cnt.get(k) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")},
+                                "pmc_formula": "busy %% = SQ_VALU_MFMA_BUSY_CYCLES / (4 x %d SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); clock = (GRBM_GUI_ACTIVE / 8) / kernel duration of the same pass" % cus})
+            c.close()
+        return out or None
+    except (subprocess.TimeoutExpired, OSError, sqlite3.Error, KeyError, ValueError):
+        return out or None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -556,7 +613,15 @@ def secondary_general_family(torch, ct, ops, h):
             A, B = mk(), mk()
             D = torch.empty((n, n), device="cuda", dtype=tdt)
             p = ops.contraction_plan(h, [n, n], "km", [n, n], "kn", [n, n], "mn", dtype=cdt)
-            ms = timed_batch(torch, lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr()), reps=reps)
+            fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr())   # noqa: E731
+            fn()
+            torch.cuda.synchronize()
+            t_end = time.perf_counter() + 0.04           # clock ramp under this kernel's own load (as the bf16 line: ~40 ms), untimed
+            while time.perf_counter() < t_end:
+                for _ in range(4):
+                    fn()
+                torch.cuda.synchronize()
+            ms = min(timed_batch(torch, fn, reps=reps), timed_batch(torch, fn, reps=reps))
             d = p.describe()
             tf = flop_per_mac * n ** 3 / (ms * 1e-3) / 1e12
             out.append({"workload": label, "dtype": str(tdt).replace("torch.", ""), "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms,
@@ -568,9 +633,9 @@ def secondary_general_family(torch, ct, ops, h):
             out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
 
     gemm("contraction fp64 C[m,n]=A[k,m]B[k,n] M=N=K=4096 (einsum.cu:36-41 with double), v_mfma_f64_16x16x4_f64", 4096, torch.float64, ct.R_64F,
-         2.0, PEAK_TFLOPS_F64_MFMA, 5)
+         2.0, PEAK_TFLOPS_F64_MFMA, 10)
     gemm("contraction complex64 M=N=K=2048 (python/einsum.h:51-63), four real fp32 MFMAs per complex product", 2048, torch.complex64, ct.C_32F,
-         8.0, PEAK_TFLOPS_F32_MFMA, 10)
+         8.0, PEAK_TFLOPS_F32_MFMA, 20)
     try:
         from cudalibrarysamples_amd import torch_einsum
         eq = "mlik,lkjm->lij"
@@ -617,6 +682,18 @@ def add_secondary_traffic(secondary):
             r["traffic_source"] = "live: two rocprofv3 --pmc passes over %d launches of %s in a child of this run" % (t["launches"], t["kernel"][:60])
         else:
             r["traffic"] = None
+        if key == "bf16 C[m,n]":    # north_star: rocprof MFMA-busy % on the line; and the kernel's own average launch duration
+            try:
+                prof = live_profile_of([sys.executable, os.path.join(ROOT, "tools", "bench_h16.py"), "--reps", "30"], "%ctamd%gett_h16%")
+            except Exception:   # noqa: BLE001
+                prof = None
+            if prof:
+                for k in ("mfma_busy_pct", "sustained_clock_ghz"):
+                    r[k] = prof.get(k)
+                r["live_trace"] = {k: prof.get(k) for k in ("kernel", "launches", "kernel_avg_us", "kernel_min_us")}
+                r["pmc_live"] = {k: prof.get(k) for k in ("kernel_avg_us_under_pmc", "wait_any_pct_of_wave_cycles", "pmc_raw", "pmc_formula")}
+                if prof.get("kernel_avg_us") and r.get("algorithmic_flop"):
+                    r["frac_from_live_trace_avg"] = r["algorithmic_flop"] / (prof["kernel_avg_us"] * 1e-6) / 1e12 / r["peak"]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -859,6 +936,23 @@ def main():
                 "traffic_raw": ({"FETCH_SIZE_KiB": traffic_live["raw_FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": traffic_live["raw_WRITE_SIZE_KiB"],
                                  "correction": "FETCH_SIZE x 2 (wide coalesced reads tallied at half their bytes on gfx950), WRITE_SIZE x 1"}
                                 if traffic_live else None)}
+        # ---- roofline.frac / achieved = algorithmic flop / the kernel's AVERAGE launch duration in a live `rocprofv3 --kernel-trace
+        #      --stats` pass over a headline-only child of this run (the committed trace of the round must agree); the event-pair figure of
+        #      the back-to-back fold-off loop above stays beside it as frac_event_pair.  north_star: MFMA-busy % and the clock, live.
+        roof["frac_event_pair"], roof["achieved_event_pair"] = roof["frac"], roof["achieved"]
+        roof["frac_source"] = "event pair (no live rocprofv3 pass in this run)"
+        if world == 1 and not args.no_pmc and not args.no_secondary and not args.einsum_only:
+            prof = live_profile_of([sys.executable, os.path.abspath(__file__), "--steps", "200", "--warmup", "20", "--no-cpu", "--no-secondary",
+                                    "--no-pmc", "--no-cold"], "%gett_f32_stream_kernel%")
+            if prof and prof.get("kernel_avg_us"):
+                roof["achieved"] = FLOP / (prof["kernel_avg_us"] * 1e-6) / 1e12
+                roof["frac"] = roof["achieved"] / peak if peak else None
+                roof["frac_source"] = ("live: rocprofv3 --kernel-trace --stats over %d launches of a headline-only child of this run, average kernel duration "
+                                       "%.2f us (min %.2f)" % (prof["launches"], prof["kernel_avg_us"], prof["kernel_min_us"]))
+                roof["live_trace"] = {k: prof.get(k) for k in ("kernel", "launches", "kernel_avg_us", "kernel_min_us")}
+            if prof and prof.get("mfma_busy_pct") is not None:
+                roof["mfma_busy_pct"], roof["sustained_clock_ghz"] = prof["mfma_busy_pct"], prof["sustained_clock_ghz"]
+                roof["pmc_live"] = {k: prof.get(k) for k in ("kernel_avg_us_under_pmc", "wait_any_pct_of_wave_cycles", "pmc_raw", "pmc_formula")}
         trace_file, trace_rows = newest_trace_summary()
         if trace_file and "gett_f32_stream_kernel" in trace_rows:
             k_avg, k_min, k_calls = trace_rows["gett_f32_stream_kernel"]
@@ -941,6 +1035,22 @@ def main():
                 secondary.append(mg_lines(one, "scaled", "-"))
             except Exception as ex:   # noqa: BLE001
                 secondary.append({"workload": "cuTENSORMg on one device", "error": "%s: %s" % (type(ex).__name__, ex)})
+            # ---- the same 4096^3 call with the gather FORCED (CUTENSORMG_AMD_FORCE_GATHER=1): a one-rank RCCL communicator, the operands
+            #      travel to the staging images by ncclAllGather / ncclSend + ncclRecv on the communication stream, the local contraction
+            #      waits for the wave event and reads the staged images — the transport and event-graph code of the N > 1 path, executed on
+            #      the one GPU of this box (gather_bytes_per_call > 0, rccl_ranks_seen = 1); not a scaling number
+            try:
+                os.environ["CUTENSORMG_AMD_FORCE_GATHER"] = "1"
+                fg = {"sample": mg_measure(1, MG_SAMPLE_EXTENT, 20, 3)}
+                ln = mg_lines(fg, "sample", "-")
+                ln["workload"] += " — gather FORCED through RCCL on one device (CUTENSORMG_AMD_FORCE_GATHER=1)"
+                for k in ("forced_gather", "rccl_ranks_seen", "rccl", "all_gather_eligible", "transport_trial_ms", "transport_chosen"):
+                    ln[k] = fg["sample"].get(k)
+                secondary.append(ln)
+            except Exception as ex:   # noqa: BLE001
+                secondary.append({"workload": "cuTENSORMg on one device, forced gather", "error": "%s: %s" % (type(ex).__name__, ex)})
+            finally:
+                os.environ.pop("CUTENSORMG_AMD_FORCE_GATHER", None)
 
     if rank == 0:
         einsum_line = {"workload": "einsum.cu 'abcd,dcbe->ae' a=e=96 b=c=d=64 fp32 (BASELINE configs[1])"
@@ -998,6 +1108,14 @@ def main():
             einsum_n_value, einsum_n_gpus, ranks_seen = spawned["value"], spawned["n_gpus"], spawned.get("rccl_ranks_seen")
         else:
             einsum_n_value, einsum_n_gpus, ranks_seen = einsum_value, world, (world if gpu_group is not None else (1 if world == 1 else 0))
+        # the numbers a user of einsum.cu sees on first contact, where a truncated reader still finds them
+        config["cold_operands_gflops"] = cold["value"] if cold and "value" in cold else None
+        config["cold_operands_frac_of_f32_mfma_peak"] = cold.get("frac_of_nominal_f32_mfma_peak") if cold else None
+        config["sample_protocol_gflops"] = sample_protocol.get("gflops") if sample_protocol else None
+        config["sample_protocol_frac_of_f32_mfma_peak"] = sample_protocol.get("frac_of_nominal_f32_mfma_peak") if sample_protocol else None
+        config["kernel_frac_live_trace"] = roof.get("frac") if roof else None
+        config["mfma_busy_pct"] = roof.get("mfma_busy_pct") if roof else None
+        config["sustained_clock_ghz"] = roof.get("sustained_clock_ghz") if roof else None
         line = {
             "metric": metric, "value": value, "unit": "GFLOP/s",
             "n_gpus": n_gpus, "requested_gpus": requested, "steps": args.steps, "warmup": args.warmup, "burn_in_ms": args.burn_in_ms,

@@ -57,9 +57,17 @@ __device__ __forceinline__ s16x4 p_round4(const f32x4& c, float alpha) {
 #endif
 }
 
-template <bool BF, int LA, int LB>
+// EP: the interior epilogue's way out of the transposed image — 2 (the default): a second, row-major image, stores of 4 rows x 256 bytes;
+// 0: straight from the transposing reads, stores of 16 rows x 64 bytes, nontemporal; 1: the same with plain stores (0 / 1: measurement,
+// CUTENSOR_AMD_H16P_EP with the TIMED instantiation — profiles/r05c_h16p_epilogue_variants.jsonl).
+// TIMED (CUTENSOR_AMD_H16_TIMED=1, bf16 mk,kn only): wave 0 of every workgroup records shader cycles at entry / first tile staged and
+// landed / end of its main loop / end of its epilogue / exit and the number of tiles it walked into p.timing (tools/h16p_timeline.py).
+template <bool BF, int LA, int LB, int EP = 2, bool TIMED = false>
 __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kPRingBytes + 8 * kPImageBytes];     // 160 KiB: the ring + two pass images per wave
+    unsigned long long wgStamp[5] = {0, 0, 0, 0, 0};
+    uint32_t tilesWalked = 0;
+    if constexpr (TIMED) wgStamp[0] = __builtin_readcyclecounter();
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -196,6 +204,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         // pieces of K-tile 1 (and, from the second tile on, waits out the previous epilogue's stores, which were issued later)
         CTAMD_H_VMCNT(16);
         __builtin_amdgcn_s_barrier();
+        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[1] = __builtin_readcyclecounter(); }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -209,6 +218,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         if (t < curTiles) { CTAMD_P_TILE(0) }
         CTAMD_H_VMCNT(0);                         // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
         x_acc_ready(acc);
+        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[2] = __builtin_readcyclecounter(); }
         // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake
         const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const uint32_t nextVb = vb + gridDim.x;
@@ -235,6 +245,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                         }
                     }
                 }
+            ++tilesWalked;
             if (!more) break;
             __syncthreads();                      // every wave has finished reading the operand ring
             vb = nextVb;
@@ -262,42 +273,92 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             const char* const rPtr1 = img + p_img_read_off(laneE, 0, 1);
             typedef s16x8 __attribute__((address_space(1))) * PGlb8;            // D is device memory: global, not flat, stores
             typedef s16x4 __attribute__((address_space(3))) * PLds4;
-            s16x8 v[2][4];
+#define CTAMD_P_TR(DST, BUF, IT)                                                                                    \
+            {                                                                                                      \
+                const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr0 + (BUF) * kPImageBytes + 1024 * (IT))); \
+                const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr1 + (BUF) * kPImageBytes + 1024 * (IT))); \
+                DST = s16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                         \
+            }
+            if constexpr (EP == 2) {
+                // Two images per wave: T (transposed, [128 columns][16 rows]) and R (row-major, [16 rows][256 bytes], 16-byte units
+                // XOR-swizzled by the row).  Pass I, software-pipelined by one pass (the LDS executes a wave's operations in order, so
+                // single images suffice): the chunks of pass I - 1 (in t[], from the transposing reads at the end of that pass) are
+                // parked in R and fetched back as 4 rows x 16 chunks (v[]); the eight fragments of pass I are converted into T; v[]
+                // leaves as four stores of 4 rows x 256 bytes, one per two fragments; the transposing reads of pass I refill t[].
+                char* const rowImg = img + kPImageBytes;
+                uint16_t* dst2 = ep.D + (int64_t)(mW + (uint32_t)(laneE >> 4)) * sM + (int64_t)(nW + 8u * (uint32_t)(laneE & 15));
+                const int64_t step4 = 4 * sM;
+                s16x8 t[4], v[4];
 #define CTAMD_P_FRAG(I, J)                                                                                          \
-            *reinterpret_cast<s16x4*>(wPtr + ((I) & 1) * kPImageBytes + 512 * (J)) = p_round4<BF>(acc[(I) < 8 ? (I) : 0][J], alpha);
-#define CTAMD_P_STORE(I, IT)                                                                                        \
-            __builtin_nontemporal_store(v[((I) - 1) & 1][IT], (PGlb8)(uintptr_t)(dst + 32 * (IT)));
-#define CTAMD_P_LOAD(I, IT)                                                                                         \
-            {                                                                                                      \
-                const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr0 + ((I) & 1) * kPImageBytes + 1024 * (IT))); \
-                const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr1 + ((I) & 1) * kPImageBytes + 1024 * (IT))); \
-                v[(I) & 1][IT] = s16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};             \
-            }
-            // pass I: the eight fragments of rows 16 I + [0, 16) go into image I & 1 while the four chunks of pass I - 1 (read out of
-            // the other image at the end of that pass) are stored, one per two fragments; then the chunks of pass I are read
+                *reinterpret_cast<s16x4*>(wPtr + 512 * (J)) = p_round4<BF>(acc[(I) < 8 ? (I) : 0][J], alpha);
+#define CTAMD_P_PARK(IT)  *reinterpret_cast<s16x8*>(rowImg + p_row_write_off(laneE, IT)) = t[IT];
+#define CTAMD_P_FETCH(IT) v[IT] = *reinterpret_cast<const s16x8*>(rowImg + p_row_read_off(laneE, IT));
+#define CTAMD_P_STORE(IT) { __builtin_nontemporal_store(v[IT], (PGlb8)(uintptr_t)dst2); dst2 += step4; }
 #define CTAMD_P_PASS(I)                                                                                             \
-            {                                                                                                      \
-                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 0) CTAMD_P_FRAG(I, 1) }                                   \
-                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 0) }                                                     \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 2) CTAMD_P_FRAG(I, 3) }                                   \
-                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 1) }                                                     \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 4) CTAMD_P_FRAG(I, 5) }                                   \
-                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 2) }                                                     \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 6) CTAMD_P_FRAG(I, 7) }                                   \
-                if constexpr ((I) > 0) { CTAMD_P_STORE(I, 3) dst += 16 * sM; }                                     \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-                if constexpr ((I) < 8) { CTAMD_P_LOAD(I, 0) CTAMD_P_LOAD(I, 1) CTAMD_P_LOAD(I, 2) CTAMD_P_LOAD(I, 3) } \
-                __builtin_amdgcn_sched_barrier(0);                                                                 \
-            }
-            CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
-            CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
+                {                                                                                                  \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 0) CTAMD_P_FRAG(I, 1) }                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) > 0) {      /* the transposing reads of pass I - 1 have had two fragments' time to return */ \
+                        CTAMD_P_PARK(0) CTAMD_P_PARK(1) CTAMD_P_PARK(2) CTAMD_P_PARK(3)                            \
+                        CTAMD_P_FETCH(0) CTAMD_P_FETCH(1) CTAMD_P_FETCH(2) CTAMD_P_FETCH(3)                        \
+                    }                                                                                              \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 2) CTAMD_P_FRAG(I, 3) }                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(0) }                                                    \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 4) CTAMD_P_FRAG(I, 5) }                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(1) CTAMD_P_STORE(2) }                                   \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 6) CTAMD_P_FRAG(I, 7) }                               \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(3) }                                                    \
+                    if constexpr ((I) < 8) { CTAMD_P_TR(t[0], 0, 0) CTAMD_P_TR(t[1], 0, 1) CTAMD_P_TR(t[2], 0, 2) CTAMD_P_TR(t[3], 0, 3) } \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                }
+                CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
+                CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
 #undef CTAMD_P_PASS
-#undef CTAMD_P_LOAD
+#undef CTAMD_P_STORE
+#undef CTAMD_P_FETCH
+#undef CTAMD_P_PARK
+#undef CTAMD_P_FRAG
+            } else {
+                // EP = 0 / 1 (measurement): straight from the transposing reads — a store writes 16 rows x 64 bytes
+                s16x8 v[2][4];
+#define CTAMD_P_FRAG(I, J)                                                                                          \
+                *reinterpret_cast<s16x4*>(wPtr + ((I) & 1) * kPImageBytes + 512 * (J)) = p_round4<BF>(acc[(I) < 8 ? (I) : 0][J], alpha);
+#define CTAMD_P_STORE(I, IT)                                                                                        \
+                {                                                                                                  \
+                    if constexpr (EP == 1) *(PGlb8)(uintptr_t)(dst + 32 * (IT)) = v[((I) - 1) & 1][IT];            \
+                    else __builtin_nontemporal_store(v[((I) - 1) & 1][IT], (PGlb8)(uintptr_t)(dst + 32 * (IT)));   \
+                }
+#define CTAMD_P_PASS(I)                                                                                             \
+                {                                                                                                  \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 0) CTAMD_P_FRAG(I, 1) }                               \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 0) }                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 2) CTAMD_P_FRAG(I, 3) }                               \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 1) }                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 4) CTAMD_P_FRAG(I, 5) }                               \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 2) }                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 6) CTAMD_P_FRAG(I, 7) }                               \
+                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 3) dst += 16 * sM; }                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                    if constexpr ((I) < 8) { CTAMD_P_TR(v[(I) & 1][0], (I) & 1, 0) CTAMD_P_TR(v[(I) & 1][1], (I) & 1, 1)   \
+                                             CTAMD_P_TR(v[(I) & 1][2], (I) & 1, 2) CTAMD_P_TR(v[(I) & 1][3], (I) & 1, 3) } \
+                    __builtin_amdgcn_sched_barrier(0);                                                             \
+                }
+                CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
+                CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
+#undef CTAMD_P_PASS
 #undef CTAMD_P_STORE
 #undef CTAMD_P_FRAG
+            }
+#undef CTAMD_P_TR
+            if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
+            ++tilesWalked;
             if (!more) break;
             staged = true;
             continue;
@@ -345,10 +406,21 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                 ep.template flush<BF, 0>(pe, mB, 0u, 0u, nW, 64u, 32u, laneE);
             }
         }
+        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
+        ++tilesWalked;
         if (!more) break;
         __syncthreads();                          // the epilogue's images in the ring are dead in every wave
         vb = nextVb;
         staged = false;
+    }
+    if constexpr (TIMED) {
+        if (p.timing != nullptr && wave == 0 && lane == 0) {
+            wgStamp[4] = __builtin_readcyclecounter();            // the stores are issued, not waited for
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
+            p.timing[64 + 8 * (size_t)blockIdx.x + 5] = tilesWalked;
+            p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+        }
     }
 }
 
@@ -368,6 +440,13 @@ static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
     grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
     if (grid == 0) grid = 8;
     if (grid > p.nBlocks) grid = p.nBlocks;
+    if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / epilogue variants
+        static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
+        static const int ep = [] { const char* e = getenv("CUTENSOR_AMD_H16P_EP"); return e ? atoi(e) : 2; }();
+        if (timed && ep == 0) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 0, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed && ep == 1) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 1, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
+        if (timed) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 2, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
+    }
     hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

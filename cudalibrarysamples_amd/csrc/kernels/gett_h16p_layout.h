@@ -35,4 +35,19 @@ CTAMD_HD uint32_t p_img_read_off(int lane, int it, int h) {
     return (uint32_t)(1024 * it + 256 * g + row * 32 + (slot << 3));
 }
 
+// ---- second image (EP = 2): the pass again as [16 rows][256 bytes], so that ONE store instruction writes 4 rows x 256 contiguous bytes
+// (whole cache lines) instead of the 16 rows x 64 bytes the transposing reads deliver.  16-byte unit u of row r lives at unit
+// u ^ (r & 7) of the row: the ds_write_b128 of 8 consecutive lanes (8 rows, one chunk) and the ds_read_b128 of a 16-lane group both
+// spread over all banks.
+// where lane (g = lane >> 4, ii = lane & 15) parks the chunk q = 4 it + g it received from the transposing reads
+CTAMD_HD uint32_t p_row_write_off(int lane, int it) {
+    const int g = lane >> 4, ii = lane & 15, q = 4 * it + g;
+    return (uint32_t)(ii * 256 + ((q ^ (ii & 7)) << 4));
+}
+// where lane (r4 = lane >> 4, ch = lane & 15) fetches 8 columns (8 ch + [0, 8)) of row 4 it2 + r4 for its store
+CTAMD_HD uint32_t p_row_read_off(int lane, int it2) {
+    const int row = 4 * it2 + (lane >> 4), ch = lane & 15;
+    return (uint32_t)(row * 256 + ((ch ^ (row & 7)) << 4));
+}
+
 }  // namespace ctamd

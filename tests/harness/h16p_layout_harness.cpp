@@ -67,6 +67,46 @@ int main() {
                 }
         }
     }
+    // ---- second image (EP = 2): every lane parks its four chunks (rows = lane & 15) in the row image and fetches 4 rows x 16 chunks back
+    {
+        uint16_t row_img[16 * 128];
+        std::memset(row_img, 0xff, sizeof(row_img));
+        int w2[4096];
+        std::memset(w2, 0, sizeof(w2));
+        for (int it = 0; it < 4; ++it)
+            for (int grp8 = 0; grp8 < 8; ++grp8) {          // ds_write_b128: 8 x 8 contiguous lanes, bank = (address / 4) mod 32
+                std::set<int> banks;
+                for (int lane = 8 * grp8; lane < 8 * grp8 + 8; ++lane) {
+                    const uint32_t off = p_row_write_off(lane, it);
+                    if (off % 16 != 0 || off + 16 > 4096u) { std::printf("row image write offset\n"); return 7; }
+                    const int row = lane & 15, q = 4 * it + (lane >> 4);
+                    for (int e = 0; e < 8; ++e) row_img[off / 2 + e] = code(row, 8 * q + e);
+                    for (int b = 0; b < 16; ++b) ++w2[off + b];
+                    for (int b = 0; b < 4; ++b) banks.insert((off / 4 + b) % 32);
+                }
+                if (banks.size() != 32) { std::printf("ds_write_b128 bank conflict: it %d lanes %d.. touch %zu banks\n", it, 8 * grp8, banks.size()); return 8; }
+            }
+        for (int b = 0; b < 4096; ++b)
+            if (w2[b] != 1) { std::printf("row image byte %d written %d times\n", b, w2[b]); return 9; }
+        static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                          {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+        for (int it2 = 0; it2 < 4; ++it2) {
+            for (int gi = 0; gi < 4; ++gi) {                // ds_read_b128: the four 16-lane groups of the MI355X guide, bank = (address / 4) mod 64
+                std::set<int> banks;
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t off = p_row_read_off(groups[gi][k], it2);
+                    for (int b = 0; b < 4; ++b) banks.insert((off / 4 + b) % 64);
+                }
+                if (banks.size() != 64) { std::printf("ds_read_b128 bank conflict: it2 %d group %d touches %zu banks\n", it2, gi, banks.size()); return 10; }
+            }
+            for (int lane = 0; lane < 64; ++lane) {
+                const uint32_t off = p_row_read_off(lane, it2);
+                const int row = 4 * it2 + (lane >> 4), ch = lane & 15;
+                for (int e = 0; e < 8; ++e)
+                    if (row_img[off / 2 + e] != code(row, 8 * ch + e)) { std::printf("row image: lane %d it2 %d element %d wrong\n", lane, it2, e); return 11; }
+            }
+        }
+    }
     std::printf("h16p layout ok\n");
     return 0;
 }

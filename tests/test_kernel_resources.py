@@ -155,7 +155,7 @@ def test_persistent_16_bit_kernel_uses_no_scratch_and_all_of_the_lds(built, tmp_
     ring + two 4-KiB epilogue images per wave); its accumulator reads wait behind the two s_nop 15 like every inline-asm MFMA kernel."""
     co = _code_object(tmp_path, "gett_h16p")
     k = _kernel_notes(co)
-    hot = {n: v for n, v in k.items() if "gett_h16w4p_kernel" in n}
+    hot = {n: v for n, v in k.items() if "gett_h16w4p_kernel" in n and n.endswith("Li2ELb0EEEvNS_10GettParamsE")}   # EP = 2, not TIMED: what the planner launches
     assert len(hot) == 8, sorted(k)
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
@@ -176,4 +176,5 @@ def test_persistent_16_bit_kernel_uses_no_scratch_and_all_of_the_lds(built, tmp_
         assert not any(l.startswith("scratch_") for l in ins), name
         # the transposed epilogue: transposing reads outside the main loop's count, 8-byte LDS writes, global (not flat) 16-byte stores
         assert any(l.startswith("ds_write2st64_b64") or l.startswith("ds_write_b64") for l in ins), name
+        assert sum(1 for l in ins if l.startswith("ds_write_b128")) >= 32, name           # the row image: 4 parks x 8 passes
         assert sum(1 for l in ins if l.startswith("global_store_dwordx4")) >= 32, name
