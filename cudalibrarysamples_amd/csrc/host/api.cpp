@@ -141,9 +141,9 @@ namespace {
 
 // any experiment knob that changes what cutensorCreatePlan decides: the memo stands aside while one is set
 bool plan_env_override() {
-    return std::getenv("CUTENSOR_AMD_FORCE") || std::getenv("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD") ||
-           std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT") || std::getenv("CUTENSOR_AMD_H16_WAVES") || std::getenv("CUTENSOR_AMD_H16_SPLITK") ||
-           std::getenv("CUTENSOR_AMD_KORDER") || std::getenv("CUTENSOR_AMD_ABLATION") || std::getenv("CUTENSOR_AMD_PEEL") || std::getenv("CUTENSOR_AMD_GEN");
+    return ctamd_research_env("CUTENSOR_AMD_FORCE") || ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD") ||
+           ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT") || std::getenv("CUTENSOR_AMD_H16_WAVES") || ctamd_research_env("CUTENSOR_AMD_H16_SPLITK") ||
+           ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || std::getenv("CUTENSOR_AMD_PEEL") || std::getenv("CUTENSOR_AMD_GEN");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
@@ -1248,7 +1248,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 if ((int)pr.algo >= 0) idx = std::min<size_t>((size_t)pr.algo, ch.size() - 1);
                 else if (pr.kernelRank > 0) idx = std::min<size_t>((size_t)pr.kernelRank, ch.size() - 1);
                 else if (patient) idx = (size_t)autotune_contraction(handle, *desc, pl->view, ch);
-                if (const char* f = std::getenv("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
+                if (const char* f = ctamd_research_env("CUTENSOR_AMD_FORCE")) {   // "kernel:splitK" experiment knob
                     int fk = -1; unsigned fs = 1;
                     if (std::sscanf(f, "%d:%u", &fk, &fs) >= 1)
                         for (size_t i = 0; i < ch.size(); ++i)
@@ -1277,7 +1277,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK >= 64 && pl->view.totL == 1 && pl->gett.tilesM * pl->gett.tilesN == 1) {
             int cnt = 0;
             const GettKernelInfo* tabf = gett_f32_kernels(&cnt);
-            const char* env = std::getenv("CUTENSOR_AMD_XCD_BALANCE");
+            const char* env = ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE");
             // opt-in: on the parts measured the clocks differ by +-1.5 %, below the 1-tile-in-32 (3 %) granularity
             // of the headline split, so the apportionment comes out uniform
             if (env && env[0] == '1' && tabf[pick.kernel].fragPartials && !tabf[pick.kernel].ablation)
@@ -1534,7 +1534,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         g_launchCounts[2].fetch_add(1, std::memory_order_relaxed);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         {
-            static const int policy = [] { const char* e = std::getenv("CUTENSOR_AMD_PARTIAL_STORE"); return e ? (e[0] == 'p' ? 1 : e[0] == 'n' ? 2 : 0) : 0; }();
+            static const int policy = [] { const char* e = ctamd_research_env("CUTENSOR_AMD_PARTIAL_STORE"); return e ? (e[0] == 'p' ? 1 : e[0] == 'n' ? 2 : 0) : 0; }();
             p.partialPolicy = policy;
         }
         if (plan->fusedFold) {
@@ -1902,6 +1902,15 @@ int ctamdProfileEnd(cutensorHandle_t handle, float* meanMs, float* minMs) try {
 
 // Instantiated fp32 GETT kernels (test coverage bookkeeping): table size, and whether entry i is a
 // measurement-only ablation variant (never planned unless CUTENSOR_AMD_ABLATION is set).
+// 1 when the library was built with RESEARCH=1 (retired kernel families, TIMED / XST / EP instantiations, measurement switches)
+int ctamdResearchKernelsBuilt(void) try {
+#if defined(CTAMD_RESEARCH_KERNELS)
+    return 1;
+#else
+    return 0;
+#endif
+} CTAMD_API_CATCH_INT
+
 int ctamdKernelCount(void) try {
     int count = 0;
     (void)gett_f32_kernels(&count);

@@ -12,6 +12,20 @@
 #include <cutensor.h>
 
 #include "api_guard.hpp"
+
+// Measurement-only environment switches (CUTENSOR_AMD_FORCE, _XCD_BALANCE, _KORDER, _ABLATION, _PARTIAL_STORE, _H16_SPLITK,
+// _H16_TRANSPOSE_T1, ...) are read in research builds only (make RESEARCH=1): the production library answers "not set".  What stays
+// live in production are the switches the test-suite and the tools drive behaviour with: CUTENSOR_LOG_LEVEL, CUTENSOR_AMD_GEN, _PEEL, _NT,
+// _FUSED_FOLD, _H16_WAVES, _H16P_GRID and the CUTENSORMG_AMD_* / CUTENSORMP_AMD_* ones.
+#include <cstdlib>
+inline const char* ctamd_research_env(const char* name) {
+#if defined(CTAMD_RESEARCH_KERNELS)
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 #include "../kernels/launch.h"
 #include "../kernels/params.h"
 

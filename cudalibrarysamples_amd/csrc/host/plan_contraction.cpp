@@ -174,7 +174,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     // explicit digit list, fastest first, e.g. "d,c:4,b,c" = mode d, the inner 4 of mode c, mode b, the
     // rest of c (labels as characters).  Any order of the contracted digits is a valid GETT view; the
     // order decides how a K slice maps to memory in A and B.
-    const char* korder = std::getenv("CUTENSOR_AMD_KORDER");
+    const char* korder = ctamd_research_env("CUTENSOR_AMD_KORDER");
     bool followB = (!kContigA && kContigB);
     bool custom = false;
     if (korder && korder[0] == 'B' && korder[1] == 0) followB = true;
@@ -290,7 +290,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
     const double hbm = 6.0e12, l2bw = 20.0e12;
     const double M = (double)v.totM, N = (double)v.totN, K = (double)v.totK, L = (double)v.totL;
 
-    const bool withAblations = std::getenv("CUTENSOR_AMD_ABLATION") != nullptr;
+    const bool withAblations = ctamd_research_env("CUTENSOR_AMD_ABLATION") != nullptr;
     // byte span of an operand beyond its batch offset: the streaming kernels address it through a buffer
     // descriptor with 32-bit byte offsets
     auto span_bytes = [&](bool slotA) {
@@ -459,8 +459,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     };
     int var = variant;
     uint64_t split = 1;
-    if (forced) {
-        if (layoutIdx + var >= count) return false;
+    const bool usable = forced && layoutIdx + var < count && tab[layoutIdx + var].ablation != 2;   // a retired family asked for in a production build: ignored
+    if (forced && usable) {
         split = auto_split(var);
     } else {
         // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below), the
@@ -477,7 +477,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         }
     }
     c.kernel = layoutIdx + var;
-    if (const char* fs = std::getenv("CUTENSOR_AMD_H16_SPLITK")) {   // measurement knob: this many slices (if the workspace allows)
+    if (const char* fs = ctamd_research_env("CUTENSOR_AMD_H16_SPLITK")) {   // measurement knob: this many slices (if the workspace allows)
         const uint64_t want = std::strtoull(fs, nullptr, 10);
         if (want >= 1 && want <= kTiles && want * perSliceBytes <= std::max<uint64_t>(wsLimit, 1)) split = want;
         if (want == 1) split = 1;
@@ -499,10 +499,11 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     if (!pick_h16_choice(v, wsLimit, numCUs, base)) return out;
     out.push_back(base);
     int count = 0;
-    (void)gett_h16_kernels(&count);
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
+    const GettKernelInfo* tab = gett_h16_kernels(&count);
     for (int other : {0, 48, 88, 56, 64, 72, 80, 40, 32, 16, 24, 8}) {  // ping-pong rows, four waves register-staged, streamed (free-running waves), four waves streamed, four waves
         if (other == variant || layoutIdx + other >= count) continue;
+        if (tab[layoutIdx + other].ablation == 2) continue;        // a retired family, not built into this library (research builds only)
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;
         out.push_back(c);

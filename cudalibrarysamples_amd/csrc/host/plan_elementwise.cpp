@@ -197,7 +197,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
                 else if (p.E0 % 128 == 0) t0 = 128;
                 if (t0 > 64) {
                     t1 = (p.E1 % 128 == 0) ? 128 : 64;
-                    if (const char* e = std::getenv("CUTENSOR_AMD_H16_TRANSPOSE_T1")) { const int v = std::atoi(e); if ((v == 64 || v == 128) && p.E1 % v == 0) t1 = v; }
+                    if (const char* e = ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1")) { const int v = std::atoi(e); if ((v == 64 || v == 128) && p.E1 % v == 0) t1 = v; }
                 }
             }
         } else if (!usesX && p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {

@@ -43,6 +43,11 @@
 
 namespace ctamd {
 
+// The five kernel families of this file are RETIRED defaults (rounds 1-3: the eight-wave ping-pong kernel and its four-wave / streamed /
+// register-staged siblings): since round 5 they are compiled only into research builds (make RESEARCH=1 -> -DCTAMD_RESEARCH_KERNELS);
+// the production library keeps their table slots (the planner's indices do not move) with a launcher that answers
+// hipErrorNotSupported and `ablation` = 2 ("not built"), which rank_h16_choices skips.  The MFMA-only rate measurement below stays.
+#if defined(CTAMD_RESEARCH_KERNELS)
 // TIMED (measurement-only instantiation, selected with CUTENSOR_AMD_H16_TIMED=1): waves 0 and 4 of workgroup 0
 // record s_memtime at the segment boundaries of K-tile 8 into p.timing (7 stamps x 4 phases per wave).
 // ABL (measurement only, wrong results; CUTENSOR_AMD_H16_ABL with the default kernel): 1 = no LDS-DMA in the main loop,
@@ -1240,6 +1245,8 @@ static hipError_t launch_h16(const GettParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#endif  // CTAMD_RESEARCH_KERNELS
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Measurement only: the rate at which THIS device sustains nothing but independent v_mfma_f32_32x32x16_{bf16,f16} on a
 // given kind of operand data (one wave per SIMD, eight operand register pairs, no memory traffic at all).  On zeros it
@@ -1367,6 +1374,14 @@ extern "C" int ctamdMeasureMfmaCeilingShape(int bf16, int dataKind, int shape, f
 namespace ctamd {
 
 // bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F)
+#if !defined(CTAMD_RESEARCH_KERNELS)
+static hipError_t launch_h16_not_built(const GettParams&, hipStream_t) { return hipErrorNotSupported; }
+#define CTAMD_H16_ENTRY(bf, la, lb)    {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 2, &launch_h16_not_built, 0},
+#define CTAMD_H16W4_ENTRY(bf, la, lb)  {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 2, 1, 2, &launch_h16_not_built, 0},
+#define CTAMD_H16S_ENTRY(bf, la, lb)   {kHTile, kHTile, 32, 2, 4, 1, la, lb, 512, 4, 1, 2, &launch_h16_not_built, 0},
+#define CTAMD_H16W4R_ENTRY(bf, la, lb) {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 3, 1, 2, &launch_h16_not_built, 0},
+#define CTAMD_H16W4S_ENTRY(bf, la, lb) {kHTile, kHTile, 32, 2, 2, 1, la, lb, 256, 5, 1, 2, &launch_h16_not_built, 0},
+#else
 #define CTAMD_H16_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 4, 1, la, lb, 512, 5, 1, 0, &launch_h16<bf, la, lb>, 0},
 #define CTAMD_H16W4_ENTRY(bf, la, lb) \
@@ -1377,6 +1392,7 @@ namespace ctamd {
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 3, 1, 0, &launch_h16w4r<bf, la, lb>, 0},
 #define CTAMD_H16W4S_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kSBK, 2, 2, 1, la, lb, 256, 5, 1, 0, &launch_h16w4s<bf, la, lb>, 0},
+#endif
 static const GettKernelInfo g_h16_table[] = {
     CTAMD_H16_ENTRY(true, LAY_K, LAY_K) CTAMD_H16_ENTRY(true, LAY_K, LAY_F)
     CTAMD_H16_ENTRY(true, LAY_F, LAY_K) CTAMD_H16_ENTRY(true, LAY_F, LAY_F)

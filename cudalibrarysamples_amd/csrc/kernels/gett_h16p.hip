@@ -197,8 +197,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             CTAMD_P_SETUP(vb)
             CTAMD_P_ISSUE2()
         }
-        const uint32_t mW = m0 + 128 * wr, nW = n0 + 128 * wc;    // this wave's quadrant of the tile about to be multiplied
-        const uint32_t tM0 = m0, tN0 = n0, curL = l, curSlice = slice;
         const int curTiles = nTiles;
         // K-tile 0 has landed: loads complete in issue order, so "at most 16 memory operations outstanding" leaves at most the 16
         // pieces of K-tile 1 (and, from the second tile on, waits out the previous epilogue's stores, which were issued later)
@@ -224,6 +222,24 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         const uint32_t nextVb = vb + gridDim.x;
         GettParams pe;                            // the epilogue's arguments in one burst of scalar loads
         h_reload_params(pe);
+        // the tile's coordinates AGAIN, from its id: only `vb` and the K-tile count stay live across the main loop (six more scalar
+        // registers there were four v_writelane per K-tile in the loop — spill traffic between the MFMAs, +80 cycles per K-tile)
+        uint32_t tM0, tN0, curL, curSlice;
+        {
+            const uint32_t tilesMN_ = pe.tilesM * pe.tilesN, tilesAll_ = tilesMN_ * pe.gL.total;
+            uint32_t id_ = xcd_remap(vb, pe.nBlocks);
+            curSlice = VOdometer::sgpr(id_ / tilesAll_);
+            id_ -= curSlice * tilesAll_;
+            curL = VOdometer::sgpr(id_ / tilesMN_);
+            id_ -= curL * tilesMN_;
+            const uint32_t perGroup_ = 8u * pe.tilesN;
+            const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;
+            const uint32_t first_ = grp_ * 8u;
+            const uint32_t gsz_ = (pe.tilesM - first_ < 8u) ? (pe.tilesM - first_) : 8u;
+            tM0 = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);
+            tN0 = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);
+        }
+        const uint32_t mW = tM0 + 128 * wr, nW = tN0 + 128 * wc;   // this wave's quadrant
         // (values read through the laundered argument pointer count as divergent for the compiler: what steers control flow is made
         // wave-uniform again explicitly, or the K loop's scalar state would be given vector registers)
         const bool more = VOdometer::sgpr(nextVb < pe.nBlocks ? 1u : 0u) != 0u;
@@ -440,6 +456,7 @@ static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
     grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
     if (grid == 0) grid = 8;
     if (grid > p.nBlocks) grid = p.nBlocks;
+#if defined(CTAMD_RESEARCH_KERNELS)
     if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / epilogue variants
         static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
         static const int ep = [] { const char* e = getenv("CUTENSOR_AMD_H16P_EP"); return e ? atoi(e) : 2; }();
@@ -447,6 +464,7 @@ static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
         if (timed && ep == 1) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 1, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 2, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
+#endif
     hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

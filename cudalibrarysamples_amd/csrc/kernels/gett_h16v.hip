@@ -21,6 +21,7 @@
 
 namespace ctamd {
 
+#if defined(CTAMD_RESEARCH_KERNELS)   // gett_h16w4v_kernel: the 32x32x16 sibling of the default, retired in round 5 (research builds only)
 template <bool BF, int LA, int LB>
 __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
@@ -188,6 +189,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4v_kernel(const GettParams p)
         ep.template flush<BF>(p, mB, 0u, 0u, nW, 64u, 32u, laneE);
     }
 }
+
+#endif  // CTAMD_RESEARCH_KERNELS
 
 // =====================================================================================================
 // gett_h16w4x_kernel (CUTENSOR_AMD_H16_WAVES=4x): the kernel above on v_mfma_f32_16x16x32_{bf16,f16}.
@@ -524,6 +527,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
+#if defined(CTAMD_RESEARCH_KERNELS)
     if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / store modes
         static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
         static const int xst = [] { const char* e = getenv("CUTENSOR_AMD_H16_XST"); return e ? atoi(e) : 0; }();
@@ -537,6 +541,7 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed && xst == 10) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 10>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
+#endif
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -1309,17 +1314,23 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4q(const GettParams& p, hipStream_t stream) {
+#if defined(CTAMD_RESEARCH_KERNELS)
     if constexpr (BF && LA == LAY_K && LB == LAY_F) {
         static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
         if (timed) { hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
+#endif
     hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w8m(const GettParams& p, hipStream_t stream) {
-    static const bool ring4 = [] { const char* e = getenv("CUTENSOR_AMD_H16_RING"); return e && e[0] == '4'; }();   // measurement: the four-deep ring
+#if defined(CTAMD_RESEARCH_KERNELS)
+    static const bool ring4 = [] { const char* e = getenv("CUTENSOR_AMD_H16_RING"); return e && e[0] == '4'; }();
+#else
+    static const bool ring4 = false;
+#endif   // measurement: the four-deep ring
     if (ring4) hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB, 4>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((gett_h16w8m_kernel<BF, LA, LB, 5>), dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
@@ -1331,6 +1342,7 @@ static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#if defined(CTAMD_RESEARCH_KERNELS)
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((gett_h16w4v_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
@@ -1340,6 +1352,10 @@ static hipError_t launch_h16w4v(const GettParams& p, hipStream_t stream) {
 // bf16 entries first, then fp16, each in the order (layA, layB) = (K,K) (K,F) (F,K) (F,F) — the order of gett_h16.hip's table
 #define CTAMD_H16W4V_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 6, 1, 0, &launch_h16w4v<bf, la, lb>, 0},
+#else
+static hipError_t launch_h16v_not_built(const GettParams&, hipStream_t) { return hipErrorNotSupported; }
+#define CTAMD_H16W4V_ENTRY(bf, la, lb) {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 6, 1, 2, &launch_h16v_not_built, 0},
+#endif
 #define CTAMD_H16W4X_ENTRY(bf, la, lb) \
     {kHTile, kHTile, kHBK, 2, 2, 1, la, lb, 256, 7, 1, 0, &launch_h16w4x<bf, la, lb>, 0},
 #define CTAMD_H16W4M_ENTRY(bf, la, lb) \

@@ -178,7 +178,7 @@ def test_headline_einsum_shape_in_bf16(env):
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=0.25)
 
 
-@pytest.mark.parametrize("variant", ["4", "s", "p", "4s", "4r", "4v", "4x", "4m", "4m4", "8m", "4q"])
+@pytest.mark.parametrize("variant", ["4", "s", "p", "4s", "4r", "4v", "4x", "4p", "4m", "4m4", "8m", "4q"])
 def test_kernel_variant_parity(built, variant):
     """The other 16-bit kernel variants (CUTENSOR_AMD_H16_WAVES=4: gett_h16w4_kernel, one wave per SIMD, 128 x 128 per
     wave; =s: gett_h16s_kernel, eight free-running waves, K-tile of 32, five-deep LDS ring, one barrier per K-tile; =p: gett_h16_kernel, two wave rows
@@ -187,6 +187,9 @@ def test_kernel_variant_parity(built, variant):
     import os
     import subprocess
     import sys
+    from cudalibrarysamples_amd import cutensor as ct
+    if variant in ("4", "s", "p", "4s", "4r", "4v") and not ct.lib.ctamdResearchKernelsBuilt():
+        pytest.skip("a retired kernel family: compiled by make RESEARCH=1 only (round 5)")
     env = dict(os.environ, CUTENSOR_AMD_H16_WAVES=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
                         "gemm_like or multi_mode or split_k or alpha_beta", "-p", "no:cacheprovider"],
@@ -212,7 +215,7 @@ def test_bf16_operand_larger_than_4_gib(built, mA):
     p = ops.contraction_plan(h, [K, M] if mA == "km" else [M, K], mA, [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF,
                              workspace_limit=1 << 30)
     d = p.describe()
-    assert d["kname"] in ("gett_h16_kernel", "gett_h16w4_kernel", "gett_h16s_kernel", "gett_h16w4s_kernel", "gett_h16w4r_kernel", "gett_h16w4v_kernel", "gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel"), d
+    assert d["kname"] in ("gett_h16_kernel", "gett_h16w4_kernel", "gett_h16s_kernel", "gett_h16w4s_kernel", "gett_h16w4r_kernel", "gett_h16w4v_kernel", "gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel", "gett_h16w4p_kernel"), d
     ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
     p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), p.required_workspace)
     torch.cuda.synchronize()

@@ -80,20 +80,25 @@ def test_mid_size_problems_run_the_128_tile_family(env):
         p.destroy()
 
 
+KEPT = {"gett_h16w4x_kernel", "gett_h16w4p_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel"}
+RETIRED = {"gett_h16_kernel", "gett_h16w4v_kernel", "gett_h16w4r_kernel", "gett_h16s_kernel", "gett_h16w4s_kernel", "gett_h16w4_kernel"}
+
+
 def test_every_variant_stays_an_autotuning_candidate(env):
+    """The ranked candidates of a 16-bit problem are the kernel families BUILT INTO the library: the six kept ones in a production build
+    (round 5: the retired families live behind make RESEARCH=1 and keep only their table slots), all twelve in a research build."""
     ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
     h = ops.Handle()
+    research = bool(ct.lib.ctamdResearchKernelsBuilt())
     names = []
     for r in range(12):
         p = _plan(ct, ops, h, 8192, 8192, 8192, algo=r, cache_mode=ct.CACHE_MODE_NONE)
         names.append(p.describe()["kname"])
         p.destroy()
-    assert names[0] == "gett_h16w4x_kernel", names
-    assert set(names) == {"gett_h16w4x_kernel", "gett_h16_kernel", "gett_h16w4v_kernel", "gett_h16w4r_kernel", "gett_h16s_kernel",
-                          "gett_h16w4s_kernel", "gett_h16w4_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w8m_kernel", "gett_h16w4q_kernel",
-                          "gett_h16w4p_kernel"}, names
+    assert names[0] in ("gett_h16w4x_kernel", "gett_h16w4p_kernel"), names
+    assert set(names) == (KEPT | RETIRED if research else KEPT), names
 
 
 @pytest.mark.parametrize("waves,want", [("8", "gett_h16_kernel"), ("4", "gett_h16w4_kernel"), ("4v", "gett_h16w4v_kernel"),
@@ -109,4 +114,10 @@ def test_the_switch_overrides_the_planner(built, waves, want):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, CUTENSOR_AMD_H16_WAVES=waves))
     assert r.returncode == 0, r.stderr[-2000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1]) == [want, want], r.stdout
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    from cudalibrarysamples_amd import cutensor as ct
+    if want in RETIRED and not ct.lib.ctamdResearchKernelsBuilt():
+        # a retired family asked for in a production build: the switch is ignored, the planner's own choice runs
+        assert all(g in KEPT for g in got), got
+    else:
+        assert got == [want, want], r.stdout

@@ -53,6 +53,8 @@ def _kernel_notes(co):
 def test_default_16_bit_kernels_use_no_scratch(built, tmp_path):
     k = _kernel_notes(_code_object(tmp_path, "gett_h16"))
     hot = {n: v for n, v in k.items() if "gett_h16_kernel" in n or "gett_h16s_kernel" in n}
+    if not hot:
+        pytest.skip("production build: the retired eight-wave families are compiled by make RESEARCH=1 only")
     assert len(hot) >= 16, sorted(k)
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
@@ -63,7 +65,7 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     256 accumulator registers + 256 others, no private segment (a scratch allocation is paid for at every dispatch)."""
     k = _kernel_notes(_code_object(tmp_path, "gett_h16v"))
     hot = {n: v for n, v in k.items() if "gett_h16w4x_kernel" in n or "gett_h16w4v_kernel" in n}
-    assert len(hot) >= 16, sorted(k)          # 8 + 8 layouts x types, plus the measurement-only instantiations
+    assert len(hot) >= 8, sorted(k)           # 8 layouts x types of the default (+ 8 of the retired 32x32x16 sibling and the measurement-only instantiations in a research build)
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
@@ -90,7 +92,7 @@ def test_inline_asm_mfma_kernel_waits_before_it_reads_its_accumulators(built, tm
     co = _code_object(tmp_path, "gett_h16v")
     k = _kernel_notes(co)
     names = [n for n in k if any(x in n for x in ("gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4q_kernel", "gett_h16w8m_kernel"))]
-    assert len(names) >= 48, sorted(k)
+    assert len(names) >= 40, sorted(k)
     for name in names:
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + name, co], check=True,
                              capture_output=True, text=True).stdout.splitlines()
@@ -123,7 +125,8 @@ def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
 
 @pytest.mark.parametrize("obj,symbol", [
     ("gett_f32_stream", "_ZN5ctamd22gett_f32_stream_kernelINS_9StreamCfgILi96ELi96ELi1ELi0ELi3ELi0EEEEEvNS_10GettParamsE"),
-    ("gett_h16", "_ZN5ctamd15gett_h16_kernelILb1ELi1ELi0ELb0ELi0EEEvNS_10GettParamsE"),
+    ("gett_h16v", "_ZN5ctamd18gett_h16w4x_kernelILb1ELi1ELi0ELb0ELi0EEEvNS_10GettParamsE"),
+    ("gett_h16p", "_ZN5ctamd18gett_h16w4p_kernelILb1ELi1ELi0ELi2ELb0EEEvNS_10GettParamsE"),
 ])
 def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, obj, symbol):
     co = _code_object(tmp_path, obj)
