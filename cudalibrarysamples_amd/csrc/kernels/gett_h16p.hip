@@ -98,6 +98,12 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     VOdometer odo;
     uint32_t m0 = 0, n0 = 0, slice = 0, l = 0;
     int nTiles = 0;
+    // ---- streaming across tiles (see CTAMD_P_SWITCH) ---------------------------------------------------------------------------
+    uint64_t relA = 0, relB = 0;                  // tile-invariant parts of the staging bases: base = rel + 2 * row0 * stride (interior tiles, flat M / N)
+    bool curOK = false;                           // the tile in flight lies inside D of a problem whose interior tiles take the fast epilogue
+    bool streamedOut = false;                     // the NEXT tile's first two K-tiles were issued by this tile's last two K-tile bodies
+    bool streamedIn = false;                      // ... and this tile arrived that way
+    int nTilesNext = 0;
     // tile of virtual workgroup id VB_ (the one-tile kernel's blockIdx.x): coordinates, staging tables, K odometer.  The arguments come
     // from a FRESH copy of the argument block and the lane index from the hardware, behind an opaque asm: nothing this block needs
     // may stay live across the main loop (kept in registers "because it is used again" it would be ~150 SGPRs of mode tables and a
@@ -129,6 +135,57 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.A) + group_offset<0>(ps_.gL, l)) + oa.base); \
         const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.B) + group_offset<1>(ps_.gL, l)) + ob.base); \
         odo.init(ps_.gK, tile0_ * kHBK, (uint32_t)nTiles, bA_, bB_);                                               \
+        HEpilogue e_;                                                                                              \
+        e_.init(ps_, l, lds, wave);                                                                                \
+        curOK = VOdometer::sgpr((e_.vecD && e_.beta == 0.f && e_.flat && ps_.partial == nullptr && ps_.gL.total == 1u &&            \
+                                 m0 + (uint32_t)kHTile <= ps_.gM.total && n0 + (uint32_t)kHTile <= ps_.gN.total) ? 1u : 0u) != 0u;  \
+        relA = h_uniform64(oa.base - (uint64_t)m0 * (uint64_t)ps_.gM.stride[0][0] * 2ull);                         \
+        relB = h_uniform64(ob.base - (uint64_t)n0 * (uint64_t)ps_.gN.stride[0][0] * 2ull);                         \
+    }
+// The tile AFTER the one in flight, staged by the main loop itself: called in k-step 0 of K-tile nTiles - 2 (instead of the odometer's
+// event check — the odometer has nothing left to do there: its last real advance moved it to K-tile nTiles - 1), it re-initialises the
+// odometer for the next tile of this workgroup's walk, so that the LDS-DMA pieces the last two K-tile bodies issue anyway ("K-tile t + 2":
+// a re-staged, never-read tile in gett_h16w4x_kernel) fetch the next tile's K-tiles 0 and 1 — no extra issue slot, no setup or staging
+// between the tiles.  What makes it cheap: for tiles that lie inside a flat problem the per-lane staging offsets (HOperand::src, 16
+// VGPRs) do not depend on the tile — only the descriptor bases move (rel + 2 * row0 * stride) — so the "setup" is scalar arithmetic.
+// Needs: this tile and the next one interior (this one takes the epilogue that stays out of the ring), an even K-tile count (the next
+// tile starts in ring buffer 0), at least two K-tiles in the next tile.  Otherwise the odometer's event check runs and the next tile is
+// staged the slow way, under / after the epilogue.
+#define CTAMD_P_SWITCH()                                                                                            \
+    {                                                                                                              \
+        GettParams pn_;                                                                                            \
+        h_reload_params(pn_);                                                                                      \
+        const uint32_t nv_ = vb + gridX;                                                                           \
+        bool ok_ = false;                                                                                          \
+        if (VOdometer::sgpr(nv_ < pn_.nBlocks ? 1u : 0u) != 0u) {                                                  \
+            const uint32_t tilesMN_ = pn_.tilesM * pn_.tilesN;                                                     \
+            const uint32_t tilesAll_ = tilesMN_ * pn_.gL.total;                                                    \
+            const uint32_t kTilesAll_ = pn_.gK.total / kHBK, tilesPerSlice_ = pn_.kPerSlice / kHBK;                \
+            uint32_t id_ = xcd_remap(nv_, pn_.nBlocks);                                                            \
+            const uint32_t slice_ = VOdometer::sgpr(id_ / tilesAll_);                                              \
+            id_ -= slice_ * tilesAll_;                                                                             \
+            const uint32_t l_ = VOdometer::sgpr(id_ / tilesMN_);                                                   \
+            id_ -= l_ * tilesMN_;                                                                                  \
+            const uint32_t perGroup_ = 8u * pn_.tilesN;                                                            \
+            const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;                                \
+            const uint32_t first_ = grp_ * 8u;                                                                     \
+            const uint32_t gsz_ = (pn_.tilesM - first_ < 8u) ? (pn_.tilesM - first_) : 8u;                         \
+            const uint32_t m0n_ = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);                              \
+            const uint32_t n0n_ = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                       \
+            const uint32_t tile0_ = slice_ * tilesPerSlice_;                                                       \
+            const uint32_t nt_ = VOdometer::sgpr((tile0_ + tilesPerSlice_ <= kTilesAll_) ? tilesPerSlice_ : (kTilesAll_ - tile0_)); \
+            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 2u) ? 1u : 0u) != 0u) { \
+                const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.A) + group_offset<0>(pn_.gL, l_)) + relA + \
+                                                 (uint64_t)m0n_ * (uint64_t)pn_.gM.stride[0][0] * 2ull);           \
+                const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.B) + group_offset<1>(pn_.gL, l_)) + relB + \
+                                                 (uint64_t)n0n_ * (uint64_t)pn_.gN.stride[0][0] * 2ull);           \
+                odo.init(pn_.gK, tile0_ * kHBK, nt_, bA_, bB_);                                                    \
+                nTilesNext = (int)nt_;                                                                             \
+                ok_ = true;                                                                                        \
+            }                                                                                                      \
+        }                                                                                                          \
+        streamedOut = ok_;                                                                                         \
+        if (!ok_) odo.advance_event(p.gK);                                                                         \
     }
 #define CTAMD_P_DMA(P, N, PAD)                                                                                      \
     {                                                                                                              \
@@ -167,29 +224,46 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     CTAMD_P_MFMA(0, 4 * (Q)) CTAMD_P_MFMA(0, 4 * (Q) + 1)                                                          \
     if constexpr ((Q) == 2) odo.advance_a();                                                                       \
     if constexpr ((Q) == 5) odo.advance_b();                                                                       \
-    if constexpr ((Q) == 8) odo.advance_event(p.gK);                                                               \
+    if constexpr ((Q) == 8) {                                                                                      \
+        if constexpr ((P) == 0) {                                                                                  \
+            if (__builtin_expect(t == switchAt, 0)) CTAMD_P_SWITCH() else odo.advance_event(p.gK);                 \
+        } else odo.advance_event(p.gK);                                                                            \
+    }                                                                                                              \
     CTAMD_P_MFMA(0, 4 * (Q) + 2) CTAMD_P_MFMA(0, 4 * (Q) + 3)                                                      \
     __builtin_amdgcn_sched_barrier(0);
     // k-step 1 (behind the barrier), group Q: one read of the next tile's k-step 0 (other buffer), one piece of tile t + 2 into
     // this buffer, four MFMAs
+// (group 0: the read goes BEHIND the first MFMA pair — inside this kernel's outer tile loop the compiler's wait-count bookkeeping
+// puts an s_waitcnt lgkmcnt(0) in front of the first MFMA after the tile barrier instead of gett_h16w4x_kernel's lgkmcnt(9); with the
+// read in front of it that wait cost the read's whole latency, +100 cycles per K-tile: profiles/r05d_h16p_timeline.jsonl)
 #define CTAMD_P_G1(P, Q)                                                                                            \
-    CTAMD_P_READ((P) ^ 1, 0, Q)                                                                                    \
+    if constexpr ((Q) != 0) CTAMD_P_READ((P) ^ 1, 0, Q)                                                            \
     CTAMD_P_MFMA(1, 4 * (Q)) CTAMD_P_MFMA(1, 4 * (Q) + 1)                                                          \
+    if constexpr ((Q) == 0) CTAMD_P_READ((P) ^ 1, 0, Q)                                                            \
     CTAMD_P_DMA(P, Q, false)                                                                                       \
     CTAMD_P_MFMA(1, 4 * (Q) + 2) CTAMD_P_MFMA(1, 4 * (Q) + 3)                                                      \
     __builtin_amdgcn_sched_barrier(0);
-#define CTAMD_P_TILE(P)                                                                                             \
+// VM = false: the tile barrier without its vmcnt(0) — K-tile 1 of a streamed-in tile is known to have landed (every wave waited for
+// it inside the previous tile's epilogue, before its first store), and a vmcnt(0) here would wait for that epilogue's stores
+#define CTAMD_P_TILE_(P, VM)                                                                                        \
     CTAMD_P_G0(P, 0) CTAMD_P_G0(P, 1) CTAMD_P_G0(P, 2) CTAMD_P_G0(P, 3) CTAMD_P_G0(P, 4) CTAMD_P_G0(P, 5)          \
     CTAMD_P_G0(P, 6) CTAMD_P_G0(P, 7) CTAMD_P_G0(P, 8) CTAMD_P_G0(P, 9) CTAMD_P_G0(P, 10) CTAMD_P_G0(P, 11)        \
     CTAMD_P_G0(P, 12) CTAMD_P_G0(P, 13) CTAMD_P_G0(P, 14) CTAMD_P_G0(P, 15)                                        \
     CTAMD_H_LGKM0();                                                                                               \
-    CTAMD_H_VMCNT(0);                                                                                              \
+    if constexpr (VM) CTAMD_H_VMCNT(0);                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     CTAMD_P_G1(P, 0) CTAMD_P_G1(P, 1) CTAMD_P_G1(P, 2) CTAMD_P_G1(P, 3) CTAMD_P_G1(P, 4) CTAMD_P_G1(P, 5)          \
     CTAMD_P_G1(P, 6) CTAMD_P_G1(P, 7) CTAMD_P_G1(P, 8) CTAMD_P_G1(P, 9) CTAMD_P_G1(P, 10) CTAMD_P_G1(P, 11)        \
     CTAMD_P_G1(P, 12) CTAMD_P_G1(P, 13) CTAMD_P_G1(P, 14) CTAMD_P_G1(P, 15)
+#define CTAMD_P_TILE(P) CTAMD_P_TILE_(P, true)
 
+    // The grid size NOW, through an opaque asm: left to the compiler, its scalar load is hoisted above the main loop and waited for
+    // behind it — and while a scalar load may be pending every LDS wait in the loop has to be lgkmcnt(0) (scalar loads return out of
+    // order): the fragment reads issued right behind the tile barrier were waited for before the first MFMA of the k-step, +100
+    // cycles per K-tile (profiles/r05d_h16p_timeline.jsonl: 2368 against gett_h16w4x_kernel's 2271).
+    uint32_t gridX = gridDim.x;
+    asm volatile("" : "+s"(gridX));
     uint32_t vb = blockIdx.x;                     // virtual workgroup id of the tile in flight
     bool staged = false;                          // its first two K-tiles are already on their way (issued under the previous epilogue)
     for (;;) {
@@ -198,9 +272,14 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             CTAMD_P_ISSUE2()
         }
         const int curTiles = nTiles;
+        // the K-tile body (even index, ring buffer 0) that hands the odometer over to the next tile: the last but one, when this tile
+        // may stream its successor in
+        const int switchAt = (curOK && (curTiles & 1) == 0 && curTiles >= 2) ? curTiles - 2 : -1;
+        streamedOut = false;
         // K-tile 0 has landed: loads complete in issue order, so "at most 16 memory operations outstanding" leaves at most the 16
-        // pieces of K-tile 1 (and, from the second tile on, waits out the previous epilogue's stores, which were issued later)
-        CTAMD_H_VMCNT(16);
+        // pieces of K-tile 1 (and, from the second tile on, waits out the previous epilogue's stores, which were issued later).  A
+        // streamed-in tile: every wave has waited for both K-tiles inside the previous epilogue.
+        if (!streamedIn) CTAMD_H_VMCNT(16);
         __builtin_amdgcn_s_barrier();
         if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[1] = __builtin_readcyclecounter(); }
 #pragma unroll
@@ -212,14 +291,16 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         CTAMD_P_READ(0, 0, 8) CTAMD_P_READ(0, 0, 9) CTAMD_P_READ(0, 0, 10) CTAMD_P_READ(0, 0, 11)
         CTAMD_P_READ(0, 0, 12) CTAMD_P_READ(0, 0, 13) CTAMD_P_READ(0, 0, 14) CTAMD_P_READ(0, 0, 15)
         int t = 0;
+        if (streamedIn) { CTAMD_P_TILE_(0, false) CTAMD_P_TILE(1) t = 2; }     // (a streamed-in tile has at least two K-tiles)
+        streamedIn = false;
         for (; t + 1 < curTiles; t += 2) { CTAMD_P_TILE(0) CTAMD_P_TILE(1) }
         if (t < curTiles) { CTAMD_P_TILE(0) }
-        CTAMD_H_VMCNT(0);                         // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
+        if (!streamedOut) CTAMD_H_VMCNT(0);       // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
         x_acc_ready(acc);
         if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[2] = __builtin_readcyclecounter(); }
         // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake
         const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const uint32_t nextVb = vb + gridDim.x;
+        const uint32_t nextVb = vb + gridX;
         GettParams pe;                            // the epilogue's arguments in one burst of scalar loads
         h_reload_params(pe);
         // the tile's coordinates AGAIN, from its id: only `vb` and the K-tile count stay live across the main loop (six more scalar
@@ -272,12 +353,12 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         HEpilogue ep;
         ep.init(pe, curL, lds, wave);
         // workgroup-uniform: the whole tile inside D, one M and one N mode, 16-byte lanes, nothing to add
-        const bool fast = VOdometer::sgpr((ep.vecD && ep.beta == 0.f && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
+        const bool fast = streamedOut || VOdometer::sgpr((ep.vecD && ep.beta == 0.f && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
         if (fast) {
             const int64_t sM = pe.gM.stride[1][0];
             uint16_t* dst = ep.D + (int64_t)(mW + (uint32_t)(laneE & 15)) * sM + (int64_t)(nW + 8u * (uint32_t)(laneE >> 4));
             const float alpha = ep.alpha;
-            if (more) {                           // the next tile's first two K-tiles arrive under this epilogue
+            if (more && !streamedOut) {           // not streamed in by the main loop: the next tile's first two K-tiles are staged now and arrive under this epilogue
                 vb = nextVb;
                 CTAMD_P_SETUP(vb)
                 CTAMD_P_ISSUE2()
@@ -331,7 +412,11 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                     if constexpr ((I) < 8) { CTAMD_P_TR(t[0], 0, 0) CTAMD_P_TR(t[1], 0, 1) CTAMD_P_TR(t[2], 0, 2) CTAMD_P_TR(t[3], 0, 3) } \
                     __builtin_amdgcn_sched_barrier(0);                                                             \
                 }
-                CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
+                CTAMD_P_PASS(0)
+                // streamed: the next tile's K-tiles 0 and 1 (issued by the last two K-tile bodies) must have landed before the next main
+                // loop reads them — waited for HERE, while no store of this epilogue is in flight yet (vmcnt counts stores too)
+                if (streamedOut) CTAMD_H_VMCNT(0);
+                CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
                 CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
 #undef CTAMD_P_PASS
 #undef CTAMD_P_STORE
@@ -366,7 +451,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                                              CTAMD_P_TR(v[(I) & 1][2], (I) & 1, 2) CTAMD_P_TR(v[(I) & 1][3], (I) & 1, 3) } \
                     __builtin_amdgcn_sched_barrier(0);                                                             \
                 }
-                CTAMD_P_PASS(0) CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
+                CTAMD_P_PASS(0)
+                if (streamedOut) CTAMD_H_VMCNT(0);
+                CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
                 CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
 #undef CTAMD_P_PASS
 #undef CTAMD_P_STORE
@@ -376,7 +463,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
             ++tilesWalked;
             if (!more) break;
+            if (streamedOut) {                    // the odometer already is the next tile's; its staging tables are this tile's
+                vb = nextVb;
+                nTiles = nTilesNext;
+                curOK = true;                     // (CTAMD_P_SWITCH checked that it lies inside D)
+            }
             staged = true;
+            streamedIn = streamedOut;
             continue;
         }
         // ---- every other tile: the epilogues of gett_h16w4x_kernel, in the (dead) ring ---------------------------------------------

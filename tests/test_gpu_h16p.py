@@ -6,6 +6,9 @@ workgroups (CUTENSOR_AMD_H16P_GRID=8): every workgroup then walks several tiles 
 image + ds_read_b64_tr_b16, in the LDS beyond the ring) runs while the next tile's first K-tiles are already landing in the ring;
 edge tiles, beta != 0 and strided outputs, which take the ring-resident epilogues and stage the next tile afterwards; mixtures of both
 in one workgroup's sequence; split-K partials; one, two, three and many K-tiles per tile; batch modes; all four operand layouts; fp16.
+Interior tiles with an even K-tile count are STREAMED: the last two K-tile bodies of a tile issue the next tile's first two K-tiles (the
+odometer is handed over inside the main loop), so the cases with 2 / 4 / 6 / 8 K-tiles per tile cover the hand-over in the first, a
+middle and the peeled body, and the ragged ones the fall-back when the next tile is an edge tile.
 A second child runs the same list with the default grid (one workgroup per CU)."""
 import os
 import subprocess
@@ -31,6 +34,10 @@ CASES = [
     (dict(m=512, n=512, k=128, l=5), "mkl", "knl", "mnl", "bfloat16", 1.0, 0.0, "batch mode: 20 tiles over 5 batches"),
     (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "float16", 1.0, 0.0, "fp16"),
     (dict(m=1000, n=712, k=192), "km", "nk", "mn", "float16", 0.75, 0.25, "fp16, ragged, beta"),
+    (dict(m=2048, n=1024, k=128), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "32 interior tiles of two K-tiles: streamed, the hand-over in the first K-tile body"),
+    (dict(m=2048, n=1024, k=512), "km", "nk", "mn", "bfloat16", 0.5, 0.0, "32 interior tiles of eight K-tiles: every tile after the first streamed in"),
+    (dict(m=1536, n=1280, k=384), "mk", "nk", "mn", "float16", 1.0, 0.0, "fp16, 30 interior tiles of six K-tiles"),
+    (dict(m=1280, n=1000, k=256), "km", "kn", "mn", "bfloat16", 1.0, 0.0, "interior tiles streaming into edge tiles and back"),
     (dict(m=512, n=256, k=8192), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "split-K partials (two tiles, long K)"),
     (dict(a=96, b=16, c=16, d=64, e=96), "dcba", "ebcd", "ea", "bfloat16", 1.0, 0.0, "the headline equation's view: one tile, split-K"),
 ]
