@@ -131,6 +131,14 @@ __device__ __forceinline__ uint16_t h_round16(float f) {
 #endif
 }
 
+// C and D are device memory: the epilogues address them through the GLOBAL address space (global_load / global_store), not through
+// generic pointers (flat_*).  A flat operation "may touch LDS" for the compiler's wait-count bookkeeping: inside a kernel that loops
+// over tiles (gett_h16p.hip) one pending flat store turned every counted LDS wait of the main loop into lgkmcnt(0).
+typedef s16x8 __attribute__((address_space(1))) * HGlbS8;
+typedef const s16x8 __attribute__((address_space(1))) * HGlbCS8;
+typedef uint16_t __attribute__((address_space(1))) * HGlbU16;
+typedef const uint16_t __attribute__((address_space(1))) * HGlbCU16;
+
 struct HEpilogue {
     const uint16_t* C;
     uint16_t*       D;
@@ -209,7 +217,7 @@ struct HEpilogue {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
                     if (beta != 0.f) {
-                        const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
+                        const s16x8 cv = *(HGlbCS8)(uintptr_t)(C + offC);
 #define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
                         CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
                         CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
@@ -217,8 +225,8 @@ struct HEpilogue {
                     }
                     const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                        (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // not read again by this kernel; keeps the operand panels in L2
-                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
+                    if constexpr (ST == 0) __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));   // not read again by this kernel; keeps the operand panels in L2
+                    else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
                 }
             }
@@ -231,8 +239,8 @@ struct HEpilogue {
                 int64_t offD, offC;
                 offsets(p, m, n, offD, offC);
                 float val = scratch[row * 64 + lane];
-                if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-                D[offD] = h_round16<BF>(val);
+                if (beta != 0.f) val += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + offC), BF);
+                *(HGlbU16)(uintptr_t)(D + offD) = h_round16<BF>(val);
             }
         }
     }
@@ -262,13 +270,13 @@ struct HEpilogue {
                     f32x4 v0 = lo, v1 = hi;              // explicit elements below: nothing here may become a stack array
                     if (beta != 0.f) {
                         if (vecC) {
-                            const s16x8 cv = *reinterpret_cast<const s16x8*>(C + offC);
+                            const s16x8 cv = *(HGlbCS8)(uintptr_t)(C + offC);
 #define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
                             CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
                             CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
 #undef CTAMD_EP_C
                         } else {
-#define CTAMD_EP_CS(E, V, I) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(C[oC_], BF); }
+#define CTAMD_EP_CS(E, V, I) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + oC_), BF); }
                             CTAMD_EP_CS(0, v0, 0) CTAMD_EP_CS(1, v0, 1) CTAMD_EP_CS(2, v0, 2) CTAMD_EP_CS(3, v0, 3)
                             CTAMD_EP_CS(4, v1, 0) CTAMD_EP_CS(5, v1, 1) CTAMD_EP_CS(6, v1, 2) CTAMD_EP_CS(7, v1, 3)
 #undef CTAMD_EP_CS
@@ -276,8 +284,8 @@ struct HEpilogue {
                     }
                     const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                        (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, reinterpret_cast<s16x8*>(D + offD));   // the result is not read again by this kernel
-                    else if constexpr (ST == 1) *reinterpret_cast<s16x8*>(D + offD) = out;
+                    if constexpr (ST == 0) __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));   // the result is not read again by this kernel
+                    else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
                 }
             }
@@ -295,8 +303,8 @@ struct HEpilogue {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
                     float val = scratch[f * 1024 + row * 32 + lane];
-                    if (beta != 0.f) val += beta * h_to_float(C[offC], BF);
-                    D[offD] = h_round16<BF>(val);
+                    if (beta != 0.f) val += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + offC), BF);
+                    *(HGlbU16)(uintptr_t)(D + offD) = h_round16<BF>(val);
                 }
             }
         }

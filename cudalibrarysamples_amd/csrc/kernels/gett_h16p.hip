@@ -266,7 +266,11 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     asm volatile("" : "+s"(gridX));
     uint32_t vb = blockIdx.x;                     // virtual workgroup id of the tile in flight
     bool staged = false;                          // its first two K-tiles are already on their way (issued under the previous epilogue)
+#if defined(CTAMD_PROBE_ONEPASS)
+    for (int once_ = 0; once_ < 1; ++once_) {
+#else
     for (;;) {
+#endif
         if (!staged) {
             CTAMD_P_SETUP(vb)
             CTAMD_P_ISSUE2()
@@ -325,6 +329,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         // wave-uniform again explicitly, or the K loop's scalar state would be given vector registers)
         const bool more = VOdometer::sgpr(nextVb < pe.nBlocks ? 1u : 0u) != 0u;
         // accumulator fragment (i, j): element r of laneE = row 16 i + 4 (laneE >> 4) + r, column 16 j + (laneE & 15)
+#if !defined(CTAMD_PROBE_NOPARTIAL)
         if (VOdometer::sgpr(pe.partial != nullptr ? 1u : 0u) != 0u) {   // split-K: fp32 partial tile, row-major [slice][l][m][n]; no LDS involved
             const uint32_t Mt = pe.gM.total, Nt = pe.gN.total;
             float* P = pe.partial + ((size_t)curSlice * pe.gL.total + curL) * (size_t)Mt * Nt;
@@ -334,7 +339,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                 for (int r = 0; r < 4; ++r) {
                     const uint32_t m = mW + 16 * i + 4 * (laneE >> 4) + r;
                     if (m < Mt) {
-                        float* row = P + (size_t)m * Nt;
+                        typedef float __attribute__((address_space(1))) * PGlbF;     // global, not flat, stores (gett_h16_common.h, HGlbS8)
+                        PGlbF row = (PGlbF)(uintptr_t)(P + (size_t)m * Nt);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const uint32_t n = nW + 16 * j + (laneE & 15);
@@ -349,6 +355,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             staged = false;
             continue;
         }
+#endif
         __syncthreads();                          // every wave has finished reading the operand ring
         HEpilogue ep;
         ep.init(pe, curL, lds, wave);
@@ -473,6 +480,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             continue;
         }
         // ---- every other tile: the epilogues of gett_h16w4x_kernel, in the (dead) ring ---------------------------------------------
+#if !defined(CTAMD_PROBE_NOGENERAL)
         if (ep.vecD && ep.beta == 0.f) {
             // beta == 0 and 16-byte lanes in D: a pass of 32 rows x 128 columns is a 16-bit image of 272-byte rows, rounded once
             uint16_t* stage = reinterpret_cast<uint16_t*>(ep.scratch);
@@ -496,7 +504,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                     if (m < ep.Mtot && n < ep.Ntot) {
                         int64_t offD, offC;
                         ep.offsets(pe, m, n, offD, offC);
-                        __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                        __builtin_nontemporal_store(v, (HGlbS8)(uintptr_t)(ep.D + offD));
                     }
                 }
             }
@@ -515,6 +523,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                 ep.template flush<BF, 0>(pe, mB, 0u, 0u, nW, 64u, 32u, laneE);
             }
         }
+#endif
         if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
         ++tilesWalked;
         if (!more) break;
