@@ -62,6 +62,32 @@ __device__ __forceinline__ s16x4 p_round4(const f32x4& c, float alpha) {
 // CUTENSOR_AMD_H16P_EP with the TIMED instantiation — profiles/r05c_h16p_epilogue_variants.jsonl).
 // TIMED (CUTENSOR_AMD_H16_TIMED=1, bf16 mk,kn only): wave 0 of every workgroup records shader cycles at entry / first tile staged and
 // landed / end of its main loop / end of its epilogue / exit and the number of tiles it walked into p.timing (tools/h16p_timeline.py).
+// VOdometer::advance_event with the K mode table read through a LAUNDERED argument pointer inside the rare branch: handed `p.gK`, the
+// compiler hoists the table's ~30 scalar loads out of the tile loop (they are loop-invariant) and keeps them alive — spilled — across
+// the main loop, whose bodies then carry v_readlane / v_writelane between their MFMAs.
+__device__ __forceinline__ void p_advance_event(VOdometer& odo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    odo.untilEvent -= 1u;
+    if (__builtin_expect(odo.untilEvent == 0u, 0)) {
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        typedef const __attribute__((address_space(4))) GettParams* PArg;
+        const ModeGroup gK = ((PArg)kp)->gK;
+        if (odo.carryPending != 0u) {                      // the advance just made wrapped digit 1: bases from the full index
+            odo.hi += 1u;
+            const uint32_t k = odo.hi * odo.e1 * gK.div[0].d;
+            if (k < gK.total) {
+                odo.addrA = h_uniform64(odo.baseA + (uint64_t)(group_offset<0>(gK, k) * 2));
+                odo.addrB = h_uniform64(odo.baseB + (uint64_t)(group_offset<1>(gK, k) * 2));
+            }
+        }
+        odo.next_segment(odo.carryLen);
+    }
+#else
+    (void)odo;
+#endif
+}
+
 template <bool BF, int LA, int LB, int EP = 2, bool TIMED = false>
 __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kPRingBytes + 8 * kPImageBytes];     // 160 KiB: the ring + two pass images per wave
@@ -149,7 +175,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
 // between the tiles.  What makes it cheap: for tiles that lie inside a flat problem the per-lane staging offsets (HOperand::src, 16
 // VGPRs) do not depend on the tile — only the descriptor bases move (rel + 2 * row0 * stride) — so the "setup" is scalar arithmetic.
 // Needs: this tile and the next one interior (this one takes the epilogue that stays out of the ring), an even K-tile count (the next
-// tile starts in ring buffer 0), at least two K-tiles in the next tile.  Otherwise the odometer's event check runs and the next tile is
+// tile starts in ring buffer 0), at least four K-tiles in the next tile (its first pair of bodies is a copy without the hand-over).  Otherwise the odometer's event check runs and the next tile is
 // staged the slow way, under / after the epilogue.
 #define CTAMD_P_SWITCH()                                                                                            \
     {                                                                                                              \
@@ -174,7 +200,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             const uint32_t n0n_ = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                       \
             const uint32_t tile0_ = slice_ * tilesPerSlice_;                                                       \
             const uint32_t nt_ = VOdometer::sgpr((tile0_ + tilesPerSlice_ <= kTilesAll_) ? tilesPerSlice_ : (kTilesAll_ - tile0_)); \
-            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 2u) ? 1u : 0u) != 0u) { \
+            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 4u) ? 1u : 0u) != 0u) { \
                 const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.A) + group_offset<0>(pn_.gL, l_)) + relA + \
                                                  (uint64_t)m0n_ * (uint64_t)pn_.gM.stride[0][0] * 2ull);           \
                 const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.B) + group_offset<1>(pn_.gL, l_)) + relB + \
@@ -185,7 +211,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             }                                                                                                      \
         }                                                                                                          \
         streamedOut = ok_;                                                                                         \
-        if (!ok_) odo.advance_event(p.gK);                                                                         \
+        if (!ok_) p_advance_event(odo);                                                                            \
     }
 #define CTAMD_P_DMA(P, N, PAD)                                                                                      \
     {                                                                                                              \
@@ -201,7 +227,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
 #define CTAMD_P_ISSUE2()                                                                                            \
     {                                                                                                              \
         CTAMD_P_DMA8(0, 0, true) CTAMD_P_DMA8(0, 8, true)                                                          \
-        odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);                                                 \
+        odo.advance_a(); odo.advance_b(); p_advance_event(odo);                                                    \
         CTAMD_P_DMA8(1, 0, true) CTAMD_P_DMA8(1, 8, true)                                                          \
     }
 
@@ -219,15 +245,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     }
 #define CTAMD_P_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
     // k-step 0, group Q: one read of k-step 1 (same buffer) and four MFMAs; three of the groups carry the odometer
-#define CTAMD_P_G0(P, Q)                                                                                            \
+#define CTAMD_P_G0(P, Q, SW)                                                                                        \
     CTAMD_P_READ(P, 1, Q)                                                                                          \
     CTAMD_P_MFMA(0, 4 * (Q)) CTAMD_P_MFMA(0, 4 * (Q) + 1)                                                          \
     if constexpr ((Q) == 2) odo.advance_a();                                                                       \
     if constexpr ((Q) == 5) odo.advance_b();                                                                       \
     if constexpr ((Q) == 8) {                                                                                      \
-        if constexpr ((P) == 0) {                                                                                  \
-            if (__builtin_expect(t == switchAt, 0)) CTAMD_P_SWITCH() else odo.advance_event(p.gK);                 \
-        } else odo.advance_event(p.gK);                                                                            \
+        if constexpr (SW) CTAMD_P_SWITCH() else p_advance_event(odo);                                              \
     }                                                                                                              \
     CTAMD_P_MFMA(0, 4 * (Q) + 2) CTAMD_P_MFMA(0, 4 * (Q) + 3)                                                      \
     __builtin_amdgcn_sched_barrier(0);
@@ -245,10 +269,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     __builtin_amdgcn_sched_barrier(0);
 // VM = false: the tile barrier without its vmcnt(0) — K-tile 1 of a streamed-in tile is known to have landed (every wave waited for
 // it inside the previous tile's epilogue, before its first store), and a vmcnt(0) here would wait for that epilogue's stores
-#define CTAMD_P_TILE_(P, VM)                                                                                        \
-    CTAMD_P_G0(P, 0) CTAMD_P_G0(P, 1) CTAMD_P_G0(P, 2) CTAMD_P_G0(P, 3) CTAMD_P_G0(P, 4) CTAMD_P_G0(P, 5)          \
-    CTAMD_P_G0(P, 6) CTAMD_P_G0(P, 7) CTAMD_P_G0(P, 8) CTAMD_P_G0(P, 9) CTAMD_P_G0(P, 10) CTAMD_P_G0(P, 11)        \
-    CTAMD_P_G0(P, 12) CTAMD_P_G0(P, 13) CTAMD_P_G0(P, 14) CTAMD_P_G0(P, 15)                                        \
+// SW = true: the body that hands the odometer over to the next tile (CTAMD_P_SWITCH in place of the odometer's event check) — a copy
+// of its own, executed once per tile behind the main pair loop: a test inside the hot bodies cost a compare, a branch and seven scalar
+// copies (the merge of two odometer states) per K-tile pair
+#define CTAMD_P_TILE_(P, VM, SW)                                                                                    \
+    CTAMD_P_G0(P, 0, SW) CTAMD_P_G0(P, 1, SW) CTAMD_P_G0(P, 2, SW) CTAMD_P_G0(P, 3, SW) CTAMD_P_G0(P, 4, SW) CTAMD_P_G0(P, 5, SW)      \
+    CTAMD_P_G0(P, 6, SW) CTAMD_P_G0(P, 7, SW) CTAMD_P_G0(P, 8, SW) CTAMD_P_G0(P, 9, SW) CTAMD_P_G0(P, 10, SW) CTAMD_P_G0(P, 11, SW)    \
+    CTAMD_P_G0(P, 12, SW) CTAMD_P_G0(P, 13, SW) CTAMD_P_G0(P, 14, SW) CTAMD_P_G0(P, 15, SW)                        \
     CTAMD_H_LGKM0();                                                                                               \
     if constexpr (VM) CTAMD_H_VMCNT(0);                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                  \
@@ -256,7 +283,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     CTAMD_P_G1(P, 0) CTAMD_P_G1(P, 1) CTAMD_P_G1(P, 2) CTAMD_P_G1(P, 3) CTAMD_P_G1(P, 4) CTAMD_P_G1(P, 5)          \
     CTAMD_P_G1(P, 6) CTAMD_P_G1(P, 7) CTAMD_P_G1(P, 8) CTAMD_P_G1(P, 9) CTAMD_P_G1(P, 10) CTAMD_P_G1(P, 11)        \
     CTAMD_P_G1(P, 12) CTAMD_P_G1(P, 13) CTAMD_P_G1(P, 14) CTAMD_P_G1(P, 15)
-#define CTAMD_P_TILE(P) CTAMD_P_TILE_(P, true)
+#define CTAMD_P_TILE(P) CTAMD_P_TILE_(P, true, false)
 
     // The grid size NOW, through an opaque asm: left to the compiler, its scalar load is hoisted above the main loop and waited for
     // behind it — and while a scalar load may be pending every LDS wait in the loop has to be lgkmcnt(0) (scalar loads return out of
@@ -295,9 +322,11 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         CTAMD_P_READ(0, 0, 8) CTAMD_P_READ(0, 0, 9) CTAMD_P_READ(0, 0, 10) CTAMD_P_READ(0, 0, 11)
         CTAMD_P_READ(0, 0, 12) CTAMD_P_READ(0, 0, 13) CTAMD_P_READ(0, 0, 14) CTAMD_P_READ(0, 0, 15)
         int t = 0;
-        if (streamedIn) { CTAMD_P_TILE_(0, false) CTAMD_P_TILE(1) t = 2; }     // (a streamed-in tile has at least two K-tiles)
+        if (streamedIn) { CTAMD_P_TILE_(0, false, false) CTAMD_P_TILE(1) t = 2; }     // (a streamed-in tile has at least four K-tiles)
         streamedIn = false;
-        for (; t + 1 < curTiles; t += 2) { CTAMD_P_TILE(0) CTAMD_P_TILE(1) }
+        const int pairEnd = switchAt >= 0 ? switchAt : curTiles;
+        for (; t + 1 < pairEnd; t += 2) { CTAMD_P_TILE(0) CTAMD_P_TILE(1) }
+        if (switchAt >= 0) { CTAMD_P_TILE_(0, true, true) CTAMD_P_TILE(1) t += 2; }      // K-tiles nTiles - 2 (the hand-over) and nTiles - 1
         if (t < curTiles) { CTAMD_P_TILE(0) }
         if (!streamedOut) CTAMD_H_VMCNT(0);       // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
         x_acc_ready(acc);
