@@ -454,6 +454,11 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         else if (var == 56) { fix = 5.0; per = wgs <= (double)numCUs ? 0.68 : 0.92; }
         else { fix = 10.0; per = 1.0; }
         double t = std::ceil(wgs / slots) * (fix + kt * per);
+        // the persistent form of the 256 x 256 kernel (88, gett_h16p.hip, round 5): a workgroup walks its tiles, interior tiles with an even
+        // K-tile count stream into each other (the next tile's first K-tiles are fetched by the last K-tile bodies) — the first tile costs
+        // what gett_h16w4x_kernel's does plus ~0.5 us of extra setup, every further one ~6 us less (profiles/r05e_h16p_vs_4x.jsonl: 8192^2 x
+        // 512 / 1024 / 2048 / 4096 / 8192 +6.8 / +3.3 / +2.5 / +1.8 / +0.8 %, one-round shapes -1 %)
+        if (var == 88) t = 10.5 + kt * per + (std::ceil(wgs / slots) - 1.0) * (4.5 + kt * per);
         if (split > 1) t += 3.0 + 2.0 * (double)split * (double)perSliceBytes / 5.0e6;
         return t;
     };
@@ -466,7 +471,9 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below), the
         // 128 x 128 mid-size family and the 64 x 64 tile, each without split-K and at its automatic split
         double best = 1e30;
-        for (int cand : {48, 64, 56, 80}) {
+        static const bool noPersistent = [] { const char* e = std::getenv("CUTENSOR_AMD_H16P"); return e && e[0] == '0'; }();
+        for (int cand : {48, 88, 64, 56, 80}) {
+            if (cand == 88 && noPersistent) continue;
             if (layoutIdx + cand >= count) continue;
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {

@@ -6,7 +6,8 @@ import json
 import os
 import sys
 
-os.environ["CUTENSOR_AMD_H16_TIMED"] = "1"
+os.environ["CUTENSOR_AMD_H16_TIMED"] = "1"          # (TIMED / XST instantiations: research builds only, make RESEARCH=1)
+os.environ.setdefault("CUTENSOR_AMD_H16_WAVES", "4x")   # the one-tile kernel (the planner takes its persistent form for 8192^3 since round 5)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
