@@ -1007,6 +1007,29 @@ def main():
                     "frac_of_nominal_f32_mfma_peak": FLOP / cold_s / 1e12 / PEAK_TFLOPS_F32_MFMA,
                     "hbm_TBps": BYTES / cold_s / 1e12,
                     "what": "%d steps (never fewer than 500), (A, B) rotate over 4 distinct pairs (805 MB > 256-MiB Infinity Cache): operands come from HBM" % cold_steps}
+            # the same rotation through a plan made under CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED (the engine's "operands come from
+            # HBM on every call" hint: nontemporal-load twin of the same kernel) — what a caller who knows its operands are cold gets
+            try:
+                plan_nt = ops.contraction_plan(h, [EXT[c] for c in "dcba"], "dcba", [EXT[c] for c in "ebcd"], "ebcd", [EXT[c] for c in "ea"], "ea",
+                                               workspace_limit=1 << 30, operands_streamed=True)
+                ws_nt = torch.empty(max(plan_nt.required_workspace, 256), dtype=torch.uint8, device="cuda")
+
+                def contract_nt(x, y, out):
+                    plan_nt.contract(1.0, x.data_ptr(), y.data_ptr(), 0.0, out.data_ptr(), out.data_ptr(), ws_nt.data_ptr(), plan_nt.required_workspace, stream)
+                for i in range(cold_warm):
+                    contract_nt(*pairs[i % 4], outs[i % nbuf])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(cold_steps):
+                    contract_nt(*pairs[i % 4], outs[i % nbuf])
+                torch.cuda.synchronize()
+                nt_s = (time.perf_counter() - t1) / cold_steps
+                cold["streamed_preference"] = {"value": FLOP / nt_s / 1e9, "unit": "GFLOP/s", "ms_per_step": nt_s * 1e3,
+                                               "frac_of_nominal_f32_mfma_peak": FLOP / nt_s / 1e12 / PEAK_TFLOPS_F32_MFMA, "nt_kernel": plan_nt.describe().get("nt"),
+                                               "what": "same rotation, plan made with CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED = 1 (nontemporal operand loads)"}
+                plan_nt.destroy()
+            except Exception as ex:   # noqa: BLE001
+                cold["streamed_preference"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             del pairs
         except Exception as ex:   # noqa: BLE001
             cold = {"error": "%s: %s" % (type(ex).__name__, ex)}
@@ -1111,6 +1134,7 @@ def main():
         # the numbers a user of einsum.cu sees on first contact, where a truncated reader still finds them
         config["cold_operands_gflops"] = cold["value"] if cold and "value" in cold else None
         config["cold_operands_frac_of_f32_mfma_peak"] = cold.get("frac_of_nominal_f32_mfma_peak") if cold else None
+        config["cold_operands_streamed_preference_gflops"] = (cold.get("streamed_preference") or {}).get("value") if cold else None
         config["sample_protocol_gflops"] = sample_protocol.get("gflops") if sample_protocol else None
         config["sample_protocol_frac_of_f32_mfma_peak"] = sample_protocol.get("frac_of_nominal_f32_mfma_peak") if sample_protocol else None
         config["kernel_frac_live_trace"] = roof.get("frac") if roof else None

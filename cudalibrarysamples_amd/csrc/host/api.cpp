@@ -100,6 +100,7 @@ bool build_memo_key(const cutensorOperationDescriptor& op, const cutensorPlanPre
     k.wsLimit = wsLimit;
     k.algo = (int32_t)pr.algo; k.kernelRank = pr.kernelRank; k.autotune = (int32_t)pr.autotune;
     k.incrementalCount = pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL ? pr.incrementalCount : 0;
+    k.operandsStreamed = (uint8_t)(pr.operandsStreamed != 0);
     k.kind = (uint8_t)op.kind; k.dtype = (uint8_t)op.A.desc.dtype; k.compute = (uint8_t)(op.compute ? op.compute->id : 255);
     k.scalarType = (uint8_t)op.scalarType;
     k.op[0] = (uint8_t)op.A.op; k.op[1] = (uint8_t)op.B.op; k.op[2] = (uint8_t)op.C.op; k.op[3] = (uint8_t)op.opReduce;
@@ -749,6 +750,7 @@ cutensorStatus_t cutensorPlanPreferenceSetAttribute(const cutensorHandle_t handl
         case CUTENSOR_PLAN_PREFERENCE_ALGO: pref->algo = (cutensorAlgo_t)v; break;
         case CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK: pref->kernelRank = v; break;
         case CUTENSOR_PLAN_PREFERENCE_JIT: pref->jit = (cutensorJitMode_t)v; break;
+        case CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED: pref->operandsStreamed = v != 0 ? 1 : 0; break;   // engine extension
         default: return CUTENSOR_STATUS_INVALID_VALUE;
     }
     return CUTENSOR_STATUS_SUCCESS;
@@ -800,7 +802,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         }
         if (v.dtype != HIP_R_32F) return CUTENSOR_STATUS_SUCCESS;
         // the largest workspace any of the best few candidates would like to have
-        std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs);
+        std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs, planPref != nullptr && planPref->operandsStreamed != 0);
         uint64_t want = 0;
         for (size_t i = 0; i < ch.size() && i < 4; ++i) want = std::max(want, ch[i].workspace);
         *workspaceSizeEstimate = want;
@@ -1197,7 +1199,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                              (pl->view.dtype == HIP_C_64F && desc->scalarType == HIP_C_64F);
         ContractionChoice pick;   // kernel = -1: simple kernel
         std::vector<ContractionChoice> ch;
-        if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+        if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs, pr.operandsStreamed != 0);
         else if (h16Path && !(std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
         if (ch.empty() && genPath && !(std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == '0')) {
@@ -1206,7 +1208,9 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         }
         if (!ch.empty()) {
             size_t idx = 0;
-            const bool useCache = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE;
+            // (a plan made under the "operands are streamed" preference neither reads nor feeds the per-problem cache: the cache is keyed by
+            // the problem alone, and its entry belongs to the default policy)
+            const bool useCache = handle->planCacheCapacity > 0 && pr.cacheMode != CUTENSOR_CACHE_MODE_NONE && pr.operandsStreamed == 0;
             const bool explicitPick = (int)pr.algo >= 0 || pr.kernelRank > 0;   // the caller names a candidate: the cache has no say
             const bool incremental = useCache && !explicitPick && pr.autotune == CUTENSOR_AUTOTUNE_MODE_INCREMENTAL;
             const bool patient = pr.algo == CUTENSOR_ALGO_DEFAULT_PATIENT;
@@ -1837,6 +1841,8 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
                           (unsigned long long)plan->gett.xcdTiles,
                           k == -2 ? "gett_wide_kernel" : k < 0 ? "gett_simple_kernel" : plan->choice.family == 2 ? "gett_gen_kernel" : plan->choice.family == 1 ? (tab[k].threads == 256 || tab[k].pf == 10 ? (tab[k].bk == 32 ? "gett_h16w4s_kernel" : tab[k].pf == 3 ? "gett_h16w4r_kernel" : tab[k].pf == 6 ? "gett_h16w4v_kernel" : tab[k].pf == 7 ? "gett_h16w4x_kernel" : tab[k].pf == 8 ? "gett_h16w4m_kernel" : tab[k].pf == 9 ? "gett_h16w4m4_kernel" : tab[k].pf == 10 ? "gett_h16w8m_kernel" : tab[k].pf == 11 ? "gett_h16w4q_kernel" : tab[k].pf == 12 ? "gett_h16w4p_kernel" : "gett_h16w4_kernel") : tab[k].pf == 4 ? "gett_h16s_kernel" : "gett_h16_kernel") : tab[k].fragPartials ? "gett_f32_stream_kernel" : "gett_f32_kernel");
         // contracted digits, fastest first: [extent, strideA, strideB]
+        if (n > 0 && (size_t)n < len && k >= 0)     // 1: the kernel streams its operands with the nontemporal policy (no Infinity-Cache allocation)
+            n += std::snprintf(buf + n, len - n, ",\"nt\":%d", tab[k].nt);
         if (n > 0 && (size_t)n < len && plan->choice.family == 2 && k >= 0)
             n += std::snprintf(buf + n, len - n, ",\"orientA\":%d,\"orientB\":%d,\"vec\":%d,\"elem\":%d", tab[k].layA, tab[k].layB, tab[k].vec, tab[k].elem);
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");

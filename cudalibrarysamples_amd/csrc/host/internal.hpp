@@ -85,6 +85,7 @@ struct cutensorPlanPreference {
     cutensorCacheMode_t    cacheMode = CUTENSOR_CACHE_MODE_PEDANTIC;
     int32_t                incrementalCount = 4;
     int32_t                kernelRank = 0;
+    int32_t                operandsStreamed = 0;   // CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED (engine extension)
 };
 
 namespace ctamd {
@@ -122,7 +123,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
                                         std::string* why);
 // Ranked candidate list (best first) under a workspace limit.
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
-                                                        int numCUs);
+                                                        int numCUs, bool operandsStreamed = false);
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
 // general MFMA family (kernels/gett_gen.inc): false only for fp32 data and for views the tiled kernels cannot describe
 bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c);
@@ -245,7 +246,7 @@ struct PlanMemoKey {
     uint8_t  kind = 0, dtype = 0, compute = 0, scalarType = 0;
     uint8_t  n[4] = {0, 0, 0, 0};
     uint8_t  op[4] = {0, 0, 0, 0};                 // opA, opB, opC, opReduce
-    uint8_t  present = 0, pad_[3] = {0, 0, 0};
+    uint8_t  present = 0, operandsStreamed = 0, pad_[2] = {0, 0};
     uint32_t used = 0;                             // int64 words of data[] in use
     uint32_t pad2_ = 0;                            // (no implicit padding anywhere in the head: it is hashed and compared bytewise)
     int64_t  data[3 * kMaxModes];                  // per tensor: modes, extents, strides

@@ -282,7 +282,7 @@ static double tile_efficiency(const GettKernelInfo& k) {
 }
 
 std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v, uint64_t wsLimit,
-                                                        int numCUs) {
+                                                        int numCUs, bool operandsStreamed) {
     std::vector<ContractionChoice> out;
     int count = 0;
     const GettKernelInfo* tab = gett_f32_kernels(&count);
@@ -318,7 +318,9 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         // operands are well beyond the 256-MiB Infinity Cache (> 1.4 x), i.e. back-to-back calls cannot find them on-die anyway (measured:
         // headline shape 201 MB: +3.6 % from HBM, -5.5 % cache-resident; b = 96, 302 MB: -5 %; b = 128, 403 MB: +6 %; profiles/r03_headline_nt.txt)
         static const bool ntAnySize = std::getenv("CUTENSOR_AMD_NT") != nullptr;   // tests: exercise the nt kernels on small read-once shapes
-        if (k.nt && !(tilesM == 1 && tilesN == 1 && (ntAnySize || 4.0 * L * (M * K + N * K) > 1.4 * 256.0 * 1024.0 * 1024.0))) continue;
+        // ... or the caller says so: CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED (include/cutensor/types.h) — "every call finds its operands in
+        // HBM", which the library cannot know for the 201 MB of the headline einsum
+        if (k.nt && !(tilesM == 1 && tilesN == 1 && (ntAnySize || operandsStreamed || 4.0 * L * (M * K + N * K) > 1.4 * 256.0 * 1024.0 * 1024.0))) continue;
         const uint64_t kTiles = (v.totK + k.bk - 1) / k.bk;
         // split-K candidates: 1, and powers of two up to what keeps >= 4 K-tiles per slice
         std::vector<uint32_t> splits = {1};

@@ -33,6 +33,7 @@ OPERATION_DESCRIPTOR_TAG, OPERATION_DESCRIPTOR_SCALAR_TYPE, OPERATION_DESCRIPTOR
 PLAN_REQUIRED_WORKSPACE = 0
 PLAN_PREFERENCE_AUTOTUNE_MODE, PLAN_PREFERENCE_CACHE_MODE, PLAN_PREFERENCE_INCREMENTAL_COUNT = 0, 1, 2
 PLAN_PREFERENCE_ALGO, PLAN_PREFERENCE_KERNEL_RANK = 3, 4
+AMD_PLAN_PREFERENCE_OPERANDS_STREAMED = 1000     # engine extension (include/cutensor/types.h): operands come from HBM on every call
 AUTOTUNE_MODE_NONE, AUTOTUNE_MODE_INCREMENTAL = 0, 1
 CACHE_MODE_NONE, CACHE_MODE_PEDANTIC = 0, 1
 

@@ -42,13 +42,14 @@ class Plan:
     """An operation descriptor + plan pair with its scalar type and workspace requirement."""
 
     def __init__(self, handle, op, kind, dtype, algo=ct.ALGO_DEFAULT, kernel_rank=0, workspace_limit=None,
-                 workspace_pref=ct.WORKSPACE_DEFAULT, autotune=None, cache_mode=None, incremental_count=None):
+                 workspace_pref=ct.WORKSPACE_DEFAULT, autotune=None, cache_mode=None, incremental_count=None, operands_streamed=None):
         self.handle, self.kind, self.dtype = handle, kind, dtype
         self.op = op
         pref = ctypes.c_void_p()
         ct.check(ct.cutensorCreatePlanPreference(handle.h, ctypes.byref(pref), algo, ct.JIT_MODE_NONE))
         for attr, val in ((ct.PLAN_PREFERENCE_KERNEL_RANK, kernel_rank or None), (ct.PLAN_PREFERENCE_AUTOTUNE_MODE, autotune),
-                          (ct.PLAN_PREFERENCE_CACHE_MODE, cache_mode), (ct.PLAN_PREFERENCE_INCREMENTAL_COUNT, incremental_count)):
+                          (ct.PLAN_PREFERENCE_CACHE_MODE, cache_mode), (ct.PLAN_PREFERENCE_INCREMENTAL_COUNT, incremental_count),
+                          (ct.AMD_PLAN_PREFERENCE_OPERANDS_STREAMED, (1 if operands_streamed else None))):
             if val is not None:   # contraction_plan_cache.cu:215-237
                 v = ctypes.c_int32(val)
                 ct.check(ct.cutensorPlanPreferenceSetAttribute(handle.h, pref, attr, ctypes.byref(v), 4))

@@ -152,7 +152,13 @@ typedef enum {
     CUTENSOR_PLAN_PREFERENCE_INCREMENTAL_COUNT = 2, /* int32_t */
     CUTENSOR_PLAN_PREFERENCE_ALGO              = 3, /* cutensorAlgo_t */
     CUTENSOR_PLAN_PREFERENCE_KERNEL_RANK       = 4, /* int32_t */
-    CUTENSOR_PLAN_PREFERENCE_JIT               = 5  /* cutensorJitMode_t */
+    CUTENSOR_PLAN_PREFERENCE_JIT               = 5, /* cutensorJitMode_t */
+    /* Engine extension (not a cuTENSOR attribute; values of 1000 and above are this library's own): int32_t, non-zero = "the operands of
+     * this contraction are streamed" — every call reads operands that are not resident in the 256-MiB Infinity Cache (a different (A, B)
+     * each call, or tensors far larger than the cache).  The planner then ranks the nontemporal-load twins of the streaming kernels for
+     * read-once problems of ANY size (the headline einsum, 201 MB of operands: +3.6 % from HBM, -5.5 % when the same operands are
+     * re-contracted out of the cache — a library cannot know which it will be, a caller can; profiles/r03_headline_nt.txt). */
+    CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED = 1000
 } cutensorPlanPreferenceAttribute_t;
 
 /* contraction.cu:231-235 */

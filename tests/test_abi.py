@@ -366,3 +366,25 @@ def test_complex_reductions_and_permutations_plan(ct, ops):
         b.destroy()
     # CONJ on real data is the identity, not an error
     ops.reduction_plan(h, [64, 8], "ab", [8], "b", opA=ct.OP_CONJ).destroy()
+
+
+def test_operands_streamed_preference_ranks_the_nontemporal_twins(ct, ops):
+    """Engine extension CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED (include/cutensor/types.h, round 5): the headline einsum's
+    201 MB of operands may or may not be resident in the 256-MiB Infinity Cache — a caller that knows they are not says so and gets
+    the nontemporal-load twin of the streaming kernel (+3.6 % from HBM, -5.5 % cache-resident: profiles/r03_headline_nt.txt); without
+    the preference the default policy stays, and the plan memo keeps the two apart."""
+    h = ops.Handle(plan_cache=64)
+    E = dict(a=96, b=64, c=64, d=64, e=96)
+    args = ([E[c] for c in "dcba"], "dcba", [E[c] for c in "ebcd"], "ebcd", [E[c] for c in "ea"], "ea")
+    seen = []
+    for streamed in (None, True, None, True):
+        p = ops.contraction_plan(h, *args, workspace_limit=1 << 30, operands_streamed=streamed)
+        d = p.describe()
+        assert d["kname"] == "gett_f32_stream_kernel" and d["splitK"] == 256 and d["nt"] == (1 if streamed else 0), (streamed, d)
+        seen.append(d["kernel"])
+        p.destroy()
+    assert seen[0] == seen[2] and seen[1] == seen[3] and seen[0] != seen[1], seen
+    # a multi-tile problem re-reads its panels: the preference changes nothing there
+    p = ops.contraction_plan(h, [4096, 4096], "mk", [4096, 4096], "kn", [4096, 4096], "mn", operands_streamed=True)
+    assert p.describe()["nt"] == 0
+    p.destroy()
