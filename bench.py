@@ -194,8 +194,9 @@ def mg_child_main(args):
     print("MGCHILD " + json.dumps(out), flush=True)
 
 
-def run_mg_child(ndev, steps, warmup, timeout_s, virtual=False):
+def run_mg_child(ndev, steps, warmup, timeout_s, virtual=False, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
@@ -390,6 +391,10 @@ def live_profile_of(cmd, kernel_like, timeout_s=240):
                 if busy and active:
                     per_xcd = active / 8.0
                     out.update({"mfma_busy_pct": 100.0 * (busy / (4.0 * cus)) / per_xcd, "sustained_clock_ghz": per_xcd / avg_ns,
+                                # GRBM_GUI_ACTIVE also counts the dispatch's ramp-in / ramp-out: for a ~40-us kernel it exceeds the kernel's own
+                                # cycles (the "clock" above then reads > 2.4 GHz and the busy share too low) — the same busy cycles against the
+                                # kernel's duration at the nominal 2.4 GHz bound the share from the other side
+                                "mfma_busy_pct_of_kernel_time_at_nominal_clock": 100.0 * (busy / (4.0 * cus)) / (avg_ns * 2.4),
                                 "kernel_avg_us_under_pmc": avg_ns / 1e3,
                                 "wait_any_pct_of_wave_cycles": (100.0 * cnt["SQ_WAIT_ANY"] / cnt["SQ_WAVE_CYCLES"]) if cnt.get("SQ_WAVE_CYCLES") and cnt.get("SQ_WAIT_ANY") else None,
                                 "pmc_raw": {k: cnt.get(k) for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")},
@@ -688,7 +693,7 @@ def add_secondary_traffic(secondary):
             except Exception:   # noqa: BLE001
                 prof = None
             if prof:
-                for k in ("mfma_busy_pct", "sustained_clock_ghz"):
+                for k in ("mfma_busy_pct", "sustained_clock_ghz", "mfma_busy_pct_of_kernel_time_at_nominal_clock"):
                     r[k] = prof.get(k)
                 r["live_trace"] = {k: prof.get(k) for k in ("kernel", "launches", "kernel_avg_us", "kernel_min_us")}
                 r["pmc_live"] = {k: prof.get(k) for k in ("kernel_avg_us_under_pmc", "wait_any_pct_of_wave_cycles", "pmc_raw", "pmc_formula")}
@@ -952,6 +957,7 @@ def main():
                 roof["live_trace"] = {k: prof.get(k) for k in ("kernel", "launches", "kernel_avg_us", "kernel_min_us")}
             if prof and prof.get("mfma_busy_pct") is not None:
                 roof["mfma_busy_pct"], roof["sustained_clock_ghz"] = prof["mfma_busy_pct"], prof["sustained_clock_ghz"]
+                roof["mfma_busy_pct_of_kernel_time_at_nominal_clock"] = prof.get("mfma_busy_pct_of_kernel_time_at_nominal_clock")
                 roof["pmc_live"] = {k: prof.get(k) for k in ("kernel_avg_us_under_pmc", "wait_any_pct_of_wave_cycles", "pmc_raw", "pmc_formula")}
         trace_file, trace_rows = newest_trace_summary()
         if trace_file and "gett_f32_stream_kernel" in trace_rows:
@@ -1062,9 +1068,12 @@ def main():
             #      travel to the staging images by ncclAllGather / ncclSend + ncclRecv on the communication stream, the local contraction
             #      waits for the wave event and reads the staged images — the transport and event-graph code of the N > 1 path, executed on
             #      the one GPU of this box (gather_bytes_per_call > 0, rccl_ranks_seen = 1); not a scaling number
+            # (in a child process: creating an RCCL communicator makes librccl print a version banner on the C stdout of its process at
+            # exit — after this process's JSON line, which has to stay the last line)
             try:
-                os.environ["CUTENSORMG_AMD_FORCE_GATHER"] = "1"
-                fg = {"sample": mg_measure(1, MG_SAMPLE_EXTENT, 20, 3)}
+                fg = run_mg_child(1, 3, 1, 300, extra_env={"CUTENSORMG_AMD_FORCE_GATHER": "1"})
+                if "error" in fg or "sample" not in fg:
+                    raise RuntimeError(fg.get("error", "no result"))
                 ln = mg_lines(fg, "sample", "-")
                 ln["workload"] += " — gather FORCED through RCCL on one device (CUTENSORMG_AMD_FORCE_GATHER=1)"
                 for k in ("forced_gather", "rccl_ranks_seen", "rccl", "all_gather_eligible", "transport_trial_ms", "transport_chosen"):
@@ -1072,8 +1081,6 @@ def main():
                 secondary.append(ln)
             except Exception as ex:   # noqa: BLE001
                 secondary.append({"workload": "cuTENSORMg on one device, forced gather", "error": "%s: %s" % (type(ex).__name__, ex)})
-            finally:
-                os.environ.pop("CUTENSORMG_AMD_FORCE_GATHER", None)
 
     if rank == 0:
         einsum_line = {"workload": "einsum.cu 'abcd,dcbe->ae' a=e=96 b=c=d=64 fp32 (BASELINE configs[1])"
