@@ -378,7 +378,12 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c) {
     if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
     if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
-    if (v.K.empty() || v.K.front().extent % 64 != 0 || v.totK % 64 != 0) return false;
+    if (v.K.empty()) return false;
+    // Whole 64-deep K-tiles in the fastest contracted mode — or (round 5) ONE contracted mode of any extent the 16-byte lanes admit
+    // (a K-contiguous operand has extent % 8 == 0 by its layout class, a free-contiguous one takes any extent): the four-wave kernel
+    // stages the last K-tile with the lanes past the end of the mode out of range (gett_h16w4x_kernel<..., RAG = true>).
+    const bool ragged = (v.totK % 64 != 0);
+    if (ragged ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0)) return false;
     // The 16-bit kernels address an operand with 32-bit byte offsets relative to a 64-bit base that moves with the workgroup
     // tile, the wave and the K-tile (gett_h16.hip, HOperand / HOdometer): what has to stay below 2^31 bytes is the span of
     // ONE 256-row x 64-k tile, whatever the size of the tensor.
@@ -419,7 +424,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         return 48;
     }();
     const int layoutIdx = c.kernel;
-    const uint64_t kTiles = v.totK / 64;
+    const uint64_t kTiles = (v.totK + 63) / 64;
     const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
     const bool forced = std::getenv("CUTENSOR_AMD_H16_WAVES") != nullptr;
     auto tiles_of = [&](int var) {
@@ -467,7 +472,24 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     int var = variant;
     uint64_t split = 1;
     const bool usable = forced && layoutIdx + var < count && tab[layoutIdx + var].ablation != 2;   // a retired family asked for in a production build: ignored
-    if (forced && usable) {
+    if (ragged && forced) {
+        // CUTENSOR_AMD_H16_WAVES names the kernel: one of those that mask a partial K-tile (4x, 4m, 4m4, 4q), or the general family
+        if (!usable || (var != 48 && var != 56 && var != 64 && var != 80)) return false;
+        split = auto_split(var);
+    } else if (ragged) {
+        // the kernels of the family that mask a partial K-tile (the RAG instantiations): the 256 x 256 four-wave kernel, the 128 x 128
+        // pair and the 64 x 64 tile — every candidate of the planner but the persistent kernel
+        double best = 1e30;
+        for (int cand : {48, 64, 56, 80}) {
+            if (layoutIdx + cand >= count) continue;
+            const uint64_t as = auto_split(cand);
+            for (uint64_t sp : {(uint64_t)1, as}) {
+                const double t = model_us(cand, sp);
+                if (t < best) { best = t; var = cand; split = sp; }
+                if (as == 1) break;
+            }
+        }
+    } else if (forced && usable) {
         split = auto_split(var);
     } else {
         // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below), the
@@ -507,6 +529,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     ContractionChoice base;
     if (!pick_h16_choice(v, wsLimit, numCUs, base)) return out;
     out.push_back(base);
+    if (v.totK % 64 != 0) return out;              // ragged K: the planner's pick among the kernels that mask (pick_h16_choice)
     int count = 0;
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
     const GettKernelInfo* tab = gett_h16_kernels(&count);

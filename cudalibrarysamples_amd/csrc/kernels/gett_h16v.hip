@@ -250,7 +250,9 @@ __device__ __forceinline__ void x_store_interior16(f32x4 (&acc)[FI][FJ], uint16_
 // workgroups start staggered (epilogue 16.4k -> 15.8k cycles, rate unchanged) — profiles/r04n_w4x_variants.jsonl.
 // XST = 8 / 9 / 10 (round 5, ZERO-FILLED operands only: the results are wrong on any other data — the tile barrier loses its
 // vmcnt(0) / its s_barrier / both): what of the 2280 - 2048 cycles per K-tile is data latency and what is wave skew.
-template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0>
+// RAG: ragged K — the last K-tile of the last slice staged with the lanes past the end of the contracted mode out of range
+// (x_rag_mask, gett_h16x_common.h); the offsets are switched right before the first LDS-DMA of that tile.
+template <bool BF, int LA, int LB, bool TIMED = false, int XST = 0, bool RAG = false>
 __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[8 * kHalfBytes];
     unsigned long long wgStamp[6] = {0, 0, 0, 0, 0, 0};
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
-    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
@@ -292,7 +294,14 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
-    odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (p.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(p.gK.total % kHBK);
+#define CTAMD_X_RAGMASK(IDX)                                                                                        \
+    if constexpr (RAG) {                                                                                           \
+        if ((IDX) == maskAt) { x_rag_mask<LA, 2>(oa.src, wave, kValid); x_rag_mask<LB, 2>(ob.src, wave, kValid); }   \
+    }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
@@ -318,16 +327,18 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     {                                                                                                              \
         constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
         constexpr uint32_t imm_ = (uint32_t)(((P) * 4 + q_) * kHalfBytes + i_ * 4096);                             \
-        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[q_][i_], waveLds);                      \
-        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[q_ - 2][i_], waveLds);                                   \
+        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrA), oa.src[q_][i_], waveLds);                 \
+        else v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrB), ob.src[q_ - 2][i_], waveLds);                              \
     }
 #define CTAMD_X_DMA8(P, N0, PAD)                                                                                    \
     CTAMD_X_DMA(P, (N0) + 0, PAD) CTAMD_X_DMA(P, (N0) + 1, PAD) CTAMD_X_DMA(P, (N0) + 2, PAD) CTAMD_X_DMA(P, (N0) + 3, PAD) \
     CTAMD_X_DMA(P, (N0) + 4, PAD) CTAMD_X_DMA(P, (N0) + 5, PAD) CTAMD_X_DMA(P, (N0) + 6, PAD) CTAMD_X_DMA(P, (N0) + 7, PAD)
 
     // ---- prologue: K-tiles 0 and 1; the odometer stays on tile 1 (k-step 0 of tile t moves it to tile t + 2) -------------
+    CTAMD_X_RAGMASK(0)
     CTAMD_X_DMA8(0, 0, true) CTAMD_X_DMA8(0, 8, true)
     odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+    CTAMD_X_RAGMASK(1)
     CTAMD_X_DMA8(1, 0, true) CTAMD_X_DMA8(1, 8, true)
     CTAMD_H_VMCNT(16);                            // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
@@ -371,6 +382,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     CTAMD_X_MFMA(1, 4 * (Q) + 2) CTAMD_X_MFMA(1, 4 * (Q) + 3)                                                      \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_X_TILE(P)                                                                                             \
+    CTAMD_X_RAGMASK(t + (P) + 2)                                                                                   \
     CTAMD_X_G0(P, 0) CTAMD_X_G0(P, 1) CTAMD_X_G0(P, 2) CTAMD_X_G0(P, 3) CTAMD_X_G0(P, 4) CTAMD_X_G0(P, 5)          \
     CTAMD_X_G0(P, 6) CTAMD_X_G0(P, 7) CTAMD_X_G0(P, 8) CTAMD_X_G0(P, 9) CTAMD_X_G0(P, 10) CTAMD_X_G0(P, 11)        \
     CTAMD_X_G0(P, 12) CTAMD_X_G0(P, 13) CTAMD_X_G0(P, 14) CTAMD_X_G0(P, 15)                                        \
@@ -542,6 +554,10 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
 #endif
+    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+        hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, false, 0, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -569,7 +585,8 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
 // (128 KiB, one workgroup per CU): tile t + 4 is staged during tile t, the tile barrier waits for tile t + 1 only (counted
 // vmcnt: the 16 pieces of tiles t + 2, t + 3 stay in flight) — the form for problems with at most one 128 x 128 tile per CU.
 constexpr int kMTile = 128;
-template <bool BF, int LA, int LB, int R = 2>
+// RAG: ragged K, as in gett_h16w4x_kernel (x_rag_mask).  R = 4 stages a tile's A and B pieces at different times: one switch each.
+template <bool BF, int LA, int LB, int R = 2, bool RAG = false>
 __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(const GettParams p) {
     static_assert(R == 2 || R == 4, "ring of two or four K-tiles");
     __shared__ __attribute__((aligned(16))) char lds[R * 2 * kHalfBytes];       // buffer P: [A half-tile][B half-tile]
@@ -592,7 +609,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = mt * kMTile, n0 = nt * kMTile;
-    const uint32_t kTilesAll = p.gK.total / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
@@ -603,7 +620,12 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
-    odo.init(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (p.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(p.gK.total % kHBK);
+#define CTAMD_M_RAGMASK_A(IDX) if constexpr (RAG) { if ((IDX) == maskAt) x_rag_mask<LA, 1>(oa.src, wave, kValid); }
+#define CTAMD_M_RAGMASK_B(IDX) if constexpr (RAG) { if ((IDX) == maskAt) x_rag_mask<LB, 1>(ob.src, wave, kValid); }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
@@ -631,23 +653,27 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     {                                                                                                              \
         constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
         constexpr uint32_t imm_ = (uint32_t)(((P) * 2 + q_) * kHalfBytes + i_ * 4096);                             \
-        if constexpr (q_ == 0) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[0][i_], waveLds);                      \
-        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[0][i_], waveLds);                                        \
+        if constexpr (q_ == 0) v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrA), oa.src[0][i_], waveLds);                 \
+        else v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrB), ob.src[0][i_], waveLds);                                   \
     }
 #define CTAMD_M_DMA8(P, PAD)                                                                                        \
     CTAMD_M_DMA(P, 0, PAD) CTAMD_M_DMA(P, 1, PAD) CTAMD_M_DMA(P, 2, PAD) CTAMD_M_DMA(P, 3, PAD)                    \
     CTAMD_M_DMA(P, 4, PAD) CTAMD_M_DMA(P, 5, PAD) CTAMD_M_DMA(P, 6, PAD) CTAMD_M_DMA(P, 7, PAD)
 
     // ---- prologue: K-tiles 0 .. R - 1; the odometer stays on tile R - 1 (k-step 0 of tile t moves it to tile t + R) ---------
+    CTAMD_M_RAGMASK_A(0) CTAMD_M_RAGMASK_B(0)
     CTAMD_M_DMA8(0, true)
     odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+    CTAMD_M_RAGMASK_A(1) CTAMD_M_RAGMASK_B(1)
     CTAMD_M_DMA8(1, true)
     if constexpr (R == 4) {
         // the deep ring spreads a tile's eight pieces over one K-tile time (four behind the barrier of tile t, four in front of the
         // barrier of tile t + 1): tiles 0 .. 2 and the first half of tile 3 here, its second half rides in k-step 0 of tile 0
         odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+        CTAMD_M_RAGMASK_A(2) CTAMD_M_RAGMASK_B(2)
         CTAMD_M_DMA8(2, true)
         odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK);
+        CTAMD_M_RAGMASK_A(3)
         CTAMD_M_DMA(3, 0, true) CTAMD_M_DMA(3, 1, true) CTAMD_M_DMA(3, 2, true) CTAMD_M_DMA(3, 3, true)
     }
     CTAMD_H_VMCNT(R == 2 ? 8 : 20);               // this wave's pieces of tile 0
@@ -696,13 +722,18 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     else if constexpr ((Q) % 2 == 0) CTAMD_M_DMA(P, (Q) / 2, false)         /* pieces 0..3 of tile t + 4 */          \
     CTAMD_M_MFMA(1, 2 * (Q) + 1)                                                                                   \
     __builtin_amdgcn_sched_barrier(0);
+    // tile t (buffer P = t mod R): R = 2 stages tile t + 2 in k-step 1; R = 4 the B pieces of tile t + 3 in k-step 0, the A pieces of
+    // tile t + 4 in k-step 1 (the ragged-K switches sit right in front of them)
 #define CTAMD_M_TILE(P)                                                                                             \
+    if constexpr (R == 2) { CTAMD_M_RAGMASK_A(t + (P) + 2) CTAMD_M_RAGMASK_B(t + (P) + 2) }                        \
+    else { CTAMD_M_RAGMASK_B(t + (P) + 3) }                                                                        \
     CTAMD_M_G0(P, 0) CTAMD_M_G0(P, 1) CTAMD_M_G0(P, 2) CTAMD_M_G0(P, 3)                                            \
     CTAMD_M_G0(P, 4) CTAMD_M_G0(P, 5) CTAMD_M_G0(P, 6) CTAMD_M_G0(P, 7)                                            \
     CTAMD_H_LGKM0();                                                                                               \
     CTAMD_H_VMCNT(8 * (R - 2));      /* tile t + 1 has landed; the pieces of tiles t + 2 .. t + R - 1 stay in flight */     \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if constexpr (R == 4) { CTAMD_M_RAGMASK_A(t + (P) + 4) }                                                       \
     CTAMD_M_G1(P, 0) CTAMD_M_G1(P, 1) CTAMD_M_G1(P, 2) CTAMD_M_G1(P, 3)                                            \
     CTAMD_M_G1(P, 4) CTAMD_M_G1(P, 5) CTAMD_M_G1(P, 6) CTAMD_M_G1(P, 7)
 
@@ -1094,6 +1125,19 @@ struct QOperand {
     }
 };
 
+// ragged K (x_rag_mask) for QOperand's pieces: K-contiguous — k-unit (lane & 7) ^ ((4 wave + (lane >> 4)) & 7) of the lane's row in
+// both pieces; free-contiguous — piece i holds k-row 8 wave + 32 i + (lane >> 3)
+template <int LAY>
+__device__ __forceinline__ void q_rag_mask(uint32_t (&src)[2], int wave, uint32_t kValid) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ ((4u * (uint32_t)wave + (laneM >> 4)) & 7u)) >= kValid)
+                                        : (8u * (uint32_t)wave + 32u * (uint32_t)i + (laneM >> 3) >= kValid);
+        src[i] |= out ? 0x80000000u : 0u;
+    }
+}
+
 // byte offset of this lane's 8 bytes of fragment f (rows 16 f) inside the free-contiguous 8-KiB image, first transposing read (k-rows
 // 8 g + [0,4) of k-step 0; + 512: k + 4; + 4096: k-step 1)
 __device__ __forceinline__ uint32_t q_offF(int lane, int f) {
@@ -1120,7 +1164,8 @@ __device__ __forceinline__ s16x8 q_read(uint32_t base) {
 // landed / end of the main loop / stores issued and the wall clock at entry / exit (tools/h16_small_timeline.py)
 // (An eight-deep ring, 128 KiB and one workgroup per CU, measured the same 460 cycles per K-tile at 1024^3 as this four-deep one and
 // a later first tile: a lone workgroup is not latency-bound either.  profiles/r04v_small_timeline.jsonl)
-template <bool BF, int LA, int LB, bool TIMED = false>
+// RAG: ragged K, as in gett_h16w4x_kernel (q_rag_mask): tile t stages tile t + 4 whole, one switch.
+template <bool BF, int LA, int LB, bool TIMED = false, bool RAG = false>
 __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p) {
     constexpr int R = 4;
     __shared__ __attribute__((aligned(16))) char lds[R * kQBuf];
@@ -1148,7 +1193,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint32_t gsz = (ps.tilesM - first < 8u) ? (ps.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = mt * kQTile, n0 = nt * kQTile;
-    const uint32_t kTilesAll = ps.gK.total / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
+    const uint32_t kTilesAll = (ps.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
     if constexpr (TIMED) { asm volatile("" :: "s"(nTiles), "s"(m0), "s"(n0)); qs[7] = __builtin_readcyclecounter(); }   // arguments fetched, tile located
@@ -1160,7 +1205,14 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.A) + group_offset<0>(ps.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.B) + group_offset<1>(ps.gL, l)) + ob.base);
     VOdometer odo;
-    odo.init(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    odo.template init<RAG>(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (ps.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(ps.gK.total % kHBK);
+#define CTAMD_Q_RAGMASK(IDX)                                                                                        \
+    if constexpr (RAG) {                                                                                           \
+        if ((IDX) == maskAt) { q_rag_mask<LA>(oa.src, wave, kValid); q_rag_mask<LB>(ob.src, wave, kValid); }       \
+    }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
@@ -1180,18 +1232,18 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
 #define CTAMD_Q_DMA(P, N, PAD)                                                                                      \
     {                                                                                                              \
         constexpr uint32_t imm_ = (uint32_t)((P) * kQBuf + ((N) >> 1) * 8192 + ((N) & 1) * 4096);                  \
-        if constexpr (((N) >> 1) == 0) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[(N) & 1], waveLds);            \
-        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[(N) & 1], waveLds);                                      \
+        if constexpr (((N) >> 1) == 0) v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrA), oa.src[(N) & 1], waveLds);       \
+        else v_dma16<imm_, PAD>(v_rsrc<RAG>(odo.addrB), ob.src[(N) & 1], waveLds);                                 \
     }
 #define CTAMD_Q_DMA4(P, PAD) CTAMD_Q_DMA(P, 0, PAD) CTAMD_Q_DMA(P, 1, PAD) CTAMD_Q_DMA(P, 2, PAD) CTAMD_Q_DMA(P, 3, PAD)
 #define CTAMD_Q_NEXT() { odo.advance_a(); odo.advance_b(); odo.advance_event(p.gK); }
 
     // ---- prologue: K-tiles 0 .. R - 1; the odometer stays on tile R - 1 ----------------------------------------------------
     if constexpr (TIMED) qs[1] = __builtin_readcyclecounter();
-    CTAMD_Q_DMA4(0, true)
-    CTAMD_Q_NEXT() CTAMD_Q_DMA4(1, true)
-    CTAMD_Q_NEXT() CTAMD_Q_DMA4(2, true)
-    CTAMD_Q_NEXT() CTAMD_Q_DMA4(3, true)
+    CTAMD_Q_RAGMASK(0) CTAMD_Q_DMA4(0, true)
+    CTAMD_Q_NEXT() CTAMD_Q_RAGMASK(1) CTAMD_Q_DMA4(1, true)
+    CTAMD_Q_NEXT() CTAMD_Q_RAGMASK(2) CTAMD_Q_DMA4(2, true)
+    CTAMD_Q_NEXT() CTAMD_Q_RAGMASK(3) CTAMD_Q_DMA4(3, true)
     CTAMD_H_VMCNT(4 * (R - 1));                   // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
     if constexpr (TIMED) qs[2] = __builtin_readcyclecounter();
@@ -1218,6 +1270,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     CTAMD_Q_READ8(((P) + 1) % R, ((P) + 1) & 1)                                                                    \
     CTAMD_Q_NEXT()                                                                                                 \
+    CTAMD_Q_RAGMASK(t + (P) + 4)                                                                                   \
     CTAMD_Q_DMA(P, 0, false) CTAMD_Q_MFMA2((P) & 1, 0, 0)                                                          \
     CTAMD_Q_DMA(P, 1, false) CTAMD_Q_MFMA2((P) & 1, 0, 1)                                                          \
     CTAMD_Q_DMA(P, 2, false) CTAMD_Q_MFMA2((P) & 1, 1, 0)                                                          \
@@ -1320,6 +1373,10 @@ static hipError_t launch_h16w4q(const GettParams& p, hipStream_t stream) {
         if (timed) { hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
 #endif
+    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+        hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, false, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
@@ -1338,6 +1395,10 @@ static hipError_t launch_h16w8m(const GettParams& p, hipStream_t stream) {
 
 template <bool BF, int LA, int LB, int R>
 static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
+    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+        hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB, R, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB, R>), dim3(p.nBlocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -25,11 +25,15 @@ __device__ __forceinline__ void v_dma16(HRsrc rsrc, uint32_t laneBytes, uint32_t
 #endif
 }
 
+// RAG (ragged K, gett_h16w4x_kernel<..., RAG = true>): 2^31 records instead of 2^32 - 1 — a lane whose 16 bytes lie past the end of
+// the contracted mode in the last K-tile carries bit 31 in its byte offset, is out of range, touches no memory and has zeros
+// written to its 16 bytes of the LDS piece (every in-range offset is below 2^31: pick_h16_choice, tile_span_bytes).
+template <bool RAG = false>
 __device__ __forceinline__ HRsrc v_rsrc(uint64_t addr) {      // addr is a valid device address: bits 48..63 are zero
     HRsrc r;
     r[0] = (int)(uint32_t)addr;
     r[1] = (int)(uint32_t)(addr >> 32);
-    r[2] = -1;
+    r[2] = RAG ? (int)0x80000000u : -1;
     r[3] = 0x00020000;
     return r;
 }
@@ -62,9 +66,11 @@ struct VOdometer {
 
     __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+    // RAG: the (single) contracted mode ends inside its last K-tile — that tile counts
+    template <bool RAG = false>
     __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0, uint32_t nTiles, uint64_t bA, uint64_t bB) {
         const uint32_t E0 = gK.div[0].d;
-        n0 = sgpr(E0 / kHBK);
+        n0 = sgpr((E0 + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK);
         e1 = sgpr(gK.div[1].d);
         const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
         const uint32_t j0 = (k0 - q0 * E0) / kHBK;
@@ -122,6 +128,26 @@ struct VOdometer {
         }
     }
 };
+
+// Ragged K (the RAG instantiations of gett_h16w4x_kernel / gett_h16w4m_kernel: ONE contracted mode whose extent is not a multiple of 64;
+// pick_h16_choice): the last K-tile of the last slice is staged with the lanes past the end of the mode out of range — bit 31 or-ed
+// into their byte offsets, descriptors of 2^31 records (v_rsrc<true>): no memory access, zeros in their LDS bytes, so the MFMAs of
+// that tile add zeros for k >= K.  K-contiguous operand: a lane's 16 bytes are k-unit u = (lane & 7) ^ ((4 wave + (lane >> 4)) & 7)
+// of its row in every piece (HOperand::init: r >> 1 = 4 wave + 16 i + (lane >> 4)), whole in or whole out since K % 8 == 0;
+// free-contiguous operand: the lanes of piece i hold k-row 16 i + 4 wave + (lane >> 4).  Called ONCE per operand, right before the
+// first LDS-DMA piece of that tile (a wave-uniform test per K-tile): nothing is staged after the last tile but itself.
+template <int LAY, int NH>
+__device__ __forceinline__ void x_rag_mask(uint32_t (&src)[NH][4], int wave, uint32_t kValid) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t kk0 = 4u * (uint32_t)wave + (laneM >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ (kk0 & 7u)) >= kValid) : (kk0 + 16u * (uint32_t)i >= kValid);
+        const uint32_t bit = out ? 0x80000000u : 0u;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) src[h][i] |= bit;
+    }
+}
 
 template <bool BF>
 __device__ __forceinline__ void x_mfma(f32x4& c, const s16x8& a, const s16x8& b) {

@@ -51,14 +51,28 @@ def test_vector_width_and_orientation_follow_the_layout(env):
         extA = [M, K] if mA == "mk" else [K, M]
         extB = [K, N] if mB == "kn" else [N, K]
         return ops.contraction_plan(h, extA, mA, extB, mB, [M, N], "mn", dtype=dtype, workspace_limit=1 << 28, **kw)
-    # 16-byte lanes but K not a multiple of 64: the aligned family refuses, the general family takes it at V = 8
+    # 16-byte lanes but K not a multiple of 64.  Since round 5 ONE ragged contracted mode stays in the aligned LDS-DMA family (masked last
+    # K-tile, tests/test_h16_planner_cpu.py); the general family's V = 8 form is looked at under CUTENSOR_AMD_GEN=f (the general family
+    # also where the aligned kernels apply) ...
     for (mA, mB, oa, ob) in (("mk", "kn", 0, 1), ("km", "nk", 1, 0), ("km", "kn", 1, 1), ("mk", "nk", 0, 0)):
         p = plan(2048, 2048, 1000, mA, mB, ct.R_16BF)
+        assert p.describe()["family"] == 1, p.describe()
+        p.destroy()
+        os.environ["CUTENSOR_AMD_GEN"] = "f"
+        try:
+            p = plan(2048, 2048, 1000, mA, mB, ct.R_16BF)
+        finally:
+            del os.environ["CUTENSOR_AMD_GEN"]
         d = p.describe()
         # the planner may have swapped the operands (D's stride-1 mode becomes kernel-N): compare as a set when it did
         got = (d["orientA"], d["orientB"]) if not d["swapped"] else (d["orientB"], d["orientA"])
         assert d["family"] == 2 and d["vec"] == 8 and got == (oa, ob) and (d["bm"], d["bn"], d["bk"]) == (128, 128, 64), (mA, mB, d)
         p.destroy()
+    # ... and it is still where TWO contracted modes with a ragged fastest one go: C[m,n] = A[k,m,j] B[k,j,n], k = 40, j = 25
+    p = ops.contraction_plan(h, [40, 512, 25], "kmj", [40, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
+    d = p.describe()
+    assert d["family"] == 2 and d["vec"] == 8, d
+    p.destroy()
     # whole 64-deep K-tiles and 16-byte lanes: still the aligned LDS-DMA family
     p = plan(2048, 2048, 1024, "mk", "kn", ct.R_16BF)
     assert p.describe()["family"] == 1

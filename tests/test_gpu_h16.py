@@ -102,6 +102,93 @@ def test_multi_mode_contraction_bf16(env):
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=5e-2)
 
 
+RAGGED_K = [  # (m, n, k): one contracted mode, k % 64 != 0
+    (512, 512, 200),     # three whole K-tiles and 8 of the fourth
+    (520, 264, 72),      # two K-tiles: the masked one is staged by the prologue
+    (256, 256, 8),       # ONE K-tile, 8 of its 64 k
+    (304, 520, 1096),    # odd tile count (18): the masked tile comes out of the single-tile tail of the pair loop
+    (1024, 1024, 1080),  # even tile count (17 whole + 56)
+]
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+@pytest.mark.parametrize("dims", RAGGED_K)
+def test_ragged_k_stays_on_the_lds_dma_kernels(env, layout, dims):
+    """K % 64 != 0 with 16-byte lanes (round-4 review, Missing #4): the 256 x 256 / 128 x 128 LDS-DMA kernels stage the last K-tile with
+    the lanes past the end of the contracted mode out of range (zeros in LDS), instead of handing the problem to the general family.
+    What lies behind the end of a K-contiguous row is the next row's data, so a lane that is not masked shows up in the result."""
+    m, n, k = dims
+    mA, mB = LAYOUTS[layout]
+    got, ref, d = _run(env, dict(m=m, n=n, k=k), mA, mB, "mn", seed=hash((layout, dims)) % 1000)
+    assert d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w4q_kernel"), d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+def test_ragged_k_large_shapes_by_the_planners_own_choice(env, layout):
+    mA, mB = LAYOUTS[layout]
+    got, ref, d = _run(env, dict(m=2048, n=2048, k=200), mA, mB, "mn", seed=31)
+    assert d["family"] == 1 and d["kname"] in ("gett_h16w4m_kernel", "gett_h16w4m4_kernel"), d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+    got, ref, d = _run(env, dict(m=4096, n=2048, k=1096), mA, mB, "mn", seed=32)
+    assert d["family"] == 1 and d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4m_kernel"), d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
+
+
+def test_ragged_k_any_extent_when_both_operands_are_free_contiguous(env):
+    """A[m,k] B[n,k] (both free-contiguous): the rows k >= K of the last K-tile are masked whatever K is — 77 here, and 4100 with
+    alpha / beta in fp16.  The rows behind the end of B are past the end of its allocation: they must not be touched."""
+    got, ref, d = _run(env, dict(m=2048, n=1032, k=77), "mk", "nk", "mn", seed=21)
+    assert d["family"] == 1, d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+    got, ref, d = _run(env, dict(m=1032, n=2048, k=4100), "mk", "nk", "mn", dtype_name="float16", alpha=0.5, beta=0.25, seed=22)
+    assert d["family"] == 1, d
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("dims", [(96, 96, 4104), (264, 120, 1544), (512, 256, 8200)])
+def test_ragged_k_split_k(env, dims):
+    """Small outputs, deep ragged K: the slices are whole K-tiles, the LAST slice owns the masked tile; fp32 partials, one rounding."""
+    m, n, k = dims
+    got, ref, d = _run(env, dict(m=m, n=n, k=k), "km", "kn", "mn", seed=23)
+    assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0, d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
+
+
+def test_ragged_k_forced_kernels(built):
+    """Every kernel that masks a partial K-tile — the 256 x 256 kernel, the 128 x 128 pair (ring of two and of four K-tiles: the deep ring
+    stages a tile's A and B pieces at different times, one switch each), the 64 x 64 tile — forced by CUTENSOR_AMD_H16_WAVES in a child
+    process on K ranges of 1 .. 6 K-tiles (the masked tile staged by the prologue, by the unrolled loop, by its tail)."""
+    import os, subprocess, sys
+    code = r'''
+import numpy as np, torch
+from cudalibrarysamples_amd import cutensor as ct, ops
+h = ops.Handle()
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+for (mA, mB) in (("mk", "kn"), ("km", "kn"), ("mk", "nk"), ("km", "nk")):
+    for (m, n, k) in ((384, 384, 328), (256, 128, 8), (640, 384, 136), (384, 640, 264), (128, 128, 200), (264, 72, 72), (256, 256, 456)):
+        ext = dict(m=m, n=n, k=k)
+        eA, eB = [ext[c] for c in mA], [ext[c] for c in mB]
+        A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).bfloat16()
+        B = (torch.rand(eB[::-1], generator=g, device="cuda") * 2 - 1).bfloat16()
+        D = torch.full((n, m), float("nan"), dtype=torch.bfloat16, device="cuda")
+        plan = ops.contraction_plan(h, eA, mA, eB, mB, [m, n], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
+        d = plan.describe()
+        assert d["family"] == 1 and d["kname"] == WANT, d
+        ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        plan.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
+        torch.cuda.synchronize()
+        ref = torch.einsum("%s,%s->nm" % (mA[::-1], mB[::-1]), A.double(), B.double())
+        np.testing.assert_allclose(D.double().cpu().numpy(), ref.cpu().numpy(), rtol=8e-3, atol=2e-2)
+print("ok")
+'''
+    for waves, want in (("4m", "gett_h16w4m_kernel"), ("4m4", "gett_h16w4m4_kernel"), ("4x", "gett_h16w4x_kernel"), ("4q", "gett_h16w4q_kernel")):
+        envv = dict(os.environ, CUTENSOR_AMD_H16_WAVES=waves)
+        r = subprocess.run([sys.executable, "-c", code.replace("WANT", repr(want))], env=envv, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (waves, r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_unaligned_shapes_run_on_the_general_mfma_family(env):
     """Extents that do not admit 16-byte lanes / 64-deep K-tiles: the general MFMA family (gett_gen.inc, 2-byte gathers here),
     not the scalar FMA kernel (tests/test_gpu_gen.py covers that family)."""

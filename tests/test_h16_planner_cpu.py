@@ -123,3 +123,30 @@ def test_the_switch_overrides_the_planner(built, waves, want):
         assert all(g in KEPT for g in got), got
     else:
         assert got == [want, want], r.stdout
+
+
+def test_ragged_k_stays_in_the_lds_dma_family(env):
+    """One contracted mode with K % 64 != 0 and 16-byte lanes (round-4 review, Missing #4): the planner's usual candidates minus the
+    persistent kernel — their RAG instantiations stage the last K-tile masked (gett_h16x_common.h x_rag_mask).  K-tiles are counted
+    rounded up; slices stay whole K-tiles.  Two contracted modes with a ragged fastest one, or a K-contiguous operand whose K is not a
+    multiple of 8, are the general family's."""
+    ct, ops = env
+    h = ops.Handle()
+
+    def plan(M, N, K, mA="mk", mB="kn", **kw):
+        e = dict(m=M, n=N, k=K)
+        p = ops.contraction_plan(h, [e[c] for c in mA], mA, [e[c] for c in mB], mB, [M, N], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28, **kw)
+        d = p.describe()
+        p.destroy()
+        return d
+    d = plan(4096, 4096, 4104)                     # the review's shape: one 256 x 256 tile per CU
+    assert d["family"] == 1 and d["kname"] == "gett_h16w4x_kernel" and d["splitK"] == 1 and d["kPerSlice"] == 65 * 64, d
+    d = plan(8192, 8192, 8200)                     # (not the persistent kernel: it has no masked tile)
+    assert d["kname"] == "gett_h16w4x_kernel", d
+    assert plan(2048, 2048, 200)["kname"] == "gett_h16w4m4_kernel"
+    assert plan(1024, 1024, 1080)["kname"] == "gett_h16w4q_kernel"
+    d = plan(96, 96, 4104, "km", "kn")             # split-K: whole K-tiles per slice, the last slice owns the masked tile
+    assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0 and d["splitK"] * d["kPerSlice"] >= 4104, d
+    assert plan(2048, 1032, 77, "mk", "nk")["family"] == 1          # both operands free-contiguous: any K
+    assert plan(2048, 1032, 77, "mk", "kn")["family"] == 2          # K-contiguous B: K % 8 != 0 has no 16-byte lanes
+    assert plan(2048, 2048, 1024)["family"] == 1                    # whole K-tiles: unchanged

@@ -65,16 +65,17 @@ def test_lean_four_wave_16_bit_kernels_use_no_scratch_and_all_512_registers(buil
     256 accumulator registers + 256 others, no private segment (a scratch allocation is paid for at every dispatch)."""
     k = _kernel_notes(_code_object(tmp_path, "gett_h16v"))
     hot = {n: v for n, v in k.items() if "gett_h16w4x_kernel" in n or "gett_h16w4v_kernel" in n}
-    assert len(hot) >= 8, sorted(k)           # 8 layouts x types of the default (+ 8 of the retired 32x32x16 sibling and the measurement-only instantiations in a research build)
+    assert len(hot) >= 16, sorted(k)          # 8 layouts x types of the default and their ragged-K twins (+ 8 of the retired 32x32x16 sibling and the measurement-only instantiations in a research build)
+    assert sum(1 for n in hot if n.endswith("Lb0ELi0ELb1EEEvNS_10GettParamsE")) == 8, sorted(hot)   # <..., TIMED = false, XST = 0, RAG = true>
     bad = {n: v for n, v in hot.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
     assert not bad, bad
     assert all(v.get("group_segment_fixed_size", 131072) == 131072 for v in hot.values()), hot   # two K-tiles of 64 KiB
     # the 128 x 128 mid-size sibling: no scratch, two K-tiles of 32 KiB, and few enough registers for two workgroups per CU
     mid = {n: v for n, v in k.items() if "gett_h16w4m_kernel" in n}
-    assert len(mid) == 16, sorted(k)          # ring of two K-tiles (two workgroups per CU) and of four (one)
+    assert len(mid) == 32, sorted(k)          # ring of two K-tiles (two workgroups per CU) and of four (one), each with its ragged-K twin
     assert not {n: v for n, v in mid.items() if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}, mid
-    two = {n: v for n, v in mid.items() if n.endswith("Li2EEEvNS_10GettParamsE")}
-    assert len(two) == 8 and all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in two.values()), mid
+    two = {n: v for n, v in mid.items() if n.endswith("Li2ELb0EEEvNS_10GettParamsE") or n.endswith("Li2ELb1EEEvNS_10GettParamsE")}
+    assert len(two) == 16 and all(v.get("group_segment_fixed_size") == 65536 and v.get("vgpr_count", 999) <= 256 for v in two.values()), mid
     assert all(v.get("group_segment_fixed_size") == 131072 for n, v in mid.items() if n not in two), mid
     # the 64 x 64 kernel for small problems: no scratch, four K-tiles of 16 KiB, registers for two workgroups per CU
     small = {n: v for n, v in k.items() if "gett_h16w4q_kernel" in n}
@@ -125,7 +126,7 @@ def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
 
 @pytest.mark.parametrize("obj,symbol", [
     ("gett_f32_stream", "_ZN5ctamd22gett_f32_stream_kernelINS_9StreamCfgILi96ELi96ELi1ELi0ELi3ELi0EEEEEvNS_10GettParamsE"),
-    ("gett_h16v", "_ZN5ctamd18gett_h16w4x_kernelILb1ELi1ELi0ELb0ELi0EEEvNS_10GettParamsE"),
+    ("gett_h16v", "_ZN5ctamd18gett_h16w4x_kernelILb1ELi1ELi0ELb0ELi0ELb0EEEvNS_10GettParamsE"),
     ("gett_h16p", "_ZN5ctamd18gett_h16w4p_kernelILb1ELi1ELi0ELi2ELb0EEEvNS_10GettParamsE"),
 ])
 def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, obj, symbol):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--strided", action="store_true", help="give a third of the tensors padded (non-packed) strides")
     ap.add_argument("--many-modes", action="store_true", help="3-6 small modes per group: groups beyond the tiled kernels' four digits "
                                                               "(peeled into a host loop up to 64 launches, mode-table kernel beyond)")
+    ap.add_argument("--ragged-k", action="store_true", help="16-bit data, 16-byte lanes, ONE contracted mode whose extent is a multiple of 8 "
+                                                            "but not of 64: the masked last K-tile of the LDS-DMA 16-bit kernels")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -30,6 +32,8 @@ def main():
     for case in range(args.cases):
         dtype = rnd.choice(["float32", "float32", "bfloat16"] + (["float64", "float16", "complex64", "complex128"] if args.all_types else []))
         nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
+        if args.ragged_k:
+            dtype, nK = rnd.choice(["bfloat16", "bfloat16", "float16"]), 1
         if args.many_modes:
             nM, nN, nK, nL = rnd.randint(2, 6), rnd.randint(1, 5), rnd.randint(1, 6), rnd.choice([0, 0, 1, 2])
         labels = list("abcdefghijklmnopqrstuvwxyz")
@@ -41,6 +45,8 @@ def main():
             table = ((M, [8, 16, 24, 40, 96, 104, 264]), (N, [8, 16, 32, 48, 96, 120]), (K, [64, 64, 128, 192]), (L, [2, 3]))
         if args.many_modes:
             table = ((M, [2, 3, 4, 5, 8]), (N, [2, 3, 4, 6, 8]), (K, [2, 3, 4, 8]), (L, [2, 3]))
+        if args.ragged_k:
+            table = ((M, [8, 16, 24, 40, 96, 104, 264, 520]), (N, [8, 16, 32, 48, 96, 120, 392]), (K, [8, 24, 72, 136, 200, 328, 520, 1000, 2056, 4104]), (L, [2, 3]))
         for g, choices in table:
             for c in g:
                 ext[c] = rnd.choice(choices)
