@@ -149,9 +149,13 @@ def test_ragged_k_any_extent_when_both_operands_are_free_contiguous(env):
 @pytest.mark.parametrize("dims", [(96, 96, 4104), (264, 120, 1544), (512, 256, 8200)])
 def test_ragged_k_split_k(env, dims):
     """Small outputs, deep ragged K: the slices are whole K-tiles, the LAST slice owns the masked tile; fp32 partials, one rounding."""
+    import os
     m, n, k = dims
-    got, ref, d = _run(env, dict(m=m, n=n, k=k), "km", "kn", "mn", seed=23)
-    assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0, d
+    got, ref, d = _run(env, dict(m=m, n=n, k=k), "km", "kn", "mn", seed=23, expect_mfma=False)
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES", "4x") in ("4x", "4m", "4m4", "4q"):   # (test_kernel_variant_parity runs this file under every variant)
+        assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0, d
+    else:
+        assert d["family"] == 2, d                 # a kernel without a masked K-tile was asked for: the general family
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
 
 
