@@ -33,6 +33,9 @@
 #define CUTENSOR_MINOR 2
 #define CUTENSOR_PATCH 0
 #define CUTENSOR_VERSION (CUTENSOR_MAJOR * 10000 + CUTENSOR_MINOR * 100 + CUTENSOR_PATCH)
+/* This header belongs to the MI355X engine: lets a caller guard the engine-prefixed extras (CUTENSOR_AMD_PLAN_PREFERENCE_*,
+ * ctamd* entry points) that cuTENSOR proper does not have. */
+#define CUTENSOR_AMD 1
 
 #ifdef __cplusplus
 extern "C" {
