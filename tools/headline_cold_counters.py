@@ -48,7 +48,18 @@ def main():
             want[key] = p
         else:
             p.destroy()
-    out = {"candidates": n, "default_plan": {k: d0[k] for k in ("kernel", "bm", "bn", "bk", "pf", "splitK", "blocks", "kname", "nt")}}
+    out = {"candidates": n, "korder": os.environ.get("CUTENSOR_AMD_KORDER"), "Kdigits": d0.get("Kdigits"),
+           "default_plan": {k: d0[k] for k in ("kernel", "bm", "bn", "bk", "pf", "splitK", "blocks", "kname", "nt")}}
+    # the default plan's result under this K order (fold ON for the check), against fp64
+    ct.lib.ctamdSetSplitKFold(h.h, 1)
+    p0.contract(1.0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), 0.0, C.data_ptr(), C.data_ptr(), ws.data_ptr(), 1 << 28, 0)
+    torch.cuda.synchronize()
+    A4 = pairs[0][0].view(*[ext[c] for c in "abcd"]).double()      # modes "dcba", d fastest = row-major [a][b][c][d]
+    B4 = pairs[0][1].view(*[ext[c] for c in "dcbe"]).double()      # modes "ebcd", e fastest = row-major [d][c][b][e]
+    ref = torch.einsum("abcd,dcbe->ae", A4, B4)
+    got = C.view(ext["a"], ext["e"]).double()                       # modes "ea", e fastest = row-major [a][e]
+    out["max_rel_err"] = float(((got - ref).abs() / ref.abs()).max())
+    ct.lib.ctamdSetSplitKFold(h.h, 0)
 
     def run(p, cold, steps=400, warm=200):
         call = lambda i: p.contract(1.0, pairs[i % 4 if cold else 0][0].data_ptr(), pairs[i % 4 if cold else 0][1].data_ptr(), 0.0,  # noqa: E731
