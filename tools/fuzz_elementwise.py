@@ -25,7 +25,8 @@ def main():
     from cudalibrarysamples_amd import cutensor as ct, ops
     rnd = random.Random(args.seed)
     h = ops.Handle()
-    DT = {"float32": (ct.R_32F, 2e-6), "float64": (ct.R_64F, 1e-13), "bfloat16": (ct.R_16BF, 1.2e-2), "float16": (ct.R_16F, 1.5e-3)}
+    DT = {"float32": (ct.R_32F, 2e-6), "float64": (ct.R_64F, 1e-13), "bfloat16": (ct.R_16BF, 1.2e-2), "float16": (ct.R_16F, 1.5e-3),
+          "complex64": (ct.C_32F, 4e-6), "complex128": (ct.C_64F, 2e-13)}     # round 5: (re, im)-pair kernels, ADD / MUL, complex scalars
     fails, done, refused = 0, {}, 0
 
     def shape(m, ext):
@@ -44,7 +45,13 @@ def main():
         return t2.permute(perm).expand(shape(m_want, ext))
 
     def rand(m, ext, tdt):
-        return (torch.rand(shape(m, ext) or [1], device="cuda", dtype=torch.float64) * 2 - 1).to(tdt).reshape(shape(m, ext))
+        r = torch.rand(shape(m, ext) or [1], device="cuda", dtype=torch.float64) * 2 - 1
+        if tdt.is_complex:
+            r = torch.complex(r, torch.rand(shape(m, ext) or [1], device="cuda", dtype=torch.float64) * 2 - 1)
+        return r.to(tdt).reshape(shape(m, ext))
+
+    def wide(t):
+        return t.to(torch.complex128) if t.is_complex() else t.double()
 
     def rand_strided(m, ext, tdt):
         """(view, column-major element strides or None): sometimes a view into a buffer with padded extents."""
@@ -53,7 +60,10 @@ def main():
         if not e or not any(pad):
             return rand(m, ext, tdt), None
         full = [x + p_ for x, p_ in zip(e, pad)]
-        base = (torch.rand(full[::-1], device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+        base = torch.rand(full[::-1], device="cuda", dtype=torch.float64) * 2 - 1
+        if tdt.is_complex:
+            base = torch.complex(base, torch.rand(full[::-1], device="cuda", dtype=torch.float64) * 2 - 1)
+        base = base.to(tdt)
         strides, run = [], 1
         for x in full:
             strides.append(run)
@@ -62,7 +72,7 @@ def main():
 
     def check(kind, got, ref, tol, scale, what):
         nonlocal fails
-        err = float((got.double() - ref).abs().max()) if ref.numel() else 0.0
+        err = float((wide(got) - ref).abs().max()) if ref.numel() else 0.0
         bound = tol * max(1.0, scale)
         if not err <= bound:
             fails += 1
@@ -71,9 +81,12 @@ def main():
 
     for case in range(args.cases):
         kind = rnd.choice(["permute", "permute", "reduce", "reduce", "binary", "trinary"])
-        dtype = rnd.choice(["float32", "float32", "float64", "bfloat16", "float16"])
+        dtype = rnd.choice(["float32", "float32", "float64", "bfloat16", "float16", "complex64", "complex128"])
+        if kind == "trinary" and dtype.startswith("complex"):
+            dtype = "float32"                      # complex trinary operations are refused
         cdt, tol = DT[dtype]
         tdt = getattr(torch, dtype)
+        cplx = dtype.startswith("complex")
         n = rnd.randint(1, 5)
         labels = rnd.sample("abcdefgh", n)
         ext = {c: rnd.choice([64, 128, 192, 256, 320, 384, 512, 72, 136, 260, 2, 3, 5] if args.wide else EXTENTS) for c in labels}
@@ -83,6 +96,8 @@ def main():
         if vol > (1 << (25 if args.wide else 22)):
             continue
         alpha, gamma, beta = rnd.choice([1.0, 0.5, -1.25]), rnd.choice([0.0, 1.0, -0.5]), rnd.choice([1.0, 0.25])
+        if cplx:
+            alpha, gamma, beta = alpha + rnd.choice([0.0, 0.75j]), gamma + rnd.choice([0.0, -0.5j]), beta + rnd.choice([0.0, 0.25j])
         try:
             if kind == "permute":
                 mA = "".join(labels)
@@ -93,13 +108,13 @@ def main():
                                             alignment=align)
                 plan.permute(alpha, A.data_ptr(), B.data_ptr())
                 torch.cuda.synchronize()
-                check(kind, B, alpha * as_modes(A.double(), mA, mB, ext), tol, 1.25,
+                check(kind, B, alpha * as_modes(wide(A), mA, mB, ext), tol, 1.25,
                       "%s->%s %s %s strides %s %s align %d" % (mA, mB, ext, dtype, sA, sB, align))
             elif kind == "reduce":
                 mA = "".join(labels)
                 kept = rnd.sample(labels, rnd.randint(0, n - 1)) if n > 1 else []
                 mC = "".join(kept)
-                op = rnd.choice(["ADD", "ADD", "MAX", "MIN"])
+                op = rnd.choice(["ADD"] if cplx else ["ADD", "ADD", "MAX", "MIN"])
                 (A, sA), (D, sC) = rand_strided(mA, ext, tdt), rand_strided(mC, ext, tdt)
                 C = D.clone()                      # D aliases C in the call (reduction.cu:219-222); C keeps the input values
                 align = rnd.choice([128, 128, 16, A.element_size()])
@@ -109,7 +124,7 @@ def main():
                 plan.reduce(alpha, A.data_ptr(), gamma, D.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
                 torch.cuda.synchronize()
                 red_dims = [i for i, c in enumerate(list(mA)[::-1]) if c not in kept]
-                a64 = A.double()
+                a64 = wide(A)
                 if op == "ADD":
                     r = a64.sum(dim=red_dims) if red_dims else a64
                 elif op == "MAX":
@@ -117,7 +132,7 @@ def main():
                 else:
                     r = a64.amin(dim=red_dims) if red_dims else a64
                 kept_in_a_order = [c for c in mA if c in kept]
-                ref = alpha * as_modes(r.reshape(shape(kept_in_a_order, ext)), "".join(kept_in_a_order), mC, ext) + gamma * C.double()
+                ref = alpha * as_modes(r.reshape(shape(kept_in_a_order, ext)), "".join(kept_in_a_order), mC, ext) + gamma * wide(C)
                 volC = 1
                 for c in mC:
                     volC *= ext[c]
@@ -127,15 +142,15 @@ def main():
             elif kind == "binary":
                 mC = "".join(labels)
                 mA = "".join(rnd.sample(labels, n))
-                op = rnd.choice(["ADD", "MUL", "MAX", "MIN"])
+                op = rnd.choice(["ADD", "MUL"] if cplx else ["ADD", "MUL", "MAX", "MIN"])
                 A = rand(mA, ext, tdt)
                 C = rand(mC, ext, tdt)
                 D = torch.empty_like(C)
                 plan = ops.binary_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mC], mC, op=op, dtype=cdt)
                 plan.binary(alpha, A.data_ptr(), beta, C.data_ptr(), D.data_ptr())
                 torch.cuda.synchronize()
-                x, y = alpha * as_modes(A.double(), mA, mC, ext), beta * C.double()
-                ref = {"ADD": x + y, "MUL": x * y, "MAX": torch.maximum(x, y), "MIN": torch.minimum(x, y)}[op]
+                x, y = alpha * as_modes(wide(A), mA, mC, ext), beta * wide(C)
+                ref = (x + y) if op == "ADD" else (x * y) if op == "MUL" else torch.maximum(x, y) if op == "MAX" else torch.minimum(x, y)
                 check(kind, D, ref, tol, 2.5, "%s,%s %s %s %s" % (mA, mC, op, ext, dtype))
             else:
                 mD = "".join(labels)
