@@ -60,10 +60,21 @@ def run(env, ext, mA, mB, mC, dtype, alpha=1.0, beta=0.0, seed=0, padA=None, pad
         PA2, PB2, PC2 = back(dA, PA), back(dB, PB), back(dC, PC)
         A, B, C = (P[tuple(slice(0, e) for e in x)] for P, x in ((PA2, eA), (PB2, eB), (PC2, eC)))
     strides = lambda V: [s // V.itemsize for s in V.strides]   # noqa: E731
-    plan = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=getattr(ct, cname), strideA=strides(A), strideB=strides(B),
-                                strideC=strides(C), workspace_limit=ws_limit, alignment=alignment,
-                                opA=ct.OP_CONJ if opA else ct.OP_IDENTITY, opB=ct.OP_CONJ if opB else ct.OP_IDENTITY,
-                                opC=ct.OP_CONJ if opC else ct.OP_IDENTITY, **({} if algo is None else dict(algo=algo)))
+    # This file tests the GENERAL family.  Since round 5 a 16-bit problem with 16-byte lanes and ONE ragged contracted mode stays on the
+    # aligned LDS-DMA kernels (tests/test_gpu_h16.py): CUTENSOR_AMD_GEN=force keeps such shapes here (the switch is read at plan
+    # creation, and a plan made under it is not memoised).
+    import os
+    forced = dtype in ("bfloat16", "float16") and "CUTENSOR_AMD_GEN" not in os.environ
+    if forced:
+        os.environ["CUTENSOR_AMD_GEN"] = "force"
+    try:
+        plan = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=getattr(ct, cname), strideA=strides(A), strideB=strides(B),
+                                    strideC=strides(C), workspace_limit=ws_limit, alignment=alignment,
+                                    opA=ct.OP_CONJ if opA else ct.OP_IDENTITY, opB=ct.OP_CONJ if opB else ct.OP_IDENTITY,
+                                    opC=ct.OP_CONJ if opC else ct.OP_IDENTITY, **({} if algo is None else dict(algo=algo)))
+    finally:
+        if forced:
+            del os.environ["CUTENSOR_AMD_GEN"]
     d = plan.describe()
     assert d["family"] == 2 and d["kname"] == "gett_gen_kernel", d
     if expect:

@@ -138,7 +138,7 @@ def main():
                     volC *= ext[c]
                 nred = vol // volC
                 check(kind, D, ref, tol, 1.25 * (nred ** 0.5 if op == "ADD" else 1.0) + 1.0,
-                      "%s->%s %s %s %s alpha %g beta %g strides %s %s align %d" % (mA, mC, op, ext, dtype, alpha, gamma, sA, sC, align))
+                      "%s->%s %s %s %s alpha %s beta %s strides %s %s align %d" % (mA, mC, op, ext, dtype, alpha, gamma, sA, sC, align))
             elif kind == "binary":
                 mC = "".join(labels)
                 mA = "".join(rnd.sample(labels, n))
