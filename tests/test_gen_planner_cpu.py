@@ -112,16 +112,24 @@ def test_vector_width_and_orientation_follow_the_layout(env):
 
 def test_split_k_of_16_bit_data_and_workspace_invariant(env):
     ct, ops, h = env
-    # one output tile, deep ragged K: split over the CUs, fp32 partials within the estimate (contraction.cu:239 asserts required <= estimate)
-    p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF)
+    # one output tile, deep ragged K: split over the CUs, fp32 partials within the estimate (contraction.cu:239 asserts required <= estimate).
+    # (K = 4004: no 16-byte lanes in the K-contiguous operands — with lanes a single ragged contracted mode stays on the aligned
+    # LDS-DMA kernels since round 5, tests/test_h16_planner_cpu.py)
+    p = ops.contraction_plan(h, [4004, 64], "km", [4004, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] > 1 and p.required_workspace == d["splitK"] * 64 * 48 * 4, d
     assert p.required_workspace <= p.workspace_estimate
     p.destroy()
     # no workspace allowed: no split
-    p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
+    p = ops.contraction_plan(h, [4004, 64], "km", [4004, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] == 1 and p.required_workspace == 0, d
+    p.destroy()
+    # the same with lanes (K = 4000): the aligned family, slices of whole K-tiles, the same workspace invariant
+    p = ops.contraction_plan(h, [4000, 64], "km", [4000, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF)
+    d = p.describe()
+    assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0 and p.required_workspace == d["splitK"] * 64 * 48 * 4, d
+    assert p.required_workspace <= p.workspace_estimate
     p.destroy()
     # fp64 / complex: partials in the accumulator type (double, float2, double2)
     for dtype, acc in ((ct.R_64F, 8), (ct.C_32F, 8), (ct.C_64F, 16)):
