@@ -364,7 +364,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 // MFMA order inside a k-step: the 8 x 8 fragment grid row by row (A fragment fixed for eight MFMAs), even rows walking their columns
 // backwards — a row change keeps the B operand of the previous MFMA, so exactly one source operand toggles per MFMA.  Under the
 // power limit that is worth +0.3 ... +0.7 percent at 8192^3 on U(-1,1) data (three alternating pairs of runs per layout on one box,
-// nothing on zeros: profiles/r05o_mfma_order_ab.jsonl); -DCTAMD_MFMA_ROWMAJOR restores the plain row-major order for comparison.
+// nothing on zeros: profiles/r05o_mfma_order_ab.jsonl; the mirrored walk — B fragment fixed, A walking — measures the same:
+// profiles/r05q_mfma_order_b_stationary_ab.jsonl); -DCTAMD_MFMA_ROWMAJOR restores the plain row-major order for comparison.
 #if defined(CTAMD_MFMA_ROWMAJOR)
 #define CTAMD_X_MFMA(S, M) x_mfma<BF>(acc[(M) >> 3][(M) & 7], a[S][(M) >> 3], b[S][(M) & 7]);
 #else
