@@ -302,6 +302,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     asm volatile("" : "+s"(gridX));
     uint32_t vb = blockIdx.x;                     // virtual workgroup id of the tile in flight
     bool staged = false;                          // its first two K-tiles are already on their way (issued under the previous epilogue)
+    // (CTAMD_PROBE_ONEPASS / _NOPARTIAL / _NOGENERAL: compile-time probes for reading the ISA — one tile per workgroup, no split-K
+    // epilogue, no general epilogue — that isolate what each part of the tile loop does to register allocation; never defined by the
+    // Makefile, wrong results when defined)
 #if defined(CTAMD_PROBE_ONEPASS)
     for (int once_ = 0; once_ < 1; ++once_) {
 #else
