@@ -1518,7 +1518,15 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (handle->prof.enabled.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
-        err = tab[plan->choice.kernel].launch(p, stream);
+        int launchKernel = plan->choice.kernel;
+        // beta is known only now: the persistent 16-bit kernel (table entries 88..95) streams its tiles for beta == 0 only and is slower
+        // than its one-tile twin (48..55: same tile, same arguments, same workspace) otherwise — plan_contraction.cpp, pick_h16_choice
+        // (CUTENSOR_AMD_H16_WAVES=4p names the kernel for every call: the tests of its beta path)
+        static const bool persistentForced = [] { const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES"); return e && e[0] == '4' && e[1] == 'p'; }();
+        if (plan->choice.family == 1 && tab[launchKernel].pf == 12 && b != 0.0 && !persistentForced && launchKernel - 40 >= 0 &&
+            tab[launchKernel - 40].pf == 7)
+            launchKernel -= 40;
+        err = tab[launchKernel].launch(p, stream);
         if (e0 && e1) {
             (void)hipEventRecord(e1, stream);
             std::lock_guard<std::mutex> g(handle->prof.mtx);

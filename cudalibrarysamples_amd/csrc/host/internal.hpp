@@ -106,6 +106,7 @@ struct ContractionView {
     bool     wide = false;               // a group has more than kMaxGroupModes unfusable modes (or >= 2^31 elements):
                                          // only the mode-table kernel (gett_wide_kernel) can run it
     uint32_t alignA = 0, alignB = 0;     // descriptor alignment (bytes) of kernel-A / kernel-B
+    uint32_t alignD = 0;                 // ... of the output
 };
 
 // One executable choice for a contraction.

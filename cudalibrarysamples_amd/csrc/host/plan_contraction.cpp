@@ -224,6 +224,7 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     }
     v.alignA = v.swapped ? op.B.desc.alignment : op.A.desc.alignment;
     v.alignB = v.swapped ? op.A.desc.alignment : op.B.desc.alignment;
+    v.alignD = op.D.desc.alignment;
     if (v.dtype == HIP_C_32F || v.dtype == HIP_C_64F) {   // complex data: the general MFMA family (pick_gen_choice) decides its own lanes
         v.layA = v.layB = LAY_S;
         return CUTENSOR_STATUS_SUCCESS;
@@ -496,8 +497,15 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         // 128 x 128 mid-size family and the 64 x 64 tile, each without split-K and at its automatic split
         double best = 1e30;
         static const bool noPersistent = [] { const char* e = std::getenv("CUTENSOR_AMD_H16P"); return e && e[0] == '0'; }();
+        // The persistent kernel earns its place by streaming interior tiles into each other, which needs the epilogue that stays out of the
+        // operand ring (gett_h16p.hip, curOK): no batch modes, one M and one N mode, 16-byte lanes in D.  Tiles that cannot stream are set up
+        // serially behind the previous epilogue and the kernel is SLOWER than the one-tile kernel then (measured with beta != 0, the one
+        // condition only the call knows: 8192^3 1377 against 1429-1435 TFLOP/s, 8192^2 x 1024 692 against 819, x 512 432 against 526,
+        // profiles/r05r_h16p_beta.jsonl — cutensorContract launches the one-tile twin for beta != 0, api.cpp).
+        const bool streamable = v.totL == 1 && v.M.size() == 1 && v.N.size() == 1 && v.N[0].sD == 1 && v.N[0].extent % 8 == 0 &&
+                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0;
         for (int cand : {48, 88, 64, 56, 80}) {
-            if (cand == 88 && noPersistent) continue;
+            if (cand == 88 && (noPersistent || !streamable)) continue;
             if (layoutIdx + cand >= count) continue;
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {

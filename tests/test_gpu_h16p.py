@@ -121,3 +121,34 @@ print("MANY_ROUNDS_OK")
 
 if __name__ == "__main__":
     _child()
+
+
+def test_beta_nonzero_on_a_plan_of_the_persistent_kernel(built):
+    """beta is known only at the call.  The persistent kernel streams its tiles for beta == 0 only and is slower than its one-tile twin
+    otherwise (profiles/r05r_h16p_beta.jsonl), so cutensorContract launches the twin — same tile, same arguments — when a plan of the
+    persistent kernel is executed with beta != 0 (api.cpp; not when CUTENSOR_AMD_H16_WAVES=4p names the kernel, which is how the parity
+    tests above reach the persistent kernel's own beta path).  Here: the planner's own choice for a two-round shape, beta = 0 and
+    beta != 0 through the SAME plan, against fp64."""
+    import torch
+    from cudalibrarysamples_amd import cutensor as ct, ops
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    M, N, K = 4352, 4352, 192
+    A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "mk": m fastest
+    B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "kn"
+    C = (torch.rand((N, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+    p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF)
+    assert p.describe()["kname"] == "gett_h16w4p_kernel", p.describe()
+    ab = B.double() @ A.double()                                                       # [N][M]
+    for alpha, beta in ((1.0, 0.0), (0.75, -0.5), (1.0, 1.0)):
+        D = C.clone()
+        p.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr())
+        torch.cuda.synchronize()
+        ref = alpha * ab + beta * C.double()
+        err = (D.double() - ref).abs()
+        tol = 8e-3 * ref.abs() + 3e-2
+        assert bool((err <= tol).all()), (alpha, beta, float((err - tol).max()))
+    p.destroy()

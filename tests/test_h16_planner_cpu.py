@@ -150,3 +150,23 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
     assert plan(2048, 1032, 77, "mk", "nk")["family"] == 1          # both operands free-contiguous: any K
     assert plan(2048, 1032, 77, "mk", "kn")["family"] == 2          # K-contiguous B: K % 8 != 0 has no 16-byte lanes
     assert plan(2048, 2048, 1024)["family"] == 1                    # whole K-tiles: unchanged
+
+
+def test_persistent_kernel_only_where_its_tiles_can_stream(env):
+    """Multi-round launches go to the persistent kernel only when interior tiles can stream into each other (no batch modes, one M and
+    one N mode after fusion, 16-byte lanes in D); everything else keeps the one-tile kernel (non-streamed tiles make the persistent
+    kernel slower: profiles/r05r_h16p_beta.jsonl)."""
+    ct, ops = env
+    if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
+        pytest.skip("the planner's own choice is under test")
+    h = ops.Handle()
+
+    def kname(eA, mA, eB, mB, eC, mC, **kw):
+        p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=ct.R_16BF, workspace_limit=1 << 28, **kw)
+        d = p.describe()
+        p.destroy()
+        return d["kname"]
+    assert kname([8192, 8192], "mk", [8192, 8192], "kn", [8192, 8192], "mn") == "gett_h16w4p_kernel"
+    assert kname([4096, 4096, 4], "mkl", [4096, 4096, 4], "knl", [4096, 4096, 4], "mnl") == "gett_h16w4x_kernel"          # batch mode
+    assert kname([64, 128, 8192], "abk", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4p_kernel"            # a, b fuse into one M mode
+    assert kname([64, 8192, 128], "akb", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4x_kernel"            # a, b apart in A: two M modes

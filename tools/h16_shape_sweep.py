@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--layout", default="mk,kn")
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--only", default="", help="M,N,K[;M,N,K...]: these shapes only")
+    ap.add_argument("--beta", type=float, default=0.0, help="beta of D = A B + beta C (C = D: in place); the persistent kernel streams tiles only for beta = 0")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -36,7 +37,9 @@ def main():
         extB = [K, N] if mB == "kn" else [N, K]
         p = ops.contraction_plan(h, extA, mA, extB, mB, [M, N], "mn", dtype=ct.R_16BF, workspace_limit=1 << 30)
         ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
-        fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)  # noqa: E731
+        if args.beta != 0.0:
+            D.zero_()
+        fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), args.beta, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)  # noqa: E731
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -57,7 +60,7 @@ def main():
         ms = e0.elapsed_time(e1) / args.reps
         d = p.describe()
         print(json.dumps({"M": M, "N": N, "K": K, "layout": args.layout, "ms": round(ms, 4), "tflops": round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1),
-                          "kname": d["kname"], "splitK": d["splitK"]}), flush=True)
+                          "kname": d["kname"], "splitK": d["splitK"], "beta": args.beta}), flush=True)
         p.destroy()
         del A, B, D, ws
 
