@@ -245,6 +245,50 @@ struct HEpilogue {
         }
     }
 
+    // ---- beta != 0 with 16-byte lanes in C and D, one chunk at a time (gett_h16w4x_kernel's pipelined beta path) ----------------------
+    // chunk IT (0 .. 7) of a pass of four parked 32 x 32 fragments (the layout of flush<.., NF = 4> below): fragment IT >> 1, 16-byte
+    // chunk (IT & 1) * 64 + lane of its 128.  Compile-time chunk numbers and caller-named registers: an array of chunks indexed by a
+    // loop variable is a stack object whenever the unroller gives up, and scratch is paid for at every dispatch.
+    template <int IT>
+    __device__ __forceinline__ void chunk_coords(uint32_t mB0, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane, uint32_t& m, uint32_t& n, int& ldsFloat) const {
+        constexpr int f = IT >> 1;
+        const uint32_t nB = nB0 + nHi * (uint32_t)(f >> 1) + nLo * (uint32_t)(f & 1);
+        const int cidx = lane + 64 * (IT & 1), row = cidx >> 2, piece = cidx & 3;
+        m = mB0 + (uint32_t)row;
+        n = nB + 8u * (uint32_t)piece;
+        ldsFloat = f * 1024 + row * 32 + piece * 8;
+    }
+    template <int IT>
+    __device__ __forceinline__ void load_c_chunk(const GettParams& p, uint32_t mB0, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane, s16x8& cv) const {
+        uint32_t m, n;
+        int at;
+        chunk_coords<IT>(mB0, nB0, nHi, nLo, lane, m, n, at);
+        if (m < Mtot && n < Ntot) {
+            int64_t offD, offC;
+            offsets(p, m, n, offD, offC);
+            cv = *(HGlbCS8)(uintptr_t)(C + offC);
+        }
+    }
+    template <bool BF, int IT>
+    __device__ __forceinline__ void store_chunk_with_c(const GettParams& p, uint32_t mB0, uint32_t nB0, uint32_t nHi, uint32_t nLo, int lane, const s16x8& cv) const {
+        uint32_t m, n;
+        int at;
+        chunk_coords<IT>(mB0, nB0, nHi, nLo, lane, m, n, at);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(scratch + at);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(scratch + at + 4);
+        if (m < Mtot && n < Ntot) {
+            int64_t offD, offC;
+            offsets(p, m, n, offD, offC);
+#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
+            CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
+            CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
+#undef CTAMD_EP_C
+            const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
+                               (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+            __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));
+        }
+    }
+
     // ---- four-fragment form (four-wave and streamed kernels) ------------------------------------------------------------
     // store the four parked fragments; fragment f covers rows mB + mHi (f >> 1) + mLo (f & 1) + [0, 32), columns alike
     // (base + steps, not arrays of four: a runtime-indexed array lands on the stack, and a scratch allocation is paid for at

@@ -520,6 +520,39 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
             }
         }
         }
+    } else if (XST == 0 && ep.vecD && ep.vecC && ep.beta != 0.f) {
+        // beta != 0 with 16-byte lanes in C and D: the fp32 image of the general path below (alpha acc + beta C is rounded ONCE), as a
+        // software pipeline over the four passes of 32 rows.  vmcnt counts loads and stores in issue order, so a wave that asks for the C
+        // chunks of a pass BEHIND the stores of the previous pass waits for those stores to be acknowledged before it may use the
+        // chunks — four write latencies per tile on top of four read latencies (8192^3: 1.40-1.43 PFLOP/s against 1.60 with beta = 0).
+        // Here the chunks of pass i + 1 are requested IN FRONT of the stores of pass i (two named register sets of eight chunks).
+#define CTAMD_X_PARK_F32(I)                                                                                                         \
+        _Pragma("unroll") for (int F = 0; F < 4; ++F)                                                                              \
+            _Pragma("unroll") for (int h = 0; h < 4; ++h) {       /* 16 x 16 quarter (h >> 1, h & 1) of 32 x 32 fragment F */      \
+                float* st = ep.scratch + F * 1024 + (16 * (h >> 1) + 4 * (laneE >> 4)) * 32 + 16 * (h & 1) + (laneE & 15);         \
+                const f32x4& c = acc[2 * (I) + (h >> 1)][2 * F + (h & 1)];                                                         \
+                st[0] = ep.alpha * c[0]; st[32] = ep.alpha * c[1]; st[64] = ep.alpha * c[2]; st[96] = ep.alpha * c[3];             \
+            }
+#define CTAMD_X_LOADC(I, R)                                                                                                         \
+        ep.template load_c_chunk<0>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##0); ep.template load_c_chunk<1>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##1); \
+        ep.template load_c_chunk<2>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##2); ep.template load_c_chunk<3>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##3); \
+        ep.template load_c_chunk<4>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##4); ep.template load_c_chunk<5>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##5); \
+        ep.template load_c_chunk<6>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##6); ep.template load_c_chunk<7>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##7);
+#define CTAMD_X_COMBINE(I, R)                                                                                                       \
+        ep.template store_chunk_with_c<BF, 0>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##0); ep.template store_chunk_with_c<BF, 1>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##1); \
+        ep.template store_chunk_with_c<BF, 2>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##2); ep.template store_chunk_with_c<BF, 3>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##3); \
+        ep.template store_chunk_with_c<BF, 4>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##4); ep.template store_chunk_with_c<BF, 5>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##5); \
+        ep.template store_chunk_with_c<BF, 6>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##6); ep.template store_chunk_with_c<BF, 7>(pe, mW + 32u * (I), nW, 64u, 32u, laneE, R##7);
+        s16x8 ca0 = {}, ca1 = {}, ca2 = {}, ca3 = {}, ca4 = {}, ca5 = {}, ca6 = {}, ca7 = {};
+        s16x8 cb0 = {}, cb1 = {}, cb2 = {}, cb3 = {}, cb4 = {}, cb5 = {}, cb6 = {}, cb7 = {};
+        CTAMD_X_LOADC(0, ca)
+        CTAMD_X_PARK_F32(0) CTAMD_X_LOADC(1, cb) CTAMD_X_COMBINE(0, ca)
+        CTAMD_X_PARK_F32(1) CTAMD_X_LOADC(2, ca) CTAMD_X_COMBINE(1, cb)
+        CTAMD_X_PARK_F32(2) CTAMD_X_LOADC(3, cb) CTAMD_X_COMBINE(2, ca)
+        CTAMD_X_PARK_F32(3) CTAMD_X_COMBINE(3, cb)
+#undef CTAMD_X_PARK_F32
+#undef CTAMD_X_LOADC
+#undef CTAMD_X_COMBINE
     } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                 // four passes of 32 rows: the epilogue's image is four 32 x 32 fp32 fragments
