@@ -3,26 +3,34 @@
 // Same tile (256 x 256 x 64), four waves (one per SIMD, a 128 x 128 quadrant = 8 x 8 accumulator fragments of
 // v_mfma_f32_16x16x32_{bf16,f16} from inline asm), LDS images, source-side swizzles, LDS-DMA staging, K odometer and main loop.
 // What changes is everything OUTSIDE the main loop — the 6.6 % of a workgroup's 313k cycles at 8192^3 (prologue 7.8k, epilogue
-// 12-13.7k; profiles/r05a_w4x_barrier_decomposition.jsonl) and more than half of them at 8192^2 x 512 — which the power-limited
-// clock gives back in full (MI355X guide, "DVFS give-back": an epilogue saving returns as throughput, a main-loop saving half):
-//   * one workgroup per CU walks the tiles (grid = min(tiles, CUs); tile ids in the XCD-grouped order of the one-tile kernel:
-//     workgroup w takes the ids w, w + grid, w + 2 grid, ... of xcd_remap's sequence, so an XCD keeps its 8 x 4 block of concurrent
-//     tiles).  For a tile that lies inside D (one M and one N mode, 16-byte lanes, beta = 0) the NEXT tile's setup (tile
-//     coordinates, staging tables, odometer) and the LDS-DMA of its first two K-tiles are issued BEFORE the epilogue of the current
-//     one: the 4.8k cycles a first K-tile takes to arrive behind a chip-wide burst, and the 3k of setup, run under the stores;
-//   * that epilogue does not use the operand ring (it is being refilled): a wave owns two 4-KiB images in the 32 KiB of LDS
-//     beyond the 128-KiB ring — 160 KiB in all — and works in eight passes of 16 rows;
+// 12-13.7k; profiles/r05a_w4x_barrier_decomposition.jsonl) and more than half of them at 8192^2 x 512.  Measured result (NOTES.md, round
+// 5a): 8192^2 x 512 +6.8 %, x 1024 +3.3 %, x 2048 +2.5 %, x 4096 +1.8 %, 8192^3 +0.8 % on U(-1,1) data (the chip is power-limited
+// there: cycles that used to idle carry MFMAs and the clock goes down by about as much), +10 % on zeros; one-round shapes -1 %.
+//   * one workgroup per CU walks the tiles (grid = CUs rounded down to a multiple of 8; tile ids in the XCD-grouped order of the
+//     one-tile kernel: workgroup w takes the ids w, w + grid, w + 2 grid, ... of xcd_remap's sequence, so an XCD keeps its 8 x 4
+//     block of concurrent tiles);
+//   * interior tiles STREAM into each other (the tile in flight and the next one inside D of a problem with one M and one N mode, no
+//     batch modes, 16-byte lanes in D, beta = 0; an even K-tile count; at least four K-tiles in the next tile): the per-lane staging
+//     offsets do not depend on the tile — only the descriptor bases move — so K-tile nTiles - 2 hands the odometer to the next tile
+//     (CTAMD_P_SWITCH, in a copy of the body pair of its own) and the LDS-DMA pieces the last two K-tile bodies issue anyway fetch the
+//     next tile's K-tiles 0 and 1; the next tile starts on a peeled pair without vmcnt(0).  No setup, no staging latency between tiles;
+//   * the streamed tile's epilogue does not use the operand ring (it is being refilled): a wave owns images in the 32 KiB of LDS beyond
+//     the 128-KiB ring — 160 KiB in all — and works in passes of 16 rows;
 //   * the image is TRANSPOSED: an accumulator fragment holds, per lane, four consecutive ROWS of one column, so after two packed
 //     conversions (v_cvt_pk_bf16_f32) the lane's four values are 8 contiguous bytes of a column-major image [128 columns][16 rows]
-//     — ONE ds_write_b64 per fragment instead of four 2-byte writes — and the way out is ds_read_b64_tr_b16, the transposing read
-//     the main loop uses for free-contiguous operands: a 16-lane group fetches a [4 columns][16 rows] block and every lane receives
-//     four consecutive columns of its row; two reads = 16 bytes of a row of D = one nontemporal 16-byte store.  Per accumulator
-//     element: 1 accumulator read + 1/2 multiply + 1/2 conversion + 1/4 LDS write + 1/4 LDS read + 1/8 store = 2.6 instructions
-//     (gett_h16w4x_kernel: 4.25).  Image row of column c at 32 R(c) bytes, R(c) = c ^ 4 ((c >> 3) & 1); the 8-byte slot of rows
-//     4 s .. 4 s + 3 inside it at s ^ ((R >> 2) & 3): the ds_write_b64 of a 16-lane group and the transposing read of a 32-lane half
-//     both touch every bank once (replayed on the CPU: tests/test_h16p_epilogue_layout_cpu.py).
-// Every other tile (edges, beta != 0, strided D, split-K partials) takes the epilogues of gett_h16w4x_kernel, in the ring, and
-// stages the next tile afterwards.  Roofline and algorithmic bytes as in gett_h16.hip (MFMA bf16; 2 M N K flop).
+//     — ONE ds_write_b64 per fragment instead of four 2-byte writes — and ds_read_b64_tr_b16, the transposing read the main loop
+//     uses for free-contiguous operands, brings four consecutive columns of a row to every lane.  EP = 2 (the default) copies them
+//     into a second, row-major image and stores four 256-byte row segments per lane group; storing straight from the transposing
+//     reads (EP = 0) gives 64-byte segments and is 5 % slower (profiles/r05b, r05c).  Image row of column c at 32 R(c) bytes,
+//     R(c) = c ^ 4 ((c >> 3) & 1); the 8-byte slot of rows 4 s .. 4 s + 3 inside it at s ^ ((R >> 2) & 3): the ds_write_b64 of a
+//     16-lane group and the transposing read of a 32-lane half both touch every bank once (gett_h16p_layout.h, replayed on the CPU:
+//     tests/test_gen_layout_cpu.py::test_persistent_kernel_epilogue_image_replay);
+//   * every global access of the epilogue goes through an address_space(1) pointer: a pending FLAT store makes each counted
+//     lgkmcnt wait of the next tile's first K-tiles a full drain.
+// Every other tile (edges, beta != 0, strided D, batch modes, split-K partials) takes the epilogues of gett_h16w4x_kernel, in the
+// ring, and is set up and staged behind them — slower than the one-tile kernel, which is why the planner offers this kernel only to
+// problems whose interior tiles can stream and cutensorContract launches the one-tile twin for beta != 0 (plan_contraction.cpp,
+// api.cpp).  Roofline and algorithmic bytes as in gett_h16.hip (MFMA bf16; 2 M N K flop).
 #include <type_traits>
 
 #include "gett_h16x_common.h"
