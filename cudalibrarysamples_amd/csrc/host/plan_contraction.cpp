@@ -373,9 +373,10 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
     return out;
 }
 
-// 16-bit data (bf16 / fp16, fp32 accumulation): one kernel shape (256 x 256 x 64, gett_h16.hip), picked
-// when both operands admit 16-byte lanes, the fastest contracted mode holds whole 64-deep K-tiles and
-// both operands can be addressed with 32-bit byte offsets.  Returns false -> the simple kernel runs.
+// 16-bit data (bf16 / fp16, fp32 accumulation) on the aligned LDS-DMA family (gett_h16v.hip, gett_h16p.hip: 256 x 256 one-tile and
+// persistent, 128 x 128 on a ring of two / four K-tiles, 64 x 64; K-tile 64): picked when both operands admit 16-byte lanes, one tile of
+// an operand spans less than 2 GiB, and the fastest contracted mode holds whole 64-deep K-tiles — or is the ONLY contracted mode
+// (ragged K: the masked last K-tile of the RAG instantiations).  Returns false -> the general MFMA family (pick_gen_choice).
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c) {
     if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
     if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
