@@ -854,6 +854,8 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
             fill_gett_params(v, ch[i], gp, rp);
             gp.A = v.swapped ? B : A;
             gp.B = v.swapped ? A : B;
+            gp.endA += (unsigned long long)(uintptr_t)gp.A;
+            gp.endB += (unsigned long long)(uintptr_t)gp.B;
             gp.C = D; gp.D = D; gp.alpha = 1.f; gp.beta = 0.f;
             gp.partial = ch[i].splitK > 1 ? static_cast<float*>(W) : nullptr;
             rp.partial = static_cast<float*>(W); rp.C = D; rp.D = D; rp.alpha = 1.f; rp.beta = 0.f;
@@ -951,6 +953,8 @@ static unsigned long long calibrate_xcd_split(cutensorHandle_t handle, const cut
                 GettParams gp = pl.gett;
                 gp.A = pl.view.swapped ? B : A;
                 gp.B = pl.view.swapped ? A : B;
+                gp.endA += (unsigned long long)(uintptr_t)gp.A;
+                gp.endB += (unsigned long long)(uintptr_t)gp.B;
                 gp.C = D; gp.D = D; gp.alpha = 1.f; gp.beta = 0.f;
                 gp.partial = static_cast<float*>(W);
                 gp.sync = nullptr;
@@ -1470,6 +1474,8 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     p.alpha = (float)a; p.beta = (float)b;
     p.alpha64 = a; p.beta64 = b;
     p.alphaIm = aIm; p.betaIm = bIm;
+    p.endA += (unsigned long long)(uintptr_t)p.A;   // the plan holds the operands' byte spans (fill_gett_params)
+    p.endB += (unsigned long long)(uintptr_t)p.B;
     p.timing = handle->timingBuffer.load(std::memory_order_relaxed);
     // incremental-autotuning trial: one event pair around everything this call launches, read later (resolve_pending_measurements)
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -1526,6 +1532,28 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         if (plan->choice.family == 1 && tab[launchKernel].pf == 12 && b != 0.0 && !persistentForced && launchKernel - 40 >= 0 &&
             tab[launchKernel - 40].pf == 7)
             launchKernel -= 40;
+        if (plan->choice.family == 1 && plan->choice.stripKernel >= 0 && plan->choice.stripKernel < count) {
+            // strip plan: the interior's whole tiles on the chosen kernel, then the two edge strips (rows past mInt x all columns, rows
+            // below mInt x columns past nInt) as ONE launch of the 64 x 64 tile with two tile rectangles
+            const GettKernelInfo& ki = tab[launchKernel];
+            const GettKernelInfo& ks = tab[plan->choice.stripKernel];
+            const uint32_t mInt = plan->choice.mInt, nInt = plan->choice.nInt, Mt = p.gM.total, Nt = p.gN.total, Lt = p.gL.total;
+            GettParams q = p;
+            q.tilesM = mInt / (uint32_t)ki.bm; q.tilesN = nInt / (uint32_t)ki.bn;
+            q.nBlocks = q.tilesM * q.tilesN * Lt;
+            err = ki.launch(q, stream);
+            GettParams s2 = p;
+            s2.mOrg = mInt; s2.nOrg = 0;
+            s2.tilesM = (Mt - mInt + (uint32_t)ks.bm - 1u) / (uint32_t)ks.bm; s2.tilesN = (Nt + (uint32_t)ks.bn - 1u) / (uint32_t)ks.bn;
+            s2.mOrg2 = 0; s2.nOrg2 = nInt;
+            s2.tilesM2 = (mInt + (uint32_t)ks.bm - 1u) / (uint32_t)ks.bm; s2.tilesN2 = (Nt - nInt + (uint32_t)ks.bn - 1u) / (uint32_t)ks.bn;
+            if (s2.tilesM * s2.tilesN == 0u) {     // no rows past the interior: the column strip is the only rectangle
+                s2.mOrg = s2.mOrg2; s2.nOrg = s2.nOrg2; s2.tilesM = s2.tilesM2; s2.tilesN = s2.tilesN2;
+                s2.tilesM2 = s2.tilesN2 = 0;
+            }
+            s2.nBlocks = (s2.tilesM * s2.tilesN + s2.tilesM2 * s2.tilesN2) * Lt;
+            if (err == hipSuccess && s2.nBlocks > 0u) err = ks.launch(s2, stream);
+        } else
         err = tab[launchKernel].launch(p, stream);
         if (e0 && e1) {
             (void)hipEventRecord(e1, stream);
@@ -1853,6 +1881,12 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
             n += std::snprintf(buf + n, len - n, ",\"nt\":%d", tab[k].nt);
         if (n > 0 && (size_t)n < len && plan->choice.family == 2 && k >= 0)
             n += std::snprintf(buf + n, len - n, ",\"orientA\":%d,\"orientB\":%d,\"vec\":%d,\"elem\":%d", tab[k].layA, tab[k].layB, tab[k].vec, tab[k].elem);
+        // 16-bit family: whether the launch is the RAG instantiation (masked / repaired last K-tile), and the strip plan — interior
+        // [0, mInt) x [0, nInt) on `kernel`, the two edge strips as one launch of the 64 x 64 tile (ContractionChoice::stripKernel)
+        if (n > 0 && (size_t)n < len && plan->choice.family == 1 && k >= 0)
+            n += std::snprintf(buf + n, len - n, ",\"rag\":%d,\"strips\":%d,\"mInt\":%u,\"nInt\":%u",
+                               (plan->gett.gK.total % 64u != 0u || (plan->gett.ragged & 1u)) ? 1 : 0, plan->choice.stripKernel >= 0 ? 1 : 0,
+                               plan->choice.mInt, plan->choice.nInt);
         if (n > 0 && (size_t)n < len) n += std::snprintf(buf + n, len - n, ",\"Kdigits\":[");
         for (size_t i = 0; i < plan->view.K.size() && n > 0 && (size_t)n < len; ++i)
             n += std::snprintf(buf + n, len - n, "%s[%lld,%lld,%lld]", i ? "," : "", (long long)plan->view.K[i].extent,

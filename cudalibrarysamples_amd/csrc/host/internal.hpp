@@ -118,6 +118,12 @@ struct ContractionChoice {
     uint32_t kPerSlice = 0;
     uint64_t workspace = 0;
     double   estimateUs = 0.0;
+    // Strip plan (16-bit family, pick_h16_choice): `kernel` covers only the interior [0, mInt) x [0, nInt) — whole tiles of its own size —
+    // and ONE launch of table entry `stripKernel` (the 64 x 64 tile) covers the two edge strips, rows [mInt, M) x all columns and
+    // rows [0, mInt) x columns [nInt, N).  4100^3 on 256 x 256 tiles is 17 x 17 = 289 tiles, two rounds on 256 CUs for 33 tiles that
+    // hold four live rows or columns each; as 16 x 16 + strips it is one round plus ~20 us.  stripKernel < 0: none.
+    int      stripKernel = -1;
+    uint32_t mInt = 0, nInt = 0;
 };
 
 cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, ContractionView& v,

@@ -244,6 +244,31 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     };
     const uint32_t alignA = v.swapped ? op.B.desc.alignment : op.A.desc.alignment;
     const uint32_t alignB = v.swapped ? op.A.desc.alignment : op.B.desc.alignment;
+    // 16-bit data (round 6): the LDS-DMA kernels take 16-byte units at ANY 2-byte address (buffer_load_dwordx4 ... lds lands the right
+    // bytes whatever the alignment: tools/ubench/ldsdma_unaligned.hip, profiles/r06a_*; 29 B/clk/CU at 4 or 8 (mod 16), 25.6 at 2 (mod 16),
+    // 31 aligned), so an operand qualifies by its stride-1 mode alone.  An extent of that mode that is not a multiple of 8 leaves a partial
+    // last unit: the kernels' RAG instantiations handle it (x_rag_mask / x_rag_fix) when the unit cannot straddle a digit boundary, i.e.
+    // when the mode is alone in its group.
+    auto pick16 = [&](bool slotA, const std::vector<CanonMode>& freeG) {
+        const std::vector<CanonMode>* groups[3] = {&freeG, &v.K, &v.L};
+        for (const std::vector<CanonMode>* g : groups)
+            for (const CanonMode& m : *g)
+                if ((slotA ? m.sA : m.sB) < 0) return (int)LAY_S;
+        if (!v.K.empty()) {
+            const CanonMode& k0 = v.K.front();
+            if ((slotA ? k0.sA : k0.sB) == 1 && (k0.extent % 8 == 0 || v.K.size() == 1)) return (int)LAY_K;
+        }
+        if (!freeG.empty()) {
+            const CanonMode& f0 = freeG.front();
+            if ((slotA ? f0.sA : f0.sB) == 1 && (f0.extent % 8 == 0 || freeG.size() == 1)) return (int)LAY_F;
+        }
+        return (int)LAY_S;
+    };
+    if (dtype_size(v.dtype) == 2) {
+        v.layA = pick16(true, v.M);
+        v.layB = pick16(false, v.N);
+        return CUTENSOR_STATUS_SUCCESS;
+    }
     auto pick = [&](bool slotA, const std::vector<CanonMode>& freeG, uint32_t align) {
         if (align % 16 != 0) return (int)LAY_S;
         std::vector<const std::vector<CanonMode>*> groups = {&freeG, &v.K, &v.L};
@@ -377,6 +402,15 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 // persistent, 128 x 128 on a ring of two / four K-tiles, 64 x 64; K-tile 64): picked when both operands admit 16-byte lanes, one tile of
 // an operand spans less than 2 GiB, and the fastest contracted mode holds whole 64-deep K-tiles — or is the ONLY contracted mode
 // (ragged K: the masked last K-tile of the RAG instantiations).  Returns false -> the general MFMA family (pick_gen_choice).
+// The launch needs the kernels' RAG instantiation (masked last K-tile of the last slice): a ragged contracted range, or a free-contiguous
+// operand whose stride-1 mode is not a multiple of 8 long (its last row-unit can reach past the end of the tensor: x_rag_mask).
+static bool h16_needs_rag(const ContractionView& v) {
+    if (v.totK % 64 != 0) return true;
+    if (v.layA == LAY_F && !v.M.empty() && v.M.front().extent % 8 != 0) return true;
+    if (v.layB == LAY_F && !v.N.empty() && v.N.front().extent % 8 != 0) return true;
+    return false;
+}
+
 bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, ContractionChoice& c) {
     if (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) return false;
     if ((v.layA != LAY_K && v.layA != LAY_F) || (v.layB != LAY_K && v.layB != LAY_F)) return false;
@@ -384,8 +418,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // Whole 64-deep K-tiles in the fastest contracted mode — or (round 5) ONE contracted mode of any extent the 16-byte lanes admit
     // (a K-contiguous operand has extent % 8 == 0 by its layout class, a free-contiguous one takes any extent): the four-wave kernel
     // stages the last K-tile with the lanes past the end of the mode out of range (gett_h16w4x_kernel<..., RAG = true>).
-    const bool ragged = (v.totK % 64 != 0);
-    if (ragged ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0)) return false;
+    if ((v.totK % 64 != 0) ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0)) return false;
+    const bool ragged = h16_needs_rag(v);         // the candidates are the kernels that have a RAG instantiation
     // The 16-bit kernels address an operand with 32-bit byte offsets relative to a 64-bit base that moves with the workgroup
     // tile, the wave and the K-tile (gett_h16.hip, HOperand / HOdometer): what has to stay below 2^31 bytes is the span of
     // ONE 256-row x 64-k tile, whatever the size of the tensor.
@@ -454,8 +488,8 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     //   64 x 64 (80), two workgroups per CU: 4.6 us fixed, 0.31 us per K-tile (4.4 / 0.223 while every workgroup has a CU to itself;
     //   profiles/r04w_sweep_4q_*: 1024^3 7.6-7.9 us, 4096^3 195-202 us)
     //   fold (splitk_reduce_wide_kernel): 3 us + partial bytes written and read back at ~5 TB/s
-    auto model_us = [&](int var, uint64_t split) {
-        const double wgs = tiles_of(var) * (double)split, slots = slots_of(var);
+    auto model_tiles_us = [&](int var, double tiles, uint64_t split) {
+        const double wgs = tiles * (double)split, slots = slots_of(var);
         const double kt = std::ceil((double)kTiles / (double)split);
         double fix, per;
         if (var == 64) { fix = 4.5; per = 0.46; }
@@ -471,6 +505,26 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         if (split > 1) t += 3.0 + 2.0 * (double)split * (double)perSliceBytes / 5.0e6;
         return t;
     };
+    auto model_us = [&](int var, uint64_t split) { return model_tiles_us(var, tiles_of(var), split); };
+    // Strip plan of a candidate (round 6): its whole tiles as the interior launch, the two edge strips as ONE launch of the 64 x 64 kernel
+    // (entry 80: two tile rectangles in one grid, GettParams::tilesM2).  Worth it when the partial tiles push the launch into another
+    // round: 4100^3 on 256 x 256 tiles = 289 tiles = two rounds (150 us by this model) against 256 tiles + 129 strip tiles (~97 us).
+    // One M and one N mode only (a strip is a contiguous index range of a mode group, but the interior's whole-tile test and the
+    // kernels' edge clamps are written for it), no split-K.  Returns the model time, 1e30 when the candidate has no strip form.
+    auto strip_us = [&](int cand, uint32_t& mInt, uint32_t& nInt) {
+        if (layoutIdx + 80 >= count || layoutIdx + cand >= count) return 1e30;
+        const GettKernelInfo& k = tab[layoutIdx + cand];
+        if (k.bm <= 64) return 1e30;
+        mInt = (uint32_t)(v.totM / k.bm) * (uint32_t)k.bm;
+        nInt = (uint32_t)(v.totN / k.bn) * (uint32_t)k.bn;
+        if ((mInt == v.totM && nInt == v.totN) || mInt == 0 || nInt == 0) return 1e30;
+        const double tilesInt = (double)(mInt / k.bm) * (double)(nInt / k.bn) * (double)v.totL;
+        const double strip = (std::ceil((double)(v.totM - mInt) / 64.0) * std::ceil((double)v.totN / 64.0) +
+                              std::ceil((double)mInt / 64.0) * std::ceil((double)(v.totN - nInt) / 64.0)) * (double)v.totL;
+        return model_tiles_us(cand, tilesInt, 1) + model_tiles_us(80, strip, 1) + 1.5;   // + the gap between the two launches
+    };
+    static const bool noStrips = [] { const char* e = std::getenv("CUTENSOR_AMD_H16_STRIPS"); return e && e[0] == '0'; }();
+    const bool stripsOK = !noStrips && v.M.size() == 1 && v.N.size() == 1;
     int var = variant;
     uint64_t split = 1;
     const bool usable = forced && layoutIdx + var < count && tab[layoutIdx + var].ablation != 2;   // a retired family asked for in a production build: ignored
@@ -487,9 +541,12 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {
                 const double t = model_us(cand, sp);
-                if (t < best) { best = t; var = cand; split = sp; }
+                if (t < best) { best = t; var = cand; split = sp; c.stripKernel = -1; }
                 if (as == 1) break;
             }
+            uint32_t mi = 0, ni = 0;
+            const double ts = stripsOK ? strip_us(cand, mi, ni) : 1e30;
+            if (ts < 0.97 * best) { best = ts; var = cand; split = 1; c.stripKernel = layoutIdx + 80; c.mInt = mi; c.nInt = ni; }
         }
     } else if (forced && usable) {
         split = auto_split(var);
@@ -511,9 +568,12 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {
                 const double t = model_us(cand, sp);
-                if (t < best) { best = t; var = cand; split = sp; }
+                if (t < best) { best = t; var = cand; split = sp; c.stripKernel = -1; }
                 if (as == 1) break;
             }
+            uint32_t mi = 0, ni = 0;
+            const double ts = stripsOK ? strip_us(cand, mi, ni) : 1e30;
+            if (ts < 0.97 * best) { best = ts; var = cand; split = 1; c.stripKernel = layoutIdx + 80; c.mInt = mi; c.nInt = ni; }
         }
     }
     c.kernel = layoutIdx + var;
@@ -527,6 +587,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     c.kPerSlice = (uint32_t)(tilesPerSlice * 64);
     c.workspace = (c.splitK > 1) ? (uint64_t)c.splitK * perSliceBytes : 0ull;
     c.estimateUs = model_us(var, c.splitK);
+    if (c.stripKernel >= 0) { uint32_t mi = 0, ni = 0; c.estimateUs = strip_us(var, mi, ni); }
     // (Rounds 2-3 sent K ranges of at most 16 K-tiles to the eight-wave kernel, whose fixed cost per workgroup was ~4 us lower; with the
     // shorter prologue and the pipelined epilogue of round 4 the four-wave kernel is ahead there too: 8192^2 x 256 / 512 / 1024
     // 71.6 / 96.4 / 148 us against 72.7 / 101 / 157, profiles/r04z_short_k_4x_vs_8.txt.)
@@ -538,7 +599,7 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
     ContractionChoice base;
     if (!pick_h16_choice(v, wsLimit, numCUs, base)) return out;
     out.push_back(base);
-    if (v.totK % 64 != 0) return out;              // ragged K: the planner's pick among the kernels that mask (pick_h16_choice)
+    if (h16_needs_rag(v)) return out;              // ragged K / partial units: the planner's pick among the kernels that mask (pick_h16_choice)
     int count = 0;
     const int layoutIdx = base.kernel % 8, variant = base.kernel - layoutIdx;
     const GettKernelInfo* tab = gett_h16_kernels(&count);
@@ -547,6 +608,8 @@ std::vector<ContractionChoice> rank_h16_choices(const ContractionView& v, uint64
         if (tab[layoutIdx + other].ablation == 2) continue;        // a retired family, not built into this library (research builds only)
         ContractionChoice c = base;
         c.kernel = layoutIdx + other;
+        c.stripKernel = -1;                                        // the whole grid on this kernel
+        c.mInt = c.nInt = 0;
         out.push_back(c);
     }
     return out;
@@ -699,6 +762,18 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
     p.splitK = c.splitK;
     p.kPerSlice = c.kPerSlice ? c.kPerSlice : (uint32_t)v.totK;
     p.nBlocks = (uint32_t)((uint64_t)p.tilesM * p.tilesN * p.splitK * v.totL);
+
+    {   // bytes from an operand's first element to one past its last (cutensorContract adds the pointer: GettParams::endA / endB)
+        const uint64_t es = (uint64_t)dtype_size(v.dtype);
+        uint64_t spanA = 1, spanB = 1;
+        for (const std::vector<CanonMode>* g : {&v.L, &v.M, &v.K})
+            for (const CanonMode& m : *g) spanA += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(m.sA);
+        for (const std::vector<CanonMode>* g : {&v.L, &v.N, &v.K})
+            for (const CanonMode& m : *g) spanB += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(m.sB);
+        p.endA = spanA * es;
+        p.endB = spanB * es;
+        p.ragged = (c.family == 1 && h16_needs_rag(v)) ? 1u : 0u;
+    }
 
     r.gM = p.gM; r.gN = p.gN; r.gL = p.gL;
     std::memcpy(r.cStrideM, p.cStrideM, sizeof(r.cStrideM));

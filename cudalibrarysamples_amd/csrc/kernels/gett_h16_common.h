@@ -158,15 +158,13 @@ struct HEpilogue {
         alpha = p.alpha; beta = p.beta;
         Mtot = p.gM.total; Ntot = p.gN.total;
         scratch = reinterpret_cast<float*>(lds + wave * bytesPerWave);
-        // 8 consecutive n stay inside the fastest N mode and are contiguous; every other stride keeps 16-byte alignment
-        bool d = (p.gN.div[0].d % 8u == 0u) && p.gN.stride[1][0] == 1 && (reinterpret_cast<uintptr_t>(D) % 16u == 0u);
-        bool c = d && p.cStrideN[0] == 1 && (reinterpret_cast<uintptr_t>(C) % 16u == 0u);
-#pragma unroll
-        for (int i = 0; i < kMaxGroupModes; ++i) {
-            d = d && (p.gM.stride[1][i] % 8 == 0) && (i == 0 || p.gN.stride[1][i] % 8 == 0);
-            c = c && (p.cStrideM[i] % 8 == 0) && (i == 0 || p.cStrideN[i] % 8 == 0);
-        }
-        vecD = d; vecC = c;
+        // 16-byte chunks: 8 consecutive n are contiguous and stay inside the fastest N mode — its extent is a multiple of 8, or it is
+        // the ONLY N mode (then a row's last chunk may be partial: store16 / load16 below).  No alignment condition (round 6): a
+        // 16-byte global access works at any 2-byte address (tools/ubench/ldsdma_unaligned.hip), so a row pitch of 4100 or 4097
+        // elements keeps the chunk path instead of 2-byte stores (~12x the time per byte).
+        const bool d = p.gN.stride[1][0] == 1 && (p.gN.n <= 1 || p.gN.div[0].d % 8u == 0u);
+        vecD = d;
+        vecC = d && p.cStrideN[0] == 1;
         flat = p.gM.n <= 1 && p.gN.n <= 1;
     }
     __device__ __forceinline__ void offsets(const GettParams& p, uint32_t m, uint32_t n, int64_t& offD, int64_t& offC) const {
@@ -179,6 +177,23 @@ struct HEpilogue {
             group_offset2<1>(p.gN, p.cStrideN, n, dn, cn);
             offD = dm + dn; offC = cm + cn;
         }
+    }
+
+    // One 16-byte chunk (columns n .. n + 7 of a row) to D / from C.  A chunk that sticks out of a ragged N mode (n + 8 > Ntot: one N
+    // mode, extent % 8 != 0) moves the columns that exist, one element at a time: nothing is read or written past the row.
+    __device__ __forceinline__ void store16(uint16_t* dst, const s16x8& v, uint32_t n) const {
+        if (n + 8u <= Ntot) { __builtin_nontemporal_store(v, (HGlbS8)(uintptr_t)dst); return; }
+#define CTAMD_EP_ST1(E) if (n + (E) < Ntot) *(HGlbU16)(uintptr_t)(dst + (E)) = (uint16_t)v[E];
+        CTAMD_EP_ST1(0) CTAMD_EP_ST1(1) CTAMD_EP_ST1(2) CTAMD_EP_ST1(3) CTAMD_EP_ST1(4) CTAMD_EP_ST1(5) CTAMD_EP_ST1(6)
+#undef CTAMD_EP_ST1
+    }
+    __device__ __forceinline__ s16x8 load16(const uint16_t* src, uint32_t n) const {
+        if (n + 8u <= Ntot) return *(HGlbCS8)(uintptr_t)src;
+        s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CTAMD_EP_LD1(E) if (n + (E) < Ntot) v[E] = (short)*(HGlbCU16)(uintptr_t)(src + (E));
+        CTAMD_EP_LD1(0) CTAMD_EP_LD1(1) CTAMD_EP_LD1(2) CTAMD_EP_LD1(3) CTAMD_EP_LD1(4) CTAMD_EP_LD1(5) CTAMD_EP_LD1(6)
+#undef CTAMD_EP_LD1
+        return v;
     }
 
     // park fragment F (0..3) of the current pass: element (row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31) = acc[r]
@@ -217,7 +232,7 @@ struct HEpilogue {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
                     if (beta != 0.f) {
-                        const s16x8 cv = *(HGlbCS8)(uintptr_t)(C + offC);
+                        const s16x8 cv = load16(C + offC, n);
 #define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
                         CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
                         CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
@@ -225,7 +240,7 @@ struct HEpilogue {
                     }
                     const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                        (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));   // not read again by this kernel; keeps the operand panels in L2
+                    if constexpr (ST == 0) store16(D + offD, out, n);   // nontemporal: not read again by this kernel; keeps the operand panels in L2
                     else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
                 }
@@ -266,7 +281,7 @@ struct HEpilogue {
         if (m < Mtot && n < Ntot) {
             int64_t offD, offC;
             offsets(p, m, n, offD, offC);
-            cv = *(HGlbCS8)(uintptr_t)(C + offC);
+            cv = load16(C + offC, n);
         }
     }
     template <bool BF, int IT>
@@ -285,7 +300,7 @@ struct HEpilogue {
 #undef CTAMD_EP_C
             const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-            __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));
+            store16(D + offD, out, n);
         }
     }
 
@@ -314,13 +329,13 @@ struct HEpilogue {
                     f32x4 v0 = lo, v1 = hi;              // explicit elements below: nothing here may become a stack array
                     if (beta != 0.f) {
                         if (vecC) {
-                            const s16x8 cv = *(HGlbCS8)(uintptr_t)(C + offC);
+                            const s16x8 cv = load16(C + offC, n);
 #define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
                             CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
                             CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
 #undef CTAMD_EP_C
                         } else {
-#define CTAMD_EP_CS(E, V, I) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + oC_), BF); }
+#define CTAMD_EP_CS(E, V, I) if (n + (E) < Ntot) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + oC_), BF); }
                             CTAMD_EP_CS(0, v0, 0) CTAMD_EP_CS(1, v0, 1) CTAMD_EP_CS(2, v0, 2) CTAMD_EP_CS(3, v0, 3)
                             CTAMD_EP_CS(4, v1, 0) CTAMD_EP_CS(5, v1, 1) CTAMD_EP_CS(6, v1, 2) CTAMD_EP_CS(7, v1, 3)
 #undef CTAMD_EP_CS
@@ -328,7 +343,7 @@ struct HEpilogue {
                     }
                     const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
                                        (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
-                    if constexpr (ST == 0) __builtin_nontemporal_store(out, (HGlbS8)(uintptr_t)(D + offD));   // the result is not read again by this kernel
+                    if constexpr (ST == 0) store16(D + offD, out, n);   // nontemporal: the result is not read again by this kernel
                     else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
                 }
@@ -392,7 +407,9 @@ struct HOperand {
                     const int kk = 4 * c + (lane >> 4), p = lane & 15;
                     const int u = p ^ (4 * ((lane >> 4) & 3)) ^ (SWZ ? 2 * ((kk >> 3) & 1) : 0);
                     uint32_t row = row0 + (IL ? 64 * (u >> 2) + 32 * h + 8 * (u & 3) : 128 * h + 8 * u);
-                    if (row >= gFree.total) row = gFree.total - 8;   // extent % 8 == 0: a unit is all in or all out
+                    // a unit past the edge is clamped to the last one that holds rows of the mode (whole when extent % 8 == 0; a ragged
+                    // extent — one M / N mode, pick_h16_choice — leaves a partial last unit whose dead rows feed outputs nobody stores)
+                    if (row >= gFree.total) row = (gFree.total - 1u) & ~7u;
                     off[h][i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
                 }
                 mn = off[h][i] < mn ? off[h][i] : mn;

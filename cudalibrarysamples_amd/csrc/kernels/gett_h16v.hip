@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t first = grp * 8u;
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
-    const uint32_t m0 = mt * kHTile, n0 = nt * kHTile;
+    const uint32_t m0 = p.mOrg + mt * kHTile, n0 = p.nOrg + nt * kHTile;
     const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
@@ -295,12 +295,37 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
     odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
-    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (p.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr(p.gK.total % kHBK);
+    // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
+    // of the last slice — and how many k of the contracted range it holds (x_rag_mask, x_rag_fix: gett_h16x_common.h)
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK);
+    uint32_t stradA = 0u, stradB = 0u;            // units of the masked tile that x_rag_fix loads element by element
+    // called with the descriptor bases ON tile IDX
 #define CTAMD_X_RAGMASK(IDX)                                                                                        \
     if constexpr (RAG) {                                                                                           \
-        if ((IDX) == maskAt) { x_rag_mask<LA, 2>(oa.src, wave, kValid); x_rag_mask<LB, 2>(ob.src, wave, kValid); }   \
+        if ((IDX) == maskAt) {                                                                                     \
+            stradA = x_rag_mask<LA, 2>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA));                      \
+            stradB = x_rag_mask<LB, 2>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB));                      \
+        }                                                                                                          \
+    }
+    // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier: repair it when it holds a partial k-unit
+    // (K-contiguous operand, K % 8 != 0: every workgroup) or may hold a unit that was kept from memory (free-contiguous operand with a
+    // ragged extent: the workgroups on the last rows) — both tests are uniform over the workgroup, as the second barrier demands
+#define CTAMD_X_RAGFIX(IDX, PB)                                                                                     \
+    if constexpr (RAG) {                                                                                           \
+        if ((IDX) == maskAt) {                                                                                     \
+            const bool fixA = (LA == LAY_K) ? (kValid & 7u) != 0u : ((p.gM.total & 7u) != 0u && m0 + (uint32_t)kHTile >= p.gM.total);   \
+            const bool fixB = (LB == LAY_K) ? (kValid & 7u) != 0u : ((p.gN.total & 7u) != 0u && n0 + (uint32_t)kHTile >= p.gN.total);   \
+            if (fixA || fixB) {                                                                                    \
+                const uint32_t kT0 = (kTilesAll - 1u) * (uint32_t)kHBK;                                            \
+                if (fixA) x_rag_fix<LA, 2, 0>(p.gM, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)), m0, kT0, kValid, stradA, \
+                                              ldsBase + (uint32_t)((PB) * 4 * kHalfBytes), wave);                  \
+                if (fixB) x_rag_fix<LB, 2, 1>(p.gN, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)), n0, kT0, kValid, stradB, \
+                                              ldsBase + (uint32_t)(((PB) * 4 + 2) * kHalfBytes), wave);            \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+                __builtin_amdgcn_s_barrier();                                                                      \
+            }                                                                                                      \
+        }                                                                                                          \
     }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -342,6 +367,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     CTAMD_X_DMA8(1, 0, true) CTAMD_X_DMA8(1, 8, true)
     CTAMD_H_VMCNT(16);                            // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
+    CTAMD_X_RAGFIX(0, 0)
 
     f32x4 acc[8][8];
 #pragma unroll
@@ -391,14 +417,15 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     CTAMD_X_MFMA(1, 4 * (Q) + 2) CTAMD_X_MFMA(1, 4 * (Q) + 3)                                                      \
     __builtin_amdgcn_sched_barrier(0);
 #define CTAMD_X_TILE(P)                                                                                             \
-    CTAMD_X_RAGMASK(t + (P) + 2)                                                                                   \
     CTAMD_X_G0(P, 0) CTAMD_X_G0(P, 1) CTAMD_X_G0(P, 2) CTAMD_X_G0(P, 3) CTAMD_X_G0(P, 4) CTAMD_X_G0(P, 5)          \
     CTAMD_X_G0(P, 6) CTAMD_X_G0(P, 7) CTAMD_X_G0(P, 8) CTAMD_X_G0(P, 9) CTAMD_X_G0(P, 10) CTAMD_X_G0(P, 11)        \
     CTAMD_X_G0(P, 12) CTAMD_X_G0(P, 13) CTAMD_X_G0(P, 14) CTAMD_X_G0(P, 15)                                        \
+    CTAMD_X_RAGMASK(t + (P) + 2)     /* behind the odometer (k-step 0), in front of the pieces of tile t + 2 (k-step 1) */ \
     CTAMD_H_LGKM0();                                                                                               \
     if constexpr (XST != 8 && XST != 10) CTAMD_H_VMCNT(0);                                                         \
     if constexpr (XST != 9 && XST != 10) __builtin_amdgcn_s_barrier();                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_X_RAGFIX(t + (P) + 1, (P) ^ 1)                                                                           \
     CTAMD_X_G1(P, 0) CTAMD_X_G1(P, 1) CTAMD_X_G1(P, 2) CTAMD_X_G1(P, 3) CTAMD_X_G1(P, 4) CTAMD_X_G1(P, 5)          \
     CTAMD_X_G1(P, 6) CTAMD_X_G1(P, 7) CTAMD_X_G1(P, 8) CTAMD_X_G1(P, 9) CTAMD_X_G1(P, 10) CTAMD_X_G1(P, 11)        \
     CTAMD_X_G1(P, 12) CTAMD_X_G1(P, 13) CTAMD_X_G1(P, 14) CTAMD_X_G1(P, 15)
@@ -515,7 +542,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
                     int64_t offD, offC;
                     ep.offsets(pe, m, n, offD, offC);
                     if constexpr (XST == 1) *reinterpret_cast<s16x8*>(ep.D + offD) = v;
-                    else __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                    else ep.store16(ep.D + offD, v, n);
                 }
             }
         }
@@ -596,7 +623,7 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
 #endif
-    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+    if (p.gK.total % (uint32_t)kHBK != 0u || (p.ragged & 1u) != 0u) {   // ragged K (one contracted mode) or a unit that can straddle the tensor's end (pick_h16_choice): the masked last K-tile
         hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, false, 0, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
@@ -650,7 +677,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint32_t first = grp * 8u;
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
-    const uint32_t m0 = mt * kMTile, n0 = nt * kMTile;
+    const uint32_t m0 = p.mOrg + mt * kMTile, n0 = p.nOrg + nt * kMTile;
     const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
@@ -663,11 +690,31 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
     odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
-    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (p.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr(p.gK.total % kHBK);
-#define CTAMD_M_RAGMASK_A(IDX) if constexpr (RAG) { if ((IDX) == maskAt) x_rag_mask<LA, 1>(oa.src, wave, kValid); }
-#define CTAMD_M_RAGMASK_B(IDX) if constexpr (RAG) { if ((IDX) == maskAt) x_rag_mask<LB, 1>(ob.src, wave, kValid); }
+    // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
+    // of the last slice — and how many k of the contracted range it holds (x_rag_mask, x_rag_fix: gett_h16x_common.h)
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK);
+    uint32_t stradA = 0u, stradB = 0u;            // units of the masked tile that x_rag_fix loads element by element
+    // called with the operand's descriptor base ON tile IDX
+#define CTAMD_M_RAGMASK_A(IDX) if constexpr (RAG) { if ((IDX) == maskAt) stradA = x_rag_mask<LA, 1>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA)); }
+#define CTAMD_M_RAGMASK_B(IDX) if constexpr (RAG) { if ((IDX) == maskAt) stradB = x_rag_mask<LB, 1>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB)); }
+    // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier (gett_h16w4x_kernel, CTAMD_X_RAGFIX)
+#define CTAMD_M_RAGFIX(IDX, PB)                                                                                     \
+    if constexpr (RAG) {                                                                                           \
+        if ((IDX) == maskAt) {                                                                                     \
+            const bool fixA = (LA == LAY_K) ? (kValid & 7u) != 0u : ((p.gM.total & 7u) != 0u && m0 + (uint32_t)kMTile >= p.gM.total);   \
+            const bool fixB = (LB == LAY_K) ? (kValid & 7u) != 0u : ((p.gN.total & 7u) != 0u && n0 + (uint32_t)kMTile >= p.gN.total);   \
+            if (fixA || fixB) {                                                                                    \
+                const uint32_t kT0 = (kTilesAll - 1u) * (uint32_t)kHBK;                                            \
+                if (fixA) x_rag_fix<LA, 1, 0>(p.gM, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)), m0, kT0, kValid, stradA, \
+                                              ldsBase + (uint32_t)((PB) * 2 * kHalfBytes), wave);                  \
+                if (fixB) x_rag_fix<LB, 1, 1>(p.gN, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)), n0, kT0, kValid, stradB, \
+                                              ldsBase + (uint32_t)(((PB) * 2 + 1) * kHalfBytes), wave);            \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+                __builtin_amdgcn_s_barrier();                                                                      \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
@@ -720,6 +767,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     }
     CTAMD_H_VMCNT(R == 2 ? 8 : 20);               // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
+    CTAMD_M_RAGFIX(0, 0)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -767,14 +815,15 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     // tile t (buffer P = t mod R): R = 2 stages tile t + 2 in k-step 1; R = 4 the B pieces of tile t + 3 in k-step 0, the A pieces of
     // tile t + 4 in k-step 1 (the ragged-K switches sit right in front of them)
 #define CTAMD_M_TILE(P)                                                                                             \
-    if constexpr (R == 2) { CTAMD_M_RAGMASK_A(t + (P) + 2) CTAMD_M_RAGMASK_B(t + (P) + 2) }                        \
-    else { CTAMD_M_RAGMASK_B(t + (P) + 3) }                                                                        \
+    if constexpr (R == 4) { CTAMD_M_RAGMASK_B(t + (P) + 3) }         /* the odometer is on tile t + 3 until group 7 of k-step 0 */ \
     CTAMD_M_G0(P, 0) CTAMD_M_G0(P, 1) CTAMD_M_G0(P, 2) CTAMD_M_G0(P, 3)                                            \
     CTAMD_M_G0(P, 4) CTAMD_M_G0(P, 5) CTAMD_M_G0(P, 6) CTAMD_M_G0(P, 7)                                            \
+    if constexpr (R == 2) { CTAMD_M_RAGMASK_A(t + (P) + 2) CTAMD_M_RAGMASK_B(t + (P) + 2) }     /* behind the odometer of k-step 0 */ \
     CTAMD_H_LGKM0();                                                                                               \
     CTAMD_H_VMCNT(8 * (R - 2));      /* tile t + 1 has landed; the pieces of tiles t + 2 .. t + R - 1 stay in flight */     \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_M_RAGFIX(t + (P) + 1, ((P) + 1) % R)                                                                     \
     if constexpr (R == 4) { CTAMD_M_RAGMASK_A(t + (P) + 4) }                                                       \
     CTAMD_M_G1(P, 0) CTAMD_M_G1(P, 1) CTAMD_M_G1(P, 2) CTAMD_M_G1(P, 3)                                            \
     CTAMD_M_G1(P, 4) CTAMD_M_G1(P, 5) CTAMD_M_G1(P, 6) CTAMD_M_G1(P, 7)
@@ -853,7 +902,7 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
                 if (m < ep.Mtot && n < ep.Ntot) {
                     int64_t offD, offC;
                     ep.offsets(pe, m, n, offD, offC);
-                    __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                    ep.store16(ep.D + offD, v, n);
                 }
             }
         }
@@ -1098,7 +1147,7 @@ __global__ void __launch_bounds__(512, 1) gett_h16w8m_kernel(const GettParams p)
                 if (m < ep.Mtot && n < ep.Ntot) {
                     int64_t offD, offC;
                     ep.offsets(pe, m, n, offD, offC);
-                    __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                    ep.store16(ep.D + offD, v, n);
                 }
             }
         }
@@ -1155,7 +1204,7 @@ struct QOperand {
                 const int kk = 8 * c + (lane >> 3), pp = lane & 7;
                 const int u = pp ^ (2 * (kk & 3));
                 uint32_t row = row0 + 8u * (uint32_t)u;
-                if (row >= gFree.total) row = gFree.total - 8;        // extent % 8 == 0: a unit is all in or all out
+                if (row >= gFree.total) row = (gFree.total - 1u) & ~7u;   // the last unit that holds rows of the mode (HOperand::init)
                 off[i] = (group_offset<0>(gFree, row) + (int64_t)kk * strideK0) * 2;
             }
             mn = off[i] < mn ? off[i] : mn;
@@ -1167,16 +1216,54 @@ struct QOperand {
     }
 };
 
-// ragged K (x_rag_mask) for QOperand's pieces: K-contiguous — k-unit (lane & 7) ^ ((4 wave + (lane >> 4)) & 7) of the lane's row in
-// both pieces; free-contiguous — piece i holds k-row 8 wave + 32 i + (lane >> 3)
+// ragged K / operands without 16-byte lanes (x_rag_mask, x_rag_fix) for QOperand's pieces: K-contiguous — k-unit
+// (lane & 7) ^ ((4 wave + (lane >> 4)) & 7) of the lane's row in both pieces; free-contiguous — piece i holds k-row 8 wave + 32 i + (lane >> 3).
+// Returns the units (bit i) that hold live data but reach past the end of the tensor: masked here, loaded element-wise by q_rag_fix.
 template <int LAY>
-__device__ __forceinline__ void q_rag_mask(uint32_t (&src)[2], int wave, uint32_t kValid) {
+__device__ __forceinline__ uint32_t q_rag_mask(uint32_t (&src)[2], int wave, uint32_t kValid, uint32_t limit) {
     const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t strad = 0u;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ ((4u * (uint32_t)wave + (laneM >> 4)) & 7u)) >= kValid)
                                         : (8u * (uint32_t)wave + 32u * (uint32_t)i + (laneM >> 3) >= kValid);
-        src[i] |= out ? 0x80000000u : 0u;
+        const bool past = !out && src[i] + 16u > limit;
+        strad |= past ? (1u << i) : 0u;
+        src[i] |= (out || past) ? 0x80000000u : 0u;
+    }
+    return strad;
+}
+// x_rag_fix for the 64 x 64 tile: ldsOp = LDS byte address of the operand's 8-KiB image in the buffer that holds the masked tile
+template <int LAY, int SLOTK>
+__device__ __forceinline__ void q_rag_fix(const ModeGroup& gFree, const ModeGroup& gK, uint64_t opBase, uint32_t row0, uint32_t kTile0, uint32_t kValid,
+                                          uint32_t strad, uint32_t ldsOp, int wave) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t c = (uint32_t)wave + 4u * (uint32_t)i;
+        const uint32_t at = ldsOp + c * 1024u + laneM * 16u;
+        const bool past = ((strad >> i) & 1u) != 0u;
+        if constexpr (LAY == LAY_K) {
+            const uint32_t u = (laneM & 7u) ^ ((4u * (uint32_t)wave + (laneM >> 4)) & 7u);
+            const uint32_t v = kValid > 8u * u ? (kValid - 8u * u < 8u ? kValid - 8u * u : 8u) : 0u;
+            if (!past && v > 0u && v < 8u) x_zero_tail(at, v);
+            if (past) {
+                uint32_t row = row0 + 8u * c + (laneM >> 3);
+                if (row >= gFree.total) row = gFree.total - 1u;
+                const uint64_t addr = opBase + (uint64_t)((group_offset<0>(gFree, row) + group_offset<SLOTK>(gK, kTile0 + 8u * u)) * 2);
+                x_patch_unit(at, addr, v);
+            }
+        } else {
+            if (past) {
+                const uint32_t kk = 8u * c + (laneM >> 3);
+                const uint32_t u = (laneM & 7u) ^ (2u * (kk & 3u));
+                uint32_t row = row0 + 8u * u;
+                if (row >= gFree.total) row = (gFree.total - 1u) & ~7u;
+                const uint32_t nv = gFree.total - row < 8u ? gFree.total - row : 8u;
+                const uint64_t addr = opBase + (uint64_t)((group_offset<0>(gFree, row) + group_offset<SLOTK>(gK, kTile0 + kk)) * 2);
+                x_patch_unit(at, addr, nv);
+            }
+        }
     }
 }
 
@@ -1223,18 +1310,23 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const int wr = wave >> 1, wc = wave & 1;
 
     uint32_t id = xcd_remap(blockIdx.x, ps.nBlocks);
-    const uint32_t tilesMN = ps.tilesM * ps.tilesN;
+    // the launch's tiles: rectangle 1 (tilesM x tilesN from (mOrg, nOrg)), then rectangle 2 (the other edge strip of a strip plan)
+    const uint32_t tiles1 = ps.tilesM * ps.tilesN;
+    const uint32_t tilesMN = tiles1 + ps.tilesM2 * ps.tilesN2;
     const uint32_t tilesAll = tilesMN * ps.gL.total;
     const uint32_t slice = id / tilesAll;
     id -= slice * tilesAll;
     const uint32_t l = id / tilesMN;
     id -= l * tilesMN;
-    const uint32_t perGroup = 8u * ps.tilesN;
+    const bool second = id >= tiles1;
+    id -= second ? tiles1 : 0u;
+    const uint32_t rTilesM = second ? ps.tilesM2 : ps.tilesM, rTilesN = second ? ps.tilesN2 : ps.tilesN;
+    const uint32_t perGroup = 8u * rTilesN;
     const uint32_t grp = id / perGroup, inGrp = id - grp * perGroup;
     const uint32_t first = grp * 8u;
-    const uint32_t gsz = (ps.tilesM - first < 8u) ? (ps.tilesM - first) : 8u;
+    const uint32_t gsz = (rTilesM - first < 8u) ? (rTilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
-    const uint32_t m0 = mt * kQTile, n0 = nt * kQTile;
+    const uint32_t m0 = (second ? ps.mOrg2 : ps.mOrg) + mt * kQTile, n0 = (second ? ps.nOrg2 : ps.nOrg) + nt * kQTile;
     const uint32_t kTilesAll = (ps.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
@@ -1248,12 +1340,35 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.B) + group_offset<1>(ps.gL, l)) + ob.base);
     VOdometer odo;
     odo.template init<RAG>(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
-    // ragged K: index (among this workgroup's K-tiles) of the tile that is staged masked, and what is left of the mode in it
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll && (ps.gK.total % kHBK) != 0u) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr(ps.gK.total % kHBK);
+    // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
+    // of the last slice — and how many k of the contracted range it holds (q_rag_mask, q_rag_fix)
+    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr((ps.gK.total % kHBK) != 0u ? ps.gK.total % kHBK : (uint32_t)kHBK);
+    uint32_t stradA = 0u, stradB = 0u;
+    // called with the descriptor bases ON tile IDX
 #define CTAMD_Q_RAGMASK(IDX)                                                                                        \
     if constexpr (RAG) {                                                                                           \
-        if ((IDX) == maskAt) { q_rag_mask<LA>(oa.src, wave, kValid); q_rag_mask<LB>(ob.src, wave, kValid); }       \
+        if ((IDX) == maskAt) {                                                                                     \
+            stradA = q_rag_mask<LA>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA));                         \
+            stradB = q_rag_mask<LB>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB));                         \
+        }                                                                                                          \
+    }
+    // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier (gett_h16w4x_kernel, CTAMD_X_RAGFIX)
+#define CTAMD_Q_RAGFIX(IDX, PB)                                                                                     \
+    if constexpr (RAG) {                                                                                           \
+        if ((IDX) == maskAt) {                                                                                     \
+            const bool fixA = (LA == LAY_K) ? (kValid & 7u) != 0u : ((p.gM.total & 7u) != 0u && m0 + (uint32_t)kQTile >= p.gM.total);   \
+            const bool fixB = (LB == LAY_K) ? (kValid & 7u) != 0u : ((p.gN.total & 7u) != 0u && n0 + (uint32_t)kQTile >= p.gN.total);   \
+            if (fixA || fixB) {                                                                                    \
+                const uint32_t kT0 = (kTilesAll - 1u) * (uint32_t)kHBK;                                            \
+                if (fixA) q_rag_fix<LA, 0>(p.gM, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)), m0, kT0, kValid, stradA, \
+                                           ldsBase + (uint32_t)((PB) * kQBuf), wave);                              \
+                if (fixB) q_rag_fix<LB, 1>(p.gN, p.gK, (uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)), n0, kT0, kValid, stradB, \
+                                           ldsBase + (uint32_t)((PB) * kQBuf + 8192), wave);                       \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+                __builtin_amdgcn_s_barrier();                                                                      \
+            }                                                                                                      \
+        }                                                                                                          \
     }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -1288,6 +1403,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     CTAMD_Q_NEXT() CTAMD_Q_RAGMASK(3) CTAMD_Q_DMA4(3, true)
     CTAMD_H_VMCNT(4 * (R - 1));                   // this wave's pieces of tile 0
     __builtin_amdgcn_s_barrier();
+    CTAMD_Q_RAGFIX(0, 0)
     if constexpr (TIMED) qs[2] = __builtin_readcyclecounter();
 
     f32x4 acc[2][2];
@@ -1310,6 +1426,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     CTAMD_H_VMCNT(4 * (R - 2));       /* tile t + 1 has landed; the pieces of tiles t + 2 .. t + R - 1 stay in flight */ \
     __builtin_amdgcn_s_barrier();                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
+    CTAMD_Q_RAGFIX(t + (P) + 1, ((P) + 1) % R)                                                                     \
     CTAMD_Q_READ8(((P) + 1) % R, ((P) + 1) & 1)                                                                    \
     CTAMD_Q_NEXT()                                                                                                 \
     CTAMD_Q_RAGMASK(t + (P) + 4)                                                                                   \
@@ -1384,7 +1501,7 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
             if (m < ep.Mtot && n < ep.Ntot) {
                 int64_t offD, offC;
                 ep.offsets(pe, m, n, offD, offC);
-                __builtin_nontemporal_store(v, reinterpret_cast<s16x8*>(ep.D + offD));
+                ep.store16(ep.D + offD, v, n);
             }
         }
     } else {
@@ -1415,7 +1532,7 @@ static hipError_t launch_h16w4q(const GettParams& p, hipStream_t stream) {
         if (timed) { hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
 #endif
-    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+    if (p.gK.total % (uint32_t)kHBK != 0u || (p.ragged & 1u) != 0u) {   // ragged K (one contracted mode) or a unit that can straddle the tensor's end (pick_h16_choice): the masked last K-tile
         hipLaunchKernelGGL((gett_h16w4q_kernel<BF, LA, LB, false, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
@@ -1437,7 +1554,7 @@ static hipError_t launch_h16w8m(const GettParams& p, hipStream_t stream) {
 
 template <bool BF, int LA, int LB, int R>
 static hipError_t launch_h16w4m(const GettParams& p, hipStream_t stream) {
-    if (p.gK.total % (uint32_t)kHBK != 0u) {       // ragged K (one contracted mode, pick_h16_choice): the masked last K-tile
+    if (p.gK.total % (uint32_t)kHBK != 0u || (p.ragged & 1u) != 0u) {   // ragged K (one contracted mode) or a unit that can straddle the tensor's end (pick_h16_choice): the masked last K-tile
         hipLaunchKernelGGL((gett_h16w4m_kernel<BF, LA, LB, R, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
         return hipGetLastError();
     }

@@ -129,24 +129,98 @@ struct VOdometer {
     }
 };
 
-// Ragged K (the RAG instantiations of gett_h16w4x_kernel / gett_h16w4m_kernel: ONE contracted mode whose extent is not a multiple of 64;
-// pick_h16_choice): the last K-tile of the last slice is staged with the lanes past the end of the mode out of range — bit 31 or-ed
-// into their byte offsets, descriptors of 2^31 records (v_rsrc<true>): no memory access, zeros in their LDS bytes, so the MFMAs of
-// that tile add zeros for k >= K.  K-contiguous operand: a lane's 16 bytes are k-unit u = (lane & 7) ^ ((4 wave + (lane >> 4)) & 7)
-// of its row in every piece (HOperand::init: r >> 1 = 4 wave + 16 i + (lane >> 4)), whole in or whole out since K % 8 == 0;
-// free-contiguous operand: the lanes of piece i hold k-row 16 i + 4 wave + (lane >> 4).  Called ONCE per operand, right before the
-// first LDS-DMA piece of that tile (a wave-uniform test per K-tile): nothing is staged after the last tile but itself.
+// Ragged K / operands without 16-byte lanes (the RAG instantiations of gett_h16w4x_kernel / gett_h16w4m_kernel; pick_h16_choice).  The
+// LAST K-tile of the last slice is staged with the lanes that must not read memory out of range — bit 31 or-ed into their byte offsets,
+// descriptors of 2^31 records (v_rsrc<true>): no memory access, zeros in their 16 bytes of the LDS piece.  Which lanes:
+//   * k past the end of the contracted range (round 5).  K-contiguous operand: a lane's 16 bytes are k-unit
+//     u = (lane & 7) ^ ((4 wave + (lane >> 4)) & 7) of its row in every piece (HOperand::init: r >> 1 = 4 wave + 16 i + (lane >> 4)) — out
+//     when 8 u >= kValid; free-contiguous operand: the lanes of piece i hold k-row 16 i + 4 wave + (lane >> 4) — out when that is >= kValid;
+//   * round 6: a unit that holds live data but whose 16 bytes reach past the END OF THE TENSOR (`limit` = bytes from the descriptor base of
+//     that tile to the end, wave-uniform, clamped to 2^31 - 1).  Possible since operands need no 16-byte lanes any more: the partial last
+//     k-unit of the last row (K-contiguous, K % 8 != 0) and the partial last row-unit of the last k-row (free-contiguous, extent % 8 != 0).
+//     These lanes are returned as a bit set (bit 4 h + i) and x_rag_fix loads their live elements one by one.
+// A partial k-unit that ends INSIDE the tensor (every other row of a K-contiguous operand with K % 8 != 0) is staged whole — its tail is the
+// head of the next row — and x_rag_fix zeroes the tail in LDS once the tile has landed.  Called ONCE per operand, right before the first
+// LDS-DMA piece of that tile, with the descriptor base already on that tile: nothing is staged after the last tile but itself.
 template <int LAY, int NH>
-__device__ __forceinline__ void x_rag_mask(uint32_t (&src)[NH][4], int wave, uint32_t kValid) {
+__device__ __forceinline__ uint32_t x_rag_mask(uint32_t (&src)[NH][4], int wave, uint32_t kValid, uint32_t limit) {
     const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t kk0 = 4u * (uint32_t)wave + (laneM >> 4);
+    uint32_t strad = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ (kk0 & 7u)) >= kValid) : (kk0 + 16u * (uint32_t)i >= kValid);
-        const uint32_t bit = out ? 0x80000000u : 0u;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) src[h][i] |= bit;
+        for (int h = 0; h < NH; ++h) {
+            const bool past = !out && src[h][i] + 16u > limit;
+            strad |= past ? (1u << (4 * h + i)) : 0u;
+            src[h][i] |= (out || past) ? 0x80000000u : 0u;
+        }
     }
+    return strad;
+}
+// bytes from `addr` (the descriptor base of the masked tile) to `end`, clamped to what a 31-bit lane offset can reach
+__device__ __forceinline__ uint32_t x_rag_limit(uint64_t end, uint64_t addr) {
+    const uint64_t d = end - addr;
+    return VOdometer::sgpr(d > 0x7fffffffull ? 0x7fffffffu : (uint32_t)d);
+}
+
+typedef uint16_t __attribute__((address_space(3))) * XLdsU16;
+typedef uint32_t __attribute__((address_space(3))) * XLdsU32;
+// zero elements v .. 7 of the 16-byte unit at LDS byte address `at` (0 < v < 8): one 2-byte write when v is odd, then whole dwords
+__device__ __forceinline__ void x_zero_tail(uint32_t at, uint32_t v) {
+    if (v & 1u) *(XLdsU16)(uintptr_t)(at + 2u * v) = (uint16_t)0;
+    const uint32_t w = (v + 1u) >> 1;
+    if (w <= 1u) *(XLdsU32)(uintptr_t)(at + 4u) = 0u;
+    if (w <= 2u) *(XLdsU32)(uintptr_t)(at + 8u) = 0u;
+    if (w <= 3u) *(XLdsU32)(uintptr_t)(at + 12u) = 0u;
+}
+// elements 0 .. nv - 1 of the unit at byte address `addr` into the (zero-filled) unit at LDS byte address `at`
+__device__ __forceinline__ void x_patch_unit(uint32_t at, uint64_t addr, uint32_t nv) {
+    const HGlbCU16 g = (HGlbCU16)(uintptr_t)addr;
+#pragma unroll 1
+    for (uint32_t e = 0; e < nv; ++e) *(XLdsU16)(uintptr_t)(at + 2u * e) = g[e];
+}
+// The masked tile has landed (every wave's pieces, behind a workgroup barrier): repair what whole 16-byte units could not express.
+//   K-contiguous operand: the tail of a partial k-unit (elements kValid - 8 u .. 7) is zeroed; a partial unit x_rag_mask kept from memory
+//   (strad) gets its live elements by 2-byte loads.   Free-contiguous operand: only strad units (live rows of the mode, by 2-byte loads).
+// opBase: byte address of the operand's element (batch index l, row 0, k 0); row0: first row of the workgroup's tile; kTile0: K index of
+// the tile's first k; ldsOp: LDS byte address of the operand's half-tile 0 in the buffer that holds the tile.  The caller follows up with
+// s_waitcnt + a workgroup barrier.  SLOTK: the operand's stride slot in the K group (0 = kernel-A, 1 = kernel-B).
+template <int LAY, int NH, int SLOTK>
+__device__ __forceinline__ void x_rag_fix(const ModeGroup& gFree, const ModeGroup& gK, uint64_t opBase, uint32_t row0, uint32_t kTile0, uint32_t kValid,
+                                          uint32_t strad, uint32_t ldsOp, int wave) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t kk0 = 4u * (uint32_t)wave + (laneM >> 4);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t c = (uint32_t)wave + 4u * (uint32_t)i;               // 1-KiB piece of the half-tile
+            const uint32_t at = ldsOp + (uint32_t)h * (uint32_t)kHalfBytes + c * 1024u + laneM * 16u;
+            const bool past = ((strad >> (4 * h + i)) & 1u) != 0u;
+            if constexpr (LAY == LAY_K) {
+                const uint32_t u = (laneM & 7u) ^ (kk0 & 7u);
+                const uint32_t v = kValid > 8u * u ? (kValid - 8u * u < 8u ? kValid - 8u * u : 8u) : 0u;
+                if (!past && v > 0u && v < 8u) x_zero_tail(at, v);
+                if (past) {
+                    uint32_t row = row0 + 128u * (uint32_t)h + 8u * c + (laneM >> 3);
+                    if (row >= gFree.total) row = gFree.total - 1u;
+                    const uint64_t addr = opBase + (uint64_t)((group_offset<0>(gFree, row) + group_offset<SLOTK>(gK, kTile0 + 8u * u)) * 2);
+                    x_patch_unit(at, addr, v);
+                }
+            } else {
+                if (past) {
+                    const uint32_t kk = kk0 + 16u * (uint32_t)i;
+                    const uint32_t u = (laneM & 15u) ^ (4u * ((laneM >> 4) & 3u)) ^ (2u * ((kk >> 3) & 1u));
+                    uint32_t row = row0 + 128u * (uint32_t)h + 8u * u;
+                    if (row >= gFree.total) row = (gFree.total - 1u) & ~7u;
+                    const uint32_t nv = gFree.total - row < 8u ? gFree.total - row : 8u;
+                    const uint64_t addr = opBase + (uint64_t)((group_offset<0>(gFree, row) + group_offset<SLOTK>(gK, kTile0 + kk)) * 2);
+                    x_patch_unit(at, addr, nv);
+                }
+            }
+        }
 }
 
 template <bool BF>

@@ -59,6 +59,19 @@ struct GettParams {
     // 0 = write-through (sc1, the default), 1 = plain (write-back: the lines stay dirty in the XCD's L2 until the kernel ends),
     // 2 = nontemporal
     int32_t     partialPolicy;
+    // Operands without 16-byte lanes on the LDS-DMA kernels (round 6).  endA / endB: byte address one past the last element of
+    // kernel-A / kernel-B (set by cutensorContract from the plan's element spans): a 16-byte unit that would read past it is staged
+    // masked and patched element by element (gett_h16x_common.h, x_rag_fix).  ragged: bit 0 — the launch needs the kernels' RAG
+    // instantiation although K holds whole K-tiles (a free-contiguous operand whose row units can straddle the end of the tensor).
+    unsigned long long endA, endB;
+    uint32_t    ragged;
+    // Origin of this launch's tile grid inside the M x N index space (elements): a plan may cover the output with an interior launch
+    // of large tiles and edge strips of small ones (plan_contraction.cpp, strip plans); tile (mt, nt) starts at (mOrg + mt BM, nOrg + nt BN).
+    uint32_t    mOrg, nOrg;
+    // A second tile rectangle in the same launch (gett_h16w4q_kernel only — the strip kernel): tile ids tilesM * tilesN .. address
+    // tilesM2 x tilesN2 tiles from (mOrg2, nOrg2); tilesM2 * tilesN2 == 0: none.  The two edge strips of an output (rows past the
+    // interior, columns past the interior) are ONE launch that way.
+    uint32_t    tilesM2, tilesN2, mOrg2, nOrg2;
 };
 
 // ---------------------------------------------------------------------------------------------

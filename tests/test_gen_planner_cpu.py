@@ -36,12 +36,13 @@ def test_reference_cases_at_their_own_extents_run_on_mfma_kernels(env, name):
     d = plan.describe()
     if meta["dtype"] == "float32":
         assert d["family"] == 0 and d["kernel"] >= 0, d
+    elif meta["dtype"] in ("float16", "bfloat16") and len(d["Kdigits"]) == 1 and d["family"] == 1:
+        # round 6: 16-bit data with ONE contracted digit whose stride-1 modes lead their groups stays on the LDS-DMA kernels whatever the
+        # extents (50 here: no 16-byte lanes, a partial k-unit, one masked K-tile) — tests/test_h16_planner_cpu.py has the rules
+        assert d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w4q_kernel"), (meta, d)
     else:
+        # (with two contracted digits the operands may disagree on which one is contiguous: 'mlik,lkjm->lij' gathers)
         assert d["family"] == 2 and d["kernel"] >= 0 and d["kname"] == "gett_gen_kernel", (meta, d)
-        if meta["dtype"] in ("float16", "bfloat16") and len(d["Kdigits"]) == 1 and all(e % 2 == 0 for e in meta["a_size"] + meta["b_size"]):
-            # even extents and ONE contracted digit: each operand's stride-1 mode leads a group -> 4-byte pairs, not 2-byte gathers
-            # (with two contracted digits the operands may disagree on which one is contiguous: 'mlik,lkjm->lij' gathers)
-            assert d["vec"] >= 2, (meta, d)
     plan.destroy()
 
 
@@ -77,16 +78,20 @@ def test_vector_width_and_orientation_follow_the_layout(env):
     p = plan(2048, 2048, 1024, "mk", "kn", ct.R_16BF)
     assert p.describe()["family"] == 1
     p.destroy()
-    # odd extents: 2-byte gathers
-    p = plan(37, 29, 51, "mk", "kn", ct.R_16F)
-    d = p.describe()
-    assert d["family"] == 2 and d["vec"] == 1 and (d["bm"], d["bn"], d["bk"]) == (64, 64, 32), d
-    p.destroy()
-    # element alignment only (descriptor alignment 2): no lanes wider than an element
-    p = plan(64, 64, 64, "km", "kn", ct.R_16BF, alignment=2)
-    d = p.describe()
-    assert d["family"] == 2 and d["vec"] == 1, d
-    p.destroy()
+    # odd extents / element alignment only: since round 6 still the LDS-DMA family (16-byte units at any 2-byte address); the general
+    # family's 2-byte gathers under CUTENSOR_AMD_GEN=f
+    for args, kw in (((37, 29, 51, "mk", "kn", ct.R_16F), {}), ((64, 64, 64, "km", "kn", ct.R_16BF), dict(alignment=2))):
+        p = plan(*args, **kw)
+        assert p.describe()["family"] == 1, p.describe()
+        p.destroy()
+        os.environ["CUTENSOR_AMD_GEN"] = "f"
+        try:
+            p = plan(*args, **kw)
+        finally:
+            del os.environ["CUTENSOR_AMD_GEN"]
+        d = p.describe()
+        assert d["family"] == 2 and d["vec"] == 1, d
+        p.destroy()
     # fp64: 16-byte lanes = two doubles; large problem -> 128 x 128 tile, small -> 64 x 64
     p = plan(4096, 4096, 4096, "km", "kn", ct.R_64F)
     d = p.describe()
@@ -113,15 +118,15 @@ def test_vector_width_and_orientation_follow_the_layout(env):
 def test_split_k_of_16_bit_data_and_workspace_invariant(env):
     ct, ops, h = env
     # one output tile, deep ragged K: split over the CUs, fp32 partials within the estimate (contraction.cu:239 asserts required <= estimate).
-    # (K = 4004: no 16-byte lanes in the K-contiguous operands — with lanes a single ragged contracted mode stays on the aligned
-    # LDS-DMA kernels since round 5, tests/test_h16_planner_cpu.py)
-    p = ops.contraction_plan(h, [4004, 64], "km", [4004, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF)
+    # (TWO contracted modes with a ragged fastest one — k = 44, j = 91: the LDS-DMA kernels mask ONE contracted mode,
+    # tests/test_h16_planner_cpu.py)
+    p = ops.contraction_plan(h, [44, 64, 91], "kmj", [44, 91, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] > 1 and p.required_workspace == d["splitK"] * 64 * 48 * 4, d
     assert p.required_workspace <= p.workspace_estimate
     p.destroy()
     # no workspace allowed: no split
-    p = ops.contraction_plan(h, [4004, 64], "km", [4004, 48], "kn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
+    p = ops.contraction_plan(h, [44, 64, 91], "kmj", [44, 91, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] == 1 and p.required_workspace == 0, d
     p.destroy()

@@ -49,11 +49,17 @@ def test_golden_cases(te, name):
 
 def _assert_mfma_kernel(torch_einsum, equation, a, b):
     """Green parity on a fallback is weaker evidence than it looks: every golden case must have run on a matrix-core kernel —
-    fp32 on the fp32 MFMA families, every other type (16-bit at these unaligned extents, fp64, complex) on the general MFMA
-    family, none on gett_simple_kernel / gett_wide_kernel."""
+    fp32 on the fp32 MFMA families, fp64 and complex on the general MFMA family, 16-bit data on the LDS-DMA kernels when ONE contracted
+    digit remains (round 6: these extents of 50 have no 16-byte lanes and a partial k-unit — the masked / repaired last K-tile) and on
+    the general family otherwise, none on gett_simple_kernel / gett_wide_kernel."""
     d = torch_einsum._plans[(equation, tuple(a.shape), tuple(b.shape), a.dtype, False, False)].describe()
     assert d["kernel"] >= 0 and d["kname"] not in ("gett_simple_kernel", "gett_wide_kernel"), d
-    assert d["family"] == (0 if str(a.dtype) == "torch.float32" else 2), d
+    if str(a.dtype) == "torch.float32":
+        assert d["family"] == 0, d
+    elif str(a.dtype) in ("torch.float16", "torch.bfloat16"):
+        assert d["family"] == (1 if len(d["Kdigits"]) == 1 else 2), d
+    else:
+        assert d["family"] == 2, d
 
 
 def test_demo_equations(te):

@@ -193,11 +193,15 @@ print("ok")
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (waves, r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_unaligned_shapes_run_on_the_general_mfma_family(env):
-    """Extents that do not admit 16-byte lanes / 64-deep K-tiles: the general MFMA family (gett_gen.inc, 2-byte gathers here),
-    not the scalar FMA kernel (tests/test_gpu_gen.py covers that family)."""
+def test_unaligned_shapes_stay_on_the_lds_dma_kernels(env):
+    """Extents that admit neither 16-byte lanes nor 64-deep K-tiles (round 6): still the LDS-DMA kernels — 16-byte units at 2-byte
+    addresses, the partial k-unit repaired in LDS (tests/test_gpu_h16_unaligned.py is that path's own file).  Two contracted modes with a
+    ragged fastest one remain the general MFMA family's (gett_gen.inc; tests/test_gpu_gen.py), never the scalar FMA kernel's."""
     got, ref, d = _run(env, dict(m=37, n=29, k=50), "mk", "kn", "mn", seed=9, expect_mfma=False)
-    assert d["family"] == 2 and d["kname"] == "gett_gen_kernel" and d["vec"] == 1, d
+    assert d["family"] == 1 and d["kname"] == "gett_h16w4q_kernel", d
+    np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
+    got, ref, d = _run(env, dict(m=37, n=29, k=50, j=3), "mkj", "jkn", "mn", seed=9, expect_mfma=False)   # (k, j do not fuse: B holds j first)
+    assert d["family"] == 2 and d["kname"] == "gett_gen_kernel", d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=2e-2)
 
 

@@ -64,7 +64,8 @@ def _run(mod, name, expect_gen=False):
     delta = {k: after[k] - before[k] for k in after}
     assert delta["simple"] == 0, (name, delta)
     if expect_gen:          # (this also shows that the counters see the reference binding's launches: one library instance)
-        assert delta["gen"] > 0, (name, delta)
+        # fp64 / complex: the general MFMA family; fp16: the LDS-DMA kernels when one contracted digit remains (round 6), else general
+        assert delta["gen"] + delta["h16"] > 0, (name, delta)
 
 # reference cases whose data type is not fp32 (einsum_test.py:55-68 complex, :84-115 fp16 / fp64): general MFMA family
 NON_F32 = {"1_test_0_complex_", "2_test_1", "5_test_4", "6_test_5", "7_test_6", "8_test_7", "9_test_8"}
@@ -133,7 +134,7 @@ def test_reference_binding_bf16(ref_test_module):
     before = ours.launch_counts()
     got = ct.EinsumFunction.apply("mlik,lkjm->lij", a, b)
     after = ours.launch_counts()
-    assert after["gen"] > before["gen"] and after["simple"] == before["simple"], (before, after)
+    assert after["gen"] + after["h16"] > before["gen"] + before["h16"] and after["simple"] == before["simple"], (before, after)
     ref = torch.einsum("mlik,lkjm->lij", a.double(), b.double())
     # K = 20*50 terms of N(0,1) products: |ref| ~ 32; bf16 output rounding 2^-8 relative
     torch.testing.assert_close(got.double(), ref, rtol=1e-2, atol=0.25)

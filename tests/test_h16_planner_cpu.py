@@ -128,8 +128,7 @@ def test_the_switch_overrides_the_planner(built, waves, want):
 def test_ragged_k_stays_in_the_lds_dma_family(env):
     """One contracted mode with K % 64 != 0 and 16-byte lanes (round-4 review, Missing #4): the planner's usual candidates minus the
     persistent kernel — their RAG instantiations stage the last K-tile masked (gett_h16x_common.h x_rag_mask).  K-tiles are counted
-    rounded up; slices stay whole K-tiles.  Two contracted modes with a ragged fastest one, or a K-contiguous operand whose K is not a
-    multiple of 8, are the general family's."""
+    rounded up; slices stay whole K-tiles.  Two contracted modes with a ragged fastest one are the general family's."""
     ct, ops = env
     h = ops.Handle()
 
@@ -148,7 +147,21 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
     d = plan(96, 96, 4104, "km", "kn")             # split-K: whole K-tiles per slice, the last slice owns the masked tile
     assert d["family"] == 1 and d["splitK"] > 1 and d["kPerSlice"] % 64 == 0 and d["splitK"] * d["kPerSlice"] >= 4104, d
     assert plan(2048, 1032, 77, "mk", "nk")["family"] == 1          # both operands free-contiguous: any K
-    assert plan(2048, 1032, 77, "mk", "kn")["family"] == 2          # K-contiguous B: K % 8 != 0 has no 16-byte lanes
+    # round 6: a K-contiguous operand with K % 8 != 0 stays too (the partial k-unit's tail is zeroed in LDS: x_rag_fix), and so do
+    # extents / pitches / base pointers without 16-byte lanes — the stride-1 mode decides, nothing else
+    assert plan(2048, 1032, 77, "mk", "kn")["family"] == 1
+    for (M, N, K) in ((4100, 4100, 4100), (4097, 4097, 4097), (50, 50, 50), (300, 204, 100)):
+        for (mA, mB) in (("mk", "kn"), ("km", "kn"), ("mk", "nk"), ("km", "nk")):
+            d = plan(M, N, K, mA, mB, alignment=2)
+            assert d["family"] == 1 and d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel", "gett_h16w4q_kernel"), d
+    # a ragged stride-1 mode must be ALONE in its group (a 16-byte unit may not straddle a digit boundary): two M modes with a ragged
+    # fastest one are the general family's; with a fastest one of 8 j they stay
+    e = dict(a=12, b=40, n=64, k=64)
+    for a, fam in ((12, 2), (16, 1)):
+        e["a"] = a
+        p = ops.contraction_plan(h, [e[c] for c in "akb"], "akb", [64, 64], "kn", [e[c] for c in "anb"], "anb", dtype=ct.R_16BF, workspace_limit=1 << 28)
+        assert p.describe()["family"] == fam, (a, p.describe())
+        p.destroy()
     assert plan(2048, 2048, 1024)["family"] == 1                    # whole K-tiles: unchanged
 
 
