@@ -105,6 +105,9 @@ struct ContractionView {
     uint64_t totL = 1, totM = 1, totN = 1, totK = 1;
     bool     wide = false;               // a group has more than kMaxGroupModes unfusable modes (or >= 2^31 elements):
                                          // only the mode-table kernel (gett_wide_kernel) can run it
+    bool     lanesA = false, lanesB = false;   // fp32: the operand has 16-byte lanes in the strict sense (pointer, extent of the stride-1
+                                         // mode and every other stride multiples of 16 bytes) — what the register-staged kernels
+                                         // (gett_f32.hip) need; the LDS-DMA ring kernels take layA / layB as they are (round 6)
     uint32_t alignA = 0, alignB = 0;     // descriptor alignment (bytes) of kernel-A / kernel-B
     uint32_t alignD = 0;                 // ... of the output
 };

@@ -286,7 +286,37 @@ cutensorStatus_t build_contraction_view(const cutensorOperationDescriptor& op, C
     };
     v.layA = pick(true, v.M, alignA);
     v.layB = pick(false, v.N, alignB);
+    v.lanesA = v.layA != LAY_S;
+    v.lanesB = v.layB != LAY_S;
+    // fp32 (round 6): like 16-bit data, the LDS-DMA ring kernels (gett_f32_stream.hip) stage 16-byte units from any 4-byte address, so
+    // the stride-1 mode alone decides the layout; a ragged extent of that mode needs it to be alone in its group.  The register-staged
+    // kernels keep the strict rule (lanesA / lanesB).
+    auto pick32 = [&](bool slotA, const std::vector<CanonMode>& freeG) {
+        const std::vector<CanonMode>* groups[3] = {&freeG, &v.K, &v.L};
+        for (const std::vector<CanonMode>* g : groups)
+            for (const CanonMode& m : *g)
+                if ((slotA ? m.sA : m.sB) < 0) return (int)LAY_S;
+        if (!v.K.empty()) {
+            const CanonMode& k0 = v.K.front();
+            if ((slotA ? k0.sA : k0.sB) == 1 && (k0.extent % 4 == 0 || v.K.size() == 1)) return (int)LAY_K;
+        }
+        if (!freeG.empty()) {
+            const CanonMode& f0 = freeG.front();
+            if ((slotA ? f0.sA : f0.sB) == 1 && (f0.extent % 4 == 0 || freeG.size() == 1)) return (int)LAY_F;
+        }
+        return (int)LAY_S;
+    };
+    if (v.dtype == HIP_R_32F) {
+        if (!v.lanesA) v.layA = pick32(true, v.M);
+        if (!v.lanesB) v.layB = pick32(false, v.N);
+    }
     return CUTENSOR_STATUS_SUCCESS;
+}
+
+// fp32 ring kernels: the launch needs the RAG instantiation (gett_f32_stream.hip) — ragged K, or an operand without strict 16-byte lanes
+// (a partial unit may reach past the end of the tensor: the RAG descriptors end with it)
+static bool f32_needs_rag(const ContractionView& v) {
+    return v.totK % 32 != 0 || !v.lanesA || !v.lanesB;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,7 +329,9 @@ static double tile_efficiency(const GettKernelInfo& k) {
     const int area = k.bm * k.bn;
     // streaming kernels: LDS-DMA ring, prefetched fragments; the 3-deep ring measures ~2 % faster than the 4- and
     // 6-deep ones in the device's steady clock state (headline einsum 42.5 vs 43.6 us per step)
-    if (k.fragPartials) return area >= 96 * 96 ? (k.pf == 3 ? 0.93 : 0.92) : 0.75;
+    // (compute-bound problems: the 4-deep ring — 4096^3 128 x 128: 148 TFLOP/s against 130 on the 3-deep one, 4098^3 alike,
+    // profiles/r06i_f32_candidates_4098_4096.jsonl; memory-bound ones tie here and the 3-deep ring wins the tie-break below)
+    if (k.fragPartials) return area >= 96 * 96 ? (k.pf == 4 ? 0.93 : 0.92) : 0.75;
     if (area >= 128 * 128) return 0.85;
     if (area >= 96 * 96) return 0.80;
     if (area >= 64 * 64) return 0.65;
@@ -326,17 +358,30 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         return n * 4ull;
     };
     const bool fits32 = span_bytes(true) < (1ull << 32) - (1ull << 20) && span_bytes(false) < (1ull << 32) - (1ull << 20);
+    // with the batch modes: what a RAG descriptor (base = operand + batch offset) and a masked lane (bit 31) must stay below
+    auto full_span_bytes = [&](bool slotA) {
+        uint64_t n = span_bytes(slotA) / 4ull;
+        for (const CanonMode& m : v.L) n += (uint64_t)(m.extent - 1) * (uint64_t)std::llabs(slotA ? m.sA : m.sB);
+        return n * 4ull;
+    };
+    const bool fits31 = full_span_bytes(true) < (1ull << 31) - (1ull << 20) && full_span_bytes(false) < (1ull << 31) - (1ull << 20);
+    const bool needRag = f32_needs_rag(v);
     for (int i = 0; i < count; ++i) {
         const GettKernelInfo& k = tab[i];
         if (k.ablation && !withAblations) continue;
         if (k.fragPartials && !fits32) continue;
-        // a kernel is usable if each operand admits its layout (LAY_S kernels take anything)
-        const bool okA = (k.layA == v.layA) || (k.layA == LAY_S);
-        const bool okB = (k.layB == v.layB) || (k.layB == LAY_S);
+        // a kernel is usable if each operand admits its layout (LAY_S kernels take anything).  The register-staged kernels see an
+        // operand without strict 16-byte lanes as LAY_S; the ring kernels (fragPartials) take the relaxed layouts — their RAG twin runs
+        // when K is ragged (one contracted mode) or an operand has no strict lanes: spans below 2^31 bytes, no nontemporal form
+        const bool rag = k.fragPartials && needRag;
+        const int effA = (k.fragPartials || v.lanesA) ? v.layA : (int)LAY_S, effB = (k.fragPartials || v.lanesB) ? v.layB : (int)LAY_S;
+        const bool okA = (k.layA == effA) || (k.layA == LAY_S);
+        const bool okB = (k.layB == effB) || (k.layB == LAY_S);
         if (!okA || !okB) continue;
         if ((k.layA == LAY_S) != (k.layB == LAY_S)) continue;   // table only holds S/S pairs
-        if (k.layA == LAY_S && v.layA != LAY_S && v.layB != LAY_S) continue;  // vector kernels exist
-        if (k.kfast && (v.K.empty() || (v.K.front().extent % k.bk) != 0)) continue;   // tile would straddle a K-mode period
+        if (k.layA == LAY_S && v.lanesA && v.lanesB) continue;  // vector kernels exist
+        if (rag && (!fits31 || k.nt || k.ablation || (v.K.size() > 1 && v.totK % k.bk != 0))) continue;
+        if (k.kfast && !(rag && v.K.size() == 1) && (v.K.empty() || (v.K.front().extent % k.bk) != 0)) continue;   // tile would straddle a K-mode period
 
         const uint64_t tilesM = (v.totM + k.bm - 1) / k.bm, tilesN = (v.totN + k.bn - 1) / k.bn;
         const uint64_t tiles = tilesM * tilesN * v.totL;
@@ -358,7 +403,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         for (uint32_t s : splits) {
             ContractionChoice c;
             c.kernel = i;
-            if (k.fragPartials && v.totK % k.bk != 0) continue;   // whole K-tiles; any number of tiles per slice
+            if (k.fragPartials && v.totK % k.bk != 0 && !rag) continue;   // whole K-tiles (or the RAG twin's masked last one); any number of tiles per slice
             const uint64_t tilesPerSlice = (kTiles + s - 1) / s;
             c.kPerSlice = (uint32_t)(tilesPerSlice * k.bk);
             c.splitK = (uint32_t)((v.totK + c.kPerSlice - 1) / c.kPerSlice);
@@ -386,7 +431,12 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
             const double bytesUnique = 4.0 * L * (M * K + N * K + M * N);
             const double bytesPartial = (c.splitK > 1) ? 2.0 * (double)c.workspace : 0.0;
             const double tMem = std::max((bytesA + bytesB) / l2bw, (bytesUnique + bytesPartial) / hbm);
-            const double tFix = (c.splitK > 1) ? 3.0e-6 : 0.0;
+            // the fold of accumulator-order partials (splitk_reduce_frag_kernel) gives 32 slice groups to every output quad: with few slices
+            // most of its lanes idle — 4098^3 in two slices folds 134 MB in ~400 us (profiles/r06i_f32_candidates_4098_4096.jsonl), the
+            // headline's 256 slices fold 9.4 MB in 4.7 us
+            // (only the EXTRA time of the idle lanes is charged: at 32 slices and beyond the term vanishes and the ranking of round 5 stands)
+            const double tFold = (c.splitK > 1 && c.splitK < 32 && k.fragPartials) ? (double)c.workspace / 5.0e12 * (32.0 / c.splitK - 1.0) : 0.0;
+            const double tFix = (c.splitK > 1) ? 3.0e-6 + tFold : 0.0;
             c.estimateUs = (std::max(tCompute, tMem) + tFix + 2.0e-6) * 1e6;
             if (k.fragPartials && k.pf == 3) c.estimateUs *= 0.999;   // tie-break for memory-bound estimates: the 3-deep ring wins by ~2 %
             if (k.nt) c.estimateUs *= 0.96;                            // eligible (see above): ahead of its default-policy twin
@@ -773,6 +823,11 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
         p.endA = spanA * es;
         p.endB = spanB * es;
         p.ragged = (c.family == 1 && h16_needs_rag(v)) ? 1u : 0u;
+        if (c.family == 0 && v.dtype == HIP_R_32F && c.kernel >= 0) {
+            int cnt = 0;
+            const GettKernelInfo* t32 = gett_f32_kernels(&cnt);
+            if (c.kernel < cnt && t32[c.kernel].fragPartials && f32_needs_rag(v)) p.ragged = 1u;
+        }
     }
 
     r.gM = p.gM; r.gN = p.gN; r.gL = p.gL;

@@ -57,13 +57,16 @@ typedef __amdgpu_buffer_rsrc_t BufRsrc;
 #else
 typedef int BufRsrc;
 #endif
-__device__ __forceinline__ BufRsrc make_rsrc(const float* base) {
+__device__ __forceinline__ BufRsrc make_rsrc(const float* base, uint32_t records = 0xffffffffu) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // raw buffer, stride 0, num_records = 2^32 - 1 bytes (the planner only selects these kernels for
-    // operands whose byte span fits 32 bits), dword 3 = gfx9 raw-buffer format word
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+    // operands whose byte span fits 32 bits), dword 3 = gfx9 raw-buffer format word.  RAG instantiations pass the EXACT
+    // number of bytes from `base` to the end of the tensor: the range check is per dword and counts soffset + voffset
+    // (tools/ubench/ldsdma_unaligned.hip), so a 16-byte unit that reaches past the last element loads the floats that
+    // exist and zeros for the rest — and a lane offset with bit 31 set (spans below 2^31) reads nothing at all.
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)records, 0x00020000);
 #else
-    (void)base; return 0;
+    (void)base; (void)records; return 0;
 #endif
 }
 __device__ __forceinline__ void store_wt_16(f32x4 v, BufRsrc rsrc, uint32_t byteOff) {
@@ -122,7 +125,7 @@ struct StreamOperand {
                 const int kr = g / UR, p = g % UR;
                 const int u = (p + 4 * ((kr >> 2) & 1)) % UR;
                 uint32_t row = row0 + 4 * u;
-                if (row >= gFree.total) row = gFree.total - 4;   // extent % 4 == 0: a unit is all in or all out
+                if (row >= gFree.total) row = (gFree.total - 1u) & ~3u;   // the last unit that holds rows of the mode (whole when extent % 4 == 0)
                 src[i] = (group_offset32<0>(gFree, row) + (uint32_t)kr * (uint32_t)strideK0) * 4u;
             }
         }
@@ -134,6 +137,45 @@ struct StreamOperand {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i)
             lds_dma_16<AUX>(X, src[i], offKBytes, stage + (wave + 4 * i) * 256);
+    }
+
+    // Ragged K / operands without 16-byte lanes (RAG instantiations; round 6).  The LAST K-tile of the last slice holds kValid < 32
+    // k, or K-contiguous rows whose last 16-byte unit is partial (K % 4 != 0).  mask(): units that lie entirely past the contracted
+    // range get bit 31 in their byte offset — out of range for the RAG descriptor (2^31 > records): no memory access, zeros in LDS.
+    // Called once, right before that tile is issued (nothing is issued after it).
+    __device__ __forceinline__ void mask(int wave, int lane, uint32_t kValid) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int c = wave + 4 * i;
+            bool out;
+            if constexpr (LAY == LAY_K) {
+                const int r = 8 * c + (lane >> 3), p = lane & 7;
+                out = 4u * (uint32_t)(p ^ ((r >> 1) & 7)) >= kValid;
+            } else {
+                out = (uint32_t)((64 * c + lane) / UR) >= kValid;
+            }
+            src[i] |= out ? 0x80000000u : 0u;
+        }
+    }
+    // fix(): K-contiguous operand, K % 4 != 0 — the partial unit of every row was staged whole (its tail is the head of the next
+    // row, or zeros past the end of the tensor): zero floats kValid - 4 u .. 3 in LDS.  Called by the data-moving wave that staged the
+    // pieces, behind its own wait for them and in front of the tile's barrier (the caller drains lgkmcnt).
+    __device__ __forceinline__ void fix(float* stage, int wave, int lane, uint32_t kValid) const {
+        if constexpr (LAY == LAY_K) {
+#pragma unroll
+            for (int i = 0; i < PER_WAVE; ++i) {
+                const int c = wave + 4 * i;
+                const int r = 8 * c + (lane >> 3), p = lane & 7;
+                const uint32_t k0 = 4u * (uint32_t)(p ^ ((r >> 1) & 7));
+                float* at = stage + c * 256 + lane * 4;
+                if (k0 < kValid && kValid < k0 + 4u) {
+                    const uint32_t v = kValid - k0;           // 1 .. 3 live floats
+                    if (v <= 1u) at[1] = 0.f;
+                    if (v <= 2u) at[2] = 0.f;
+                    at[3] = 0.f;
+                }
+            }
+        }
     }
 
     // per-lane constant part of the fragment address (floats) for the 16-row fragment at rbase
@@ -178,9 +220,11 @@ struct KOdometer {
 
     __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+    // RAG: the (single) contracted mode ends inside its last K-tile — that tile counts
+    template <bool RAG = false>
     __device__ __forceinline__ void init(const ModeGroup& gK, uint32_t k0) {
         const uint32_t E0 = gK.div[0].d;
-        n0 = sgpr(E0 / kStreamBK);
+        n0 = sgpr((E0 + (RAG ? (uint32_t)kStreamBK - 1u : 0u)) / kStreamBK);
         e1 = sgpr(gK.div[1].d);
         const uint32_t q0 = (E0 < 2) ? k0 : fast_div(k0, gK.div[0]);
         j0 = sgpr((k0 - q0 * E0) / kStreamBK);
@@ -211,9 +255,11 @@ struct KOdometer {
     }
 };
 
-template <int BM_, int BN_, int LA_, int LB_, int S_, int ABL_ = 0>
+template <int BM_, int BN_, int LA_, int LB_, int S_, int ABL_ = 0, bool RAG_ = false>
 struct StreamCfg {
     static constexpr int BM = BM_, BN = BN_, LA = LA_, LB = LB_, S = S_;
+    static constexpr bool RAG = RAG_;  // ragged K (one contracted mode, K % 32 != 0) / operands without 16-byte lanes: the last K-tile of the
+                                       // last slice is staged masked and repaired (StreamOperand::mask / fix), exact descriptor ranges
     static constexpr int ABL = ABL_;   // measurement-only: 1 = no refills (LDS + MFMA only), 2 = no MFMA (memory path only),
                                        // 3 = full kernel + wait-time accounting (slots 8-10 of the timing buffer),
                                        // 4 = full kernel (correct results), data movers at s_setprio 3
@@ -292,26 +338,49 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
     } else {
         uint32_t kEnd = kBegin + p.kPerSlice;
         if (kEnd > p.gK.total) kEnd = p.gK.total;
-        nTiles = (int)((kEnd - kBegin) / BK);
+        nTiles = (int)((kEnd - kBegin + (Cfg::RAG ? (uint32_t)BK - 1u : 0u)) / BK);
     }
 
     if (loader) {
         // =========================== data movers ======================================================
-        const BufRsrc A = make_rsrc(static_cast<const float*>(p.A) + group_offset<0>(p.gL, l));
-        const BufRsrc B = make_rsrc(static_cast<const float*>(p.B) + group_offset<1>(p.gL, l));
+        const float* baseA = static_cast<const float*>(p.A) + group_offset<0>(p.gL, l);
+        const float* baseB = static_cast<const float*>(p.B) + group_offset<1>(p.gL, l);
+        // RAG: descriptors that end with the tensor (spans below 2^31 bytes: rank_contraction_choices)
+        const BufRsrc A = Cfg::RAG ? make_rsrc(baseA, KOdometer::sgpr((uint32_t)(p.endA - (unsigned long long)(uintptr_t)baseA))) : make_rsrc(baseA);
+        const BufRsrc B = Cfg::RAG ? make_rsrc(baseB, KOdometer::sgpr((uint32_t)(p.endB - (unsigned long long)(uintptr_t)baseB))) : make_rsrc(baseB);
         if constexpr (Cfg::ABL == 4) __builtin_amdgcn_s_setprio(3);   // experiment: data movers outrank the multipliers
         OpA oa;
         OpB ob;
         oa.template init<0>(p.gM, p.gK, m0, wave, lane);
         ob.template init<1>(p.gN, p.gK, n0, wave, lane);
         KOdometer odo;
-        odo.init(p.gK, kBegin);
+        odo.template init<Cfg::RAG>(p.gK, kBegin);
+        // RAG: the tile (index among this workgroup's) that is staged masked — the last K-tile of the last slice — and the k it holds
+        const uint32_t kTilesAll = (p.gK.total + (uint32_t)BK - 1u) / (uint32_t)BK;
+        const int maskAt = (Cfg::RAG && kBegin / (uint32_t)BK + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+        const uint32_t kValid = KOdometer::sgpr((p.gK.total % (uint32_t)BK) != 0u ? p.gK.total % (uint32_t)BK : (uint32_t)BK);
+        int issued = 0;
         auto issue = [&](int slot) {
             float* stage = lds + slot * STAGE;
             constexpr int AUX = (Cfg::ABL == 5) ? 2 : 0;       // 5 = correct results, nontemporal operand stream
+            if constexpr (Cfg::RAG) {
+                if (issued == maskAt) { oa.mask(wave, lane, kValid); ob.mask(wave, lane, kValid); }
+                ++issued;
+            }
             oa.template issue<AUX>(A, odo.offA, stage, wave);
             ob.template issue<AUX>(B, odo.offB, stage + OpA::FLOATS, wave);
             odo.advance(p.gK);
+        };
+        // the masked tile has landed (this wave's pieces: it waited for them): zero the tail of partial k-units, in front of the barrier
+        auto fix_last = [&]() {
+            if constexpr (Cfg::RAG) {
+                if (maskAt != 0x7fffffff && (kValid & 3u) != 0u) {
+                    float* stage = lds + (maskAt % S) * STAGE;
+                    oa.fix(stage, wave, lane, kValid);
+                    ob.fix(stage + OpA::FLOATS, wave, lane, kValid);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
         };
         if (tlog != nullptr && tid == 256) tlog[7] = __builtin_readcyclecounter();   // setup done, first issue
         // Progressive start: the multiplying waves are released as soon as tile 0 has landed, while the
@@ -323,6 +392,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
             CTAMD_WAIT_VMCNT(LOADS);
         } else {
             CTAMD_WAIT_VMCNT(0);
+            fix_last();                                    // ONE tile: it is the masked one
         }
         __builtin_amdgcn_s_barrier();                      // #0
 #pragma unroll
@@ -346,7 +416,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         // every tile is on its way: one barrier per remaining tile, waiting for exactly the tiles behind it
         for (; t + 1 < nTiles; ++t) {
             const int behind = nTiles - t - 2;             // tiles issued after tile t+1: 0 .. S-2
-            if (behind <= 0) CTAMD_WAIT_VMCNT(0);
+            if (behind <= 0) { CTAMD_WAIT_VMCNT(0); fix_last(); }   // tile t + 1 is the last one
             else if (behind == 1) CTAMD_WAIT_VMCNT(LOADS);
             else if (behind == 2) CTAMD_WAIT_VMCNT(LOADS * 2);
             else if (behind == 3) CTAMD_WAIT_VMCNT((S > 4 ? LOADS * 3 : 0));
@@ -837,6 +907,15 @@ hipError_t launch_splitk_reduce_frag(const SplitKReduceParams& p, hipStream_t st
 // ---------------------------------------------------------------------------------------------
 template <class Cfg>
 static hipError_t launch_stream(const GettParams& p, hipStream_t stream) {
+    if constexpr (Cfg::ABL == 0) {
+        // ragged K (one contracted mode) or operands without 16-byte lanes (rank_contraction_choices): the RAG twin of this tile on the
+        // 4-deep ring — masked + repaired last K-tile, descriptors that end with the tensor
+        if (p.gK.total % (uint32_t)kStreamBK != 0u || (p.ragged & 1u) != 0u) {
+            using R = StreamCfg<Cfg::BM, Cfg::BN, Cfg::LA, Cfg::LB, 4, 0, true>;
+            hipLaunchKernelGGL(gett_f32_stream_kernel<R>, dim3(p.nBlocks), dim3(512), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(gett_f32_stream_kernel<Cfg>, dim3(p.nBlocks), dim3(512), 0, stream, p);
     return hipGetLastError();
 }

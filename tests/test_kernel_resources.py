@@ -125,7 +125,7 @@ def test_fp32_stream_kernels_do_not_spill_vector_registers(built, tmp_path):
 
 
 @pytest.mark.parametrize("obj,symbol", [
-    ("gett_f32_stream", "_ZN5ctamd22gett_f32_stream_kernelINS_9StreamCfgILi96ELi96ELi1ELi0ELi3ELi0EEEEEvNS_10GettParamsE"),
+    ("gett_f32_stream", "_ZN5ctamd22gett_f32_stream_kernelINS_9StreamCfgILi96ELi96ELi1ELi0ELi3ELi0ELb0EEEEEvNS_10GettParamsE"),
     ("gett_h16v", "_ZN5ctamd18gett_h16w4x_kernelILb1ELi1ELi0ELb0ELi0ELb0EEEvNS_10GettParamsE"),
     ("gett_h16p", "_ZN5ctamd18gett_h16w4p_kernelILb1ELi1ELi0ELi2ELb0EEEvNS_10GettParamsE"),
 ])

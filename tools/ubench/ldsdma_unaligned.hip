@@ -89,6 +89,40 @@ static void check_store(char* ddst, const char* dsrc, const std::vector<uint8_t>
         }
 }
 
+// range check WITH a scalar offset (the fp32 streaming kernels put the K-tile's byte offset into soffset): is soffset part of what is
+// compared with num_records?  Lane l reads 16 bytes at soff + (records - soff - 16 + 4 l).
+__global__ void __launch_bounds__(64, 1) land_soff(const char* src, uint32_t records, uint32_t soff, uint32_t* out) {
+    __shared__ __attribute__((aligned(16))) char lds[1024];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) reinterpret_cast<uint32_t*>(lds)[i] = 0xdeadbeefu;
+    __syncthreads();
+    const rsrc_t rs = make_rsrc((uint64_t)(uintptr_t)src, records);
+    const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const uint32_t off = records - soff - 16u + 4u * (uint32_t)lane;
+    const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)soff);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_waitcnt vmcnt(0)" ::"s"(ldsBase), "v"(off), "s"(rs), "s"(so) : "memory");
+    __syncthreads();
+    for (int i = lane; i < 256; i += 64) out[i] = reinterpret_cast<uint32_t*>(lds)[i];
+}
+static void check_range_soff(const char* dsrc, const std::vector<uint8_t>& hsrc, uint32_t* dout) {
+    const uint32_t records = 8192u;
+    for (uint32_t soff : {0u, 4096u}) {
+        hipLaunchKernelGGL(land_soff, dim3(1), dim3(64), 0, nullptr, dsrc, records, soff, dout);
+        hipDeviceSynchronize();
+        std::vector<uint8_t> got(1024);
+        hipMemcpy(got.data(), dout, 1024, hipMemcpyDeviceToHost);
+        for (int lane = 0; lane <= 5; ++lane) {
+            char line[64] = {0};
+            for (int b = 0; b < 16; ++b) {
+                const size_t at = (size_t)records - 16 + 4 * lane + b;
+                const uint8_t g = got[lane * 16 + b];
+                line[b] = (g == hsrc[at]) ? (at < records ? 'd' : 'X') : (g == 0 ? '0' : '?');
+            }
+            printf("{\"test\":\"range with soffset\",\"records\":%u,\"soffset\":%u,\"unit_start_rel_end\":%d,\"bytes\":\"%s\"}\n", records, soff, 4 * lane - 16, line);
+        }
+    }
+}
+
 // range check: lanes 0..8 read 16 bytes at records - 16 + 2 * lane (lane 0 whole inside, lane 8 whole outside)
 static void check_range(const char* dsrc, const std::vector<uint8_t>& hsrc, uint32_t* dout) {
     for (uint32_t records : {4096u, 4098u, 4100u, 4104u}) {
@@ -215,6 +249,7 @@ int main() {
     check_land<1>(d, h, out, 8194u);
     check_land<2>(d, h, out, 66u);
     check_range(d, h, out);
+    check_range_soff(d, h, out);
     // descriptor BASE misaligned by 2 / 6 / 10 bytes (the kernels put a per-wave minimum offset into the base)
     for (uint32_t b : {2u, 6u, 10u}) {
         std::vector<uint8_t> hs(h.begin() + b, h.end());
