@@ -258,6 +258,61 @@ static bool peel_wide_contraction(const cutensorOperationDescriptor& desc, cuten
     }
     return false;
 }
+// Contractions with a mode that ONE input carries and nothing else ('ijk,kl->il': j).  cutensorCreateContraction's GEMM view has no
+// group for such a mode, but the reference's N-ary front end builds exactly these steps — _compute_target_tensor drops every mode no
+// later operand or the target needs (cuTENSOR/python/cutensor/torch/einsum.py:111-156) — and torch.einsum, its comparator, sums the
+// mode away.  Here: the operand is reduced over its lone modes first (cutensorReduce, OP_ADD) into a packed temporary in the workspace,
+// then the ordinary contraction runs on the temporary.  (Summing first is also the cheap order: the contraction shrinks by the mode's
+// extent.)  Returns false when the descriptor has no such mode; fills `inner` (the contraction on the temporaries) and the
+// reductions otherwise.
+struct LoneSplit {
+    cutensorOperationDescriptor inner, redA, redB;
+    bool hasA = false, hasB = false;
+    uint64_t bytesA = 0, bytesB = 0;       // packed sizes of the temporaries
+};
+static bool split_lone_modes(const cutensorOperationDescriptor& desc, LoneSplit& out) {
+    auto has = [](const std::vector<int32_t>& v, int32_t l) { return std::find(v.begin(), v.end(), l) != v.end(); };
+    auto reduce_operand = [&](const TensorUse& X, const TensorUse& other, cutensorOperationDescriptor& red, TensorUse& kept, uint64_t& bytes) {
+        bool lone = false;
+        for (size_t i = 0; i < X.modes.size(); ++i)
+            if (X.desc.extent[i] != 1 && !has(other.modes, X.modes[i]) && !has(desc.C.modes, X.modes[i])) lone = true;
+        if (!lone) return false;
+        kept = TensorUse{};
+        kept.present = true;
+        kept.op = X.op;                                         // conj(sum) = sum(conj): the inner contraction conjugates
+        kept.desc.dtype = X.desc.dtype;
+        kept.desc.alignment = 256;                              // a 256-byte-aligned piece of the workspace
+        int64_t run = 1;
+        for (size_t i = 0; i < X.modes.size(); ++i) {
+            if (!has(other.modes, X.modes[i]) && !has(desc.C.modes, X.modes[i])) continue;   // summed away (extent-1 lone modes too)
+            kept.modes.push_back(X.modes[i]);
+            kept.desc.extent.push_back(X.desc.extent[i]);
+            kept.desc.stride.push_back(run);
+            run *= X.desc.extent[i];
+        }
+        kept.desc.numModes = (uint32_t)kept.modes.size();
+        bytes = (uint64_t)run * dtype_size(X.desc.dtype);
+        red = cutensorOperationDescriptor{};
+        red.kind = OpKind::Reduction;
+        red.A = X;
+        red.A.op = CUTENSOR_OP_IDENTITY;
+        red.C = kept; red.C.op = CUTENSOR_OP_IDENTITY;
+        red.D = red.C;
+        red.opReduce = CUTENSOR_OP_ADD;
+        red.compute = desc.compute;
+        red.scalarType = desc.scalarType;
+        return true;
+    };
+    TensorUse keptA, keptB;
+    out.hasA = reduce_operand(desc.A, desc.B, out.redA, keptA, out.bytesA);
+    out.hasB = reduce_operand(desc.B, desc.A, out.redB, keptB, out.bytesB);
+    if (!out.hasA && !out.hasB) return false;
+    out.inner = desc;
+    if (out.hasA) out.inner.A = keptA;
+    if (out.hasB) out.inner.B = keptB;
+    return true;
+}
+
 // pointer alignment the offset operands of a peeled contraction still have
 static void peel_fix_alignment(cutensorOperationDescriptor& inner, const std::vector<PeelMode>& peel) {
     const int64_t es = (int64_t)dtype_size(inner.A.desc.dtype);
@@ -448,6 +503,21 @@ cutensorStatus_t cutensorCreateContraction(const cutensorHandle_t handle, cutens
     op.scalarType = scalar_type_for(op.A.desc.dtype, descCompute);
     ContractionView v;
     std::string why;
+    {
+        LoneSplit ls;     // a mode only one input carries: validated as the reduction(s) + the contraction on the temporaries (split_lone_modes)
+        if (split_lone_modes(op, ls)) {
+            ReducePlan rp;
+            if (ls.hasA && (st = plan_reduction(ls.redA, 0, handle->numCUs, rp, &why)) != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateContraction: %s", why.c_str()); return st; }
+            if (ls.hasB && (st = plan_reduction(ls.redB, 0, handle->numCUs, rp, &why)) != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateContraction: %s", why.c_str()); return st; }
+            st = build_contraction_view(ls.inner, v, &why);
+            if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateContraction: %s", why.c_str()); return st; }
+            op.flops = 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK + (ls.hasA ? num_elements(op.A.desc) : 0.0) +
+                       (ls.hasB ? num_elements(op.B.desc) : 0.0);
+            const double esz = (double)dtype_size(op.A.desc.dtype);
+            op.movedBytes = esz * (num_elements(op.A.desc) + num_elements(op.B.desc) + num_elements(op.D.desc));
+            return new_op(desc, op);
+        }
+    }
     st = build_contraction_view(op, v, &why);
     if (st != CUTENSOR_STATUS_SUCCESS) { CT_LOG("cutensorCreateContraction: %s", why.c_str()); return st; }
     // contraction.cu:61 / :274-276
@@ -778,6 +848,18 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
     if (workspacePref == CUTENSOR_WORKSPACE_MIN) return CUTENSOR_STATUS_SUCCESS;
     const uint64_t cap = (workspacePref == CUTENSOR_WORKSPACE_MAX) ? (4ull << 30) : (1ull << 30);
     if (desc->kind == OpKind::Contraction) {
+        {
+            LoneSplit ls;     // the temporaries + the largest need of the reductions and the inner contraction
+            if (split_lone_modes(*desc, ls)) {
+                uint64_t wI = 0, wA = 0, wB = 0;
+                cutensorStatus_t st = cutensorEstimateWorkspaceSize(handle, &ls.inner, planPref, workspacePref, &wI);
+                if (st == CUTENSOR_STATUS_SUCCESS && ls.hasA) st = cutensorEstimateWorkspaceSize(handle, &ls.redA, planPref, workspacePref, &wA);
+                if (st == CUTENSOR_STATUS_SUCCESS && ls.hasB) st = cutensorEstimateWorkspaceSize(handle, &ls.redB, planPref, workspacePref, &wB);
+                if (st != CUTENSOR_STATUS_SUCCESS) return st;
+                *workspaceSizeEstimate = ((ls.bytesA + 255) & ~255ull) + ((ls.bytesB + 255) & ~255ull) + std::max(wI, std::max(wA, wB));
+                return CUTENSOR_STATUS_SUCCESS;
+            }
+        }
         ContractionView v;
         cutensorStatus_t st = build_contraction_view(*desc, v, nullptr);
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
@@ -1094,6 +1176,26 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
     }
 
     if (desc->kind == OpKind::Contraction) {
+        LoneSplit ls;
+        if (split_lone_modes(*desc, ls)) {
+            // reduce the operand(s) over the modes nothing else carries into packed temporaries at the head of the workspace, then contract
+            const uint64_t offB = (ls.bytesA + 255) & ~255ull, offW = offB + ((ls.bytesB + 255) & ~255ull);
+            if (workspaceSizeLimit < offW) { delete pl; CT_LOG("cutensorCreatePlan: a contraction with a mode that one input alone carries needs %llu bytes for its temporaries", (unsigned long long)offW); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
+            cutensorPlan_t pi = nullptr, pa = nullptr, pb = nullptr;
+            st = cutensorCreatePlan(handle, &pi, &ls.inner, pref, workspaceSizeLimit - offW);
+            if (st == CUTENSOR_STATUS_SUCCESS && ls.hasA) st = cutensorCreatePlan(handle, &pa, &ls.redA, pref, workspaceSizeLimit - offW);
+            if (st == CUTENSOR_STATUS_SUCCESS && ls.hasB) st = cutensorCreatePlan(handle, &pb, &ls.redB, pref, workspaceSizeLimit - offW);
+            if (st != CUTENSOR_STATUS_SUCCESS) { delete pi; delete pa; delete pb; delete pl; return st; }
+            pl->sub1 = pi; pl->loneA = pa; pl->loneB = pb;
+            pl->loneBytesA = ls.bytesA; pl->loneBytesB = ls.bytesB;
+            pl->choice = ContractionChoice{};
+            pl->choice.kernel = -4;
+            pl->requiredWorkspace = offW + std::max<uint64_t>(pi->requiredWorkspace, std::max<uint64_t>(pa ? pa->requiredWorkspace : 0, pb ? pb->requiredWorkspace : 0));
+            CT_LOG("plan: contraction with modes that one input alone carries -> %s%sreduced first (%llu + %llu bytes of temporaries), then the contraction",
+                   pa ? "A " : "", pb ? "B " : "", (unsigned long long)ls.bytesA, (unsigned long long)ls.bytesB);
+            *plan = pl;
+            return CUTENSOR_STATUS_SUCCESS;
+        }
         st = build_contraction_view(*desc, pl->view, &why);
         if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
         if (pl->view.wide && !(std::getenv("CUTENSOR_AMD_PEEL") && std::getenv("CUTENSOR_AMD_PEEL")[0] == '0')) {
@@ -1392,6 +1494,8 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
 cutensorPlan::~cutensorPlan() {
     delete sub1;
     delete sub2;
+    delete loneA;
+    delete loneB;
     if (wide.modes != nullptr) (void)hipFree(const_cast<ctamd::WideMode*>(wide.modes));
 }
 
@@ -1430,6 +1534,30 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
     if (plan->requiredWorkspace > 0 && (workspace == nullptr || workspaceSize < plan->requiredWorkspace))
         return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE;
 
+    if (plan->choice.kernel == -4) {
+        // a mode that one input alone carries (split_lone_modes): reduce that input over it into its temporary, contract the temporaries
+        if (plan->sub1 == nullptr) return CUTENSOR_STATUS_INVALID_VALUE;
+        const uint64_t offB = (plan->loneBytesA + 255) & ~255ull, offW = offB + ((plan->loneBytesB + 255) & ~255ull);
+        char* ws = static_cast<char*>(workspace);
+        const float onef[2] = {1.f, 0.f}, zerof[2] = {0.f, 0.f};
+        const double oned[2] = {1.0, 0.0}, zerod[2] = {0.0, 0.0};
+        const bool wideScalar = plan->scalarType == HIP_R_64F || plan->scalarType == HIP_C_64F;
+        const void* one = wideScalar ? static_cast<const void*>(oned) : static_cast<const void*>(onef);
+        const void* zero = wideScalar ? static_cast<const void*>(zerod) : static_cast<const void*>(zerof);
+        const void* a = A;
+        const void* bb = B;
+        cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+        if (plan->loneA) {
+            st = cutensorReduce(handle, plan->loneA, one, A, zero, ws, ws, ws + offW, workspaceSize - offW, stream);
+            a = ws;
+        }
+        if (st == CUTENSOR_STATUS_SUCCESS && plan->loneB) {
+            st = cutensorReduce(handle, plan->loneB, one, B, zero, ws + offB, ws + offB, ws + offW, workspaceSize - offW, stream);
+            bb = ws + offB;
+        }
+        if (st != CUTENSOR_STATUS_SUCCESS) return st;
+        return cutensorContract(handle, plan->sub1, alpha, a, bb, beta, C, D, ws + offW, workspaceSize - offW, stream);
+    }
     if (plan->choice.kernel == -3) {
         // peeled contraction: every index combination of the peeled modes is one launch of the inner plan on offset operands;
         // a combination whose contracted indices are all zero writes its region of D first (caller's beta, caller's C), the
@@ -1856,6 +1984,16 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
         const int m = ctamdDescribePlan(plan->sub1, buf + n - 1, len - (size_t)n + 1);   // overwrite our '{' + keep theirs: splice below
         if (m < 0) return -1;
         // buf now holds  {"peeled_modes":..,"peel_launches":..   followed (from n - 1) by the inner object  {...}: turn its '{' into ','
+        buf[n - 1] = ',';
+        return n - 1 + m;
+    }
+    if (plan->kind == OpKind::Contraction && plan->choice.kernel == -4 && plan->sub1 != nullptr) {
+        // a mode that one input alone carries: which operands are reduced first, then the inner contraction's description
+        n = std::snprintf(buf, len, "{\"lone_reduce_A\":%d,\"lone_reduce_B\":%d,\"lone_bytes\":%llu,", plan->loneA ? 1 : 0, plan->loneB ? 1 : 0,
+                          (unsigned long long)(plan->loneBytesA + plan->loneBytesB));
+        if (n < 0 || (size_t)n >= len) return -1;
+        const int m = ctamdDescribePlan(plan->sub1, buf + n - 1, len - (size_t)n + 1);
+        if (m < 0) return -1;
         buf[n - 1] = ',';
         return n - 1 + m;
     }

@@ -209,6 +209,11 @@ struct cutensorPlan {
     cutensorPlan* sub1 = nullptr;                    // (also: the inner plan of a peeled contraction, choice.kernel == -3)
     cutensorPlan* sub2 = nullptr;
     std::vector<PeelMode> peel;
+    // contraction with a mode that one input alone carries (choice.kernel == -4, api.cpp split_lone_modes): reductions of A / B over
+    // those modes into packed temporaries at the head of the workspace (nullptr: the operand is used as it is); sub1 = the contraction
+    cutensorPlan* loneA = nullptr;
+    cutensorPlan* loneB = nullptr;
+    uint64_t    loneBytesA = 0, loneBytesB = 0;
     uint64_t    tBytes = 0;
     int         triOrder[3] = {0, 1, 2};
     OpKind      kind;

@@ -235,3 +235,23 @@ def test_against_reference_golden_at_the_reference_extents(name):
              "complex64": dict(rtol=2e-4, atol=2e-4)}.get(dt, dict(rtol=1e-12, atol=1e-12))
     np.testing.assert_allclose(got, ref, **tight)
     np.testing.assert_allclose(np.abs(np.asarray(out)).sum(), float(z["sum_abs"]), rtol=1e-3 if dt in ("float16", "bfloat16") else 1e-5)
+
+
+@pytest.mark.parametrize("eq,sa,sb", [("ijk,kl->il", (3, 4, 5), (5, 6)), ("ij,jk->k", (3, 4), (4, 5)), ("ik,jkl->ij", (3, 5), (4, 5, 2)),
+                                      ("aij,kbj->ik", (2, 3, 5), (4, 3, 5)), ("ij,kl->", (3, 4), (2, 5)), ("bij,bjk->bk", (2, 3, 5), (2, 5, 4))])
+def test_modes_that_one_input_alone_carries_are_summed_over_it(eq, sa, sb):
+    """'ijk,kl->il': j lives in A alone — K is every mode the output does not carry (torch.einsum's reading; the pairwise steps
+    cuTENSOR/python/cutensor/torch/einsum.py:111-156 builds).  Every dtype's entry point against numpy.einsum."""
+    rng = np.random.default_rng(5)
+    for dt, rtol in ((np.float32, 1e-5), (np.float64, 1e-12), (np.complex64, 1e-5), (np.complex128, 1e-12)):
+        a = rng.random(sa).astype(dt)
+        b = rng.random(sb).astype(dt)
+        if np.issubdtype(dt, np.complexfloating):
+            a = a + 1j * rng.random(sa).astype(dt)
+            b = b - 1j * rng.random(sb).astype(dt)
+        np.testing.assert_allclose(oracle.einsum(eq, a, b), np.einsum(eq, a, b), rtol=rtol)
+    for kind in ("bf16", "f16"):
+        a = oracle.to_bits(rng.random(sa), kind)
+        b = oracle.to_bits(rng.random(sb), kind)
+        want = np.einsum(eq, oracle.from_bits(a, kind), oracle.from_bits(b, kind))
+        np.testing.assert_allclose(oracle.from_bits(oracle.einsum(eq, a, b, h16=kind), kind), want, rtol=2.0 ** -8 if kind == "bf16" else 2.0 ** -11)
