@@ -119,8 +119,15 @@ def test_error_behaviour(ct, ops):
     with pytest.raises(ct.CuTensorError) as e:      # extent mismatch between A and B for mode k
         ops.contraction_plan(h, [4, 5], "mk", [6, 7], "kn", [4, 7], "mn")
     assert e.value.status == ct.STATUS_INVALID_VALUE
-    with pytest.raises(ct.CuTensorError) as e:      # a mode that appears in one tensor only
-        ops.contraction_plan(h, [4, 5, 3], "mkz", [5, 7], "kn", [4, 7], "mn")
+    # a mode that ONE INPUT alone carries is summed over that input since round 6 (tests/test_gpu_lone_modes.py) ...
+    p = ops.contraction_plan(h, [4, 5, 3], "mkz", [5, 7], "kn", [4, 7], "mn", workspace_limit=1 << 20)
+    assert p.describe()["lone_reduce_A"] == 1 and p.required_workspace >= 4 * 5 * 4
+    p.destroy()
+    with pytest.raises(ct.CuTensorError) as e:      # ... but its temporary lives in the workspace
+        ops.contraction_plan(h, [4, 5, 3], "mkz", [5, 7], "kn", [4, 7], "mn", workspace_limit=0)
+    assert e.value.status == ct.STATUS_INSUFFICIENT_WORKSPACE
+    with pytest.raises(ct.CuTensorError) as e:      # a mode that only the OUTPUT carries (a broadcast) is no contraction
+        ops.contraction_plan(h, [4, 5], "mk", [5, 7], "kn", [4, 7, 3], "mnz")
     assert e.value.status == ct.STATUS_NOT_SUPPORTED
     d = ctypes.c_void_p()
     assert ct.cutensorCreateTensorDescriptor(h.h, ctypes.byref(d), 2, ct.i64([4, -1]), None, ct.R_32F, 128) == ct.STATUS_INVALID_VALUE
