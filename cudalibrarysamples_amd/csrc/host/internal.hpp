@@ -167,7 +167,8 @@ struct ReducePlan {
     EwPlan       perm;
 };
 
-cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why);
+// allowWide = false: never the tiled kernels of 8- / 16-byte elements (the trinary planner: they take no E / X operand)
+cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why, bool allowWide = true);
 cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op, EwTrinaryPlan& plan, std::string* why);
 cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t wsLimit, int numCUs,
                                 ReducePlan& plan, std::string* why);

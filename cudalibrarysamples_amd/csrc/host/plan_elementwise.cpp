@@ -71,7 +71,7 @@ bool fill_rest(ModeGroup& g, const std::vector<EwMode>& modes) {
 
 }  // namespace
 
-cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why) {
+cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan& plan, std::string* why, bool allowWide) {
     auto fail = [&](cutensorStatus_t st, const char* msg) {
         if (why) *why = msg;
         return st;
@@ -166,8 +166,11 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     // ---- variant --------------------------------------------------------------------------
     // vector paths: fp32 (4-element lanes) and bf16 / fp16 (8-element lanes); "mult4" = multiple of the lane width
     const bool h16 = D.desc.dtype == HIP_R_16BF || D.desc.dtype == HIP_R_16F;
-    const bool f32 = D.desc.dtype == HIP_R_32F || (h16 && !usesX);
-    const int64_t vec = h16 ? 8 : 4;
+    // 8- / 16-byte elements (round 6; elementwise.hip ew_transpose_wide_kernel / ew_rowcopy_wide_kernel): permutations and binary
+    // operations on fp64 / complex64 / complex128 — a 16-byte lane holds 2 / 2 / 1 elements; never with a trinary operand (E / X)
+    const bool wide = allowWide && !usesX && (D.desc.dtype == HIP_R_64F || cplx);
+    const bool f32 = D.desc.dtype == HIP_R_32F || (h16 && !usesX) || wide;
+    const int64_t vec = wide ? 16 / (int64_t)dtype_size(D.desc.dtype) : h16 ? 8 : 4;
     const bool aligned = (A.desc.alignment % 16 == 0) && (D.desc.alignment % 16 == 0) &&
                          (!usesC || C.desc.alignment % 16 == 0);
     auto mult4 = [vec](int64_t s) { return s % vec == 0; };
@@ -191,6 +194,10 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
                 const int64_t widest = usesX ? 128 : 256;
                 for (int64_t cand = widest; cand > 64; cand /= 2)
                     if (p.E0 % cand == 0 || p.E0 >= 4 * cand) { t0 = (int)cand; break; }
+            } else if (wide) {
+                // fp64 / complex64: 128 x 32 elements (1-KiB written, 256-B read segments); complex128: 64 x 32 (1 KiB / 512 B)
+                t0 = D.desc.dtype == HIP_C_64F ? 64 : 128;
+                t1 = 32;
             } else if (h16 && p.E1 % 64 == 0) {
                 // 16-bit: the wide kernel handles full tiles only (T0 x T1 elements: 512-B / 256-B written, 256-B / 128-B read segments)
                 if (p.E0 % 256 == 0) t0 = 256;
@@ -201,7 +208,7 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
                 }
             }
         } else if (!usesX && p.sA0 == 1 && mult4(p.sA1) && mult4(p.sD1)) {
-            plan.variant = EW_ROWCOPY; t0 = h16 ? 512 : 256; t1 = 8;
+            plan.variant = EW_ROWCOPY; t0 = wide ? 64 * (int)vec : h16 ? 512 : 256; t1 = 8;
         }
     }
     plan.usesX = usesX;
@@ -219,8 +226,8 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     p.order = 0;
     p.idsPerXcd = (uint32_t)((nb + 7) / 8);
     p.divRest = make_fastdiv(p.rest.total);
-    const int64_t esz = h16 ? 2 : 4;
-    if (plan.variant == EW_TRANSPOSE && (D.desc.dtype == HIP_R_32F || (h16 && t0 > 64)) && p.rest.total >= 64 && nb >= 4096 &&
+    const int64_t esz = wide ? (int64_t)dtype_size(D.desc.dtype) : h16 ? 2 : 4;
+    if (plan.variant == EW_TRANSPOSE && (D.desc.dtype == HIP_R_32F || wide || (h16 && t0 > 64)) && p.rest.total >= 64 && nb >= 4096 &&
         p.sA0 * esz >= (1 << 20) && p.sD1 * esz >= (1 << 20))
         p.order = 1;
     return CUTENSOR_STATUS_SUCCESS;
@@ -272,7 +279,7 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
         both.A = op.A;            // tile path
         both.B = op.B;            // second tile (X)
         EwPlan one;
-        if (plan_elementwise(both, one, nullptr) == CUTENSOR_STATUS_SUCCESS && one.usesX && one.variant == EW_TRANSPOSE) {
+        if (plan_elementwise(both, one, nullptr, false) == CUTENSOR_STATUS_SUCCESS && one.usesX && one.variant == EW_TRANSPOSE) {
             plan.twoPass = false;
             plan.bothPermuted = true;
             plan.last = one;
@@ -284,11 +291,11 @@ cutensorStatus_t plan_elementwise_trinary(const cutensorOperationDescriptor& op,
         cutensorOperationDescriptor first = op;
         first.kind = OpKind::Permutation;
         first.C = TensorUse{};
-        cutensorStatus_t st = plan_elementwise(first, plan.first, why);
+        cutensorStatus_t st = plan_elementwise(first, plan.first, why, false);
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
         last.A = op.B;
     }
-    cutensorStatus_t st = plan_elementwise(last, plan.last, why);
+    cutensorStatus_t st = plan_elementwise(last, plan.last, why, false);
     if (st != CUTENSOR_STATUS_SUCCESS) return st;
     plan.last.p.opAB = (int32_t)op.opAB;
     plan.last.p.opAC = (int32_t)op.opReduce;
@@ -369,25 +376,30 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
     p.conjA = (cplx && A.op == CUTENSOR_OP_CONJ) ? 1 : 0;
     p.conjC = (cplx && C.op == CUTENSOR_OP_CONJ) ? 1 : 0;
 
-    const bool f32 = A.desc.dtype == HIP_R_32F;
     const bool acc64 = (op.compute != nullptr && op.compute->id == 5 /*64F*/) || A.desc.dtype == HIP_R_64F;
     const bool aligned = A.desc.alignment % 16 == 0;
-    auto others_mult4 = [&](const EwMode* except) {
-        for (const EwMode& m : kept) if (&m != except && m.sA % 4 != 0) return false;
-        for (const EwMode& m : red)  if (&m != except && m.sA % 4 != 0) return false;
+    // the tiled kernels (reduce.hip): a lane owns 16 bytes = nv elements along A's stride-1 mode — fp32 4; fp64 / complex64 2, complex128 1,
+    // bf16 / fp16 8 (round 6: wide_elem.h); a compute type wider than the data's own (fp32 / complex64 data accumulated in 64 bits) keeps
+    // the generic kernel
+    const int64_t nv = 16 / (int64_t)dtype_size(A.desc.dtype);
+    const bool wider = op.compute != nullptr && op.compute->id == 5 && A.desc.dtype != HIP_R_64F && A.desc.dtype != HIP_C_64F;
+    const bool tiled = aligned && !wider;
+    auto others_mult = [&](const EwMode* except) {
+        for (const EwMode& m : kept) if (&m != except && m.sA % nv != 0) return false;
+        for (const EwMode& m : red)  if (&m != except && m.sA % nv != 0) return false;
         return true;
     };
     plan.variant = RED_GENERIC;
-    if (f32 && !acc64 && aligned) {
-        if (!kept.empty() && kept[0].sA == 1 && kept[0].extent % 4 == 0 && others_mult4(&kept[0])) plan.variant = RED_COL;
-        else if (red[0].sA == 1 && red[0].extent % 4 == 0 && others_mult4(&red[0])) plan.variant = RED_ROW;
+    if (tiled) {
+        if (!kept.empty() && kept[0].sA == 1 && kept[0].extent % nv == 0 && others_mult(&kept[0])) plan.variant = RED_COL;
+        else if (red[0].sA == 1 && red[0].extent % nv == 0 && others_mult(&red[0])) plan.variant = RED_ROW;
     }
 
     // ---- how far to split the reduced range ------------------------------------------------
     const uint64_t keptTot = p.kept.total, redTot = p.red.total;
     uint64_t items, wantItems, minRedPerSplit, gran;
-    if (plan.variant == RED_COL)      { items = keptTot / 4; wantItems = (uint64_t)numCUs * 1024; minRedPerSplit = 32;   gran = 4; }
-    else if (plan.variant == RED_ROW) { items = keptTot;     wantItems = (uint64_t)numCUs * 32;   minRedPerSplit = 8192; gran = 1024; }
+    if (plan.variant == RED_COL)      { items = keptTot / (uint64_t)nv; wantItems = (uint64_t)numCUs * 1024; minRedPerSplit = 32;   gran = 4; }
+    else if (plan.variant == RED_ROW) { items = keptTot;     wantItems = (uint64_t)numCUs * 32;   minRedPerSplit = 8192; gran = 256 * (uint64_t)nv; }
     else                              { items = keptTot;     wantItems = (uint64_t)numCUs * 512;  minRedPerSplit = 64;   gran = 4; }
     uint64_t split = 1;
     if (items < wantItems) split = (wantItems + items - 1) / std::max<uint64_t>(items, 1);

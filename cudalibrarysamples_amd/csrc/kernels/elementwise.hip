@@ -28,6 +28,7 @@
 
 #include "launch.h"
 #include "params.h"
+#include "wide_elem.h"
 
 namespace ctamd {
 
@@ -599,6 +600,147 @@ __global__ void __launch_bounds__(256) ew_generic_cplx_kernel(const Ew2DParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EW_TRANSPOSE / EW_ROWCOPY for 8- and 16-byte elements (fp64, complex64, complex128; round 6, wide_elem.h):
+//   D = opAC(alpha * op(perm(A)), gamma * op(C))       op in {IDENTITY, CONJ}; opAC: ADD / MUL (+ MAX / MIN on fp64)
+// the fp32 kernels' structure with a 16-byte lane = Tr::NV elements (2 / 2 / 1).  Transposing form: a T0 x T1 tile (T0 along dim0 = D's
+// stride-1 mode: 1-KiB written row segments; T1 along dim1 = A's stride-1 mode: 256-B read segments) is read with 16-byte lanes along
+// dim1, NV rows per lane, transposed NV x NV in registers, parked in LDS as [dim1][dim0] and written with 16-byte lanes along dim0.
+// Planner conditions (plan_elementwise): sD0 == 1, sA1 == 1 (transposing) or sA0 == 1 (row copy), extents and every other stride
+// multiples of NV, 16-byte-aligned descriptors, no E / X operand.  HBM-bound: 2 |D| bytes (+ |C|).
+// ---------------------------------------------------------------------------------------------
+template <class Tr>
+__device__ __forceinline__ typename Tr::Acc w_ew_finish(const Ew2DParams& p, typename Tr::Acc a, const typename Tr::Elem* cp, bool hasC) {
+    typename Tr::Acc v = Tr::scale(p.alpha64, p.alphaIm, a);
+    if (hasC) v = Tr::apply(p.opAC == 0 ? W_OP_ADD : p.opAC, v, Tr::scale(p.gamma64, p.gammaIm, Tr::load1(cp, Tr::CX && p.conjC != 0)));
+    return v;
+}
+
+template <class Tr, int T0, int T1>
+__global__ void __launch_bounds__(256) ew_transpose_wide_kernel(const Ew2DParams p) {
+    typedef typename Tr::Elem Elem;
+    typedef typename Tr::Acc Acc;
+    constexpr int NV = Tr::NV;
+    constexpr int LD = T0 + NV;                     // LDS row stride (elements)
+    constexpr int LPR = T1 / NV;                    // read: lanes per dim0 row
+    constexpr int RPP = (256 / LPR) * NV;           //       dim0 rows per pass
+    constexpr int RD_PASSES = T0 / RPP;
+    constexpr int LPW = T0 / NV;                    // write: lanes per dim1 row
+    constexpr int RPW = 256 / LPW;                  //        dim1 rows per pass
+    constexpr int WR_PASSES = T1 / RPW;
+    static_assert(T0 % RPP == 0 && T1 % RPW == 0 && 256 % LPR == 0 && 256 % LPW == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) Elem tile[T1 * LD];   // [dim1][dim0]
+    const Elem* A = static_cast<const Elem*>(p.A);
+    const Elem* C = static_cast<const Elem*>(p.C);
+    Elem*       D = static_cast<Elem*>(p.D);
+    const int tid = threadIdx.x;
+    const bool conjA = Tr::CX && p.conjA != 0;
+    const uint32_t nIds = p.order ? 8u * p.idsPerXcd : p.nBlocks;
+    for (uint32_t b = blockIdx.x; b < nIds; b += gridDim.x) {
+        TileId t;
+        if (!ordered_tile(p, b, t)) continue;
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t i0 = t.t0 * T0, i1 = t.t1 * T1;
+        const bool full = (i0 + T0 <= p.E0) && (i1 + T1 <= p.E1);
+        {   // ---- read: lane -> (dim1 unit c1 = tid % LPR, dim0 rows r0 .. r0 + NV - 1), RD_PASSES passes
+            const int      l1 = NV * (tid % LPR);
+            const uint32_t c1 = i1 + l1;
+            wu32x4 in[RD_PASSES][NV];
+#pragma unroll
+            for (int ps = 0; ps < RD_PASSES; ++ps) {
+                const uint32_t r0 = i0 + NV * (tid / LPR) + RPP * ps;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) {
+                    in[ps][r] = wu32x4{0u, 0u, 0u, 0u};
+                    if (full || (c1 < p.E1 && (r0 + r) < p.E0))
+                        in[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const wu32x4*>(A + oA + (int64_t)(r0 + r) * p.sA0 + c1));
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < RD_PASSES; ++ps) {
+                const int l0 = NV * (tid / LPR) + RPP * ps;
+                // NV x NV register transpose: unit j of the output = element j of every input row
+                Acc v[NV][NV];
+#pragma unroll
+                for (int r = 0; r < NV; ++r) Tr::unpack(in[ps][r], v[r], conjA);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    Acc o[NV];
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) o[r] = v[r][j];
+                    *reinterpret_cast<wu32x4*>(&tile[(l1 + j) * LD + l0]) = Tr::pack(o);
+                }
+            }
+        }
+        __syncthreads();
+        {   // ---- write: lane -> (dim0 unit c0 = tid % LPW, dim1 row tid / LPW + RPW * pass)
+            const int      l0 = NV * (tid % LPW);
+            const uint32_t c0 = i0 + l0;
+#pragma unroll 2
+            for (int pass = 0; pass < WR_PASSES; ++pass) {
+                const int      lr = tid / LPW + RPW * pass;
+                const uint32_t r1 = i1 + lr;
+                if (full || (c0 < p.E0 && r1 < p.E1)) {
+                    Acc v[NV];
+                    Tr::unpack(*reinterpret_cast<const wu32x4*>(&tile[lr * LD + l0]), v, false);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e)
+                        v[e] = w_ew_finish<Tr>(p, v[e], C + oC + (int64_t)r1 * p.sC1 + (int64_t)(c0 + e) * p.sC0, C != nullptr);
+                    __builtin_nontemporal_store(Tr::pack(v), reinterpret_cast<wu32x4*>(D + oD + (int64_t)r1 * p.sD1 + c0));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// row copy: A and D share the stride-1 mode — tile = 64 lanes x NV dim0 elements x 8 dim1 rows (4 waves x 2 rows), no LDS
+template <class Tr>
+__global__ void __launch_bounds__(256) ew_rowcopy_wide_kernel(const Ew2DParams p) {
+    typedef typename Tr::Elem Elem;
+    typedef typename Tr::Acc Acc;
+    constexpr int NV = Tr::NV;
+    const Elem* A = static_cast<const Elem*>(p.A);
+    const Elem* C = static_cast<const Elem*>(p.C);
+    Elem*       D = static_cast<Elem*>(p.D);
+    const int tid = threadIdx.x;
+    const bool conjA = Tr::CX && p.conjA != 0;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * (64u * NV) + (uint32_t)NV * (tid & 63);
+        if (c0 >= p.E0) continue;
+        wu32x4 raw[2];
+        uint32_t r1[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            r1[r] = t.t1 * 8u + (tid >> 6) * 2 + r;
+            raw[r] = wu32x4{0u, 0u, 0u, 0u};
+            if (r1[r] < p.E1) raw[r] = __builtin_nontemporal_load(reinterpret_cast<const wu32x4*>(A + oA + (int64_t)r1[r] * p.sA1 + c0));
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r1[r] >= p.E1) continue;
+            Acc v[NV];
+            Tr::unpack(raw[r], v, conjA);
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                v[e] = w_ew_finish<Tr>(p, v[e], C + oC + (int64_t)r1[r] * p.sC1 + (int64_t)(c0 + e) * p.sC0, C != nullptr);
+            __builtin_nontemporal_store(Tr::pack(v), reinterpret_cast<wu32x4*>(D + oD + (int64_t)r1[r] * p.sD1 + c0));
+        }
+    }
+}
+
+template <class Tr, int T0, int T1>
+static hipError_t launch_wide_ew(const Ew2DParams& p, int variant, unsigned grid, hipStream_t stream) {
+    if (p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;    // the planner never pairs these variants with a trinary operand
+    if (variant == EW_TRANSPOSE) hipLaunchKernelGGL((ew_transpose_wide_kernel<Tr, T0, T1>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ew_rowcopy_wide_kernel<Tr>, dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 // Contiguous fill with 16-byte stores (HBM-bound: n * sizeof(T) bytes written).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct FillPattern { uint32_t w[4]; };
@@ -683,6 +825,12 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
         hipLaunchKernelGGL(ew_rowcopy_h16_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
     } else if (variant == EW_ROWCOPY && dtype == HIP_R_16F) {
         hipLaunchKernelGGL(ew_rowcopy_h16_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
+    } else if ((variant == EW_TRANSPOSE || variant == EW_ROWCOPY) && dtype == HIP_R_64F) {
+        return launch_wide_ew<WF64, 128, 32>(p, variant, grid, stream);
+    } else if ((variant == EW_TRANSPOSE || variant == EW_ROWCOPY) && dtype == HIP_C_32F) {
+        return launch_wide_ew<WCplx<float>, 128, 32>(p, variant, grid, stream);
+    } else if ((variant == EW_TRANSPOSE || variant == EW_ROWCOPY) && dtype == HIP_C_64F) {
+        return launch_wide_ew<WCplx<double>, 64, 32>(p, variant, grid, stream);
     } else if (variant == EW_GENERIC) {
         switch (dtype) {
             case HIP_R_32F:  hipLaunchKernelGGL(ew_generic_kernel<float>, dim3(grid), dim3(256), 0, stream, p); break;

@@ -25,6 +25,7 @@
 
 #include "launch.h"
 #include "params.h"
+#include "wide_elem.h"
 
 namespace ctamd {
 
@@ -172,6 +173,143 @@ __global__ void __launch_bounds__(256) reduce_row_f32_kernel(const ReduceParams 
 }
 
 // ---------------------------------------------------------------------------------------------
+// RED_COL / RED_ROW for every other element type (round 6; wide_elem.h): fp64, complex64, complex128 in the data's own precision,
+// bf16 / fp16 with fp32 accumulation.  The fp32 kernels above, with a 16-byte lane = Tr::NV elements (2 / 2 / 1 / 8) and the
+// arithmetic of the traits class: ADD / MUL / MAX / MIN on real data, ADD / MUL with conjugation of A on complex data.  Partials are
+// [splitR][kept] values of the accumulator type — what reduce_finalize_kernel / reduce_finalize_cplx_kernel fold.
+// ---------------------------------------------------------------------------------------------
+template <class Tr>
+__device__ __forceinline__ void w_finish(const ReduceParams& p, uint32_t k, typename Tr::Acc acc) {
+    typedef typename Tr::Elem Elem;
+    typename Tr::Acc val = Tr::scale(p.alpha64, p.alphaIm, acc);
+    if (p.beta64 != 0.0 || (Tr::CX && p.betaIm != 0.0))
+        val = Tr::apply(W_OP_ADD, val, Tr::scale(p.beta64, p.betaIm, Tr::load1(static_cast<const Elem*>(p.C) + rd_offset<2>(p.kept, k), Tr::CX && p.conjC != 0)));
+    Tr::store1(static_cast<Elem*>(p.D) + rd_offset<1>(p.kept, k), val);
+}
+
+template <class Tr>
+__global__ void __launch_bounds__(256) reduce_col_wide_kernel(const ReduceParams p) {
+    typedef typename Tr::Elem Elem;
+    typedef typename Tr::Acc Acc;
+    constexpr int NV = Tr::NV;
+    const uint32_t unit = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t kv = unit * (uint32_t)NV;
+    if (kv >= p.kept.total) return;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const bool conj = Tr::CX && p.conjA != 0;
+    const Elem* A = static_cast<const Elem*>(p.A) + rd_offset<0>(p.kept, kv);
+    Acc acc[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[e] = Tr::identity(op);
+    uint32_t r = rBegin;
+    if (p.red.n == 1) {        // one reduced mode: eight rows in flight per lane, addresses one addition apart
+        const int64_t step = p.red.stride[0][0];
+        const Elem* q = A + (int64_t)r * step;
+        for (; r + 8 <= rEnd; r += 8, q += 8 * step) {
+            wu32x4 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const wu32x4*>(q + (int64_t)u * step));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                Acc v[NV];
+                Tr::unpack(raw[u], v, conj);
+#pragma unroll
+                for (int e = 0; e < NV; ++e) acc[e] = Tr::apply(op, acc[e], v[e]);
+            }
+        }
+    }
+    for (; r + 4 <= rEnd; r += 4) {
+        wu32x4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const wu32x4*>(A + rd_offset<0>(p.red, r + u)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Acc v[NV];
+            Tr::unpack(raw[u], v, conj);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) acc[e] = Tr::apply(op, acc[e], v[e]);
+        }
+    }
+    for (; r < rEnd; ++r) {
+        Acc v[NV];
+        Tr::unpack(*reinterpret_cast<const wu32x4*>(A + rd_offset<0>(p.red, r)), v, conj);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[e] = Tr::apply(op, acc[e], v[e]);
+    }
+    if (p.partial != nullptr) {
+        Acc* P = static_cast<Acc*>(p.partial) + (size_t)split * p.kept.total + kv;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) P[e] = acc[e];
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) w_finish<Tr>(p, kv + e, acc[e]);
+}
+
+// one wave per (kept element, split): its lanes stride over the reduced range with 16-byte loads (reduced mode 0 is contiguous, its
+// extent and redPerSplit multiples of NV) and meet through lane shuffles
+template <class Tr>
+__global__ void __launch_bounds__(256) reduce_row_wide_kernel(const ReduceParams p) {
+    typedef typename Tr::Elem Elem;
+    typedef typename Tr::Acc Acc;
+    constexpr int NV = Tr::NV;
+    constexpr uint32_t CH = 64u * NV;          // elements one wave-load covers
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= p.kept.total) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const bool conj = Tr::CX && p.conjA != 0;
+    const Elem* A = static_cast<const Elem*>(p.A) + rd_offset<0>(p.kept, k);
+    Acc acc = Tr::identity(op);
+    uint32_t r = rBegin + (uint32_t)NV * (uint32_t)lane;
+    for (; r + 3u * CH < rEnd; r += 4u * CH) {
+        wu32x4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = __builtin_nontemporal_load(reinterpret_cast<const wu32x4*>(A + rd_offset<0>(p.red, r + CH * u)));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Acc v[NV];
+            Tr::unpack(raw[u], v, conj);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) acc = Tr::apply(op, acc, v[e]);
+        }
+    }
+    for (; r < rEnd; r += CH) {
+        Acc v[NV];
+        Tr::unpack(*reinterpret_cast<const wu32x4*>(A + rd_offset<0>(p.red, r)), v, conj);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc = Tr::apply(op, acc, v[e]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = Tr::apply(op, acc, Tr::shfl_down(acc, off));
+    if (lane != 0) return;
+    if (p.partial != nullptr) {
+        static_cast<Acc*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
+        return;
+    }
+    w_finish<Tr>(p, k, acc);
+}
+
+template <class Tr>
+static void launch_wide_t(const ReduceParams& p, int variant, hipStream_t stream) {
+    if (variant == RED_COL) {
+        const dim3 grid(((p.kept.total / (uint32_t)Tr::NV) + 255u) / 256u, p.splitR);
+        hipLaunchKernelGGL(reduce_col_wide_kernel<Tr>, grid, dim3(256), 0, stream, p);
+    } else {
+        const dim3 grid((p.kept.total + 3u) / 4u, p.splitR);
+        hipLaunchKernelGGL(reduce_row_wide_kernel<Tr>, grid, dim3(256), 0, stream, p);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // RED_GENERIC: any dtype / strides.  One lane per (kept element, split).
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ double rg_load(const T* p) { return (double)(*p); }
@@ -296,6 +434,15 @@ hipError_t launch_reduce(const ReduceParams& p, int variant, int dtype, bool acc
     } else if (variant == RED_ROW && dtype == HIP_R_32F) {
         const dim3 grid((p.kept.total + 3u) / 4u, p.splitR);
         hipLaunchKernelGGL(reduce_row_f32_kernel, grid, dim3(256), 0, stream, p);
+    } else if ((variant == RED_COL || variant == RED_ROW) && dtype != HIP_R_32F && (!acc64 || dtype == HIP_R_64F || dtype == HIP_C_64F)) {
+        switch (dtype) {       // the tiled kernels of the other element types (wide_elem.h)
+            case HIP_R_64F:  launch_wide_t<WF64>(p, variant, stream); break;
+            case HIP_R_16F:  launch_wide_t<WH16<false>>(p, variant, stream); break;
+            case HIP_R_16BF: launch_wide_t<WH16<true>>(p, variant, stream); break;
+            case HIP_C_32F:  launch_wide_t<WCplx<float>>(p, variant, stream); break;
+            case HIP_C_64F:  launch_wide_t<WCplx<double>>(p, variant, stream); break;
+            default: return hipErrorInvalidValue;
+        }
     } else if (variant == RED_GENERIC) {
         switch (dtype) {
             case HIP_R_32F:  if (acc64) launch_generic_t<float, double>(p, stream); else launch_generic_t<float, float>(p, stream); break;

@@ -20,17 +20,20 @@ def main():
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", action="store_true", help="sampled gather check against torch indexing")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"], help="element type (permutations only for the 16-bit types)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "f64", "c64", "c128"], help="element type")
+    ap.add_argument("--ext", default="", help="extents a,b,c (default: n,n,n) — e.g. 2048,2048,1024 for the fp64 case of VERDICT r5")
     ap.add_argument("--only", default="", help="comma list of cases, e.g. permute:cab,reduce:ac (default: all) — bench.py's PMC children")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     import torch
     from cudalibrarysamples_amd import ops, cutensor as ct
     n = args.n
-    tdt, cdt, es = {"f32": (torch.float32, ct.R_32F, 4), "bf16": (torch.bfloat16, ct.R_16BF, 2), "f16": (torch.float16, ct.R_16F, 2)}[args.dtype]
-    numel = n * n * n
+    tdt, cdt, es = {"f32": (torch.float32, ct.R_32F, 4), "bf16": (torch.bfloat16, ct.R_16BF, 2), "f16": (torch.float16, ct.R_16F, 2),
+                    "f64": (torch.float64, ct.R_64F, 8), "c64": (torch.complex64, ct.C_32F, 8), "c128": (torch.complex128, ct.C_64F, 16)}[args.dtype]
+    ea, eb, ec = (int(x) for x in args.ext.split(",")) if args.ext else (n, n, n)
+    numel = ea * eb * ec
     free, _ = torch.cuda.mem_get_info()
-    need = 2 * numel * 4 + (1 << 30)
+    need = 2 * numel * max(es, 4) + numel * 4 + (1 << 30)
     if free < need:
         raise SystemExit("not enough free HBM: need %d have %d" % (need, free))
     h = ops.Handle()
@@ -43,9 +46,13 @@ def main():
         idx = torch.arange(s, e, device="cuda", dtype=torch.int64)
         A[s:e] = ((idx * 2654435761 + 1234) % 16777216).to(torch.float32) / 16777216.0
         del idx
-    if tdt != torch.float32:
+    if tdt in (torch.complex64, torch.complex128):
+        re = A.to(torch.float32 if tdt == torch.complex64 else torch.float64)
+        A = torch.complex(re, 0.5 - re)
+        del re
+    elif tdt != torch.float32:
         A = A.to(tdt)
-    ext = dict(a=n, b=n, c=n)
+    ext = dict(a=ea, b=eb, c=ec)
 
     def timed(fn):
         for _ in range(2):
@@ -66,16 +73,16 @@ def main():
         if only and "permute:" + mB not in only:
             continue
         D = torch.empty(numel, dtype=tdt, device="cuda")
-        p = ops.permutation_plan(h, [n, n, n], "abc", [ext[c] for c in mB], mB, dtype=cdt)
+        p = ops.permutation_plan(h, [ea, eb, ec], "abc", [ext[c] for c in mB], mB, dtype=cdt)
         ms = timed(lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream))
         gbs = 2.0 * numel * es / (ms * 1e-3) / 1e9
-        line = {"op": "permute abc->" + mB, "dtype": args.dtype, "n": n, "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
+        line = {"op": "permute abc->" + mB, "dtype": args.dtype, "n": n, "ext": [ea, eb, ec], "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
                 "plan": p.describe()}
         if args.check:
-            At = A.view(n, n, n)    # At[c][b][a] (row-major view of the column-major tensor)
-            Dt = D.view(n, n, n)    # Dt[m2][m1][m0] with modes mB = m0 m1 m2
+            At = A.view(ec, eb, ea)    # At[c][b][a] (row-major view of the column-major tensor)
+            Dt = D.view(ext[mB[2]], ext[mB[1]], ext[mB[0]])    # Dt[m2][m1][m0] with modes mB = m0 m1 m2
             g = torch.Generator(device="cuda"); g.manual_seed(7)
-            ia, ib, ic = (torch.randint(0, n, (1 << 16,), generator=g, device="cuda") for _ in range(3))
+            ia, ib, ic = (torch.randint(0, e, (1 << 16,), generator=g, device="cuda") for e in (ea, eb, ec))
             pos = dict(a=ia, b=ib, c=ic)
             got = Dt[pos[mB[2]], pos[mB[1]], pos[mB[0]]]
             line["sampled_mismatches"] = int((got != At[ic, ib, ia]).sum().item())
@@ -83,23 +90,24 @@ def main():
         p.destroy()
         del D
     # ---- reductions -------------------------------------------------------------------------------------
-    for mC in (("ac", "c", "a", "bc") if args.dtype == "f32" else ()):
+    for mC in ("ac", "c", "a", "bc"):
         if only and "reduce:" + mC not in only:
             continue
         eC = [ext[c] for c in mC]
         outn = int(np.prod(eC))
-        D = torch.zeros(outn, dtype=torch.float32, device="cuda")
-        p = ops.reduction_plan(h, [n, n, n], "abc", eC, mC, workspace_limit=1 << 30)
+        D = torch.zeros(outn, dtype=tdt, device="cuda")
+        p = ops.reduction_plan(h, [ea, eb, ec], "abc", eC, mC, dtype=cdt, workspace_limit=1 << 30)
         ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
         ms = timed(lambda: p.reduce(1.1, A.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream))
-        gbs = (numel + outn) * 4.0 / (ms * 1e-3) / 1e9
-        line = {"op": "reduce abc->" + mC, "n": n, "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
+        gbs = (numel + outn) * float(es) / (ms * 1e-3) / 1e9
+        line = {"op": "reduce abc->" + mC, "dtype": args.dtype, "n": n, "ext": [ea, eb, ec], "ms": ms, "GBps": gbs, "frac_hbm_peak": gbs / (HBM_PEAK_TBPS * 1e3),
                 "plan": p.describe()}
         if args.check:
             dims = tuple(i for i, c in enumerate("cba") if c not in mC)
-            ref = (A.view(n, n, n).sum(dim=dims, dtype=torch.float64) * 1.1)
+            wide = torch.complex128 if tdt.is_complex else torch.float64
+            ref = (A.view(ec, eb, ea).sum(dim=dims, dtype=wide) * 1.1)
             # ref is indexed in row-major order of the kept modes in 'cba' order == column-major mC order reversed
-            got = D.view(*[ext[c] for c in reversed(mC)]).double()
+            got = D.view(*[ext[c] for c in reversed(mC)]).to(wide)
             line["max_rel_err"] = float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item())
         print(json.dumps(line), flush=True)
         p.destroy()
