@@ -357,9 +357,12 @@ def test_complex_reductions_and_permutations_plan(ct, ops):
     h = ops.Handle()
     for dt, es in ((ct.C_32F, 8), (ct.C_64F, 16)):
         p = ops.permutation_plan(h, [50, 64], "ij", [64, 50], "ji", dtype=dt)
-        assert p.scalar_type == dt and p.describe()["variant"] == 2          # EW_GENERIC: one (re, im) pair per lane
+        assert p.scalar_type == dt and p.describe()["variant"] == 0          # round 6: the tiled transposing kernel of 8- / 16-byte elements
         p.destroy()
-        r = ops.reduction_plan(h, [4096, 6], "ab", [6], "b", dtype=dt, opA=ct.OP_CONJ)
+        p = ops.permutation_plan(h, [51, 63], "ij", [63, 51], "ji", dtype=dt)
+        assert p.describe()["variant"] == (2 if es == 8 else 0)              # odd extents: complex64 pairs need even ones (EW_GENERIC), complex128 does not
+        p.destroy()
+        r = ops.reduction_plan(h, [65536, 6], "ab", [6], "b", dtype=dt, opA=ct.OP_CONJ)    # (tiled RED_ROW since round 6: splits from 8192 reduced elements per workgroup on)
         assert r.scalar_type == dt and r.required_workspace % (6 * es) == 0 and r.required_workspace > 0   # [splitR][kept] pairs
         assert r.required_workspace <= r.workspace_estimate
         r.destroy()
