@@ -663,6 +663,100 @@ def secondary_general_family(torch, ct, ops, h):
     return out
 
 
+def secondary_round6(torch, ct, ops, h, stream, with_counters):
+    """Round 6: the off-happy-path shapes the round-5 review asked to put against a roofline — contractions whose operands have no
+    16-byte lanes (bf16 4100^3: every row at 8 (mod 16) bytes, 17 x 17 tiles of 256 -> interior + strip plan; fp32 4098^3: the RAG twin
+    of the ring kernel) and the tiled bandwidth kernels of 8-byte elements (complex64 permutation / reduction at 1024^3)."""
+    out = []
+    for (label, E, tdt, cdt, peak, es) in (("contraction bf16 C[m,n]=A[m,k]B[k,n] M=N=K=4100 (no 16-byte lanes: rows at 8 mod 16 bytes), U(-1,1) data",
+                                            4100, torch.bfloat16, ct.R_16BF, PEAK_TFLOPS_BF16_MFMA, 2),
+                                           ("contraction fp32 C[m,n]=A[m,k]B[k,n] M=N=K=4098 (no 16-byte lanes, ragged K), U(0,1) data",
+                                            4098, torch.float32, ct.R_32F, PEAK_TFLOPS_F32_MFMA, 4)):
+        try:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(3)
+            A = torch.rand((E, E), generator=g, device="cuda")
+            B = torch.rand((E, E), generator=g, device="cuda")
+            if tdt != torch.float32:
+                A, B = (A * 2 - 1).to(tdt), (B * 2 - 1).to(tdt)
+            D = torch.empty((E, E), device="cuda", dtype=tdt)
+            p = ops.contraction_plan(h, [E, E], "mk", [E, E], "kn", [E, E], "mn", dtype=cdt, workspace_limit=1 << 30)
+            ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+            fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)   # noqa: E731
+            for _ in range(60):
+                fn()
+            ms = min(timed_batch(torch, fn, reps=30), timed_batch(torch, fn, reps=30))
+            flop = 2.0 * float(E) ** 3
+            tf = flop / (ms * 1e-3) / 1e12
+            d = p.describe()
+            line = {"workload": label, "dtype": "bf16" if es == 2 else "f32", "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms,
+                    "kernel": d["kname"], "rag": d.get("rag"), "strip_plan": d.get("strips"), "splitK": d["splitK"],
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                 "algorithmic_flop": flop, "algorithmic_bytes": 3.0 * es * E * E}}
+            p.destroy()
+            del A, B, D, ws
+            out.append(line)
+        except Exception as ex:   # noqa: BLE001
+            out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- complex64 1024^3: permutation abc->cab and reduction abc->ac on the tiled kernels of 8-byte elements ----------------
+    try:
+        n = 1024
+        numel = n ** 3
+        re = torch.rand(numel, device="cuda")
+        A = torch.complex(re, 0.5 - re)
+        del re
+        D = torch.empty(numel, dtype=torch.complex64, device="cuda")
+        p = ops.permutation_plan(h, [n, n, n], "abc", [n, n, n], "cab", dtype=ct.C_32F)
+        ms = timed_batch(torch, lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream), reps=5, warm=2)
+        gbs = 2.0 * numel * 8 / (ms * 1e-3) / 1e9
+        out.append({"workload": "cutensorPermute A[a,b,c]->C[c,a,b] complex64 1024^3 (tiled kernel of 8-byte elements; einsum.cc:83 dispatches the type)",
+                    "dtype": "c64", "value": gbs, "unit": "GB/s", "ms_per_call": ms, "variant": p.describe().get("variant"),
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
+                                 "algorithmic_bytes": 2.0 * numel * 8}})
+        p.destroy()
+        del D
+        R = torch.zeros(n * n, dtype=torch.complex64, device="cuda")
+        p = ops.reduction_plan(h, [n, n, n], "abc", [n, n], "ac", dtype=ct.C_32F, workspace_limit=1 << 30)
+        ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+        ms = timed_batch(torch, lambda: p.reduce(1.1, A.data_ptr(), 0.0, R.data_ptr(), R.data_ptr(), ws.data_ptr(), p.required_workspace, stream), reps=5, warm=2)
+        gbs = (numel + n * n) * 8.0 / (ms * 1e-3) / 1e9
+        out.append({"workload": "cutensorReduce C[a,c]=1.1*sum_b A[a,b,c] complex64 1024^3 (tiled kernel of 8-byte elements)", "dtype": "c64", "value": gbs,
+                    "unit": "GB/s", "ms_per_call": ms, "variant": p.describe().get("variant"),
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS,
+                                 "algorithmic_bytes": (numel + n * n) * 8.0}})
+        p.destroy()
+        del A, R, ws
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "permute / reduce complex64 1024^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    torch.cuda.empty_cache()
+    return out
+
+
+def add_mfma_counters(secondary):
+    """mfma_busy_pct / sustained_clock_ghz on the bf16 secondary lines (round-5 review: the mid-size lines move +-9 % between boxes and
+    nothing on the line says why): two live rocprofv3 passes (trace, PMC — never combined) over a child that runs the line's shape."""
+    tool = os.path.join(ROOT, "tools", "bench_unaligned.py")
+    for line in secondary:
+        w = line.get("workload", "")
+        if "roofline" not in line or not w.startswith("contraction bf16") or "8192" in w:
+            continue
+        import re as _re
+        m = _re.search(r"M=(\d+) N=(\d+) K=(\d+)", w) or _re.search(r"M=N=K=(\d+)", w)
+        if not m:
+            continue
+        dims = [int(x) for x in m.groups()]
+        if len(dims) == 1:
+            dims = dims * 3
+        try:
+            prof = live_profile_of([sys.executable, tool, "--shapes", "%d,%d,%d" % tuple(dims), "--layouts", "mk,kn", "--reps", "100", "--warm", "100"],
+                                   "%gett_h16w4%", timeout_s=120)
+        except Exception:   # noqa: BLE001
+            prof = None
+        if prof:
+            line["roofline"]["counters"] = {k: prof.get(k) for k in ("kernel", "launches", "kernel_avg_us", "kernel_min_us", "mfma_busy_pct", "sustained_clock_ghz",
+                                                                       "kernel_avg_us_under_pmc")}
+
+
 def add_secondary_traffic(secondary):
     """roofline.traffic of the bf16 / permute / reduce secondary lines, measured live like the headline's: two rocprofv3 --pmc passes
     over a short child that runs only that workload (tools/bench_h16.py, tools/bench_bandwidth.py --only ...)."""
@@ -1052,8 +1146,10 @@ def main():
             torch.cuda.empty_cache()
             secondary += secondary_single_gpu(torch, ct, ops, h, stream)
             secondary += secondary_general_family(torch, ct, ops, h)
+            secondary += secondary_round6(torch, ct, ops, h, stream, not args.no_pmc)
             if not args.no_pmc:
                 add_secondary_traffic(secondary)
+                add_mfma_counters(secondary)
             try:
                 secondary.append(einsum_flow_line())
             except Exception as ex:   # noqa: BLE001
