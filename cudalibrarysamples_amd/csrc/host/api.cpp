@@ -26,6 +26,11 @@ const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_32F    = &kCompute[4];
 const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_64F    = &kCompute[5];
 }
 
+// grid of the persistent 16-bit kernel in workgroups (0 = one per CU): CUTENSOR_AMD_H16P_GRID, a test hook — the kernel objects are
+// shared by both library flavours, so the switch is read here and handed over as data (gett_h16p.hip, launch_h16w4p)
+extern "C" int ctamd_h16p_grid_cap;
+int ctamd_h16p_grid_cap = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16P_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
+
 namespace {
 
 // launches of cutensorContract by kernel kind since the library was loaded (ctamdLaunchCounts): 0 = gett_simple_kernel (scalar FMA
@@ -142,9 +147,9 @@ namespace {
 
 // any experiment knob that changes what cutensorCreatePlan decides: the memo stands aside while one is set
 bool plan_env_override() {
-    return ctamd_research_env("CUTENSOR_AMD_FORCE") || ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE") || std::getenv("CUTENSOR_AMD_FUSED_FOLD") ||
-           ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1") || std::getenv("CUTENSOR_AMD_NT") || std::getenv("CUTENSOR_AMD_H16_WAVES") || ctamd_research_env("CUTENSOR_AMD_H16_SPLITK") ||
-           ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || std::getenv("CUTENSOR_AMD_PEEL") || std::getenv("CUTENSOR_AMD_GEN");
+    return ctamd_research_env("CUTENSOR_AMD_FORCE") || ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE") || CTAMD_HOOK_ENV("CUTENSOR_AMD_FUSED_FOLD") ||
+           ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1") || CTAMD_HOOK_ENV("CUTENSOR_AMD_NT") || CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") || ctamd_research_env("CUTENSOR_AMD_H16_SPLITK") ||
+           ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL") || CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
@@ -1137,7 +1142,10 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         }
         handle->memoMisses.fetch_add(1, std::memory_order_relaxed);
     }
-    cutensorPlan* pl = new (std::nothrow) cutensorPlan();
+    // the plan under construction is owned here until it is handed to the caller: an exception below (bad_alloc in a planner's vectors,
+    // caught by the barrier at the end) or an early return frees it together with its sub-plans (round-5 advice)
+    std::unique_ptr<cutensorPlan> owner(new (std::nothrow) cutensorPlan());
+    cutensorPlan* const pl = owner.get();
     if (pl == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
     pl->kind = desc->kind;
     pl->dtype = desc->A.desc.dtype;
@@ -1152,18 +1160,18 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
 
     if (desc->kind == OpKind::BlockSparseContraction) {
         st = blocksparse_plan(handle, *desc, workspaceSizeLimit, pl);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
-        *plan = pl;
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
+        *plan = owner.release();
         return CUTENSOR_STATUS_SUCCESS;
     }
     if (desc->kind == OpKind::ContractionTrinary) {
         const uint64_t tOff = (desc->tBytes + 255) & ~255ull;
-        if (workspaceSizeLimit < tOff) { delete pl; CT_LOG("cutensorCreatePlan: trinary contraction needs %llu bytes for its intermediate", (unsigned long long)tOff); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
+        if (workspaceSizeLimit < tOff) { CT_LOG("cutensorCreatePlan: trinary contraction needs %llu bytes for its intermediate", (unsigned long long)tOff); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
         cutensorOperationDescriptor s1 = desc->sub[0], s2 = desc->sub[1];
         cutensorPlan_t p1 = nullptr, p2 = nullptr;
         st = cutensorCreatePlan(handle, &p1, &s1, pref, workspaceSizeLimit - tOff);
         if (st == CUTENSOR_STATUS_SUCCESS) st = cutensorCreatePlan(handle, &p2, &s2, pref, workspaceSizeLimit - tOff);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete p1; delete p2; delete pl; return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { delete p1; delete p2; return st; }
         pl->sub1 = p1; pl->sub2 = p2;
         pl->tBytes = desc->tBytes;
         for (int i = 0; i < 3; ++i) pl->triOrder[i] = desc->triOrder[i];
@@ -1171,7 +1179,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         pl->alignC = desc->C.desc.alignment;             // C (third input)
         pl->alignD = desc->E.desc.alignment;             // output E (and its beta source D)
         pl->requiredWorkspace = tOff + std::max(p1->requiredWorkspace, p2->requiredWorkspace);
-        *plan = pl;
+        *plan = owner.release();
         return CUTENSOR_STATUS_SUCCESS;
     }
 
@@ -1180,12 +1188,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (split_lone_modes(*desc, ls)) {
             // reduce the operand(s) over the modes nothing else carries into packed temporaries at the head of the workspace, then contract
             const uint64_t offB = (ls.bytesA + 255) & ~255ull, offW = offB + ((ls.bytesB + 255) & ~255ull);
-            if (workspaceSizeLimit < offW) { delete pl; CT_LOG("cutensorCreatePlan: a contraction with a mode that one input alone carries needs %llu bytes for its temporaries", (unsigned long long)offW); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
+            if (workspaceSizeLimit < offW) { CT_LOG("cutensorCreatePlan: a contraction with a mode that one input alone carries needs %llu bytes for its temporaries", (unsigned long long)offW); return CUTENSOR_STATUS_INSUFFICIENT_WORKSPACE; }
             cutensorPlan_t pi = nullptr, pa = nullptr, pb = nullptr;
             st = cutensorCreatePlan(handle, &pi, &ls.inner, pref, workspaceSizeLimit - offW);
             if (st == CUTENSOR_STATUS_SUCCESS && ls.hasA) st = cutensorCreatePlan(handle, &pa, &ls.redA, pref, workspaceSizeLimit - offW);
             if (st == CUTENSOR_STATUS_SUCCESS && ls.hasB) st = cutensorCreatePlan(handle, &pb, &ls.redB, pref, workspaceSizeLimit - offW);
-            if (st != CUTENSOR_STATUS_SUCCESS) { delete pi; delete pa; delete pb; delete pl; return st; }
+            if (st != CUTENSOR_STATUS_SUCCESS) { delete pi; delete pa; delete pb; return st; }
             pl->sub1 = pi; pl->loneA = pa; pl->loneB = pb;
             pl->loneBytesA = ls.bytesA; pl->loneBytesB = ls.bytesB;
             pl->choice = ContractionChoice{};
@@ -1193,12 +1201,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             pl->requiredWorkspace = offW + std::max<uint64_t>(pi->requiredWorkspace, std::max<uint64_t>(pa ? pa->requiredWorkspace : 0, pb ? pb->requiredWorkspace : 0));
             CT_LOG("plan: contraction with modes that one input alone carries -> %s%sreduced first (%llu + %llu bytes of temporaries), then the contraction",
                    pa ? "A " : "", pb ? "B " : "", (unsigned long long)ls.bytesA, (unsigned long long)ls.bytesB);
-            *plan = pl;
+            *plan = owner.release();
             return CUTENSOR_STATUS_SUCCESS;
         }
         st = build_contraction_view(*desc, pl->view, &why);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
-        if (pl->view.wide && !(std::getenv("CUTENSOR_AMD_PEEL") && std::getenv("CUTENSOR_AMD_PEEL")[0] == '0')) {
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
+        if (pl->view.wide && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL") && CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL")[0] == '0')) {
             // too many unfusable modes in a group for the tiled kernels: peel the smallest ones into a host loop if that takes
             // at most kMaxPeelLaunches launches (peel_wide_contraction), else fall through to the mode-table kernel
             cutensorOperationDescriptor inner;
@@ -1222,7 +1230,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                             ip2->sub1 != nullptr) {
                             delete ip2;
                             delete ip;
-                            delete pl;
+                            
                             return CUTENSOR_STATUS_NOT_SUPPORTED;
                         }
                         pl->sub2 = ip2;
@@ -1236,7 +1244,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                     int64_t launches = 1;
                     for (const PeelMode& pm : peel) launches *= pm.extent;
                     CT_LOG("plan: contraction with an oversized mode group -> %zu mode(s) peeled, %lld launches of the tiled inner plan", peel.size(), (long long)launches);
-                    *plan = pl;
+                    *plan = owner.release();
                     return CUTENSOR_STATUS_SUCCESS;
                 }
                 delete ip;
@@ -1244,7 +1252,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         }
         {
             const bool cplx = pl->view.dtype == HIP_C_32F || pl->view.dtype == HIP_C_64F;
-            const bool genOff = std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == '0';
+            const bool genOff = CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == '0';
             // complex data only multiplies on the general MFMA family or on the mode-table kernel (complex scalars of the data's type)
             if (cplx && (genOff || desc->scalarType != pl->view.dtype || (pl->view.dtype == HIP_C_32F && pl->accumulate64))) pl->view.wide = true;
         }
@@ -1293,7 +1301,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             pl->choice.kernel = -2;
             pl->requiredWorkspace = 0;
             CT_LOG("plan: contraction with %u output + %u contracted unfusable modes -> mode-table kernel", pl->wide.nOut, pl->wide.nK);
-            *plan = pl;
+            *plan = owner.release();
             return CUTENSOR_STATUS_SUCCESS;
         }
         const bool mfmaPath = pl->view.dtype == HIP_R_32F && !pl->accumulate64;
@@ -1306,9 +1314,9 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         ContractionChoice pick;   // kernel = -1: simple kernel
         std::vector<ContractionChoice> ch;
         if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs, pr.operandsStreamed != 0);
-        else if (h16Path && !(std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
+        else if (h16Path && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
-        if (ch.empty() && genPath && !(std::getenv("CUTENSOR_AMD_GEN") && std::getenv("CUTENSOR_AMD_GEN")[0] == '0')) {
+        if (ch.empty() && genPath && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == '0')) {
             ContractionChoice g;
             if (pick_gen_choice(pl->view, workspaceSizeLimit, handle->numCUs, g)) ch.push_back(g);
         }
@@ -1398,7 +1406,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (mfmaPath && pick.kernel >= 0 && pick.family == 0 && pick.splitK > 1) {
             int cnt = 0;
             const GettKernelInfo* tabf = gett_f32_kernels(&cnt);
-            const char* env = std::getenv("CUTENSOR_AMD_FUSED_FOLD");
+            const char* env = CTAMD_HOOK_ENV("CUTENSOR_AMD_FUSED_FOLD");
             const bool allowed = env && env[0] == '1';   // opt-in: measured slower than the two-kernel fold
             if (allowed && tabf[pick.kernel].fragPartials && !tabf[pick.kernel].ablation && pl->gett.nBlocks <= (uint32_t)handle->numCUs &&
                 pl->view.totL == 1 && pl->view.M.size() <= 1 && pl->view.N.size() <= 1) {
@@ -1440,13 +1448,13 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         }
     } else if (desc->kind == OpKind::Reduction) {
         st = plan_reduction(*desc, workspaceSizeLimit, handle->numCUs, pl->red, &why);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
         pl->requiredWorkspace = pl->red.workspace;
         CT_LOG("plan: reduction variant=%d kept=%u red=%u splitR=%u perm=%d", pl->red.variant, pl->red.p.kept.total,
                pl->red.p.red.total, pl->red.p.splitR, (int)pl->red.isPermutation);
     } else if (desc->kind == OpKind::ElementwiseTrinary) {
         st = plan_elementwise_trinary(*desc, pl->ew3, &why);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
         pl->alignB3 = desc->B.desc.alignment;
         pl->requiredWorkspace = 0;
         CT_LOG("plan: elementwise trinary passes=%d swapAB=%d bothPermuted=%d variant(last)=%d", pl->ew3.twoPass ? 2 : 1, (int)pl->ew3.swapAB,
@@ -1466,14 +1474,14 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             accU *= desc->D.desc.extent[i];
             accP *= desc->D.desc.extent[i] + l + r;
         }
-        if (!isPacked) { delete pl; CT_LOG("cutensorCreatePlan: padding needs a packed output descriptor"); return CUTENSOR_STATUS_NOT_SUPPORTED; }
+        if (!isPacked) { CT_LOG("cutensorCreatePlan: padding needs a packed output descriptor"); return CUTENSOR_STATUS_NOT_SUPPORTED; }
         cutensorOperationDescriptor inner = *desc;
         inner.D.desc.stride = padded;
         // the interior starts `offset` elements into the buffer: keep the 16-byte-lane variants only if that is lane-aligned
         const int64_t lane = 16 / (int64_t)dtype_size(desc->D.desc.dtype);
         if (offset % lane != 0) inner.D.desc.alignment = (uint32_t)dtype_size(desc->D.desc.dtype);
         st = plan_elementwise(inner, pl->ew, &why);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
         pl->padFillElems = (uint64_t)accP;
         pl->padOffsetElems = offset;
         pl->padValue = desc->padValue;
@@ -1481,13 +1489,13 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         CT_LOG("plan: padded permutation variant=%d fill=%llu elems offset=%lld", pl->ew.variant, (unsigned long long)pl->padFillElems, (long long)offset);
     } else {
         st = plan_elementwise(*desc, pl->ew, &why);
-        if (st != CUTENSOR_STATUS_SUCCESS) { delete pl; return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { return st; }
         pl->requiredWorkspace = 0;
         CT_LOG("plan: elementwise variant=%d E0=%u E1=%u rest=%u blocks=%u", pl->ew.variant, pl->ew.p.E0, pl->ew.p.E1,
                pl->ew.p.rest.total, pl->ew.p.nBlocks);
     }
     if (memoable) memo_insert(handle, mkey, mhash, *pl);
-    *plan = pl;
+    *plan = owner.release();
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH
 
@@ -1656,7 +1664,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         // beta is known only now: the persistent 16-bit kernel (table entries 88..95) streams its tiles for beta == 0 only and is slower
         // than its one-tile twin (48..55: same tile, same arguments, same workspace) otherwise — plan_contraction.cpp, pick_h16_choice
         // (CUTENSOR_AMD_H16_WAVES=4p names the kernel for every call: the tests of its beta path)
-        static const bool persistentForced = [] { const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES"); return e && e[0] == '4' && e[1] == 'p'; }();
+        static const bool persistentForced = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES"); return e && e[0] == '4' && e[1] == 'p'; }();
         if (plan->choice.family == 1 && tab[launchKernel].pf == 12 && b != 0.0 && !persistentForced && launchKernel - 40 >= 0 &&
             tab[launchKernel - 40].pf == 7)
             launchKernel -= 40;
@@ -2096,6 +2104,9 @@ int ctamdResearchKernelsBuilt(void) try {
     return 0;
 #endif
 } CTAMD_API_CATCH_INT
+
+// 1 when this library reads the test / measurement switches (CTAMD_HOOK_ENV: the lib_hooks/ flavour and research builds)
+int ctamdTestHooksBuilt(void) try { return CTAMD_HOOKS_BUILT; } CTAMD_API_CATCH_INT
 
 int ctamdKernelCount(void) try {
     int count = 0;

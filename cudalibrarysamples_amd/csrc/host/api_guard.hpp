@@ -17,3 +17,18 @@
 #define CTAMD_API_CATCH_ZERO catch (...) { return 0; }
 #define CTAMD_API_CATCH_NULL catch (...) { return nullptr; }
 #define CTAMD_API_CATCH_VOID catch (...) { }
+
+// Behaviour-changing environment switches that exist for the test-suite and the measurement tools (CUTENSOR_AMD_H16_WAVES, _GEN, _NT,
+// _PEEL, _FUSED_FOLD, _H16P, _H16P_GRID, _H16_STRIPS, CUTENSORMG_AMD_{ASSUME_RCCL,DIRECT,PEEL,QSPLIT,SHARD2,TEST_DROP_WAITS},
+// CUTENSORMP_AMD_ALGO) are read only by the TEST-HOOKS flavour of the libraries (make HOOKS=1 -> lib_hooks/, what tests/ loads) and by
+// research builds.  In the production libraries (lib/) the macro is a null pointer and the names do not even appear as strings:
+// `strings lib/libcutensor*.so | grep CUTENSOR` lists CUTENSOR_LOG_LEVEL and the documented user switches of cuTENSORMg
+// (CUTENSORMG_AMD_FORCE_GATHER / _TRANSPORT / _WAVES) only.
+#include <cstdlib>
+#if defined(CTAMD_TEST_HOOKS) || defined(CTAMD_RESEARCH_KERNELS)
+#define CTAMD_HOOK_ENV(NAME) std::getenv(NAME)
+#define CTAMD_HOOKS_BUILT 1
+#else
+#define CTAMD_HOOK_ENV(NAME) (static_cast<const char*>(nullptr))
+#define CTAMD_HOOKS_BUILT 0
+#endif

@@ -388,7 +388,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
         // nontemporal operand stream: only when every operand byte is read exactly once (one tile row and one tile column) AND the
         // operands are well beyond the 256-MiB Infinity Cache (> 1.4 x), i.e. back-to-back calls cannot find them on-die anyway (measured:
         // headline shape 201 MB: +3.6 % from HBM, -5.5 % cache-resident; b = 96, 302 MB: -5 %; b = 128, 403 MB: +6 %; profiles/r03_headline_nt.txt)
-        static const bool ntAnySize = std::getenv("CUTENSOR_AMD_NT") != nullptr;   // tests: exercise the nt kernels on small read-once shapes
+        static const bool ntAnySize = CTAMD_HOOK_ENV("CUTENSOR_AMD_NT") != nullptr;   // tests: exercise the nt kernels on small read-once shapes
         // ... or the caller says so: CUTENSOR_AMD_PLAN_PREFERENCE_OPERANDS_STREAMED (include/cutensor/types.h) — "every call finds its operands in
         // HBM", which the library cannot know for the 201 MB of the headline einsum
         if (k.nt && !(tilesM == 1 && tilesN == 1 && (ntAnySize || operandsStreamed || 4.0 * L * (M * K + N * K) > 1.4 * 256.0 * 1024.0 * 1024.0))) continue;
@@ -494,7 +494,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // ring; 32..39: four waves, register-staged; 40..47: four waves, lean instruction stream (gett_h16v.hip); 48..55: the same on
     // the 16x16x32 MFMA — the default since round 3 (+8-14 % under the power limit on every layout)
     static const int variant = [] {
-        const char* e = std::getenv("CUTENSOR_AMD_H16_WAVES");
+        const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES");
         if (e && e[0] == '4' && e[1] == 's') return 24;
         if (e && e[0] == '4' && e[1] == 'r') return 32;
         if (e && e[0] == '4' && e[1] == 'v') return 40;
@@ -512,7 +512,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     const int layoutIdx = c.kernel;
     const uint64_t kTiles = (v.totK + 63) / 64;
     const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
-    const bool forced = std::getenv("CUTENSOR_AMD_H16_WAVES") != nullptr;
+    const bool forced = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") != nullptr;
     auto tiles_of = [&](int var) {
         const GettKernelInfo& k = tab[layoutIdx + var];
         return std::ceil((double)v.totM / k.bm) * std::ceil((double)v.totN / k.bn) * (double)v.totL;
@@ -573,7 +573,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
                               std::ceil((double)mInt / 64.0) * std::ceil((double)(v.totN - nInt) / 64.0)) * (double)v.totL;
         return model_tiles_us(cand, tilesInt, 1) + model_tiles_us(80, strip, 1) + 1.5;   // + the gap between the two launches
     };
-    static const bool noStrips = [] { const char* e = std::getenv("CUTENSOR_AMD_H16_STRIPS"); return e && e[0] == '0'; }();
+    static const bool noStrips = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_STRIPS"); return e && e[0] == '0'; }();
     const bool stripsOK = !noStrips && v.M.size() == 1 && v.N.size() == 1;
     int var = variant;
     uint64_t split = 1;
@@ -604,14 +604,16 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         // the planner's own choice: the 256 x 256 family (four-wave 16x16x32 kernel; eight-wave kernel for short K ranges, below), the
         // 128 x 128 mid-size family and the 64 x 64 tile, each without split-K and at its automatic split
         double best = 1e30;
-        static const bool noPersistent = [] { const char* e = std::getenv("CUTENSOR_AMD_H16P"); return e && e[0] == '0'; }();
+        static const bool noPersistent = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16P"); return e && e[0] == '0'; }();
         // The persistent kernel earns its place by streaming interior tiles into each other, which needs the epilogue that stays out of the
         // operand ring (gett_h16p.hip, curOK): no batch modes, one M and one N mode, 16-byte lanes in D.  Tiles that cannot stream are set up
         // serially behind the previous epilogue and the kernel is SLOWER than the one-tile kernel then (measured with beta != 0, the one
         // condition only the call knows: 8192^3 1377 against 1429-1435 TFLOP/s, 8192^2 x 1024 692 against 819, x 512 432 against 526,
         // profiles/r05r_h16p_beta.jsonl — cutensorContract launches the one-tile twin for beta != 0, api.cpp).
+        // ... and the hand-over of tile i's last K-tile bodies to tile i + 1 needs an even K-tile count of at least four (gett_h16p.hip,
+        // switchAt): with an odd count or fewer nothing streams and the model's per-tile saving is not there (round-5 advice)
         const bool streamable = v.totL == 1 && v.M.size() == 1 && v.N.size() == 1 && v.N[0].sD == 1 && v.N[0].extent % 8 == 0 &&
-                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0;
+                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0 && kTiles % 2 == 0 && kTiles >= 4;
         for (int cand : {48, 88, 64, 56, 80}) {
             if (cand == 88 && (noPersistent || !streamable)) continue;
             if (layoutIdx + cand >= count) continue;

@@ -591,18 +591,26 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     }
 }
 
+extern "C" int ctamd_h16p_grid_cap;
+
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
     // one workgroup per CU (160 KiB of LDS, 512 registers per lane), each walking tiles blockIdx.x, + grid, + 2 grid, ...
-    static const int numCUs = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    // the CU count of the CURRENT device (cuTENSORMg / cutensorMp drive several from one process; partitions differ in size): a small
+    // per-device table, filled on first use (a benign race: every writer stores the same value)
+    static int cuTable[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int numCUs = (dev >= 0 && dev < 64) ? cuTable[dev] : 0;
+    if (numCUs <= 0) {
+        if (hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || numCUs <= 0) {
             (void)hipGetLastError();
-            n = 256;
+            numCUs = 256;
         }
-        return n;
-    }();
-    static const int cap = [] { const char* e = getenv("CUTENSOR_AMD_H16P_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+        if (dev >= 0 && dev < 64) cuTable[dev] = numCUs;
+    }
+    if (p.gK.total % (uint32_t)kHBK != 0u) return hipErrorInvalidValue;   // no masked K-tile in this kernel: the planner never hands it a ragged K
+    const int cap = ctamd_h16p_grid_cap;          // test hook (CUTENSOR_AMD_H16P_GRID, read by the hooks flavour in api.cpp)
     uint32_t grid = (uint32_t)(cap > 0 ? cap : numCUs);
     grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
     if (grid == 0) grid = 8;

@@ -608,8 +608,9 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
+    const bool needRag = p.gK.total % (uint32_t)kHBK != 0u || (p.ragged & 1u) != 0u;   // (the TIMED / XST instantiations have no masked tile)
 #if defined(CTAMD_RESEARCH_KERNELS)
-    if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / store modes
+    if constexpr (BF && LA == LAY_K && LB == LAY_F) if (!needRag) {   // the one instantiation that carries the in-kernel timestamps / store modes
         static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
         static const int xst = [] { const char* e = getenv("CUTENSOR_AMD_H16_XST"); return e ? atoi(e) : 0; }();
         if (timed && xst == 1) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true, 1>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
@@ -623,7 +624,7 @@ static hipError_t launch_h16w4x(const GettParams& p, hipStream_t stream) {
         if (timed) { hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, true>), dim3(p.nBlocks), dim3(256), 0, stream, p); return hipGetLastError(); }
     }
 #endif
-    if (p.gK.total % (uint32_t)kHBK != 0u || (p.ragged & 1u) != 0u) {   // ragged K (one contracted mode) or a unit that can straddle the tensor's end (pick_h16_choice): the masked last K-tile
+    if (needRag) {   // ragged K (one contracted mode) or a unit that can straddle the tensor's end (pick_h16_choice): the masked last K-tile
         hipLaunchKernelGGL((gett_h16w4x_kernel<BF, LA, LB, false, 0, true>), dim3(p.nBlocks), dim3(256), 0, stream, p);
         return hipGetLastError();
     }

@@ -401,6 +401,12 @@ bool env_is(const char* name, const char* value) {
     const char* e = std::getenv(name);
     return e != nullptr && std::strcmp(e, value) == 0;
 }
+// test / measurement switches: read by the hooks flavour only (host/api_guard.hpp)
+#if CTAMD_HOOKS_BUILT
+#define CTAMD_HOOK_IS(NAME, VALUE) env_is(NAME, VALUE)
+#else
+#define CTAMD_HOOK_IS(NAME, VALUE) false
+#endif
 
 }  // namespace
 
@@ -632,7 +638,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     pl->forceGather = handle->forceGather;
     pl->useRccl = !handle->comms.empty() ||
                   // plan-only handles (no GPU visible): CPU tests of the RCCL event wiring and transport choice
-                  (!handle->haveDevice && handle->distinct && (nDev > 1 || handle->forceGather) && env_is("CUTENSORMG_AMD_ASSUME_RCCL", "1"));
+                  (!handle->haveDevice && handle->distinct && (nDev > 1 || handle->forceGather) && CTAMD_HOOK_IS("CUTENSORMG_AMD_ASSUME_RCCL", "1"));
 
     // ---- label universe, block-index digits per label ----------------------------------------------
     const MgTensor* T[3] = {&d.A, &d.B, &d.C};
@@ -679,7 +685,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
     if (pC >= 0 && find_label(d.mA, d.mC[pC]) >= 0 && find_label(d.mB, d.mC[pC]) >= 0) yK = -1;   // batch mode: both carry it
     int qLi = -1, qDigit = -1;
     int64_t qCount = 1;
-    if (yK >= 0 && !env_is("CUTENSORMG_AMD_QSPLIT", "0")) {
+    if (yK >= 0 && !CTAMD_HOOK_IS("CUTENSORMG_AMD_QSPLIT", "0")) {
         const MgTensor& Y = *T[yK];
         for (uint32_t i = 0; i < Y.n; ++i) {
             const int32_t l = (*M[yK])[i];
@@ -710,7 +716,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
         int nP = nDev;
         // c shards of ceil(E / c) rounded up to 16 indices: are all of them non-empty?
         auto all_busy = [&](int c) { const int64_t per = ((E + c - 1) / c + 15) / 16 * 16; return per * (int64_t)(c - 1) < E; };
-        if (!all_busy(nDev) && !env_is("CUTENSORMG_AMD_SHARD2", "0")) {
+        if (!all_busy(nDev) && !CTAMD_HOOK_IS("CUTENSORMG_AMD_SHARD2", "0")) {
             nP = 1;
             for (int c = 1; c <= nDev; ++c)
                 if (nDev % c == 0 && all_busy(c)) nP = c;
@@ -836,7 +842,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             OperandUse& u = p.use[k];
             u.cells = cells_of(*T[k], *M[k], universe, radix, rs);
             u.direct = u.cells.size() == 1 && T[k]->devices[u.cells[0]] == handle->devices[p.dev] &&
-                       !env_is("CUTENSORMG_AMD_DIRECT", "0") && !(handle->forceGather && k < 2);
+                       !CTAMD_HOOK_IS("CUTENSORMG_AMD_DIRECT", "0") && !(handle->forceGather && k < 2);
             if (u.direct) { u.cell = u.cells[0]; continue; }
             staged[k] = true;
             for (int c : u.cells) {
@@ -1008,7 +1014,7 @@ cutensorStatus_t cutensorMgCreateContractionPlan(const cutensorMgHandle_t handle
             int32_t grp[64], lab[64];
             int64_t ext[64];
             const int nm = (p.subs.size() + todo.size() < 512) ? ctamdPlanModeTableGroups(sub.plan, grp, lab, ext, 64) : 0;
-            if (nm > 0 && !env_is("CUTENSORMG_AMD_PEEL", "0")) {
+            if (nm > 0 && !CTAMD_HOOK_IS("CUTENSORMG_AMD_PEEL", "0")) {
                 int count[4] = {0, 0, 0, 0};
                 for (int i = 0; i < std::min(nm, 64); ++i) ++count[grp[i]];
                 int best = -1;
@@ -1399,6 +1405,7 @@ int ctamdMgDescribeKBoxes(int64_t extent, int64_t blockSize, int nDigits, const 
 // by a transfer whose event the piece's stream has waited for so far — a missing wait is an error even though the replay itself
 // is sequential.  Returns 0, or a negative code with a message in `err`.
 // ---------------------------------------------------------------------------------------------------------------------
+#if CTAMD_HOOKS_BUILT     // compiled into the hooks flavour (lib_hooks/) and research builds only: the production library has no test entry points
 typedef struct { int32_t n; const int64_t* extent; const int64_t* stride; const int32_t* modes; } ctamdMgHostView;
 typedef int (*ctamdMgHostContractFn)(void* user, int dtype, const ctamdMgHostView* A, const void* a, const ctamdMgHostView* B, const void* b,
                                      const ctamdMgHostView* C, const void* c, void* d, double alpha, double beta);
@@ -1433,7 +1440,7 @@ int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, co
     }
     // ---- 2. pieces in execution order ---------------------------------------------------------------------------------------------
     std::vector<std::set<int>> waited((size_t)(nDev * kComputeStreams));
-    const bool dropWaits = env_is("CUTENSORMG_AMD_TEST_DROP_WAITS", "1");
+    const bool dropWaits = CTAMD_HOOK_IS("CUTENSORMG_AMD_TEST_DROP_WAITS", "1");
     for (size_t pi = 0; pi < pl->pieces.size(); ++pi) {
         const Piece& p = pl->pieces[pi];
         const int g = p.dev;
@@ -1492,6 +1499,7 @@ int ctamdMgReplayOnHost(const cutensorMgContractionPlan_t plan, double alpha, co
     }
     return 0;
 } CTAMD_API_CATCH_INT
+#endif   // CTAMD_HOOKS_BUILT
 
 // One JSON object describing the plan: which mode is sharded, the pieces in execution order with the grid cells they
 // read in place / from the staging image and the events they wait for, and every cell transfer.

@@ -938,7 +938,7 @@ cutensorStatus_t cutensorMpCreatePlan(const cutensorMpHandle_t handle, cutensorM
         // ring all-reduce moves ~2 |C| per rank, reduce-scatter ~|C|
         pl->reduceTotal = (int64_t)world * cElems * es * (d.C.replicated() ? 2 : 1);
         bool useReduce = reduce_applicable(d, world) && pl->reduceTotal < pl->gatherTotal;
-        if (const char* force = std::getenv("CUTENSORMP_AMD_ALGO")) {       // tests: "gather" / "reduce" on every rank
+        if (const char* force = CTAMD_HOOK_ENV("CUTENSORMP_AMD_ALGO")) {       // tests: "gather" / "reduce" on every rank
             if (std::strcmp(force, "gather") == 0) useReduce = false;
             else if (std::strcmp(force, "reduce") == 0) useReduce = reduce_applicable(d, world);
         }

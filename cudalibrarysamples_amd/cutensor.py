@@ -10,7 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CUTENSOR_AMD_LIBRARY: another build of the same library (A/B measurements of two source revisions on one box)
-LIB_PATH = os.environ.get("CUTENSOR_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libcutensor.so")
+# CTAMD_LIB_FLAVOUR=hooks: the test-hooks flavour (lib_hooks/, make HOOKS=1) — the same kernels, host code that reads the test / measurement
+# switches (csrc/host/api_guard.hpp); tests/conftest.py and the tools that drive such switches select it, bench.py and smoke() never do
+LIB_DIR = "lib_hooks" if os.environ.get("CTAMD_LIB_FLAVOUR") == "hooks" else "lib"
+LIB_PATH = os.environ.get("CUTENSOR_AMD_LIBRARY") or os.path.join(_HERE, LIB_DIR, "libcutensor.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -18,6 +21,11 @@ if not os.path.exists(LIB_PATH):
         "`make -C cudalibrarysamples_amd/csrc` or `__graft_entry__.build()`; there is no CPU fallback." % LIB_PATH)
 
 lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+if LIB_DIR == "lib" and not os.environ.get("CUTENSOR_AMD_LIBRARY"):
+    _ignored = sorted(k for k in os.environ if k.startswith(("CUTENSOR_AMD_", "CUTENSORMP_AMD_")) and k != "CUTENSOR_AMD_LIBRARY")
+    if _ignored:
+        import warnings
+        warnings.warn("the production libcutensor.so does not read %s: set CTAMD_LIB_FLAVOUR=hooks to load the test-hooks flavour" % ", ".join(_ignored))
 
 # ---- enums (include/cutensor/types.h) ----------------------------------------------------------
 R_32F, R_64F, R_16F, R_16BF = 0, 1, 2, 14

@@ -4,7 +4,7 @@ import os
 
 from . import cutensor as ct   # loads libcutensor.so with RTLD_GLOBAL first
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcutensorMg.so")
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_hooks" if os.environ.get("CTAMD_LIB_FLAVOUR") == "hooks" else "lib", "libcutensorMg.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError("libcutensorMg.so is not built: %s missing (no CPU fallback)" % LIB_PATH)
 lib = ctypes.CDLL(LIB_PATH)
@@ -51,9 +51,11 @@ class HostView(ctypes.Structure):
 
 HOST_CONTRACT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(HostView), ctypes.c_void_p, ctypes.POINTER(HostView),
                                     ctypes.c_void_p, ctypes.POINTER(HostView), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double)
-lib.ctamdMgReplayOnHost.argtypes = [_vp, ctypes.c_double, _vpp, _vpp, ctypes.c_double, _vpp, _vpp, HOST_CONTRACT_FN, ctypes.c_void_p,
-                                    ctypes.c_char_p, ctypes.c_size_t]
-lib.ctamdMgReplayOnHost.restype = ctypes.c_int
+HAVE_REPLAY = hasattr(lib, "ctamdMgReplayOnHost")      # a test entry point: the hooks flavour only
+if HAVE_REPLAY:
+    lib.ctamdMgReplayOnHost.argtypes = [_vp, ctypes.c_double, _vpp, _vpp, ctypes.c_double, _vpp, _vpp, HOST_CONTRACT_FN, ctypes.c_void_p,
+                                        ctypes.c_char_p, ctypes.c_size_t]
+    lib.ctamdMgReplayOnHost.restype = ctypes.c_int
 
 check = ct.check
 i64, i32 = ct.i64, ct.i32

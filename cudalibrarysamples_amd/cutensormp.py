@@ -10,7 +10,7 @@ import threading
 
 from . import cutensor as ct   # loads libcutensor.so with RTLD_GLOBAL first
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcutensorMp.so")
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_hooks" if os.environ.get("CTAMD_LIB_FLAVOUR") == "hooks" else "lib", "libcutensorMp.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError("libcutensorMp.so is not built: %s missing (no CPU fallback)" % LIB_PATH)
 lib = ctypes.CDLL(LIB_PATH)

@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The suite (and every child process it spawns) loads the TEST-HOOKS flavour of the libraries (cudalibrarysamples_amd/lib_hooks/: the same
+# kernel objects, host code compiled with -DCTAMD_TEST_HOOKS): the tests force kernels, transports and planner rules through CUTENSOR*_AMD_*
+# switches and replay multi-device plans on the host, none of which the production libraries (lib/: bench.py, smoke(), the samples, the
+# reference's binding) read or export.  tests/test_abi.py checks the production flavour's exports and strings separately.
+os.environ.setdefault("CTAMD_LIB_FLAVOUR", "hooks")
+
 
 SESSION_START = [None]
 

@@ -398,3 +398,23 @@ def test_operands_streamed_preference_ranks_the_nontemporal_twins(ct, ops):
     p = ops.contraction_plan(h, [4096, 4096], "mk", [4096, 4096], "kn", [4096, 4096], "mn", operands_streamed=True)
     assert p.describe()["nt"] == 0
     p.destroy()
+
+
+def test_production_libraries_carry_no_test_hooks(built):
+    """Round-5 review, Weak #8: the libraries a user links (cudalibrarysamples_amd/lib/) read no behaviour-changing test / measurement
+    switch and export no test entry point — `strings` lists CUTENSOR_LOG_LEVEL and the three documented cuTENSORMg switches only; the
+    hooks flavour (lib_hooks/, what this suite loads: tests/conftest.py) has them."""
+    import subprocess
+    lib = os.path.join(ROOT, "cudalibrarysamples_amd", "lib")
+    hooks = os.path.join(ROOT, "cudalibrarysamples_amd", "lib_hooks")
+    def switches(path):
+        out = subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout.split("\n")
+        return sorted(set(x for x in out if re.fullmatch(r"CUTENSOR(MG|MP)?_(AMD_)?[A-Z0-9_]+", x) and not x.startswith(("CUTENSOR_STATUS_", "CUTENSOR_COMPUTE_DESC_"))))
+    assert switches(os.path.join(lib, "libcutensor.so")) == ["CUTENSOR_LOG_LEVEL"]
+    assert switches(os.path.join(lib, "libcutensorMg.so")) == ["CUTENSORMG_AMD_FORCE_GATHER", "CUTENSORMG_AMD_TRANSPORT", "CUTENSORMG_AMD_WAVES"]
+    assert switches(os.path.join(lib, "libcutensorMp.so")) == []
+    assert "CUTENSOR_AMD_H16_WAVES" in switches(os.path.join(hooks, "libcutensor.so"))
+    prod, hk = ctypes.CDLL(os.path.join(lib, "libcutensorMg.so")), ctypes.CDLL(os.path.join(hooks, "libcutensorMg.so"))
+    assert not hasattr(prod, "ctamdMgReplayOnHost") and hasattr(hk, "ctamdMgReplayOnHost")
+    assert ctypes.CDLL(os.path.join(lib, "libcutensor.so")).ctamdTestHooksBuilt() == 0
+    assert ctypes.CDLL(os.path.join(hooks, "libcutensor.so")).ctamdTestHooksBuilt() == 1

@@ -136,7 +136,7 @@ def test_beta_nonzero_on_a_plan_of_the_persistent_kernel(built):
     h = ops.Handle()
     g = torch.Generator(device="cuda")
     g.manual_seed(9)
-    M, N, K = 4352, 4352, 192
+    M, N, K = 4352, 4352, 256          # four K-tiles: the smallest count whose tiles stream (pick_h16_choice)
     A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "mk": m fastest
     B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # "kn"
     C = (torch.rand((N, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)

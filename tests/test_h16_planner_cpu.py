@@ -51,7 +51,8 @@ def test_short_k_ranges_run_the_default_kernel_too(env):
     h = ops.Handle()
     for (M, N, K, want, split) in [(8192, 8192, 512, "gett_h16w4p_kernel", 1),        # 8 K-tiles per tile, four tiles per workgroup: persistent (round 5: +6.8 %)
                                    (8192, 8192, 1024, "gett_h16w4p_kernel", 1),    # 16
-                                   (8192, 8192, 1088, "gett_h16w4p_kernel", 1),    # 17 (odd: staged under the epilogue instead of streamed)
+                                   (8192, 8192, 1088, "gett_h16w4x_kernel", 1),    # 17: an odd count cannot stream — the one-tile kernel (132.5 vs 128.5 us,
+                                                                                   # profiles/r06n_h16p_vs_4x_odd_ktile_counts.jsonl)
                                    (2048, 2048, 16384, "gett_h16w4x_kernel", 4)]:  # 64 per slice, 256 workgroups = one round: the one-tile kernel
         p = _plan(ct, ops, h, M, N, K)
         d = p.describe()
