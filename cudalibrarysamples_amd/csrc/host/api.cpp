@@ -36,6 +36,7 @@ namespace {
 // launches of cutensorContract by kernel kind since the library was loaded (ctamdLaunchCounts): 0 = gett_simple_kernel (scalar FMA
 // fallback), 1 = gett_wide_kernel (mode table), 2 = fp32 MFMA families, 3 = aligned 16-bit MFMA family, 4 = general MFMA family
 std::atomic<uint64_t> g_launchCounts[5];
+std::atomic<int> g_lastH16Kernel{-1};   // table entry of the last launch of the aligned 16-bit family (ctamdLastH16Kernel: which twin ran)
 
 bool valid_compute(cutensorComputeDescriptor_t c) { return c >= &kCompute[0] && c <= &kCompute[5]; }
 
@@ -1661,13 +1662,16 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         if (handle->prof.enabled.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, stream);
         int launchKernel = plan->choice.kernel;
-        // beta is known only now: the persistent 16-bit kernel (table entries 88..95) streams its tiles for beta == 0 only and is slower
-        // than its one-tile twin (48..55: same tile, same arguments, same workspace) otherwise — plan_contraction.cpp, pick_h16_choice
-        // (CUTENSOR_AMD_H16_WAVES=4p names the kernel for every call: the tests of its beta path)
+        // beta is known only now.  The persistent 16-bit kernel (table entries 88..95) streams its tiles with beta != 0 too since round 6
+        // (C joins the accumulators through the idle row image: gett_h16p.hip) — when C has the 16-byte lanes of D (its fastest N mode
+        // contiguous).  Any other C sends every tile through the ring-resident epilogue, where the kernel is slower than its one-tile
+        // twin (48..55: same tile, same arguments, same workspace; profiles/r05r_h16p_beta.jsonl): the twin is launched then
+        // (CUTENSOR_AMD_H16_WAVES=4p names the kernel for every call: the tests of that path)
         static const bool persistentForced = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES"); return e && e[0] == '4' && e[1] == 'p'; }();
-        if (plan->choice.family == 1 && tab[launchKernel].pf == 12 && b != 0.0 && !persistentForced && launchKernel - 40 >= 0 &&
+        if (plan->choice.family == 1 && tab[launchKernel].pf == 12 && b != 0.0 && p.cStrideN[0] != 1 && !persistentForced && launchKernel - 40 >= 0 &&
             tab[launchKernel - 40].pf == 7)
             launchKernel -= 40;
+        if (plan->choice.family == 1) g_lastH16Kernel.store(launchKernel, std::memory_order_relaxed);
         if (plan->choice.family == 1 && plan->choice.stripKernel >= 0 && plan->choice.stripKernel < count) {
             // strip plan: the interior's whole tiles on the chosen kernel, then the two edge strips (rows past mInt x all columns, rows
             // below mInt x columns past nInt) as ONE launch of the 64 x 64 tile with two tile rectangles
@@ -1968,6 +1972,8 @@ int ctamdPlanPeelLaunches(const cutensorPlan_t plan) try {
 // cutensorContract launches by kernel kind since the library was loaded: out[0] gett_simple_kernel (scalar FMA fallback), [1]
 // gett_wide_kernel (mode table), [2] fp32 MFMA families, [3] aligned 16-bit MFMA family, [4] general MFMA family.  Lets a test that
 // drives the library through someone else's binding (the reference's own einsum.cc) assert which kernels its cases ran on.
+int ctamdLastH16Kernel(void) try { return g_lastH16Kernel.load(std::memory_order_relaxed); } CTAMD_API_CATCH_INT
+
 void ctamdLaunchCounts(uint64_t out[5]) try {
     for (int i = 0; i < 5; ++i) out[i] = g_launchCounts[i].load(std::memory_order_relaxed);
 } CTAMD_API_CATCH_VOID

@@ -65,6 +65,20 @@ __device__ __forceinline__ s16x4 p_round4(const f32x4& c, float alpha) {
 #endif
 }
 
+// ... the same with beta * C added in fp32 before the ONE rounding (cv: the four 16-bit values of C at the fragment's positions):
+// fma(beta, c, alpha * acc) — the arithmetic of HEpilogue::flush_pair, so both kernels of a plan give the same bits
+template <bool BF>
+__device__ __forceinline__ s16x4 p_round4c(const f32x4& c, float alpha, float beta, const s16x4& cv) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x4 x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaf(beta, h_to_float((uint16_t)cv[r], BF), alpha * c[r]);
+    return p_round4<BF>(x, 1.f);
+#else
+    (void)c; (void)alpha; (void)beta; (void)cv; return s16x4{};
+#endif
+}
+
 // EP: the interior epilogue's way out of the transposed image — 2 (the default): a second, row-major image, stores of 4 rows x 256 bytes;
 // 0: straight from the transposing reads, stores of 16 rows x 64 bytes, nontemporal; 1: the same with plain stores (0 / 1: measurement,
 // CUTENSOR_AMD_H16P_EP with the TIMED instantiation — profiles/r05c_h16p_epilogue_variants.jsonl).
@@ -171,7 +185,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         odo.init(ps_.gK, tile0_ * kHBK, (uint32_t)nTiles, bA_, bB_);                                               \
         HEpilogue e_;                                                                                              \
         e_.init(ps_, l, lds, wave);                                                                                \
-        curOK = VOdometer::sgpr((e_.vecD && e_.beta == 0.f && e_.flat && ps_.partial == nullptr && ps_.gL.total == 1u &&            \
+        curOK = VOdometer::sgpr((e_.vecD && (e_.beta == 0.f || e_.vecC) && e_.flat && ps_.partial == nullptr && ps_.gL.total == 1u && \
                                  m0 + (uint32_t)kHTile <= ps_.gM.total && n0 + (uint32_t)kHTile <= ps_.gN.total) ? 1u : 0u) != 0u;  \
         relA = h_uniform64(oa.base - (uint64_t)m0 * (uint64_t)ps_.gM.stride[0][0] * 2ull);                         \
         relB = h_uniform64(ob.base - (uint64_t)n0 * (uint64_t)ps_.gN.stride[0][0] * 2ull);                         \
@@ -409,7 +423,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         HEpilogue ep;
         ep.init(pe, curL, lds, wave);
         // workgroup-uniform: the whole tile inside D, one M and one N mode, 16-byte lanes, nothing to add
-        const bool fast = streamedOut || VOdometer::sgpr((ep.vecD && ep.beta == 0.f && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
+        const bool fast = streamedOut || VOdometer::sgpr((ep.vecD && (ep.beta == 0.f || ep.vecC) && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
         if (fast) {
             const int64_t sM = pe.gM.stride[1][0];
             uint16_t* dst = ep.D + (int64_t)(mW + (uint32_t)(laneE & 15)) * sM + (int64_t)(nW + 8u * (uint32_t)(laneE >> 4));
@@ -468,12 +482,105 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                     if constexpr ((I) < 8) { CTAMD_P_TR(t[0], 0, 0) CTAMD_P_TR(t[1], 0, 1) CTAMD_P_TR(t[2], 0, 2) CTAMD_P_TR(t[3], 0, 3) } \
                     __builtin_amdgcn_sched_barrier(0);                                                             \
                 }
+                if (VOdometer::sgpr(ep.beta != 0.f ? 1u : 0u) != 0u) {
+                    // beta != 0 (round 6): C joins the accumulators in fp32, BEFORE the one rounding.  The pass's 16 rows of C are loaded
+                    // the way D is stored (cg: 4 rows x 256 bytes per instruction, two passes ahead), written row-major into the row image
+                    // while it is idle (after the fetch of pass I - 1) and brought into the accumulator layout by the transposing read run
+                    // the other way round (cf: fragment j = four rows of one column per lane, read back once the previous pass's fragments are out; gett_h16p_layout.h, p_c_*): 4 loads, 4
+                    // ds_write_b128 and 8 ds_read_b64_tr_b16 per pass on top of the beta == 0 pipeline, no second rounding, no fp32 image.
+                    const float beta = ep.beta;
+                    const int64_t sMc = pe.cStrideM[0];
+                    const uint16_t* src2 = ep.C + (int64_t)(mW + (uint32_t)(laneE >> 4)) * sMc + (int64_t)(nW + 8u * (uint32_t)(laneE & 15));
+                    const int64_t cstep4 = 4 * sMc;
+                    typedef const s16x8 __attribute__((address_space(1))) * PGlbC8;
+                    // kPCDepth: register sets of C chunks (16 VGPRs each) = passes of C requested ahead.  Memory operations complete in order,
+                    // so a request issued behind the stores of an earlier pass returns once those are acknowledged — but three sets (every
+                    // request but the last two in front of the first store) measure the same as two (profiles/r06s_h16p_beta_depth_ab.jsonl:
+                    // 8192^3 1.48-1.53 against 1.50-1.52 PFLOP/s, 8192^2 x 1024 1.03-1.05 both), four and more spill vector registers
+#if defined(CTAMD_P_C_DEPTH)
+                    constexpr int kPCDepth = CTAMD_P_C_DEPTH;
+#else
+                    constexpr int kPCDepth = 2;
+#endif
+                    s16x8 cg[kPCDepth][4];
+                    s16x4 cf[8];
+                    uint32_t cRd[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cRd[j] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(rowImg + p_c_read_off(laneE, j));
+#define CTAMD_P_CG(I)                                                                                               \
+                    {                                                                                              \
+                        cg[(I) % kPCDepth][0] = *(PGlbC8)(uintptr_t)src2; src2 += cstep4;                                  \
+                        cg[(I) % kPCDepth][1] = *(PGlbC8)(uintptr_t)src2; src2 += cstep4;                                  \
+                        cg[(I) % kPCDepth][2] = *(PGlbC8)(uintptr_t)src2; src2 += cstep4;                                  \
+                        cg[(I) % kPCDepth][3] = *(PGlbC8)(uintptr_t)src2; src2 += cstep4;                                  \
+                    }
+#define CTAMD_P_CW(I)                                                                                               \
+                    {                                                                                              \
+                        *reinterpret_cast<s16x8*>(rowImg + p_c_write_off(laneE, 0)) = cg[(I) % kPCDepth][0];               \
+                        *reinterpret_cast<s16x8*>(rowImg + p_c_write_off(laneE, 1)) = cg[(I) % kPCDepth][1];               \
+                        *reinterpret_cast<s16x8*>(rowImg + p_c_write_off(laneE, 2)) = cg[(I) % kPCDepth][2];               \
+                        *reinterpret_cast<s16x8*>(rowImg + p_c_write_off(laneE, 3)) = cg[(I) % kPCDepth][3];               \
+                    }
+#define CTAMD_P_CR1(I, J) cf[J] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)cRd[J]);
+#define CTAMD_P_CR(I) CTAMD_P_CR1(I, 0) CTAMD_P_CR1(I, 1) CTAMD_P_CR1(I, 2) CTAMD_P_CR1(I, 3) CTAMD_P_CR1(I, 4) CTAMD_P_CR1(I, 5) CTAMD_P_CR1(I, 6) CTAMD_P_CR1(I, 7)
+#define CTAMD_P_FRAGC(I, J)                                                                                         \
+                    *reinterpret_cast<s16x4*>(wPtr + 512 * (J)) = p_round4c<BF>(acc[(I) < 8 ? (I) : 0][J], alpha, beta, cf[J]);
+#define CTAMD_P_PASSC(I)                                                                                            \
+                    {                                                                                              \
+                        if constexpr ((I) < 8) { CTAMD_P_FRAGC(I, 0) CTAMD_P_FRAGC(I, 1) }                         \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr ((I) > 0) {                                                                   \
+                            CTAMD_P_PARK(0) CTAMD_P_PARK(1) CTAMD_P_PARK(2) CTAMD_P_PARK(3)                        \
+                            CTAMD_P_FETCH(0) CTAMD_P_FETCH(1) CTAMD_P_FETCH(2) CTAMD_P_FETCH(3)                    \
+                        }                                                                                          \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr ((I) + 1 < 8) { CTAMD_P_CW((I) + 1) }                        /* the row image is idle: C of the next pass goes into it */ \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr (kPCDepth < 8 && (I) + 1 + kPCDepth < 8) { CTAMD_P_CG((I) + 1 + kPCDepth) }   /* (its registers were just written out) */ \
+                        if constexpr ((I) < 8) { CTAMD_P_FRAGC(I, 2) CTAMD_P_FRAGC(I, 3) }                         \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr ((I) > 0) { CTAMD_P_STORE(0) }                                                \
+                        if constexpr ((I) < 8) { CTAMD_P_FRAGC(I, 4) CTAMD_P_FRAGC(I, 5) }                         \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr ((I) > 0) { CTAMD_P_STORE(1) CTAMD_P_STORE(2) }                               \
+                        if constexpr ((I) < 8) { CTAMD_P_FRAGC(I, 6) CTAMD_P_FRAGC(I, 7) }                         \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                        if constexpr ((I) + 1 < 8) { CTAMD_P_CR((I) + 1) }                        /* ... and out again, now that this pass's fragments are done with cf */ \
+                        if constexpr ((I) > 0) { CTAMD_P_STORE(3) }                                                \
+                        if constexpr ((I) < 8) { CTAMD_P_TR(t[0], 0, 0) CTAMD_P_TR(t[1], 0, 1) CTAMD_P_TR(t[2], 0, 2) CTAMD_P_TR(t[3], 0, 3) } \
+                        __builtin_amdgcn_sched_barrier(0);                                                         \
+                    }
+                    // all of C is requested up front (pass 0 goes through the image at once); streamed: the vmcnt(0) that waits for the next
+                    // tile's first K-tiles also waits for it, before any store is in flight
+                    CTAMD_P_CG(0) CTAMD_P_CG(1)
+                    if constexpr (kPCDepth > 2) { CTAMD_P_CG(2) }
+                    if constexpr (kPCDepth > 3) { CTAMD_P_CG(3) }
+                    if constexpr (kPCDepth > 4) { CTAMD_P_CG(4) }
+                    if constexpr (kPCDepth > 5) { CTAMD_P_CG(5) }
+                    if constexpr (kPCDepth > 6) { CTAMD_P_CG(6) }
+                    if constexpr (kPCDepth > 7) { CTAMD_P_CG(7) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    CTAMD_P_CW(0) CTAMD_P_CR(0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (kPCDepth < 8) { CTAMD_P_CG(kPCDepth) }
+                    CTAMD_P_PASSC(0)
+                    if (streamedOut) CTAMD_H_VMCNT(0);
+                    CTAMD_P_PASSC(1) CTAMD_P_PASSC(2) CTAMD_P_PASSC(3) CTAMD_P_PASSC(4)
+                    CTAMD_P_PASSC(5) CTAMD_P_PASSC(6) CTAMD_P_PASSC(7) CTAMD_P_PASSC(8)
+#undef CTAMD_P_PASSC
+#undef CTAMD_P_FRAGC
+#undef CTAMD_P_CR
+#undef CTAMD_P_CR1
+#undef CTAMD_P_CW
+#undef CTAMD_P_CG
+                } else {
                 CTAMD_P_PASS(0)
                 // streamed: the next tile's K-tiles 0 and 1 (issued by the last two K-tile bodies) must have landed before the next main
                 // loop reads them — waited for HERE, while no store of this epilogue is in flight yet (vmcnt counts stores too)
                 if (streamedOut) CTAMD_H_VMCNT(0);
                 CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
                 CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
+                }
 #undef CTAMD_P_PASS
 #undef CTAMD_P_STORE
 #undef CTAMD_P_FETCH

@@ -50,4 +50,23 @@ CTAMD_HD uint32_t p_row_read_off(int lane, int it2) {
     return (uint32_t)(row * 256 + ((ch ^ (row & 7)) << 4));
 }
 
+// ---- C image (beta != 0, round 6): the pass's 16 rows x 128 columns of C, row-major in the row image's 4 KiB while that image is idle
+// (between the fetch of pass I - 1 and the park of pass I).  C arrives the way D leaves — lane (r4 = lane >> 4, ch = lane & 15) holds the
+// 16-byte chunk ch of row 4 it + r4 — and has to reach the accumulator layout: fragment j, lane (g, cl) = rows 4 g + [0, 4) of column
+// 16 j + cl.  That is the transposing read again, the other way round: four ROWS are the lines, a fragment's 16 columns the elements.
+// 32-byte pair P (columns 16 P + [0, 16) = fragment P) of row r lives at pair P ^ (r & 7): the 8 rows a 32-lane half of the read touches
+// (4 g + (cl >> 2), g = 0, 1 or 2, 3) sit in 8 different pairs = all 64 banks once; 8 consecutive lanes of the ds_write_b128 (one row,
+// chunks 0-7 or 8-15) cover four whole pairs that differ mod 128 bytes.
+// where lane (r4, ch) writes the chunk it loaded from C for row 4 it + r4
+CTAMD_HD uint32_t p_c_write_off(int lane, int it) {
+    const int row = 4 * it + (lane >> 4), ch = lane & 15;
+    return (uint32_t)(row * 256 + (((ch >> 1) ^ (row & 7)) << 5) + ((ch & 1) << 4));
+}
+// the 8 bytes lane (g, cl) supplies to the transposing read of fragment j: row 4 g + (cl >> 2), columns 16 j + 4 (cl & 3) + [0, 4); after
+// the read it holds column 16 j + cl of rows 4 g + [0, 4)
+CTAMD_HD uint32_t p_c_read_off(int lane, int j) {
+    const int g = lane >> 4, cl = lane & 15, row = 4 * g + (cl >> 2);
+    return (uint32_t)(row * 256 + ((j ^ (row & 7)) << 5) + ((cl & 3) << 3));
+}
+
 }  // namespace ctamd

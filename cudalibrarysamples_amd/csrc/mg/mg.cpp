@@ -29,13 +29,18 @@
 // differ when they divide each other (e.g. B distributed along j, C not): the block index is then split
 // into common mixed-radix digits.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
 #include <set>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -45,6 +50,7 @@
 #include <cutensorMg.h>
 
 #include "../host/api_guard.hpp"
+#include "mg_kernels.h"
 
 extern "C" int ctamdPlanPeelLaunches(const cutensorPlan_t plan);
 extern "C" int ctamdPlanModeTableGroups(const cutensorPlan_t plan, int32_t* group, int32_t* label, int64_t* extent, int maxOut);   // libcutensor.so diagnostic
@@ -125,7 +131,79 @@ struct Transfer {                 // one cell copied into a device's staging ima
 
 }  // namespace
 
+// One worker thread per handle device (round 6; round-5 review, Weak #6).  cutensorMgContraction is driven by ONE host thread
+// (contraction_multi_gpu.cu:286-345), and at 8 devices that thread's enqueue work — per device: staging copies, event waits, one or
+// more cutensorContract calls — was measured at 184-195 us per call (tools/mg_host_cost_n.py, 8 logical devices), more than the
+// 170 us of device time the sample's 4096^3 leaves each of 8 GPUs.  The per-device parts of a call (local staging copies; the pieces'
+// event waits + local contractions + scatters) only touch that device's streams, so worker g — which set its device ONCE — issues them
+// while the calling thread keeps everything that orders devices against each other (fork, RCCL groups / peer copies, wave events,
+// join).  A phase is handed out with run() and collected with wait(); workers spin briefly for the next phase of a call and sleep
+// on a condition variable between calls.
+struct MgWorkers {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> phase{0};
+    std::atomic<int> pending{0};
+    std::atomic<int> failed{0};
+    const std::function<cutensorStatus_t(int)>* fn = nullptr;
+    bool stop = false;
+
+    void start(const std::vector<int32_t>& devices) {
+        const int n = (int)devices.size();
+        for (int g = 0; g < n; ++g) {
+            const int dev = devices[(size_t)g];
+            threads.emplace_back([this, g, dev] {
+                (void)hipSetDevice(dev);
+                uint64_t seen = 0;
+                for (;;) {
+                    // a new phase: spin for a while (the next phase of the same call arrives within microseconds), then sleep
+                    int spins = 0;
+                    while (phase.load(std::memory_order_acquire) == seen && ++spins < 20000) __builtin_ia32_pause();
+                    if (phase.load(std::memory_order_acquire) == seen) {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return stop || phase.load(std::memory_order_acquire) != seen; });
+                    }
+                    if (phase.load(std::memory_order_acquire) == seen) return;     // stop
+                    seen = phase.load(std::memory_order_acquire);
+                    cutensorStatus_t st = CUTENSOR_STATUS_INTERNAL_ERROR;
+                    try { st = (*fn)(g); } catch (...) { }
+                    if (st != CUTENSOR_STATUS_SUCCESS) failed.store((int)st, std::memory_order_relaxed);
+                    pending.fetch_sub(1, std::memory_order_acq_rel);
+                }
+            });
+        }
+    }
+    bool active() const { return !threads.empty(); }
+    // every worker g runs f(g); returns at once — wait() collects
+    void run(const std::function<cutensorStatus_t(int)>& f) {
+        fn = &f;
+        failed.store(0, std::memory_order_relaxed);
+        pending.store((int)threads.size(), std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m);     // pairs with the sleepers' predicate check
+            phase.fetch_add(1, std::memory_order_acq_rel);
+        }
+        cv.notify_all();
+    }
+    cutensorStatus_t wait() {
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        const int f = failed.load(std::memory_order_relaxed);
+        return f == 0 ? CUTENSOR_STATUS_SUCCESS : (cutensorStatus_t)f;
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (std::thread& t : threads) t.join();
+        threads.clear();
+    }
+};
+
 struct cutensorMgHandle {
+    MgWorkers workers;               // one per handle device when there are several (and a GPU is visible)
     std::vector<int32_t> devices;
     std::vector<cutensorHandle_t> handles;
     bool distinct = true;
@@ -440,6 +518,9 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
         std::vector<int> devs(h->devices.begin(), h->devices.end());
         if (ncclCommInitAll(h->comms.data(), (int)numDevices, devs.data()) != ncclSuccess) h->comms.clear();
     }
+    // worker threads for the per-device parts of a call (MgWorkers): from two handle devices on; CUTENSORMG_AMD_THREADS=0 (a
+    // measurement hook) keeps everything on the calling thread
+    if (count > 0 && numDevices > 1 && !CTAMD_HOOK_IS("CUTENSORMG_AMD_THREADS", "0")) h->workers.start(h->devices);
     *handle = h;
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH
@@ -453,6 +534,7 @@ cutensorStatus_t cutensorMgDestroy(cutensorMgHandle_t handle) try {
         for (hipStream_t s : handle->commStreams[g]) (void)hipStreamDestroy(s);
         if (g < handle->auxStreams.size() && handle->auxStreams[g]) (void)hipStreamDestroy(handle->auxStreams[g]);
     }
+    handle->workers.shutdown();
     for (ncclComm_t c : handle->comms) (void)ncclCommDestroy(c);
     for (cutensorHandle_t h : handle->handles) cutensorDestroy(h);
     delete handle;
@@ -1184,25 +1266,48 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         if (pl->usesAux[(size_t)g]) MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 0), 0));
         if (!pl->usesComm[(size_t)g]) continue;
         for (hipStream_t cs : handle->commStreams[(size_t)g]) {
-            // a communication stream reads the owners' cells: behind the caller's stream of every device
+            // Peer copies PULL the owners' cells: the communication stream goes behind the caller's stream of every device.  Under RCCL
+            // every rank's own communication stream takes part in a transfer (the owner sends from ITS stream), so a stream only has to
+            // follow its own device's caller stream — 8 waits per call instead of 64 at eight devices (round 6: host cost of the call)
+            if (pl->useRccl) { MG_HIP(hipStreamWaitEvent(cs, ev(g, 0), 0)); continue; }
             for (int o = 0; o < nDev; ++o) MG_HIP(hipStreamWaitEvent(cs, ev(o, 0), 0));
         }
     }
 
     // ---- 1. gather ---------------------------------------------------------------------------------------------
-    // local cells (same physical device): device copies on the caller's stream
-    for (const Transfer& t : pl->transfers) {
-        if (!t.local || (t.tensor == 2 && b == 0.0)) continue;
-        MG_HIP(hipSetDevice(handle->devices[t.dst]));
-        MG_HIP(hipMemcpyAsync(staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes, src[t.tensor][t.cell], (size_t)t.bytes,
-                              hipMemcpyDeviceToDevice, streams[t.dst]));
-    }
-    for (int g = 0; g < nDev; ++g) {
-        if (!pl->usesAux[(size_t)g]) continue;
-        MG_HIP(hipSetDevice(handle->devices[g]));
-        MG_HIP(hipEventRecord(ev(g, 1), streams[g]));
-        MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 1), 0));
-    }
+    // local cells (same physical device): device copies on the caller's stream of the receiving device, then the auxiliary stream
+    // joins behind them — per device, so worker g issues device g's (MgWorkers) while this thread goes on with the remote transfers
+    const bool threaded = handle->workers.active();
+    auto local_stage = [&](int g) -> cutensorStatus_t {
+        // up to kMgCopyBatch cells per launch (mg_kernels.hip): a device copy per cell costs the issuing thread 2-3 us
+        MgCopyBatch batch;
+        for (const Transfer& t : pl->transfers) {
+            if (t.dst != g || !t.local || (t.tensor == 2 && b == 0.0) || t.bytes <= 0) continue;
+            batch.src[batch.n] = src[t.tensor][t.cell];
+            batch.dst[batch.n] = staging(t.dst, t.tensor) + (size_t)t.cell * (size_t)t.bytes;
+            batch.bytes[batch.n] = (uint64_t)t.bytes;
+            if (++batch.n == kMgCopyBatch) { MG_HIP(mg_copy_cells(batch, streams[g])); batch.n = 0; }
+        }
+        MG_HIP(mg_copy_cells(batch, streams[g]));
+        if (pl->usesAux[(size_t)g]) {
+            MG_HIP(hipEventRecord(ev(g, 1), streams[g]));
+            MG_HIP(hipStreamWaitEvent(handle->auxStreams[(size_t)g], ev(g, 1), 0));
+        }
+        return CUTENSOR_STATUS_SUCCESS;
+    };
+    // a call without remote cells has nothing for this thread to do in between: the workers run staging and pieces in ONE phase (below)
+    const bool onePhase = threaded && pl->numWaves == 0 && !anyComm;
+    const std::function<cutensorStatus_t(int)> localStageFn = local_stage;
+    if (onePhase) { }
+    else if (threaded) handle->workers.run(localStageFn);
+    else
+        for (int g = 0; g < nDev; ++g) {
+            MG_HIP(hipSetDevice(handle->devices[g]));
+            const cutensorStatus_t stl = local_stage(g);
+            if (stl != CUTENSOR_STATUS_SUCCESS) return stl;
+        }
+    // (from here to the wait() below an early return must collect the workers first: MG_HIP_W)
+#define MG_HIP_W(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); if (threaded) (void)handle->workers.wait(); return CUTENSOR_STATUS_EXECUTION_FAILED; } } while (0)
     // transport of this call: all-gather for the tensors that qualify, or send/recv pairs for everything
     bool useAllGather = false;
     int trial = -1;   // auto: 0 / 1 = this call is the timed all-gather / send-recv trial
@@ -1229,7 +1334,7 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         if (hipEventCreate(&pl->trialEv[2 * trial]) != hipSuccess || hipEventCreate(&pl->trialEv[2 * trial + 1]) != hipSuccess) { (void)hipGetLastError(); trial = -1; }
     }
     ++pl->calls;
-    if (trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial], handle->commStreams[0][0])); }
+    if (trial >= 0) { MG_HIP_W(hipSetDevice(handle->devices[0])); MG_HIP_W(hipEventRecord(pl->trialEv[2 * trial], handle->commStreams[0][0])); }
     // remote cells, wave by wave
     for (int w = 0; w < pl->numWaves; ++w) {
         bool grouped = false;
@@ -1272,25 +1377,32 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
             touched.insert(t.event);
         }
         if (grouped && ncclGroupEnd() != ncclSuccess) st = CUTENSOR_STATUS_EXECUTION_FAILED;   // also closes the group on the error path
-        if (st != CUTENSOR_STATUS_SUCCESS) { (void)hipGetLastError(); return st; }
+        if (st != CUTENSOR_STATUS_SUCCESS) { (void)hipGetLastError(); if (threaded) (void)handle->workers.wait(); return st; }
         for (int e : touched) {
             const int g = e / pl->evPerDevice;
             const int slot = (e - (g * pl->evPerDevice + 3 + pl->commPerDevice)) % (pl->useRccl ? 1 : pl->commPerDevice);
-            MG_HIP(hipSetDevice(handle->devices[g]));
-            MG_HIP(hipEventRecord(pl->events[(size_t)e], handle->commStreams[(size_t)g][(size_t)slot]));
+            MG_HIP_W(hipSetDevice(handle->devices[g]));
+            MG_HIP_W(hipEventRecord(pl->events[(size_t)e], handle->commStreams[(size_t)g][(size_t)slot]));
         }
-        if (w == 0 && trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
+        if (w == 0 && trial >= 0) { MG_HIP_W(hipSetDevice(handle->devices[0])); MG_HIP_W(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
     }
-    if (pl->numWaves == 0 && trial >= 0) { MG_HIP(hipSetDevice(handle->devices[0])); MG_HIP(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
+    if (pl->numWaves == 0 && trial >= 0) { MG_HIP_W(hipSetDevice(handle->devices[0])); MG_HIP_W(hipEventRecord(pl->trialEv[2 * trial + 1], handle->commStreams[0][0])); }
 
     // ---- 2. local contractions, 3. scatter ----------------------------------------------------------------------
-    std::set<std::pair<int, int>> waited;   // (device * 2 + stream, event): each stream waits for an event once
+    if (threaded && !onePhase) {       // the workers' staging copies are queued: the pieces of a device follow them on the same worker
+        const cutensorStatus_t stw = handle->workers.wait();
+        if (stw != CUTENSOR_STATUS_SUCCESS) return stw;
+    }
     const float onef = 1.f;
     const double oned = 1.0;
     const void* one = f64 ? static_cast<const void*>(&oned) : static_cast<const void*>(&onef);
+    // the pieces of device g, in plan order: waits for the wave events (all recorded above, by this thread), local contractions, scatters
+    auto run_pieces = [&](int gWanted) -> cutensorStatus_t {
+    std::set<std::pair<int, int>> waited;   // (device * 2 + stream, event): each stream waits for an event once
     for (const Piece& p : pl->pieces) {
         const int g = p.dev;
-        MG_HIP(hipSetDevice(handle->devices[g]));
+        if (gWanted >= 0 && g != gWanted) continue;
+        if (gWanted < 0) MG_HIP(hipSetDevice(handle->devices[g]));
         hipStream_t cs = compute_stream(g, p.stream);
         for (int e : p.waitEvents) {
             if (b == 0.0) {   // events of waves that carried only C cells were never recorded
@@ -1327,24 +1439,10 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
             if (st != CUTENSOR_STATUS_SUCCESS) return st;
         }
     }
-
-    // ---- 4. join: the caller's stream of every device ends behind its helper streams — and behind every OTHER device's
-    //         stream that stored into its cells of D (remote scatter) or still reads its cells of A / B / C (peer copies):
-    //         a caller that synchronises only streams[owner], or chains a second call on it, sees finished cells
-    for (int g = 0; g < nDev; ++g) {
-        for (int sidx = 0; sidx < kComputeStreams; ++sidx) {
-            const std::vector<int>& owners = pl->scatterOwners[(size_t)(g * kComputeStreams + sidx)];
-            if (owners.empty()) continue;
-            MG_HIP(hipSetDevice(handle->devices[g]));
-            MG_HIP(hipEventRecord(ev(g, pl->evScatter + sidx), compute_stream(g, sidx)));
-            for (int o : owners) {
-                MG_HIP(hipSetDevice(handle->devices[o]));
-                MG_HIP(hipStreamWaitEvent(streams[o], ev(g, pl->evScatter + sidx), 0));
-            }
-        }
-    }
-    for (int g = 0; g < nDev; ++g) {
-        MG_HIP(hipSetDevice(handle->devices[g]));
+    // the device's own join: its caller's stream ends behind its auxiliary and communication streams (every transfer of this call was
+    // queued on them before the pieces started)
+    for (int g = (gWanted >= 0 ? gWanted : 0); g < (gWanted >= 0 ? gWanted + 1 : nDev); ++g) {
+        if (gWanted < 0) MG_HIP(hipSetDevice(handle->devices[g]));
         if (pl->usesAux[(size_t)g]) {
             MG_HIP(hipEventRecord(ev(g, 2), handle->auxStreams[(size_t)g]));
             MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 2), 0));
@@ -1352,15 +1450,67 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
         for (size_t k = 0; pl->usesComm[(size_t)g] && k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k) {
             MG_HIP(hipEventRecord(ev(g, 3 + (int)k), handle->commStreams[(size_t)g][k]));
             MG_HIP(hipStreamWaitEvent(streams[g], ev(g, 3 + (int)k), 0));
-            if (pl->useRccl) continue;    // RCCL: the owner's own communication stream takes part in the transfer and is joined above
-            for (int o : pl->readOwners[(size_t)g]) {
-                MG_HIP(hipSetDevice(handle->devices[o]));
-                MG_HIP(hipStreamWaitEvent(streams[o], ev(g, 3 + (int)k), 0));
-            }
-            MG_HIP(hipSetDevice(handle->devices[g]));
         }
     }
+    // ... and the events the OTHER devices' caller streams wait for in step 4: the end of each compute stream that stored into cells of D
+    // another handle device owns
+    for (int g = (gWanted >= 0 ? gWanted : 0); g < (gWanted >= 0 ? gWanted + 1 : nDev); ++g)
+        for (int sidx = 0; sidx < kComputeStreams; ++sidx) {
+            if (pl->scatterOwners[(size_t)(g * kComputeStreams + sidx)].empty()) continue;
+            if (gWanted < 0) MG_HIP(hipSetDevice(handle->devices[g]));
+            MG_HIP(hipEventRecord(ev(g, pl->evScatter + sidx), compute_stream(g, sidx)));
+        }
+    return CUTENSOR_STATUS_SUCCESS;
+    };
+    {
+        const std::function<cutensorStatus_t(int)> piecesFn = run_pieces;
+        const std::function<cutensorStatus_t(int)> bothFn = [&](int g) -> cutensorStatus_t {
+            const cutensorStatus_t s1 = local_stage(g);
+            return s1 != CUTENSOR_STATUS_SUCCESS ? s1 : run_pieces(g);
+        };
+        cutensorStatus_t stp;
+        if (threaded) { handle->workers.run(onePhase ? bothFn : piecesFn); stp = handle->workers.wait(); }
+        else stp = run_pieces(-1);
+        if (stp != CUTENSOR_STATUS_SUCCESS) return stp;
+    }
+
+    // ---- 4. join: the caller's stream of every device ends behind its helper streams (the device's own part ran with its pieces, above)
+    //         — and behind every OTHER device's stream that stored into its cells of D (remote scatter) or still reads its cells of
+    //         A / B / C (peer copies; under RCCL the owner's own communication stream takes part in the transfer and is joined there):
+    //         a caller that synchronises only streams[owner], or chains a second call on it, sees finished cells.  All events were
+    //         recorded by now; the waits of owner o only touch o's caller stream, so worker o issues them.
+    bool anyCross = false;
+    for (int g = 0; g < nDev && !anyCross; ++g) {
+        for (int sidx = 0; sidx < kComputeStreams; ++sidx) anyCross = anyCross || !pl->scatterOwners[(size_t)(g * kComputeStreams + sidx)].empty();
+        anyCross = anyCross || (!pl->useRccl && pl->usesComm[(size_t)g] && !pl->readOwners[(size_t)g].empty());
+    }
+    auto cross_join = [&](int oWanted) -> cutensorStatus_t {
+        for (int g = 0; g < nDev; ++g) {
+            for (int sidx = 0; sidx < kComputeStreams; ++sidx)
+                for (int o : pl->scatterOwners[(size_t)(g * kComputeStreams + sidx)]) {
+                    if (oWanted >= 0 && o != oWanted) continue;
+                    if (oWanted < 0) MG_HIP(hipSetDevice(handle->devices[o]));
+                    MG_HIP(hipStreamWaitEvent(streams[o], ev(g, pl->evScatter + sidx), 0));
+                }
+            if (pl->useRccl || !pl->usesComm[(size_t)g]) continue;
+            for (size_t k = 0; k < handle->commStreams[(size_t)g].size() && (int)k < pl->commPerDevice; ++k)
+                for (int o : pl->readOwners[(size_t)g]) {
+                    if (oWanted >= 0 && o != oWanted) continue;
+                    if (oWanted < 0) MG_HIP(hipSetDevice(handle->devices[o]));
+                    MG_HIP(hipStreamWaitEvent(streams[o], ev(g, 3 + (int)k), 0));
+                }
+        }
+        return CUTENSOR_STATUS_SUCCESS;
+    };
+    if (anyCross) {
+        const std::function<cutensorStatus_t(int)> joinFn = cross_join;
+        cutensorStatus_t stj;
+        if (threaded) { handle->workers.run(joinFn); stj = handle->workers.wait(); }
+        else stj = cross_join(-1);
+        if (stj != CUTENSOR_STATUS_SUCCESS) return stj;
+    }
 #undef MG_HIP
+#undef MG_HIP_W
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH
 

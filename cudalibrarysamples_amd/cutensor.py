@@ -112,6 +112,8 @@ lib.ctamdPlanMemoStats.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.
 lib.ctamdPlanMemoStats.restype = None
 lib.ctamdLaunchCounts.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
 lib.ctamdLaunchCounts.restype = None
+lib.ctamdLastH16Kernel.argtypes = []
+lib.ctamdLastH16Kernel.restype = ctypes.c_int
 lib.ctamdSetTimingBuffer.argtypes = [_vp, _vp]
 lib.ctamdSetTimingBuffer.restype = None
 lib.ctamdSetSplitKFold.argtypes = [_vp, ctypes.c_int]
@@ -152,6 +154,12 @@ def launch_counts():
     out = (ctypes.c_uint64 * 5)()
     lib.ctamdLaunchCounts(out)
     return dict(zip(("simple", "wide", "f32", "h16", "gen"), [int(v) for v in out]))
+
+
+def last_h16_kernel():
+    """Table entry of the kernel the last cutensorContract of the aligned 16-bit family launched (-1: none yet): 48..55 the one-tile
+    256 x 256 kernel, 88..95 its persistent form — which twin ran is decided at the call (beta, the layout of C)."""
+    return int(lib.ctamdLastH16Kernel())
 
 
 def compute_desc(name):

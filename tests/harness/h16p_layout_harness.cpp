@@ -107,6 +107,52 @@ int main() {
             }
         }
     }
+    // ---- C image (beta != 0): lanes write the chunks they loaded from C (row 4 it + (lane >> 4), chunk lane & 15) row-major, the transposing
+    //      read of fragment j must hand lane (g, cl) rows 4 g + [0, 4) of column 16 j + cl — the accumulator fragment's layout
+    {
+        uint16_t c_img[16 * 128];
+        std::memset(c_img, 0xff, sizeof(c_img));
+        int w3[4096];
+        std::memset(w3, 0, sizeof(w3));
+        for (int it = 0; it < 4; ++it)
+            for (int grp8 = 0; grp8 < 8; ++grp8) {          // ds_write_b128: 8 x 8 contiguous lanes, bank = (address / 4) mod 32
+                std::set<int> banks;
+                for (int lane = 8 * grp8; lane < 8 * grp8 + 8; ++lane) {
+                    const uint32_t off = p_c_write_off(lane, it);
+                    if (off % 16 != 0 || off + 16 > 4096u) { std::printf("C image write offset\n"); return 12; }
+                    const int row = 4 * it + (lane >> 4), ch = lane & 15;
+                    for (int e = 0; e < 8; ++e) c_img[off / 2 + e] = code(row, 8 * ch + e);
+                    for (int b = 0; b < 16; ++b) ++w3[off + b];
+                    for (int b = 0; b < 4; ++b) banks.insert((off / 4 + b) % 32);
+                }
+                if (banks.size() != 32) { std::printf("C image ds_write_b128 bank conflict: it %d lanes %d.. touch %zu banks\n", it, 8 * grp8, banks.size()); return 13; }
+            }
+        for (int b = 0; b < 4096; ++b)
+            if (w3[b] != 1) { std::printf("C image byte %d written %d times\n", b, w3[b]); return 14; }
+        for (int j = 0; j < 8; ++j) {
+            for (int half = 0; half < 2; ++half) {           // ds_read_b64_tr_b16: 2 x 32 lanes, bank = (address / 4) mod 64
+                std::set<int> banks;
+                for (int lane = 32 * half; lane < 32 * half + 32; ++lane) {
+                    const uint32_t off = p_c_read_off(lane, j);
+                    if (off % 8 != 0 || off + 8 > 4096u) { std::printf("C image read offset\n"); return 15; }
+                    banks.insert((off / 4) % 64);
+                    banks.insert((off / 4 + 1) % 64);
+                }
+                if (banks.size() != 64) { std::printf("C image ds_read_b64_tr_b16 bank conflict: fragment %d half %d touches %zu banks\n", j, half, banks.size()); return 16; }
+            }
+            for (int grp = 0; grp < 4; ++grp)
+                for (int i = 0; i < 16; ++i)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int src = 16 * grp + 4 * kk + (i >> 2);
+                        const uint16_t got = c_img[p_c_read_off(src, j) / 2 + (i & 3)];
+                        if (got != code(4 * grp + kk, 16 * j + i)) {
+                            std::printf("C image: fragment %d lane %d element %d: got (row %d, col %d), want (row %d, col %d)\n", j, 16 * grp + i, kk,
+                                        got / 128, got % 128, 4 * grp + kk, 16 * j + i);
+                            return 17;
+                        }
+                    }
+        }
+    }
     std::printf("h16p layout ok\n");
     return 0;
 }

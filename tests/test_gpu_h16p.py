@@ -29,7 +29,11 @@ CASES = [
     (dict(m=768, n=1280, k=128), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "two K-tiles"),
     (dict(m=768, n=1280, k=192), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "three K-tiles (odd: the tail body)"),
     (dict(m=1000, n=712, k=320), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "ragged M and N: interior and edge tiles in one sequence"),
-    (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "bfloat16", 1.25, -0.5, "beta != 0: the fp32 image in the ring"),
+    (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "bfloat16", 1.25, -0.5, "beta != 0, interior tiles: C through the row image (round 6)"),
+    (dict(m=2048, n=1024, k=512), "km", "nk", "mn", "bfloat16", 0.5, 0.5, "beta != 0, 32 streamed tiles of eight K-tiles"),
+    (dict(m=1536, n=1280, k=384), "mk", "nk", "mn", "float16", 1.0, -1.0, "fp16, beta != 0, six K-tiles"),
+    (dict(m=1280, n=1000, k=256), "km", "kn", "mn", "bfloat16", 1.0, 2.0, "beta != 0, interior tiles streaming into edge tiles and back"),
+    (dict(m=768, n=1280, k=192), "mk", "kn", "mn", "bfloat16", 1.0, 1.0, "beta != 0, three K-tiles (nothing streams)"),
     (dict(m=1024, n=512, k=256), "mk", "kn", "nm", "bfloat16", 1.0, 0.0, "D with n fastest (orientation swap)"),
     (dict(m=512, n=512, k=128, l=5), "mkl", "knl", "mnl", "bfloat16", 1.0, 0.0, "batch mode: 20 tiles over 5 batches"),
     (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "float16", 1.0, 0.0, "fp16"),
@@ -87,6 +91,62 @@ def test_persistent_kernel_parity(built, grid):
     assert r.returncode == 0 and "H16P_CHILD_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+_BITS_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from cudalibrarysamples_amd import cutensor as ct, ops
+h = ops.Handle()
+g = torch.Generator(device="cuda")
+out = {}
+cases = [(2048, 1024, 512, "bfloat16", 0.75, -0.5, "own"), (1536, 1280, 256, "float16", 1.0, 1.0, "own"), (1280, 1000, 384, "bfloat16", 1.0, 0.25, "own"),
+         (2048, 1024, 256, "bfloat16", 1.0, 1.0, "inplace"), (1024, 1024, 256, "bfloat16", 0.5, 0.5, "pitch")]
+for idx, (M, N, K, dt, alpha, beta, how) in enumerate(cases):
+    tdt = getattr(torch, dt)
+    g.manual_seed(40 + idx)
+    A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(tdt)     # "mk": m fastest
+    B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(tdt)     # "kn"
+    Cbig = (torch.rand((N, M + 24), generator=g, device="cuda") * 2 - 1).to(tdt)
+    C = Cbig[:, :M] if how == "pitch" else Cbig[:, :M].contiguous()          # [N][M], m fastest; "pitch": rows of C 24 elements longer than D's
+    D = C.clone() if how != "pitch" else torch.empty((N, M), device="cuda", dtype=tdt)
+    p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF if dt == "bfloat16" else ct.R_16F,
+                             strideC=[1, C.stride(0)], strideD=[1, D.stride(0)], workspace_limit=0)
+    want = sys.argv[2]
+    assert p.describe()["kname"] == want and p.describe()["splitK"] == 1, p.describe()      # no split-K: the epilogue with C is under test
+    cptr = D.data_ptr() if how == "inplace" else C.data_ptr()
+    p.contract(alpha, A.data_ptr(), B.data_ptr(), beta, cptr, D.data_ptr())
+    torch.cuda.synchronize()
+    ref = alpha * (B.double() @ A.double()) + beta * C.double()
+    err = (D.double() - ref).abs()
+    tol = (8e-3 if dt == "bfloat16" else 2e-3) * ref.abs() + 5e-2
+    assert bool((err <= tol).all()), (idx, float((err - tol).max()))
+    out["d%%d" %% idx] = D.view(torch.int16).cpu()
+    p.destroy()
+torch.save(out, sys.argv[1])
+print("BITS_CHILD_OK")
+''' % ROOT
+
+
+def test_beta_path_gives_the_bits_of_the_one_tile_kernel(built, tmp_path):
+    """beta != 0 in the persistent kernel's streaming epilogue (round 6: C through the idle row image, joined with the accumulators in fp32
+    before the one rounding) against the one-tile twin's fp32-image epilogue: same main loop, same fma(beta, c, alpha * acc) — the SAME
+    bits, on C of its own, C = D in place, and a C whose rows are longer than D's.  Both children also check against fp64."""
+    outs = []
+    for waves, kname in (("4p", "gett_h16w4p_kernel"), ("4x", "gett_h16w4x_kernel")):
+        f = str(tmp_path / ("bits_%s.pt" % waves))
+        r = subprocess.run([sys.executable, "-c", _BITS_CHILD, f, kname], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, CUTENSOR_AMD_H16_WAVES=waves), cwd=ROOT)
+        assert r.returncode == 0 and "BITS_CHILD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(f)
+    import torch
+    a, b = torch.load(outs[0]), torch.load(outs[1])
+    assert sorted(a) == sorted(b) and len(a) == 5
+    for k in a:
+        if not torch.equal(a[k], b[k]):
+            idx = (a[k] != b[k]).nonzero()[:8]
+            vals = [(tuple(int(x) for x in i), hex(int(a[k][tuple(i)]) & 0xffff), hex(int(b[k][tuple(i)]) & 0xffff)) for i in idx]
+            raise AssertionError((k, int((a[k] != b[k]).sum()), vals))
+
+
 def test_many_rounds_at_full_grid(built):
     """More tiles than CUs without the grid cap: 4352 x 4352 x 128 = 289 tiles on 256 workgroups (33 of them walk two tiles), checked by
     sampled fp64 dot products; and the size class of the bench line at reduced K (8192 x 8192 x 256: 1024 tiles, four rounds)."""
@@ -124,11 +184,11 @@ if __name__ == "__main__":
 
 
 def test_beta_nonzero_on_a_plan_of_the_persistent_kernel(built):
-    """beta is known only at the call.  The persistent kernel streams its tiles for beta == 0 only and is slower than its one-tile twin
-    otherwise (profiles/r05r_h16p_beta.jsonl), so cutensorContract launches the twin — same tile, same arguments — when a plan of the
-    persistent kernel is executed with beta != 0 (api.cpp; not when CUTENSOR_AMD_H16_WAVES=4p names the kernel, which is how the parity
-    tests above reach the persistent kernel's own beta path).  Here: the planner's own choice for a two-round shape, beta = 0 and
-    beta != 0 through the SAME plan, against fp64."""
+    """beta is known only at the call.  Since round 6 the persistent kernel streams its tiles with beta != 0 too when C has the 16-byte
+    lanes of D; with any other C every tile would take the ring-resident epilogue, where it is slower than its one-tile twin
+    (profiles/r05r_h16p_beta.jsonl), and cutensorContract launches the twin — same tile, same arguments (api.cpp; not when
+    CUTENSOR_AMD_H16_WAVES=4p names the kernel).  Here: the planner's own choice for a two-round shape, beta = 0 and beta != 0 through
+    the SAME plan, against fp64, with the kernel that ran read back (ct.last_h16_kernel)."""
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
@@ -147,7 +207,22 @@ def test_beta_nonzero_on_a_plan_of_the_persistent_kernel(built):
         D = C.clone()
         p.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr())
         torch.cuda.synchronize()
+        assert 88 <= ct.last_h16_kernel() < 96, ct.last_h16_kernel()      # round 6: the persistent kernel itself, beta or not
         ref = alpha * ab + beta * C.double()
+        err = (D.double() - ref).abs()
+        tol = 8e-3 * ref.abs() + 3e-2
+        assert bool((err <= tol).all()), (alpha, beta, float((err - tol).max()))
+    p.destroy()
+    # a C without the 16-byte lanes of D (m is not its stride-1 mode): beta == 0 on the persistent kernel, beta != 0 on the one-tile twin
+    Ct = (torch.rand((M, N), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)     # element (m, n) at m * N + n
+    p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF, strideC=[N, 1], strideD=[1, M])
+    assert p.describe()["kname"] == "gett_h16w4p_kernel", p.describe()
+    for alpha, beta, lo in ((1.0, 0.0, 88), (1.0, 0.5, 48)):
+        D = torch.zeros((N, M), device="cuda", dtype=torch.bfloat16)
+        p.contract(alpha, A.data_ptr(), B.data_ptr(), beta, Ct.data_ptr(), D.data_ptr())
+        torch.cuda.synchronize()
+        assert lo <= ct.last_h16_kernel() < lo + 8, (beta, ct.last_h16_kernel())
+        ref = alpha * ab + beta * Ct.double().t()
         err = (D.double() - ref).abs()
         tol = 8e-3 * ref.abs() + 3e-2
         assert bool((err <= tol).all()), (alpha, beta, float((err - tol).max()))
