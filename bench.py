@@ -698,6 +698,36 @@ def secondary_round6(torch, ct, ops, h, stream, with_counters):
             out.append(line)
         except Exception as ex:   # noqa: BLE001
             out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- bf16 8192^2 x 2048 with beta != 0, in place (D = A B + 0.5 D: the form contraction.cu:43 states): the persistent kernel's
+    #      streaming epilogue with C (round 6); the kernel that actually ran is read back (cutensorContract picks the twin at the call)
+    try:
+        M = N = 8192
+        K = 2048
+        g = torch.Generator(device="cuda")
+        g.manual_seed(4)
+        A = (torch.rand((K, M), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        B = (torch.rand((N, K), generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+        D = torch.zeros((N, M), device="cuda", dtype=torch.bfloat16)
+        p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", dtype=ct.R_16BF, workspace_limit=1 << 30)
+        ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+        rates = {}
+        for beta in (0.5, 0.0):
+            fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), beta, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)   # noqa: E731
+            for _ in range(40):
+                fn()
+            ms = min(timed_batch(torch, fn, reps=30), timed_batch(torch, fn, reps=30))
+            rates[beta] = (ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, ct.last_h16_kernel())
+        ms, tf, kidx = rates[0.5]
+        out.append({"workload": "contraction bf16 D[m,n]=A[m,k]B[k,n]+0.5*D M=N=8192 K=2048 (beta != 0, in place), U(-1,1) data", "dtype": "bf16",
+                    "value": tf * 1e3, "unit": "GFLOP/s", "ms_per_call": ms, "kernel": p.describe()["kname"], "launched_table_entry": kidx,
+                    "launched": "persistent (88..95)" if 88 <= kidx < 96 else "one-tile twin (48..55)",
+                    "same_plan_beta_0_gflops": rates[0.0][1] * 1e3,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS_BF16_MFMA,
+                                 "algorithmic_flop": 2.0 * M * N * K, "algorithmic_bytes": 2.0 * (M * K + K * N + 2 * M * N)}})
+        p.destroy()
+        del A, B, D, ws
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "contraction bf16 8192^2 x 2048 beta != 0", "error": "%s: %s" % (type(ex).__name__, ex)})
     # ---- complex64 1024^3: permutation abc->cab and reduction abc->ac on the tiled kernels of 8-byte elements ----------------
     try:
         n = 1024

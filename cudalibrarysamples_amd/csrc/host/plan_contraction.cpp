@@ -752,11 +752,13 @@ bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // (fp32 for 16-bit data, double / float2 / double2 for fp64 / complex64 / complex128)
     const uint64_t accBytes = (elem <= GEN_F16) ? 4ull : (elem == GEN_C64) ? 16ull : 8ull;
     const uint64_t perSliceBytes = v.totL * v.totM * v.totN * accBytes;
-    // (48 K-tiles or more: below that the fold's second launch costs what the split saves — the reference's fp16 case
-    // 'mlik,lkjm->lij' at 50 batches x 32 K-tiles measured 19.2 us unsplit, 19.8 us in five slices)
+    // From 16 K-tiles on, slices of at least four.  (Round 4 raised this to 48 K-tiles on a misread pair of numbers; the records say the
+    // opposite — the reference's fp16 case 'mlik,lkjm->lij', 50 batches x 32 K-tiles on 2-byte gathers: 19.2 us in five slices
+    // (profiles/r04a_bench_gen.jsonl, 250 workgroups), 32.1-32.6 us unsplit (the bench line of rounds 4-6, 50 workgroups on 256 CUs):
+    // a K-tile of this family costs ~0.8 us, the fold's launch ~4.)
     uint64_t split = 1;
-    if (tiles * 2.0 <= (double)numCUs && kTiles >= 48) {
-        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 8);
+    if (tiles * 2.0 <= (double)numCUs && kTiles >= 16) {
+        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
         while (split > 1 && split * perSliceBytes > wsLimit) --split;
         if (split < 2) split = 1;
     }

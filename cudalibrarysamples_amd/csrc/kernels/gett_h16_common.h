@@ -131,6 +131,38 @@ __device__ __forceinline__ uint16_t h_round16(float f) {
 #endif
 }
 
+// round16(v + beta * c), c a 16-bit value of the tensor's type, with ONE rounding (round 6).  bf16: the fma is an fp32 operation whatever
+// the compiler makes of it (v_fma_f32 / v_pk_fma_f32), then one conversion.  fp16: v_fma_mixlo_f16 by hand — the sum is rounded once,
+// straight to 16 bits.  Written as `v += beta * (float)c; (_Float16)v` the compiler picks per element between that instruction and
+// v_pk_fma_f32 + v_cvt_pk_f16_f32 (an fp32 sum rounded a second time), depending on how the neighbours vectorise: two kernels of one plan
+// (gett_h16w4x_kernel / gett_h16w4p_kernel) then differ in the last bit of a few results per million (profiles/r06w, r06x).
+template <bool BF>
+__device__ __forceinline__ uint16_t h_round16_with_c(float v, float beta, uint16_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (BF) return h_round16<true>(__builtin_fmaf(beta, __uint_as_float((uint32_t)c << 16), v));
+    else {
+        uint32_t r;
+        const uint32_t cw = c;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(beta), "v"(cw), "v"(v));
+        return (uint16_t)r;
+    }
+#else
+    (void)v; (void)beta; (void)c; return 0;
+#endif
+}
+template <bool BF>
+__device__ __forceinline__ s16x8 h_round8(const f32x4& v0, const f32x4& v1) {
+    return s16x8{(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
+                 (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+}
+template <bool BF>
+__device__ __forceinline__ s16x8 h_round8_with_c(const f32x4& v0, const f32x4& v1, float beta, const s16x8& cv) {
+    return s16x8{(short)h_round16_with_c<BF>(v0[0], beta, (uint16_t)cv[0]), (short)h_round16_with_c<BF>(v0[1], beta, (uint16_t)cv[1]),
+                 (short)h_round16_with_c<BF>(v0[2], beta, (uint16_t)cv[2]), (short)h_round16_with_c<BF>(v0[3], beta, (uint16_t)cv[3]),
+                 (short)h_round16_with_c<BF>(v1[0], beta, (uint16_t)cv[4]), (short)h_round16_with_c<BF>(v1[1], beta, (uint16_t)cv[5]),
+                 (short)h_round16_with_c<BF>(v1[2], beta, (uint16_t)cv[6]), (short)h_round16_with_c<BF>(v1[3], beta, (uint16_t)cv[7])};
+}
+
 // C and D are device memory: the epilogues address them through the GLOBAL address space (global_load / global_store), not through
 // generic pointers (flat_*).  A flat operation "may touch LDS" for the compiler's wait-count bookkeeping: inside a kernel that loops
 // over tiles (gett_h16p.hip) one pending flat store turned every counted LDS wait of the main loop into lgkmcnt(0).
@@ -231,15 +263,9 @@ struct HEpilogue {
                 if (m < Mtot && n < Ntot) {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
-                    if (beta != 0.f) {
-                        const s16x8 cv = load16(C + offC, n);
-#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
-                        CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
-                        CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
-#undef CTAMD_EP_C
-                    }
-                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
-                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+                    s16x8 out;
+                    if (beta != 0.f) out = h_round8_with_c<BF>(v0, v1, beta, load16(C + offC, n));
+                    else out = h_round8<BF>(v0, v1);
                     if constexpr (ST == 0) store16(D + offD, out, n);   // nontemporal: not read again by this kernel; keeps the operand panels in L2
                     else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
@@ -254,8 +280,7 @@ struct HEpilogue {
                 int64_t offD, offC;
                 offsets(p, m, n, offD, offC);
                 float val = scratch[row * 64 + lane];
-                if (beta != 0.f) val += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + offC), BF);
-                *(HGlbU16)(uintptr_t)(D + offD) = h_round16<BF>(val);
+                *(HGlbU16)(uintptr_t)(D + offD) = (beta != 0.f) ? h_round16_with_c<BF>(val, beta, *(HGlbCU16)(uintptr_t)(C + offC)) : h_round16<BF>(val);
             }
         }
     }
@@ -294,12 +319,7 @@ struct HEpilogue {
         if (m < Mtot && n < Ntot) {
             int64_t offD, offC;
             offsets(p, m, n, offD, offC);
-#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
-            CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
-            CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
-#undef CTAMD_EP_C
-            const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
-                               (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+            const s16x8 out = h_round8_with_c<BF>(v0, v1, beta, cv);
             store16(D + offD, out, n);
         }
     }
@@ -326,23 +346,18 @@ struct HEpilogue {
                 if (m < Mtot && n < Ntot) {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
-                    f32x4 v0 = lo, v1 = hi;              // explicit elements below: nothing here may become a stack array
+                    const f32x4 v0 = lo, v1 = hi;
+                    s16x8 out;
                     if (beta != 0.f) {
-                        if (vecC) {
-                            const s16x8 cv = load16(C + offC, n);
-#define CTAMD_EP_C(E, V, I) V[I] += beta * h_to_float((uint16_t)cv[E], BF);
-                            CTAMD_EP_C(0, v0, 0) CTAMD_EP_C(1, v0, 1) CTAMD_EP_C(2, v0, 2) CTAMD_EP_C(3, v0, 3)
-                            CTAMD_EP_C(4, v1, 0) CTAMD_EP_C(5, v1, 1) CTAMD_EP_C(6, v1, 2) CTAMD_EP_C(7, v1, 3)
-#undef CTAMD_EP_C
-                        } else {
-#define CTAMD_EP_CS(E, V, I) if (n + (E) < Ntot) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); V[I] += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + oC_), BF); }
-                            CTAMD_EP_CS(0, v0, 0) CTAMD_EP_CS(1, v0, 1) CTAMD_EP_CS(2, v0, 2) CTAMD_EP_CS(3, v0, 3)
-                            CTAMD_EP_CS(4, v1, 0) CTAMD_EP_CS(5, v1, 1) CTAMD_EP_CS(6, v1, 2) CTAMD_EP_CS(7, v1, 3)
+                        s16x8 cv = {0, 0, 0, 0, 0, 0, 0, 0};     // explicit elements below: nothing here may become a stack array
+                        if (vecC) cv = load16(C + offC, n);
+                        else {                                    // C is gathered element by element (a column past the end contributes zero)
+#define CTAMD_EP_CS(E) if (n + (E) < Ntot) { int64_t oD_, oC_; offsets(p, m, n + (E), oD_, oC_); cv[E] = (short)*(HGlbCU16)(uintptr_t)(C + oC_); }
+                            CTAMD_EP_CS(0) CTAMD_EP_CS(1) CTAMD_EP_CS(2) CTAMD_EP_CS(3) CTAMD_EP_CS(4) CTAMD_EP_CS(5) CTAMD_EP_CS(6) CTAMD_EP_CS(7)
 #undef CTAMD_EP_CS
                         }
-                    }
-                    const s16x8 out = {(short)h_round16<BF>(v0[0]), (short)h_round16<BF>(v0[1]), (short)h_round16<BF>(v0[2]), (short)h_round16<BF>(v0[3]),
-                                       (short)h_round16<BF>(v1[0]), (short)h_round16<BF>(v1[1]), (short)h_round16<BF>(v1[2]), (short)h_round16<BF>(v1[3])};
+                        out = h_round8_with_c<BF>(v0, v1, beta, cv);
+                    } else out = h_round8<BF>(v0, v1);
                     if constexpr (ST == 0) store16(D + offD, out, n);   // nontemporal: the result is not read again by this kernel
                     else if constexpr (ST == 1) *(HGlbS8)(uintptr_t)(D + offD) = out;
                     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(D + offD), "v"(out) : "memory");
@@ -362,8 +377,7 @@ struct HEpilogue {
                     int64_t offD, offC;
                     offsets(p, m, n, offD, offC);
                     float val = scratch[f * 1024 + row * 32 + lane];
-                    if (beta != 0.f) val += beta * h_to_float(*(HGlbCU16)(uintptr_t)(C + offC), BF);
-                    *(HGlbU16)(uintptr_t)(D + offD) = h_round16<BF>(val);
+                    *(HGlbU16)(uintptr_t)(D + offD) = (beta != 0.f) ? h_round16_with_c<BF>(val, beta, *(HGlbCU16)(uintptr_t)(C + offC)) : h_round16<BF>(val);
                 }
             }
         }

@@ -10,7 +10,7 @@
 //     one-tile kernel: workgroup w takes the ids w, w + grid, w + 2 grid, ... of xcd_remap's sequence, so an XCD keeps its 8 x 4
 //     block of concurrent tiles);
 //   * interior tiles STREAM into each other (the tile in flight and the next one inside D of a problem with one M and one N mode, no
-//     batch modes, 16-byte lanes in D, beta = 0; an even K-tile count; at least four K-tiles in the next tile): the per-lane staging
+//     batch modes, 16-byte lanes in D; an even K-tile count; at least four K-tiles in the next tile): the per-lane staging
 //     offsets do not depend on the tile — only the descriptor bases move — so K-tile nTiles - 2 hands the odometer to the next tile
 //     (CTAMD_P_SWITCH, in a copy of the body pair of its own) and the LDS-DMA pieces the last two K-tile bodies issue anyway fetch the
 //     next tile's K-tiles 0 and 1; the next tile starts on a peeled pair without vmcnt(0).  No setup, no staging latency between tiles;
@@ -19,18 +19,24 @@
 //   * the image is TRANSPOSED: an accumulator fragment holds, per lane, four consecutive ROWS of one column, so after two packed
 //     conversions (v_cvt_pk_bf16_f32) the lane's four values are 8 contiguous bytes of a column-major image [128 columns][16 rows]
 //     — ONE ds_write_b64 per fragment instead of four 2-byte writes — and ds_read_b64_tr_b16, the transposing read the main loop
-//     uses for free-contiguous operands, brings four consecutive columns of a row to every lane.  EP = 2 (the default) copies them
-//     into a second, row-major image and stores four 256-byte row segments per lane group; storing straight from the transposing
-//     reads (EP = 0) gives 64-byte segments and is 5 % slower (profiles/r05b, r05c).  Image row of column c at 32 R(c) bytes,
+//     uses for free-contiguous operands, brings four consecutive columns of a row to every lane.  They are copied
+//     into a second, row-major image and leave as four 256-byte row segments per lane group; storing straight from the transposing
+//     reads gives 64-byte segments and is 5 % slower (profiles/r05b, r05c).  Image row of column c at 32 R(c) bytes,
 //     R(c) = c ^ 4 ((c >> 3) & 1); the 8-byte slot of rows 4 s .. 4 s + 3 inside it at s ^ ((R >> 2) & 3): the ds_write_b64 of a
 //     16-lane group and the transposing read of a 32-lane half both touch every bank once (gett_h16p_layout.h, replayed on the CPU:
 //     tests/test_gen_layout_cpu.py::test_persistent_kernel_epilogue_image_replay);
 //   * every global access of the epilogue goes through an address_space(1) pointer: a pending FLAT store makes each counted
 //     lgkmcnt wait of the next tile's first K-tiles a full drain.
-// Every other tile (edges, beta != 0, strided D, batch modes, split-K partials) takes the epilogues of gett_h16w4x_kernel, in the
-// ring, and is set up and staged behind them — slower than the one-tile kernel, which is why the planner offers this kernel only to
-// problems whose interior tiles can stream and cutensorContract launches the one-tile twin for beta != 0 (plan_contraction.cpp,
-// api.cpp).  Roofline and algorithmic bytes as in gett_h16.hip (MFMA bf16; 2 M N K flop).
+//   * beta != 0 (round 6): C joins the accumulators in fp32 before the ONE rounding and the tile still streams — the pass's 16 rows of
+//     C are loaded the way D is stored, written row-major into the row image while it is idle and brought into the accumulator layout
+//     by the transposing read run the other way round (four ROWS of one column per lane; p_c_write_off / p_c_read_off, replayed on the
+//     CPU with the other images).  Same bits as the one-tile kernel's fp32-image epilogue (tests/test_gpu_h16p.py); on one box 8192^3
+//     beta = 0.5 1.48-1.53 PFLOP/s against 1.42-1.45 on the one-tile kernel, 8192^2 x 2048 1.30-1.32 against 1.04-1.07, x 1024
+//     1.03-1.06 against 0.76-0.77 (profiles/r06r_h16p_beta_vs_one_tile_ab.jsonl, r06s_h16p_beta_depth_ab.jsonl).
+// Every other tile (edges, strided D, a C without the 16-byte lanes of D, batch modes, split-K partials) takes the epilogues of
+// gett_h16w4x_kernel, in the ring, and is set up and staged behind them — slower than the one-tile kernel, which is why the planner
+// offers this kernel only to problems whose interior tiles can stream and cutensorContract launches the one-tile twin for beta != 0 with
+// such a C (plan_contraction.cpp, api.cpp).  Roofline and algorithmic bytes as in gett_h16.hip (MFMA bf16; 2 M N K flop).
 #include <type_traits>
 
 #include "gett_h16x_common.h"
@@ -65,25 +71,18 @@ __device__ __forceinline__ s16x4 p_round4(const f32x4& c, float alpha) {
 #endif
 }
 
-// ... the same with beta * C added in fp32 before the ONE rounding (cv: the four 16-bit values of C at the fragment's positions):
-// fma(beta, c, alpha * acc) — the arithmetic of HEpilogue::flush_pair, so both kernels of a plan give the same bits
+// ... the same with beta * C added before the ONE rounding (cv: the four 16-bit values of C at the fragment's positions): h_round16_with_c,
+// the arithmetic of every HEpilogue path (gett_h16_common.h), so both kernels of a plan give the same bits
 template <bool BF>
 __device__ __forceinline__ s16x4 p_round4c(const f32x4& c, float alpha, float beta, const s16x4& cv) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    f32x4 x;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = __builtin_fmaf(beta, h_to_float((uint16_t)cv[r], BF), alpha * c[r]);
-    return p_round4<BF>(x, 1.f);
-#else
-    (void)c; (void)alpha; (void)beta; (void)cv; return s16x4{};
-#endif
+    return s16x4{(short)h_round16_with_c<BF>(alpha * c[0], beta, (uint16_t)cv[0]), (short)h_round16_with_c<BF>(alpha * c[1], beta, (uint16_t)cv[1]),
+                 (short)h_round16_with_c<BF>(alpha * c[2], beta, (uint16_t)cv[2]), (short)h_round16_with_c<BF>(alpha * c[3], beta, (uint16_t)cv[3])};
 }
 
-// EP: the interior epilogue's way out of the transposed image — 2 (the default): a second, row-major image, stores of 4 rows x 256 bytes;
-// 0: straight from the transposing reads, stores of 16 rows x 64 bytes, nontemporal; 1: the same with plain stores (0 / 1: measurement,
-// CUTENSOR_AMD_H16P_EP with the TIMED instantiation — profiles/r05c_h16p_epilogue_variants.jsonl).
-// TIMED (CUTENSOR_AMD_H16_TIMED=1, bf16 mk,kn only): wave 0 of every workgroup records shader cycles at entry / first tile staged and
-// landed / end of its main loop / end of its epilogue / exit and the number of tiles it walked into p.timing (tools/h16p_timeline.py).
+// (Round 5 compared three ways out of the transposed image with a TIMED instantiation of this kernel — a second, row-major image and
+// stores of 4 rows x 256 bytes; straight from the transposing reads, stores of 16 rows x 64 bytes, nontemporal or plain: 5 % slower,
+// profiles/r05b, r05c_h16p_epilogue_variants.jsonl.  The row image stayed; the variants and the in-kernel time stamps, which had read
+// zeros since the tiles stream into each other, were removed in round 6.)
 // VOdometer::advance_event with the K mode table read through a LAUNDERED argument pointer inside the rare branch: handed `p.gK`, the
 // compiler hoists the table's ~30 scalar loads out of the tile loop (they are loop-invariant) and keeps them alive — spilled — across
 // the main loop, whose bodies then carry v_readlane / v_writelane between their MFMAs.
@@ -110,12 +109,9 @@ __device__ __forceinline__ void p_advance_event(VOdometer& odo) {
 #endif
 }
 
-template <bool BF, int LA, int LB, int EP = 2, bool TIMED = false>
+template <bool BF, int LA, int LB>
 __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p) {
     __shared__ __attribute__((aligned(16))) char lds[kPRingBytes + 8 * kPImageBytes];     // 160 KiB: the ring + two pass images per wave
-    unsigned long long wgStamp[5] = {0, 0, 0, 0, 0};
-    uint32_t tilesWalked = 0;
-    if constexpr (TIMED) wgStamp[0] = __builtin_readcyclecounter();
     prefetch_kernarg<(int)sizeof(GettParams)>();
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
@@ -346,7 +342,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         // streamed-in tile: every wave has waited for both K-tiles inside the previous epilogue.
         if (!streamedIn) CTAMD_H_VMCNT(16);
         __builtin_amdgcn_s_barrier();
-        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[1] = __builtin_readcyclecounter(); }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -364,7 +359,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         if (t < curTiles) { CTAMD_P_TILE(0) }
         if (!streamedOut) CTAMD_H_VMCNT(0);       // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
         x_acc_ready(acc);
-        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[2] = __builtin_readcyclecounter(); }
         // the lane index again, from the hardware: nothing lane-derived stays live across the main loop for the epilogue's sake
         const int laneE = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const uint32_t nextVb = vb + gridX;
@@ -411,7 +405,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                         }
                     }
                 }
-            ++tilesWalked;
             if (!more) break;
             __syncthreads();                      // every wave has finished reading the operand ring
             vb = nextVb;
@@ -426,7 +419,6 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         const bool fast = streamedOut || VOdometer::sgpr((ep.vecD && (ep.beta == 0.f || ep.vecC) && ep.flat && tM0 + (uint32_t)kHTile <= ep.Mtot && tN0 + (uint32_t)kHTile <= ep.Ntot) ? 1u : 0u) != 0u;
         if (fast) {
             const int64_t sM = pe.gM.stride[1][0];
-            uint16_t* dst = ep.D + (int64_t)(mW + (uint32_t)(laneE & 15)) * sM + (int64_t)(nW + 8u * (uint32_t)(laneE >> 4));
             const float alpha = ep.alpha;
             if (more && !streamedOut) {           // not streamed in by the main loop: the next tile's first two K-tiles are staged now and arrive under this epilogue
                 vb = nextVb;
@@ -446,7 +438,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
                 const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((PLds4)(uintptr_t)(uint32_t)(uintptr_t)(rPtr1 + (BUF) * kPImageBytes + 1024 * (IT))); \
                 DST = s16x8{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                         \
             }
-            if constexpr (EP == 2) {
+            {
                 // Two images per wave: T (transposed, [128 columns][16 rows]) and R (row-major, [16 rows][256 bytes], 16-byte units
                 // XOR-swizzled by the row).  Pass I, software-pipelined by one pass (the LDS executes a wave's operations in order, so
                 // single images suffice): the chunks of pass I - 1 (in t[], from the transposing reads at the end of that pass) are
@@ -586,45 +578,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
 #undef CTAMD_P_FETCH
 #undef CTAMD_P_PARK
 #undef CTAMD_P_FRAG
-            } else {
-                // EP = 0 / 1 (measurement): straight from the transposing reads — a store writes 16 rows x 64 bytes
-                s16x8 v[2][4];
-#define CTAMD_P_FRAG(I, J)                                                                                          \
-                *reinterpret_cast<s16x4*>(wPtr + ((I) & 1) * kPImageBytes + 512 * (J)) = p_round4<BF>(acc[(I) < 8 ? (I) : 0][J], alpha);
-#define CTAMD_P_STORE(I, IT)                                                                                        \
-                {                                                                                                  \
-                    if constexpr (EP == 1) *(PGlb8)(uintptr_t)(dst + 32 * (IT)) = v[((I) - 1) & 1][IT];            \
-                    else __builtin_nontemporal_store(v[((I) - 1) & 1][IT], (PGlb8)(uintptr_t)(dst + 32 * (IT)));   \
-                }
-#define CTAMD_P_PASS(I)                                                                                             \
-                {                                                                                                  \
-                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 0) CTAMD_P_FRAG(I, 1) }                               \
-                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 0) }                                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                             \
-                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 2) CTAMD_P_FRAG(I, 3) }                               \
-                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 1) }                                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                             \
-                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 4) CTAMD_P_FRAG(I, 5) }                               \
-                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 2) }                                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                             \
-                    if constexpr ((I) < 8) { CTAMD_P_FRAG(I, 6) CTAMD_P_FRAG(I, 7) }                               \
-                    if constexpr ((I) > 0) { CTAMD_P_STORE(I, 3) dst += 16 * sM; }                                 \
-                    __builtin_amdgcn_sched_barrier(0);                                                             \
-                    if constexpr ((I) < 8) { CTAMD_P_TR(v[(I) & 1][0], (I) & 1, 0) CTAMD_P_TR(v[(I) & 1][1], (I) & 1, 1)   \
-                                             CTAMD_P_TR(v[(I) & 1][2], (I) & 1, 2) CTAMD_P_TR(v[(I) & 1][3], (I) & 1, 3) } \
-                    __builtin_amdgcn_sched_barrier(0);                                                             \
-                }
-                CTAMD_P_PASS(0)
-                if (streamedOut) CTAMD_H_VMCNT(0);
-                CTAMD_P_PASS(1) CTAMD_P_PASS(2) CTAMD_P_PASS(3) CTAMD_P_PASS(4)
-                CTAMD_P_PASS(5) CTAMD_P_PASS(6) CTAMD_P_PASS(7) CTAMD_P_PASS(8)
-#undef CTAMD_P_PASS
-#undef CTAMD_P_STORE
-#undef CTAMD_P_FRAG
             }
 #undef CTAMD_P_TR
-            if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
-            ++tilesWalked;
             if (!more) break;
             if (streamedOut) {                    // the odometer already is the next tile's; its staging tables are this tile's
                 vb = nextVb;
@@ -680,21 +635,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             }
         }
 #endif
-        if constexpr (TIMED) { if (tilesWalked == 0) wgStamp[3] = __builtin_readcyclecounter(); }
-        ++tilesWalked;
         if (!more) break;
         __syncthreads();                          // the epilogue's images in the ring are dead in every wave
         vb = nextVb;
         staged = false;
-    }
-    if constexpr (TIMED) {
-        if (p.timing != nullptr && wave == 0 && lane == 0) {
-            wgStamp[4] = __builtin_readcyclecounter();            // the stores are issued, not waited for
-#pragma unroll
-            for (int i = 0; i < 5; ++i) p.timing[64 + 8 * (size_t)blockIdx.x + i] = wgStamp[i];
-            p.timing[64 + 8 * (size_t)blockIdx.x + 5] = tilesWalked;
-            p.timing[64 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
-        }
     }
 }
 
@@ -722,15 +666,6 @@ static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
     grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
     if (grid == 0) grid = 8;
     if (grid > p.nBlocks) grid = p.nBlocks;
-#if defined(CTAMD_RESEARCH_KERNELS)
-    if constexpr (BF && LA == LAY_K && LB == LAY_F) {   // the one instantiation that carries the in-kernel timestamps / epilogue variants
-        static const bool timed = [] { const char* e = getenv("CUTENSOR_AMD_H16_TIMED"); return e && e[0] == '1'; }();
-        static const int ep = [] { const char* e = getenv("CUTENSOR_AMD_H16P_EP"); return e ? atoi(e) : 2; }();
-        if (timed && ep == 0) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 0, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
-        if (timed && ep == 1) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 1, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
-        if (timed) { hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB, 2, true>), dim3(grid), dim3(256), 0, stream, p); return hipGetLastError(); }
-    }
-#endif
     hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -120,6 +120,7 @@ for idx, (M, N, K, dt, alpha, beta, how) in enumerate(cases):
     tol = (8e-3 if dt == "bfloat16" else 2e-3) * ref.abs() + 5e-2
     assert bool((err <= tol).all()), (idx, float((err - tol).max()))
     out["d%%d" %% idx] = D.view(torch.int16).cpu()
+    out["ref%%d" %% idx] = ref.cpu()
     p.destroy()
 torch.save(out, sys.argv[1])
 print("BITS_CHILD_OK")
@@ -139,12 +140,13 @@ def test_beta_path_gives_the_bits_of_the_one_tile_kernel(built, tmp_path):
         outs.append(f)
     import torch
     a, b = torch.load(outs[0]), torch.load(outs[1])
-    assert sorted(a) == sorted(b) and len(a) == 5
+    assert sorted(a) == sorted(b) and len(a) == 10
     for k in a:
-        if not torch.equal(a[k], b[k]):
+        if k.startswith("d") and not torch.equal(a[k], b[k]):
             idx = (a[k] != b[k]).nonzero()[:8]
-            vals = [(tuple(int(x) for x in i), hex(int(a[k][tuple(i)]) & 0xffff), hex(int(b[k][tuple(i)]) & 0xffff)) for i in idx]
-            raise AssertionError((k, int((a[k] != b[k]).sum()), vals))
+            fdt = torch.float16 if k == "d1" else torch.bfloat16
+            vals = [(tuple(int(x) for x in i), float(a[k].view(fdt)[tuple(i)]), float(b[k].view(fdt)[tuple(i)]), float(a["ref" + k[1:]][tuple(i)])) for i in idx]
+            raise AssertionError((k, int((a[k] != b[k]).sum()), "(index, persistent, one-tile, fp64)", vals))
 
 
 def test_many_rounds_at_full_grid(built):
