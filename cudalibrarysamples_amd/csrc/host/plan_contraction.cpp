@@ -758,7 +758,10 @@ bool pick_gen_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // a K-tile of this family costs ~0.8 us, the fold's launch ~4.)
     uint64_t split = 1;
     if (tiles * 2.0 <= (double)numCUs && kTiles >= 16) {
-        split = std::min<uint64_t>((uint64_t)((double)numCUs / tiles), kTiles / 4);
+        // (the 64 x 64 kernels run two workgroups per CU — tests/test_kernel_resources.py pins their 256 registers — so their slices
+        // may number twice the idle CUs)
+        const double slots = (double)numCUs * ((k.bm * k.bn <= 64 * 64) ? 2.0 : 1.0);
+        split = std::min<uint64_t>((uint64_t)(slots / tiles), kTiles / 4);
         while (split > 1 && split * perSliceBytes > wsLimit) --split;
         if (split < 2) split = 1;
     }

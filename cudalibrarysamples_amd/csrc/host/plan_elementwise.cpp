@@ -133,6 +133,28 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     }
     std::stable_sort(modes.begin(), modes.end(), [](const EwMode& x, const EwMode& y) { return x.sD < y.sD; });
     fuse(modes, usesC);
+    // Everything fused into ONE contiguous mode (identical layouts: a flat copy / axpby, e.g. the packed identity permutations of
+    // cutensorMp, 'ij->ij', elementwise_binary.cu with equal mode orders): as a single row the row-copy kernel gets one 1-KiB segment per
+    // workgroup and 7 of its 8 tile rows idle — 1.85 TB/s on 96 MB (profiles/r06z_trinary_parts.jsonl).  Cut the row into rows of d
+    // elements, d the largest divisor of the extent in [256, 4096] that keeps 16-byte lanes: the same bytes as a 2-D row copy (round 6).
+    if (modes.size() == 1 && modes[0].sD == 1 && modes[0].sA == 1 && (!usesC || modes[0].sC == 1) && (!usesX || modes[0].sX == 1) &&
+        modes[0].extent >= 2 * 4096) {
+        const int64_t E = modes[0].extent;
+        int64_t d = 0;
+        for (int64_t cand = 4096; cand >= 256; cand -= 16)
+            if (E % cand == 0) { d = cand; break; }
+        if (d > 0) {
+            EwMode lo = modes[0], hi = modes[0];
+            lo.extent = d;
+            hi.extent = E / d;
+            hi.sA = hi.sD = d;
+            hi.sC = usesC ? d : 0;
+            hi.sX = usesX ? d : 0;
+            modes.clear();
+            modes.push_back(lo);
+            modes.push_back(hi);
+        }
+    }
 
     plan = EwPlan{};
     plan.usesC = usesC;

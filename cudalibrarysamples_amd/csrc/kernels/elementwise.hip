@@ -170,6 +170,9 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
                         *reinterpret_cast<f32x4*>(&tile[(4 * (tid & 15) + j) * LD + 4 * (tid >> 4) + 64 * ps]) = o;
                     }
             } else {
+                // edge tile: one pass at a time under per-row bounds tests.  (Round 6 tried the interior's two phases under predicates —
+                // all loads of the tile first: 10 % SLOWER on 400 x 200 x 300, profiles/r06zc_*; what ragged extents cost is the row pitch,
+                // 1200- and 1600-byte rows against 128-byte lines, not the rolled loop.)
 #pragma unroll 1
                 for (int ps = 0; ps < RD_PASSES; ++ps) {
                     const int      l0 = 4 * (tid >> 4) + 64 * ps;
@@ -192,6 +195,22 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
             }
             if constexpr (HASX) {
                 const int64_t oX = rest_offset_x(p.rest, p.restX, t.rest);
+                if (full) {      // as A's interior path: every load of the tile in flight before the first one is used (round 6)
+                    const float* src = X + oX + (int64_t)(i0 + 4 * (tid >> 4)) * p.sX0 + c1;
+                    f32x4 in[RD_PASSES][4];
+#pragma unroll
+                    for (int ps = 0; ps < RD_PASSES; ++ps)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            in[ps][r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (int64_t)(64 * ps + r) * p.sX0));
+#pragma unroll
+                    for (int ps = 0; ps < RD_PASSES; ++ps)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 o = {in[ps][0][j], in[ps][1][j], in[ps][2][j], in[ps][3][j]};
+                            *reinterpret_cast<f32x4*>(&tileX[(4 * (tid & 15) + j) * LD + 4 * (tid >> 4) + 64 * ps]) = o;
+                        }
+                } else
 #pragma unroll 1
                 for (int ps = 0; ps < RD_PASSES; ++ps) {
                     const int      l0 = 4 * (tid >> 4) + 64 * ps;
@@ -223,6 +242,33 @@ __global__ void __launch_bounds__(256) ew_transpose_f32_kernel(const Ew2DParams 
                     f32x4 v = *reinterpret_cast<const f32x4*>(&tile[(tid / LPW + RPW * pass) * LD + l0]);
                     v *= p.alpha;
                     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (int64_t)(RPW * pass) * p.sD1));
+                }
+            } else if (full && (C == nullptr || p.sC0 == 1)) {
+                // interior tile of a binary / trinary form (round 6): the rows of C and E this lane combines with are requested for ALL
+                // passes before the first one is used, no bounds tests — the rolled loop below serialises a load's latency per pass
+                // (the sample's trinary form at 512 x 256 x 256: 4.4 TB/s against 5.4 for the plain permutation of the same tensor)
+                const int64_t rowD = oD + (int64_t)(i1 + tid / LPW) * p.sD1 + c0;
+                f32x4 cv[WR_PASSES], ev[WR_PASSES];
+                if (C != nullptr) {
+                    const float* cp = C + oC + (int64_t)(i1 + tid / LPW) * p.sC1 + c0;
+#pragma unroll
+                    for (int pass = 0; pass < WR_PASSES; ++pass)
+                        cv[pass] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(cp + (int64_t)(RPW * pass) * p.sC1));
+                }
+                if (E != nullptr) {
+#pragma unroll
+                    for (int pass = 0; pass < WR_PASSES; ++pass)
+                        ev[pass] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(E + rowD + (int64_t)(RPW * pass) * p.sD1));
+                }
+#pragma unroll
+                for (int pass = 0; pass < WR_PASSES; ++pass) {
+                    const int lr = tid / LPW + RPW * pass;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&tile[lr * LD + l0]);
+                    v *= p.alpha;
+                    if constexpr (HASX) v = ew_comb4(p.opAB, p.xi * *reinterpret_cast<const f32x4*>(&tileX[lr * LD + l0]), v);
+                    if (E != nullptr) v = ew_comb4(p.opAB, p.delta * ev[pass], v);
+                    if (C != nullptr) v = ew_comb4(p.opAC, v, p.gamma * cv[pass]);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(D + rowD + (int64_t)(RPW * pass) * p.sD1));
                 }
             } else {
 #pragma unroll 1

@@ -145,6 +145,12 @@ def test_permutation_and_reduction_plans(ct, ops):
     # einsum.cu:449-450: a reduction descriptor without reduced modes is a permutation
     q = ops.reduction_plan(h, [5, 4, 2], "jin", [2, 5, 4], "nji")
     assert q.describe()["op"] == "elementwise"
+    # identical layouts fuse into ONE contiguous mode (a flat copy: the packed identity permutations of cutensorMp, 'ij->ij'): cut into rows
+    # of the largest divisor in [256, 4096] so that the row-copy kernel's 8-row tiles are full (round 6: 1.85 -> 6 TB/s on 96 MB)
+    d = ops.permutation_plan(h, [400, 200, 300], "abc", [400, 200, 300], "abc").describe()
+    assert d["variant"] == 1 and d["E0"] == 4000 and d["E1"] == 6000, d
+    d = ops.permutation_plan(h, [7, 11, 13], "abc", [7, 11, 13], "abc").describe()          # too small to cut: as before
+    assert d["E0"] == 7 * 11 * 13 and d["E1"] == 1, d
 
 
 def test_plan_cache_file_roundtrip(ct, ops, tmp_path):
