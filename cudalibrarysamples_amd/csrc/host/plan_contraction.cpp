@@ -606,14 +606,14 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         double best = 1e30;
         static const bool noPersistent = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16P"); return e && e[0] == '0'; }();
         // The persistent kernel earns its place by streaming interior tiles into each other, which needs the epilogue that stays out of the
-        // operand ring (gett_h16p.hip, curOK): no batch modes, one M and one N mode, 16-byte lanes in D.  Tiles that cannot stream are set up
+        // operand ring (gett_h16p.hip, curOK): one M and one N mode, 16-byte lanes in D (batch modes stream since round 6).  Tiles that cannot stream are set up
         // serially behind the previous epilogue and the kernel is SLOWER than the one-tile kernel then (measured with beta != 0, the one
         // condition only the call knows: 8192^3 1377 against 1429-1435 TFLOP/s, 8192^2 x 1024 692 against 819, x 512 432 against 526,
         // profiles/r05r_h16p_beta.jsonl — cutensorContract launches the one-tile twin for beta != 0, api.cpp).
-        // ... and the hand-over of tile i's last K-tile bodies to tile i + 1 needs an even K-tile count of at least four (gett_h16p.hip,
-        // switchAt): with an odd count or fewer nothing streams and the model's per-tile saving is not there (round-5 advice)
-        const bool streamable = v.totL == 1 && v.M.size() == 1 && v.N.size() == 1 && v.N[0].sD == 1 && v.N[0].extent % 8 == 0 &&
-                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0 && kTiles % 2 == 0 && kTiles >= 4;
+        // ... and the hand-over of tile i's last K-tile bodies to tile i + 1 needs an even K-tile count (gett_h16p.hip, switchAt; two
+        // K-tiles per tile stream since round 6): with an odd count nothing streams and the model's per-tile saving is not there (round-5 advice)
+        const bool streamable = v.M.size() == 1 && v.N.size() == 1 && v.N[0].sD == 1 && v.N[0].extent % 8 == 0 &&
+                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0 && kTiles % 2 == 0 && kTiles >= 2;
         for (int cand : {48, 88, 64, 56, 80}) {
             if (cand == 88 && (noPersistent || !streamable)) continue;
             if (layoutIdx + cand >= count) continue;

@@ -9,8 +9,9 @@
 //   * one workgroup per CU walks the tiles (grid = CUs rounded down to a multiple of 8; tile ids in the XCD-grouped order of the
 //     one-tile kernel: workgroup w takes the ids w, w + grid, w + 2 grid, ... of xcd_remap's sequence, so an XCD keeps its 8 x 4
 //     block of concurrent tiles);
-//   * interior tiles STREAM into each other (the tile in flight and the next one inside D of a problem with one M and one N mode, no
-//     batch modes, 16-byte lanes in D; an even K-tile count; at least four K-tiles in the next tile): the per-lane staging
+//   * interior tiles STREAM into each other (the tile in flight and the next one inside D of a problem with one M and one N mode and
+//     16-byte lanes in D — batch modes included since round 6: the hand-over computes the next tile's batch offset as it does its row
+//     offsets; an even K-tile count): the per-lane staging
 //     offsets do not depend on the tile — only the descriptor bases move — so K-tile nTiles - 2 hands the odometer to the next tile
 //     (CTAMD_P_SWITCH, in a copy of the body pair of its own) and the LDS-DMA pieces the last two K-tile bodies issue anyway fetch the
 //     next tile's K-tiles 0 and 1; the next tile starts on a peeled pair without vmcnt(0).  No setup, no staging latency between tiles;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         odo.init(ps_.gK, tile0_ * kHBK, (uint32_t)nTiles, bA_, bB_);                                               \
         HEpilogue e_;                                                                                              \
         e_.init(ps_, l, lds, wave);                                                                                \
-        curOK = VOdometer::sgpr((e_.vecD && (e_.beta == 0.f || e_.vecC) && e_.flat && ps_.partial == nullptr && ps_.gL.total == 1u && \
+        curOK = VOdometer::sgpr((e_.vecD && (e_.beta == 0.f || e_.vecC) && e_.flat && ps_.partial == nullptr &&                        \
                                  m0 + (uint32_t)kHTile <= ps_.gM.total && n0 + (uint32_t)kHTile <= ps_.gN.total) ? 1u : 0u) != 0u;  \
         relA = h_uniform64(oa.base - (uint64_t)m0 * (uint64_t)ps_.gM.stride[0][0] * 2ull);                         \
         relB = h_uniform64(ob.base - (uint64_t)n0 * (uint64_t)ps_.gN.stride[0][0] * 2ull);                         \
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
 // between the tiles.  What makes it cheap: for tiles that lie inside a flat problem the per-lane staging offsets (HOperand::src, 16
 // VGPRs) do not depend on the tile — only the descriptor bases move (rel + 2 * row0 * stride) — so the "setup" is scalar arithmetic.
 // Needs: this tile and the next one interior (this one takes the epilogue that stays out of the ring), an even K-tile count (the next
-// tile starts in ring buffer 0), at least four K-tiles in the next tile (its first pair of bodies is a copy without the hand-over).  Otherwise the odometer's event check runs and the next tile is
+// tile starts in ring buffer 0); a streamed-in tile's first pair of bodies is a copy without the first barrier's vmcnt(0), and with two K-tiles per tile that pair is the hand-over as well (a third copy, round 6).  Otherwise the odometer's event check runs and the next tile is
 // staged the slow way, under / after the epilogue.
 #define CTAMD_P_SWITCH()                                                                                            \
     {                                                                                                              \
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             const uint32_t n0n_ = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                       \
             const uint32_t tile0_ = slice_ * tilesPerSlice_;                                                       \
             const uint32_t nt_ = VOdometer::sgpr((tile0_ + tilesPerSlice_ <= kTilesAll_) ? tilesPerSlice_ : (kTilesAll_ - tile0_)); \
-            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 4u) ? 1u : 0u) != 0u) { \
+            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 2u) ? 1u : 0u) != 0u) { \
                 const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.A) + group_offset<0>(pn_.gL, l_)) + relA + \
                                                  (uint64_t)m0n_ * (uint64_t)pn_.gM.stride[0][0] * 2ull);           \
                 const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.B) + group_offset<1>(pn_.gL, l_)) + relB + \
@@ -351,11 +352,15 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         CTAMD_P_READ(0, 0, 8) CTAMD_P_READ(0, 0, 9) CTAMD_P_READ(0, 0, 10) CTAMD_P_READ(0, 0, 11)
         CTAMD_P_READ(0, 0, 12) CTAMD_P_READ(0, 0, 13) CTAMD_P_READ(0, 0, 14) CTAMD_P_READ(0, 0, 15)
         int t = 0;
-        if (streamedIn) { CTAMD_P_TILE_(0, false, false) CTAMD_P_TILE(1) t = 2; }     // (a streamed-in tile has at least four K-tiles)
+        // a streamed-in tile starts on a peeled pair (no vmcnt(0) at its first tile barrier).  With TWO K-tiles per tile (round 6: K = 128 —
+        // attention scores, 'ik,kj->ij' with a short k) that pair is also the one that hands the odometer over: a third copy of the pair
+        const bool onlyPair = streamedIn && curTiles == 2;
+        if (onlyPair) { CTAMD_P_TILE_(0, false, true) CTAMD_P_TILE(1) t = 2; }
+        else if (streamedIn) { CTAMD_P_TILE_(0, false, false) CTAMD_P_TILE(1) t = 2; }
         streamedIn = false;
         const int pairEnd = switchAt >= 0 ? switchAt : curTiles;
         for (; t + 1 < pairEnd; t += 2) { CTAMD_P_TILE(0) CTAMD_P_TILE(1) }
-        if (switchAt >= 0) { CTAMD_P_TILE_(0, true, true) CTAMD_P_TILE(1) t += 2; }      // K-tiles nTiles - 2 (the hand-over) and nTiles - 1
+        if (switchAt >= 0 && !onlyPair) { CTAMD_P_TILE_(0, true, true) CTAMD_P_TILE(1) t += 2; }      // K-tiles nTiles - 2 (the hand-over) and nTiles - 1
         if (t < curTiles) { CTAMD_P_TILE(0) }
         if (!streamedOut) CTAMD_H_VMCNT(0);       // the re-staged tail: no LDS-DMA may be in flight when the ring is staged again
         x_acc_ready(acc);

@@ -36,6 +36,10 @@ CASES = [
     (dict(m=768, n=1280, k=192), "mk", "kn", "mn", "bfloat16", 1.0, 1.0, "beta != 0, three K-tiles (nothing streams)"),
     (dict(m=1024, n=512, k=256), "mk", "kn", "nm", "bfloat16", 1.0, 0.0, "D with n fastest (orientation swap)"),
     (dict(m=512, n=512, k=128, l=5), "mkl", "knl", "mnl", "bfloat16", 1.0, 0.0, "batch mode: 20 tiles over 5 batches"),
+    (dict(m=512, n=768, k=256, l=7), "mkl", "knl", "mnl", "bfloat16", 1.0, 0.0, "batch mode, four K-tiles: 42 tiles stream across batch boundaries (round 6)"),
+    (dict(m=768, n=512, k=384, l=3), "kml", "nkl", "mnl", "float16", 0.5, 0.75, "batch mode, fp16, beta != 0, six K-tiles"),
+    (dict(m=1024, n=1280, k=128), "km", "nk", "mn", "bfloat16", 0.5, 0.5, "two K-tiles per tile, beta != 0: every tile after the first streamed in through the pair that is also the hand-over (round 6)"),
+    (dict(m=512, n=512, k=128, l=9), "kml", "knl", "mnl", "float16", 1.0, 0.0, "two K-tiles, batch mode, fp16"),
     (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "float16", 1.0, 0.0, "fp16"),
     (dict(m=1000, n=712, k=192), "km", "nk", "mn", "float16", 0.75, 0.25, "fp16, ragged, beta"),
     (dict(m=2048, n=1024, k=128), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "32 interior tiles of two K-tiles: streamed, the hand-over in the first K-tile body"),

@@ -167,9 +167,9 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
 
 
 def test_persistent_kernel_only_where_its_tiles_can_stream(env):
-    """Multi-round launches go to the persistent kernel only when interior tiles can stream into each other (no batch modes, one M and
-    one N mode after fusion, 16-byte lanes in D); everything else keeps the one-tile kernel (non-streamed tiles make the persistent
-    kernel slower: profiles/r05r_h16p_beta.jsonl)."""
+    """Multi-round launches go to the persistent kernel only when interior tiles can stream into each other (one M and one N mode after
+    fusion, 16-byte lanes in D; batch modes stream since round 6); everything else keeps the one-tile kernel (non-streamed tiles make
+    the persistent kernel slower: profiles/r05r_h16p_beta.jsonl)."""
     ct, ops = env
     if os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         pytest.skip("the planner's own choice is under test")
@@ -181,6 +181,6 @@ def test_persistent_kernel_only_where_its_tiles_can_stream(env):
         p.destroy()
         return d["kname"]
     assert kname([8192, 8192], "mk", [8192, 8192], "kn", [8192, 8192], "mn") == "gett_h16w4p_kernel"
-    assert kname([4096, 4096, 4], "mkl", [4096, 4096, 4], "knl", [4096, 4096, 4], "mnl") == "gett_h16w4x_kernel"          # batch mode
+    assert kname([4096, 4096, 4], "mkl", [4096, 4096, 4], "knl", [4096, 4096, 4], "mnl") == "gett_h16w4p_kernel"          # batch mode: 4 x 256 tiles
     assert kname([64, 128, 8192], "abk", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4p_kernel"            # a, b fuse into one M mode
     assert kname([64, 8192, 128], "akb", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4x_kernel"            # a, b apart in A: two M modes

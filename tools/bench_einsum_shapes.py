@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Shapes a user of an einsum library brings that are NOT the GEMM-like benchmark shapes: batched contractions with a short contracted
+range (attention scores / values), skinny outputs, many small batches.  Each through torch_einsum.einsum (the C ABI, planner's choice)
+beside torch.einsum (the vendor BLAS) on the same tensors: us per call, TFLOP/s, the kernel the planner took.  One JSON line per shape."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CASES = [
+    ("bhqd,bhkd->bhqk", dict(b=8, h=8, q=2048, k=2048, d=128), "attention scores: K = 128, 64 batches, 537 MB of output"),
+    ("bhqk,bhkd->bhqd", dict(b=8, h=8, q=2048, k=2048, d=128), "attention values: N = 128"),
+    ("bhqd,bhkd->bhqk", dict(b=4, h=16, q=1024, k=1024, d=64), "attention scores: K = 64, one K-tile"),
+    ("bij,bjk->bik", dict(b=64, i=1024, j=1024, k=1024), "64 batches of 1024^3"),
+    ("bij,bjk->bik", dict(b=512, i=256, j=256, k=256), "512 batches of 256^3"),
+    ("ik,kj->ij", dict(i=16384, j=16384, k=128), "flat, K = 128: 537 MB of output"),
+    ("ik,kj->ij", dict(i=8192, j=128, k=8192), "skinny N = 128"),
+    ("bik,bjk->bij", dict(b=32, i=2048, j=2048, k=256), "both K-contiguous, 4 K-tiles, batched"),
+]
+
+
+def timed(torch, fn, reps):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+def main():
+    import torch
+    from cudalibrarysamples_amd import torch_einsum
+    dt = torch.bfloat16
+    for eq, ext, note in CASES:
+        ins, out = eq.split("->")
+        a_m, b_m = ins.split(",")
+        a = (torch.rand([ext[c] for c in a_m], device="cuda") * 2 - 1).to(dt)
+        b = (torch.rand([ext[c] for c in b_m], device="cuda") * 2 - 1).to(dt)
+        flop = 2.0
+        for c in set(a_m + b_m):
+            flop *= ext[c]
+        res = torch_einsum.einsum(eq, a, b)
+        ref = torch.einsum(eq, a, b)
+        err = float((res.float() - ref.float()).abs().max() / ref.float().abs().max())
+        p = torch_einsum._plans[(eq, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
+        d = p.describe()
+        ws = torch_einsum._get_workspace(a.device, p.required_workspace)
+        o = torch.empty_like(res)
+        ms = timed(torch, lambda: p.execute(a, b, o, ws), 20)
+        ms_v = timed(torch, lambda: torch.einsum(eq, a, b), 20)
+        nbytes = 2.0 * (a.numel() + b.numel() + res.numel())
+        print(json.dumps({"equation": eq, "extents": ext, "note": note, "us": round(ms * 1e3, 1), "tflops": round(flop / (ms * 1e-3) / 1e12, 1),
+                          "GBps_algorithmic": round(nbytes / (ms * 1e-3) / 1e9), "vendor_us": round(ms_v * 1e3, 1),
+                          "vendor_tflops": round(flop / (ms_v * 1e-3) / 1e12, 1), "kernel": d.get("kname"), "tile": [d.get("bm"), d.get("bn"), d.get("bk")],
+                          "splitK": d.get("splitK"), "blocks": d.get("blocks"), "max_rel_diff_vs_vendor": err}), flush=True)
+        del a, b, res, ref, o
+
+
+if __name__ == "__main__":
+    main()
