@@ -29,6 +29,8 @@ const cutensorComputeDescriptor_t CUTENSOR_COMPUTE_DESC_64F    = &kCompute[5];
 // grid of the persistent 16-bit kernel in workgroups (0 = one per CU): CUTENSOR_AMD_H16P_GRID, a test hook — the kernel objects are
 // shared by both library flavours, so the switch is read here and handed over as data (gett_h16p.hip, launch_h16w4p)
 extern "C" int ctamd_h16p_grid_cap;
+extern "C" int ctamd_h16p_stagger;
+int ctamd_h16p_stagger = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16P_STAGGER"); return e ? std::atoi(e) : -1; }();   // -1: the launcher's own step
 int ctamd_h16p_grid_cap = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16P_GRID"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 0; }();
 
 namespace {

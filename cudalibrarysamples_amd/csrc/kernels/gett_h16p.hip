@@ -118,6 +118,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+    // staggered start (GettParams::mOrg2, a field only the strip kernel uses otherwise; set by launch_h16w4p): with a short contracted
+    // range a tile is mostly epilogue, and 256 workgroups that start together store together and idle the memory side together — the
+    // workgroups of an XCD start (id / 8) % 4 quarter-phases apart (units of 1024 cycles per phase step)
+    if (p.mOrg2 != 0u) {
+        const uint32_t steps = ((blockIdx.x >> 3) & 3u) * p.mOrg2;
+        for (uint32_t i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     const uint32_t ldsBase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
     const uint32_t waveLds = VOdometer::sgpr(ldsBase + (uint32_t)wave * 1024u);
@@ -648,6 +655,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
 }
 
 extern "C" int ctamd_h16p_grid_cap;
+extern "C" int ctamd_h16p_stagger;
 
 template <bool BF, int LA, int LB>
 static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
@@ -671,7 +679,19 @@ static hipError_t launch_h16w4p(const GettParams& p, hipStream_t stream) {
     grid &= ~7u;                                  // a multiple of the XCD count: tile id % 8 = XCD for every tile of a workgroup
     if (grid == 0) grid = 8;
     if (grid > p.nBlocks) grid = p.nBlocks;
-    hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, p);
+    // Staggered start for short contracted ranges (round 6).  A streamed tile is kt K-tiles of ~2270 cycles that leave the memory side
+    // idle and an epilogue of ~12k cycles during which 256 workgroups store 33 MB: started together, the workgroups keep alternating
+    // between the two in step.  Four phase groups per XCD, a quarter of a tile's period apart: 8192^2 x 128 / 256 / 512 50.0 / 61.2 / 82.4
+    // -> 45.9 / 56.4 / 78.0 us, 16384^2 x 128 160 -> 155; at 16 K-tiles +1.6 % slower, nothing from 32 on: up to 8 K-tiles (profiles/r06zg_*, r06zh_*).  At least four
+    // rounds of tiles, or the late starters are the tail.  (CUTENSOR_AMD_H16P_STAGGER, hooks flavour: 0 = off, n = step of n x 1024 cycles)
+    GettParams q = p;
+    q.mOrg2 = 0u;
+    const uint32_t kt = p.kPerSlice / (uint32_t)kHBK;
+    if (p.nBlocks >= 4u * grid && p.partial == nullptr) {
+        if (ctamd_h16p_stagger > 0) q.mOrg2 = (uint32_t)ctamd_h16p_stagger;
+        else if (ctamd_h16p_stagger < 0 && kt <= 8u) q.mOrg2 = (kt * 2270u + 12000u + 2048u) / 4096u;
+    }
+    hipLaunchKernelGGL((gett_h16w4p_kernel<BF, LA, LB>), dim3(grid), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
