@@ -436,7 +436,19 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
             // headline's 256 slices fold 9.4 MB in 4.7 us
             // (only the EXTRA time of the idle lanes is charged: at 32 slices and beyond the term vanishes and the ranking of round 5 stands)
             const double tFold = (c.splitK > 1 && c.splitK < 32 && k.fragPartials) ? (double)c.workspace / 5.0e12 * (32.0 / c.splitK - 1.0) : 0.0;
-            const double tFix = (c.splitK > 1) ? 3.0e-6 + tFold : 0.0;
+            // What a workgroup costs outside its K-tiles (setup, first loads, epilogue), per ROUND of workgroups (round 6): measured on short
+            // contracted ranges, where it decides — 16384^2 x 128 on 128 x 128 tiles: 64 rounds in 967 us with 7.4 us of MFMA work each;
+            // 8192 x 128 x 8192: the 32-slice candidate (8 rounds) 216 us where this model said 122 and the unsplit 64 x 64 one (one round)
+            // 121 (profiles/r06zk_tune_*.jsonl).  ~2 us + ~0.34 us per 1024 tile elements; a single round pays it once like everybody else.
+            // Ring kernels whose LDS is at most half a CU's (64 x 64 on four K-tiles, 96 x 96 on three: 64 / 72 KiB) run two workgroups per
+            // CU and overlap one's fixed cost with the other's K-tiles (16384^2 x 128: 96 x 96 ring 3 836 us, 128 x 128 ring 4 967).  Long
+            // contracted ranges have these costs inside tile_efficiency() already (calibrated at >= 64 K-tiles): only the excess is charged.
+            const double ldsBytes = k.fragPartials ? (double)k.pf * (k.bm + k.bn) * k.bk * 4.0 : 0.0;
+            const double overlap = (!k.fragPartials || ldsBytes <= 80.0 * 1024.0) ? 2.0 : 1.0;
+            const double roundsEff = std::ceil(blocks / (numCUs * overlap));
+            const double shortK = std::max(0.0, 1.0 - (double)tilesPerSlice / 64.0);
+            const double tRound = (roundsEff > 1.0) ? (roundsEff - 1.0) * (2.0e-6 + 0.34e-6 * (double)(k.bm * k.bn) / 1024.0) * shortK : 0.0;
+            const double tFix = ((c.splitK > 1) ? 3.0e-6 + tFold : 0.0) + tRound;
             c.estimateUs = (std::max(tCompute, tMem) + tFix + 2.0e-6) * 1e6;
             if (k.fragPartials && k.pf == 3) c.estimateUs *= 0.999;   // tie-break for memory-bound estimates: the 3-deep ring wins by ~2 %
             if (k.nt) c.estimateUs *= 0.96;                            // eligible (see above): ahead of its default-policy twin

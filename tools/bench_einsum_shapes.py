@@ -36,13 +36,22 @@ def timed(torch, fn, reps):
     return best
 
 
+def flop_of(ext, a_m, b_m):
+    f = 2.0
+    for c in set(a_m + b_m):
+        f *= ext[c]
+    return f
+
+
 def main():
     import torch
     from cudalibrarysamples_amd import torch_einsum
-    dt = torch.bfloat16
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
     for eq, ext, note in CASES:
         ins, out = eq.split("->")
         a_m, b_m = ins.split(",")
+        if dt == torch.float32 and flop_of(ext, a_m, b_m) > 4e11:
+            continue                                   # (the largest cases are bf16-sized)
         a = (torch.rand([ext[c] for c in a_m], device="cuda") * 2 - 1).to(dt)
         b = (torch.rand([ext[c] for c in b_m], device="cuda") * 2 - 1).to(dt)
         flop = 2.0
@@ -57,8 +66,8 @@ def main():
         o = torch.empty_like(res)
         ms = timed(torch, lambda: p.execute(a, b, o, ws), 20)
         ms_v = timed(torch, lambda: torch.einsum(eq, a, b), 20)
-        nbytes = 2.0 * (a.numel() + b.numel() + res.numel())
-        print(json.dumps({"equation": eq, "extents": ext, "note": note, "us": round(ms * 1e3, 1), "tflops": round(flop / (ms * 1e-3) / 1e12, 1),
+        nbytes = float(a.element_size()) * (a.numel() + b.numel() + res.numel())
+        print(json.dumps({"dtype": str(dt), "equation": eq, "extents": ext, "note": note, "us": round(ms * 1e3, 1), "tflops": round(flop / (ms * 1e-3) / 1e12, 1),
                           "GBps_algorithmic": round(nbytes / (ms * 1e-3) / 1e9), "vendor_us": round(ms_v * 1e3, 1),
                           "vendor_tflops": round(flop / (ms_v * 1e-3) / 1e12, 1), "kernel": d.get("kname"), "tile": [d.get("bm"), d.get("bn"), d.get("bk")],
                           "splitK": d.get("splitK"), "blocks": d.get("blocks"), "max_rel_diff_vs_vendor": err}), flush=True)

@@ -16,6 +16,12 @@ PROBLEMS = {
     "einsum48": (dict(a=96, b=48, c=64, d=64, e=96), "dcba", "ebcd", "ea"),
     "contraction": (dict(m=96, n=96, u=96, v=64, h=64, k=64), "mhkn", "ukvh", "munv"),
     "gemm4096": (dict(i=4096, j=4096, k=4096), "ik", "kj", "ij"),
+    # round 6: short contracted ranges, batched (tools/bench_einsum_shapes.py; modes listed first-fastest)
+    "scores128": (dict(b=8, h=8, q=2048, k=2048, d=128), "dqhb", "dkhb", "kqhb"),      # bhqd,bhkd->bhqk
+    "scores64": (dict(b=4, h=16, q=1024, k=1024, d=64), "dqhb", "dkhb", "kqhb"),
+    "flat128": (dict(i=16384, j=16384, k=128), "ki", "jk", "ji"),                     # ik,kj->ij
+    "batch256": (dict(b=512, i=256, j=256, k=256), "jib", "kjb", "kib"),              # bij,bjk->bik
+    "skinny": (dict(i=8192, j=128, k=8192), "ki", "jk", "ji"),
 }
 
 
