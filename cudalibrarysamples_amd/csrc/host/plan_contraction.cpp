@@ -563,7 +563,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         // K-tile count stream into each other (the next tile's first K-tiles are fetched by the last K-tile bodies) — the first tile costs
         // what gett_h16w4x_kernel's does plus ~0.5 us of extra setup, every further one ~6 us less (profiles/r05e_h16p_vs_4x.jsonl: 8192^2 x
         // 512 / 1024 / 2048 / 4096 / 8192 +6.8 / +3.3 / +2.5 / +1.8 / +0.8 %, one-round shapes -1 %)
-        if (var == 88) t = 10.5 + kt * per + (std::ceil(wgs / slots) - 1.0) * (4.5 + kt * per);
+        if (var == 88) { const double ke = kt + (std::fmod(kt, 2.0) != 0.0 ? 1.0 : 0.0); t = 10.5 + ke * per + (std::ceil(wgs / slots) - 1.0) * (4.5 + ke * per); }
         if (split > 1) t += 3.0 + 2.0 * (double)split * (double)perSliceBytes / 5.0e6;
         return t;
     };
@@ -623,9 +623,11 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         // condition only the call knows: 8192^3 1377 against 1429-1435 TFLOP/s, 8192^2 x 1024 692 against 819, x 512 432 against 526,
         // profiles/r05r_h16p_beta.jsonl — cutensorContract launches the one-tile twin for beta != 0, api.cpp).
         // ... and the hand-over of tile i's last K-tile bodies to tile i + 1 needs an even K-tile count (gett_h16p.hip, switchAt; two
-        // K-tiles per tile stream since round 6): with an odd count nothing streams and the model's per-tile saving is not there (round-5 advice)
+        // K-tiles per tile stream since round 6).  An odd count is made even by a zero K-tile (the odometer closes the descriptors once the
+        // K range is exhausted: no memory access, zeros in LDS, 2270 cycles of MFMAs on zeros) — worth it while that is a small price for
+        // the 7.8k-cycle prologue it saves per tile: up to 15 K-tiles (K = 64: attention scores with 64-wide heads)
         const bool streamable = v.M.size() == 1 && v.N.size() == 1 && v.N[0].sD == 1 && v.N[0].extent % 8 == 0 &&
-                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0 && kTiles % 2 == 0 && kTiles >= 2;
+                                v.M[0].sD % 8 == 0 && v.alignD % 16 == 0 && (kTiles % 2 == 0 || kTiles <= 15);
         for (int cand : {48, 88, 64, 56, 80}) {
             if (cand == 88 && (noPersistent || !streamable)) continue;
             if (layoutIdx + cand >= count) continue;

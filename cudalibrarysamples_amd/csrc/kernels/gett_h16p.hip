@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.A) + group_offset<0>(ps_.gL, l)) + oa.base); \
         const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps_.B) + group_offset<1>(ps_.gL, l)) + ob.base); \
         odo.init(ps_.gK, tile0_ * kHBK, (uint32_t)nTiles, bA_, bB_);                                               \
+        nTiles += (int)VOdometer::sgpr((ps_.partial == nullptr && (nTiles & 1) != 0) ? 1u : 0u);   /* odd count: a zero K-tile is appended (VOdometer::recs) */ \
         HEpilogue e_;                                                                                              \
         e_.init(ps_, l, lds, wave);                                                                                \
         curOK = VOdometer::sgpr((e_.vecD && (e_.beta == 0.f || e_.vecC) && e_.flat && ps_.partial == nullptr &&                        \
@@ -226,13 +227,13 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             const uint32_t n0n_ = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                       \
             const uint32_t tile0_ = slice_ * tilesPerSlice_;                                                       \
             const uint32_t nt_ = VOdometer::sgpr((tile0_ + tilesPerSlice_ <= kTilesAll_) ? tilesPerSlice_ : (kTilesAll_ - tile0_)); \
-            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 2u) ? 1u : 0u) != 0u) { \
+            if (VOdometer::sgpr((m0n_ + (uint32_t)kHTile <= pn_.gM.total && n0n_ + (uint32_t)kHTile <= pn_.gN.total && nt_ >= 1u) ? 1u : 0u) != 0u) { \
                 const uint64_t bA_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.A) + group_offset<0>(pn_.gL, l_)) + relA + \
                                                  (uint64_t)m0n_ * (uint64_t)pn_.gM.stride[0][0] * 2ull);           \
                 const uint64_t bB_ = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(pn_.B) + group_offset<1>(pn_.gL, l_)) + relB + \
                                                  (uint64_t)n0n_ * (uint64_t)pn_.gN.stride[0][0] * 2ull);           \
                 odo.init(pn_.gK, tile0_ * kHBK, nt_, bA_, bB_);                                                    \
-                nTilesNext = (int)nt_;                                                                             \
+                nTilesNext = (int)(nt_ + (nt_ & 1u));                                                              \
                 ok_ = true;                                                                                        \
             }                                                                                                      \
         }                                                                                                          \
@@ -243,8 +244,8 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
     {                                                                                                              \
         constexpr int q_ = (N) >> 2, i_ = (N) & 3;                                                                 \
         constexpr uint32_t imm_ = (uint32_t)(((P) * 4 + q_) * kHalfBytes + i_ * 4096);                             \
-        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc(odo.addrA), oa.src[q_][i_], waveLds);                      \
-        else v_dma16<imm_, PAD>(v_rsrc(odo.addrB), ob.src[q_ - 2][i_], waveLds);                                   \
+        if constexpr (q_ < 2) v_dma16<imm_, PAD>(v_rsrc_n(odo.addrA, odo.recs), oa.src[q_][i_], waveLds);          \
+        else v_dma16<imm_, PAD>(v_rsrc_n(odo.addrB, odo.recs), ob.src[q_ - 2][i_], waveLds);                       \
     }
 #define CTAMD_P_DMA8(P, N0, PAD)                                                                                    \
     CTAMD_P_DMA(P, (N0) + 0, PAD) CTAMD_P_DMA(P, (N0) + 1, PAD) CTAMD_P_DMA(P, (N0) + 2, PAD) CTAMD_P_DMA(P, (N0) + 3, PAD) \

@@ -38,6 +38,17 @@ __device__ __forceinline__ HRsrc v_rsrc(uint64_t addr) {      // addr is a valid
     return r;
 }
 
+// ... with the record count from the odometer (VOdometer::recs: 0xffffffff, or 0 once the K range is exhausted — every lane out of
+// range: no memory access, zeros in LDS.  gett_h16w4p_kernel, round 6: the zero K-tile that pads an odd K-tile count)
+__device__ __forceinline__ HRsrc v_rsrc_n(uint64_t addr, uint32_t recs) {
+    HRsrc r;
+    r[0] = (int)(uint32_t)addr;
+    r[1] = (int)(uint32_t)(addr >> 32);
+    r[2] = (int)recs;
+    r[3] = 0x00020000;
+    return r;
+}
+
 // One fragment (32 rows x 16 k) from LDS byte address base + IMM.  LAY_K: one ds_read_b128; LAY_F: two transposing reads.
 template <int LAY, int IMM>
 __device__ __forceinline__ s16x8 v_read(uint32_t base) {
@@ -62,6 +73,7 @@ struct VOdometer {
     uint64_t addrA, addrB, stepA, stepB, wrapA, wrapB;     // hot
     uint32_t untilWrap, n0, untilEvent;                    // hot
     uint32_t left, carryLen, hi, e1, carryPending;         // cold (event path)
+    uint32_t recs, ended;                                  // records of the descriptors (v_rsrc_n); the last valid advance has happened
     uint64_t baseA, baseB;                                 // cold: descriptor bases at K index 0
 
     __device__ static __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -90,14 +102,20 @@ struct VOdometer {
         left = sgpr(nTiles - 1u);
         carryPending = 0;
         untilEvent = 1;
+        recs = 0xffffffffu;
+        ended = 0;
         next_segment(untilCarry);
     }
     // the valid advances that are left are cut into segments that end at a carry past digit 1 or at the end of the K range
     __device__ __forceinline__ void next_segment(uint32_t toCarry) {
         if (left == 0u) {
+            // no valid advance is left: the bases stay where they are.  ONE more event, at the next advance (the first one past the range),
+            // closes the descriptors (recs = 0): what is staged from then on is zeros and reads no memory — the re-staged, never-read tiles
+            // at the end of a K loop, and the zero K-tile the persistent kernel appends to an odd K-tile count
             stepA = stepB = wrapA = wrapB = 0;
-            untilEvent = 0x7fffffffu;
             carryPending = 0;
+            if (ended == 0u) { ended = 1u; untilEvent = 1u; }
+            else { recs = 0u; untilEvent = 0x7fffffffu; }
         } else {
             const uint32_t seg = toCarry < left ? toCarry : left;
             left = sgpr(left - seg);

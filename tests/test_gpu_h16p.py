@@ -40,6 +40,10 @@ CASES = [
     (dict(m=768, n=512, k=384, l=3), "kml", "nkl", "mnl", "float16", 0.5, 0.75, "batch mode, fp16, beta != 0, six K-tiles"),
     (dict(m=1024, n=1280, k=128), "km", "nk", "mn", "bfloat16", 0.5, 0.5, "two K-tiles per tile, beta != 0: every tile after the first streamed in through the pair that is also the hand-over (round 6)"),
     (dict(m=512, n=512, k=128, l=9), "kml", "knl", "mnl", "float16", 1.0, 0.0, "two K-tiles, batch mode, fp16"),
+    (dict(m=1024, n=1280, k=64), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "ONE K-tile per tile: a zero K-tile is appended, every tile streams (round 6)"),
+    (dict(m=768, n=1024, k=64, l=6), "kml", "nkl", "mnl", "float16", 0.5, 0.5, "one K-tile, batch mode, fp16, beta != 0"),
+    (dict(m=1280, n=1024, k=320), "km", "kn", "mn", "bfloat16", 1.0, 0.0, "five K-tiles: padded to six"),
+    (dict(m=1000, n=712, k=192), "mk", "nk", "mn", "bfloat16", 1.0, 1.0, "three K-tiles, ragged M and N, beta: padded interior tiles streaming into edge tiles"),
     (dict(m=1024, n=768, k=256), "mk", "kn", "mn", "float16", 1.0, 0.0, "fp16"),
     (dict(m=1000, n=712, k=192), "km", "nk", "mn", "float16", 0.75, 0.25, "fp16, ragged, beta"),
     (dict(m=2048, n=1024, k=128), "mk", "kn", "mn", "bfloat16", 1.0, 0.0, "32 interior tiles of two K-tiles: streamed, the hand-over in the first K-tile body"),
