@@ -728,6 +728,29 @@ def secondary_round6(torch, ct, ops, h, stream, with_counters):
         del A, B, D, ws
     except Exception as ex:   # noqa: BLE001
         out.append({"workload": "contraction bf16 8192^2 x 2048 beta != 0", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- a short contracted range with batch modes: attention scores 'bhqd,bhkd->bhqk' (8, 8, 2048, 2048, 128) in bf16 — 64 batches of
+    #      2048 x 2048 x 128, 537 MB of output: the persistent kernel streams two-K-tile tiles across batch boundaries (round 6)
+    try:
+        from cudalibrarysamples_amd import torch_einsum
+        a = (torch.rand((8, 8, 2048, 128), device="cuda") * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand((8, 8, 2048, 128), device="cuda") * 2 - 1).to(torch.bfloat16)
+        eq = "bhqd,bhkd->bhqk"
+        res = torch_einsum.einsum(eq, a, b)
+        pl = torch_einsum._plans[(eq, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
+        wsp = torch_einsum._get_workspace(a.device, pl.required_workspace)
+        fn = lambda: pl.execute(a, b, res, wsp)   # noqa: E731
+        for _ in range(20):
+            fn()
+        ms = min(timed_batch(torch, fn, reps=20), timed_batch(torch, fn, reps=20))
+        flop = 2.0 * 64 * 2048 * 2048 * 128
+        nbytes = 2.0 * (a.numel() + b.numel() + res.numel())
+        out.append({"workload": "einsum 'bhqd,bhkd->bhqk' bf16 (8, 8, 2048, 2048, 128): attention scores, K = 128, 64 batches, 537 MB of output", "dtype": "bf16",
+                    "value": flop / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "us_per_call": ms * 1e3, "kernel": pl.describe()["kname"],
+                    "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, "algorithmic_bytes": nbytes, "algorithmic_flop": flop}})
+        del a, b, res
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "einsum bhqd,bhkd->bhqk bf16", "error": "%s: %s" % (type(ex).__name__, ex)})
     # ---- complex64 1024^3: permutation abc->cab and reduction abc->ac on the tiled kernels of 8-byte elements ----------------
     try:
         n = 1024
