@@ -204,6 +204,7 @@ struct MgWorkers {
 
 struct cutensorMgHandle {
     MgWorkers workers;               // one per handle device when there are several (and a GPU is visible)
+    std::mutex callMutex;            // the workers take one phase at a time: concurrent cutensorMgContraction calls on ONE handle queue up here
     std::vector<int32_t> devices;
     std::vector<cutensorHandle_t> handles;
     bool distinct = true;
@@ -1298,6 +1299,11 @@ cutensorStatus_t cutensorMgContraction(const cutensorMgHandle_t handle, const cu
     // a call without remote cells has nothing for this thread to do in between: the workers run staging and pieces in ONE phase (below)
     const bool onePhase = threaded && pl->numWaves == 0 && !anyComm;
     const std::function<cutensorStatus_t(int)> localStageFn = local_stage;
+    // (whatever leaves this function while a phase is in flight — an error return, an exception on its way to the ABI's catch — collects
+    // the workers first: they run lambdas that live on this stack frame)
+    std::unique_lock<std::mutex> callLock(handle->callMutex, std::defer_lock);
+    if (threaded) callLock.lock();
+    struct PhaseGuard { MgWorkers* w; ~PhaseGuard() { if (w != nullptr) (void)w->wait(); } } phaseGuard{threaded ? &handle->workers : nullptr};
     if (onePhase) { }
     else if (threaded) handle->workers.run(localStageFn);
     else
