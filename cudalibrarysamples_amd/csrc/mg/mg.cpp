@@ -519,9 +519,12 @@ cutensorStatus_t cutensorMgCreate(cutensorMgHandle_t* handle, uint32_t numDevice
         std::vector<int> devs(h->devices.begin(), h->devices.end());
         if (ncclCommInitAll(h->comms.data(), (int)numDevices, devs.data()) != ncclSuccess) h->comms.clear();
     }
-    // worker threads for the per-device parts of a call (MgWorkers): from two handle devices on; CUTENSORMG_AMD_THREADS=0 (a
-    // measurement hook) keeps everything on the calling thread
-    if (count > 0 && numDevices > 1 && !CTAMD_HOOK_IS("CUTENSORMG_AMD_THREADS", "0")) h->workers.start(h->devices);
+    // worker threads for the per-device parts of a call (MgWorkers): from FOUR handle devices on — measured (tools/mg_host_cost_n.py, bench
+    // layout, us per call idle / back to back, workers against one thread): two devices 21 / 15 against 14 / 14, four 28 / 20 against
+    // 23 / 26, eight 35 / 27.5 against 47 / 48 (profiles/r06r_mg_host_cost_*).  CUTENSORMG_AMD_THREADS (hooks flavour): 0 keeps
+    // everything on the calling thread, 1 starts the workers from two devices on
+    const bool wantWorkers = CTAMD_HOOK_IS("CUTENSORMG_AMD_THREADS", "1") ? numDevices > 1 : (numDevices >= 4 && !CTAMD_HOOK_IS("CUTENSORMG_AMD_THREADS", "0"));
+    if (count > 0 && wantWorkers) h->workers.start(h->devices);
     *handle = h;
     return CUTENSOR_STATUS_SUCCESS;
 } CTAMD_API_CATCH

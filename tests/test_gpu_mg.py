@@ -153,6 +153,10 @@ def _gather_cells(cells, shape, bs, dc, dtype):
     (4, 512, 0.5, {"CUTENSORMG_AMD_WAVES": "3"}),        # gather in three waves, one event each
     (4, 256, 0.5, {"CUTENSORMG_AMD_DIRECT": "0"}),       # everything through the staging images + scatter
     (3, 384, 0.0, {"CUTENSORMG_AMD_QSPLIT": "0"}),       # no cut along j: one piece per device behind the whole gather
+    (2, 256, 0.5, {"CUTENSORMG_AMD_THREADS": "1"}),      # round 6: per-device worker threads (default from four devices on) forced on at two
+    (3, 384, 0.0, {"CUTENSORMG_AMD_THREADS": "1", "CUTENSORMG_AMD_DIRECT": "0"}),   # ... with staging images + scatter: the cross-device join on the workers
+    (4, 512, 0.5, {"CUTENSORMG_AMD_THREADS": "0"}),      # ... and off at four: the whole call on the calling thread
+    (8, 512, 0.5, {}),                                   # eight handle devices: workers, batched cell copies of eight cells per device
 ])
 def test_mg_free_mode_shard_layout(mg, monkeypatch, n, E, beta, env):
     """The cuTENSORMg case bench.py times (largest free mode sharded over the devices, B all-gathered) on n
