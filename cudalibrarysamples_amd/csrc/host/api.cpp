@@ -1716,7 +1716,7 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         g_launchCounts[2].fetch_add(1, std::memory_order_relaxed);
         p.partial = (plan->choice.splitK > 1) ? static_cast<float*>(workspace) : nullptr;
         {
-            static const int policy = [] { const char* e = ctamd_research_env("CUTENSOR_AMD_PARTIAL_STORE"); return e ? (e[0] == 'p' ? 1 : e[0] == 'n' ? 2 : 0) : 0; }();
+            static const int policy = [] { const char* e = CTAMD_HOOK_ENV("CUTENSOR_AMD_PARTIAL_STORE"); return e ? (e[0] == 'p' ? 1 : e[0] == 'n' ? 2 : e[0] == 's' ? 3 : 0) : 0; }();   // hooks flavour; 's': the row epilogue skips its stores (timing only)
             p.partialPolicy = policy;
         }
         if (plan->fusedFold) {

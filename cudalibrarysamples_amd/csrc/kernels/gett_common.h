@@ -203,4 +203,102 @@ __device__ __forceinline__ void reload_params(GettParams& q) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// The same tile on its way out as WHOLE ROWS, through a per-wave LDS image (round 6) — for outputs with ONE M mode and ONE N mode (batch
+// modes as they come) whose N mode is contiguous in D and a multiple of 4 long, 16-byte lanes everywhere (gett_f32_rows_ok).  That is the
+// orientation the planner gives every GEMM-like output (plan_contraction.cpp: the free group that carries D's stride-1 mode becomes
+// kernel-N), and there the direct form above has no 16-byte path: a lane's four registers are four different ROWS, so a fragment
+// leaves as four instructions of 4 rows x 64 bytes, 4 bytes per lane — 64 store instructions per wave of a 128 x 128 tile.  Inside a
+// contraction with a short contracted range the workgroups then spend more than half of their life in the epilogue (31-35k of 59k
+// cycles at 16384^2 x 128, profiles/r06zw_*), and as a pure store stream half-line pieces are what the memory side absorbs worst (the
+// 1.07 GB of a 16384^2 fp32 output: 342 us as 64-byte pieces, 186 us as whole rows; tools/ubench/store_f32_pieces.hip, profiles/r06zu_*).
+// Here one instruction covers 4 rows x 64 TN bytes (256 B for the 128 x 128 tiles), 16 bytes per lane: 16 instructions per wave.
+//   The image: 16 rows (one fragment row block i at a time) of 16 TN + 4 floats.  In: register r of fragment (i, j) is row 4 g + r,
+// columns 16 j + (lane & 15) — four ds_write_b32 per fragment, each 4 rows x 64 B, the 4-float padding puts the four rows on disjoint
+// bank ranges.  Out: ds_read_b128 of 16 B per lane, contiguous per row.  `img` is this wave's own gett_f32_image_floats<TN>() floats,
+// 16-byte aligned, not in use by any other wave: the LDS unit executes a wave's instructions in order, so no barrier is needed
+// between the passes.  Same arithmetic (alpha * acc, then fma(beta, c, .)), same bits as the direct form.
+//   The arguments are read HERE, through a laundered kernel-argument pointer and field by field: nothing the epilogue needs is loaded at
+// kernel entry and kept (spilled) across the main loop.
+// ---------------------------------------------------------------------------------------------
+template <int TN>
+__host__ __device__ constexpr int gett_f32_image_floats() { return 16 * (16 * TN + 4); }
+
+typedef const __attribute__((address_space(4))) GettParams* GettArgPtr;
+__device__ __forceinline__ GettArgPtr gett_arg_ptr() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return (GettArgPtr)kp;
+#else
+    return nullptr;
+#endif
+}
+
+// wave-uniform: may this launch's tiles leave as whole rows?  Cl / Dl: C and D at the workgroup's batch index l (the bases must keep
+// 16-byte alignment)
+__device__ __forceinline__ bool gett_f32_rows_ok(GettArgPtr q, uint32_t l, const float*& Cl, float*& Dl) {
+    int64_t oD = 0, oC = 0;
+    if (q->gL.total > 1u) {
+        uint32_t idx = l;
+#pragma unroll
+        for (int i = 0; i < kMaxGroupModes; ++i) {
+            const uint32_t dd = q->gL.div[i].d;
+            const uint32_t qq = __umulhi(idx, q->gL.div[i].magic) >> q->gL.div[i].shift;
+            const uint32_t digit = idx - qq * dd;
+            oD += (int64_t)digit * q->gL.stride[2][i];
+            oC += (int64_t)digit * q->cStrideL[i];
+            idx = qq;
+        }
+    }
+    Dl = static_cast<float*>(q->D) + oD;
+    Cl = static_cast<const float*>(q->C) + oC;
+    bool ok = q->gM.n <= 1 && q->gN.n <= 1 && q->gN.stride[1][0] == 1 && (q->gN.div[0].d & 3u) == 0u && (q->gM.stride[1][0] & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(Dl) & 15u) == 0u;
+    if (q->beta != 0.f) ok = ok && q->cStrideN[0] == 1 && (q->cStrideM[0] & 3) == 0 && (reinterpret_cast<uintptr_t>(Cl) & 15u) == 0u;
+    return ok;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gett_store_tile_f32_rows(GettArgPtr q, const float* C, float* D, const f32x4 (&acc)[TM][TN], uint32_t mBase,
+                                                         uint32_t nBase, int lane, float* img) {
+    constexpr int ROWF = 16 * TN + 4;
+    const uint32_t Mtot = q->gM.total, Ntot = q->gN.total;
+    const float alpha = q->alpha, beta = q->beta;
+    const int64_t sDm = q->gM.stride[1][0], sCm = q->cStrideM[0];
+    const int pol = q->partialPolicy;              // measurement switch (hooks flavour): 1 = plain stores, 3 = none
+    const int g = lane >> 4, c16 = lane & 15;
+    // on the way out this lane holds n = nOut .. nOut + 3 of a row (lanes c16 < 4 TN); Ntot is a multiple of 4: all in or all out
+    const uint32_t nOut = nBase + 4u * (uint32_t)c16;
+    const bool okN = c16 < 4 * TN && nOut < Ntot;
+    float* dCol = D + nOut;
+    const float* cCol = C + nOut;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        // in: register r of fragment (i, j) — image row 4 g + r (row 16 i + 4 g + r of the wave's tile), float 16 j + c16
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[(4 * g + r) * ROWF + 16 * j + c16] = alpha * acc[i][j][r];
+        asm volatile("" ::: "memory");             // the reads below are other lanes' writes: keep the program order (the LDS unit keeps it too)
+        // out: four instructions of four rows
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = 4 * r4 + g;
+            const uint32_t m = mBase + 16u * (uint32_t)i + (uint32_t)row;
+            if (okN && m < Mtot) {
+                f32x4 val = *reinterpret_cast<const f32x4*>(img + row * ROWF + 4 * c16);
+                if (beta != 0.f) {
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(cCol + (int64_t)m * sCm);
+                    val[0] += beta * cv[0]; val[1] += beta * cv[1]; val[2] += beta * cv[2]; val[3] += beta * cv[3];
+                }
+                if (pol == 0) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm));
+                else if (pol == 1) *reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm) = val;
+                else if (val[0] == 12345.678f) *reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm) = val;   // measurement: no store
+            }
+        }
+        asm volatile("" ::: "memory");             // ... and the next pass's writes stay behind these reads
+    }
+}
+
 }  // namespace ctamd

@@ -479,7 +479,23 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         return;
     }
 
+    // flat outputs: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave (gett_common.h, round 6)
+    constexpr int IMG = gett_f32_image_floats<TN>();
+    if constexpr (WM * WN * IMG <= LDS_FLOATS) {
+        const GettArgPtr q = gett_arg_ptr();
+        const float* Cl;
+        float* Dl;
+        if (gett_f32_rows_ok(q, l, Cl, Dl)) {
+            __syncthreads();   // every wave is done with the stage buffers (and with the other waves' partial sums in them)
+            gett_store_tile_f32_rows<TM, TN>(q, Cl, Dl, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, lds + (wn * WM + wm) * IMG);
+            stamp(4);
+            stamp(6);
+            return;
+        }
+    }
     gett_store_tile_f32<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l, lane);
+    stamp(4);
+    stamp(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,7 +695,23 @@ __global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(
         stamp(6);
         return;
     }
+    // flat outputs: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave (gett_common.h, round 6)
+    constexpr int IMG = gett_f32_image_floats<TN>();
+    if constexpr (WM * WN * IMG <= LDS_FLOATS) {
+        const GettArgPtr q = gett_arg_ptr();
+        const float* Cl;
+        float* Dl;
+        if (gett_f32_rows_ok(q, l, Cl, Dl)) {
+            __syncthreads();   // every wave is done with the stage buffers (and with the other waves' partial sums in them)
+            gett_store_tile_f32_rows<TM, TN>(q, Cl, Dl, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane, lds + (wn * WM + wm) * IMG);
+            stamp(4);
+            stamp(6);
+            return;
+        }
+    }
     gett_store_tile_f32<TM, TN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), l, lane);
+    stamp(4);
+    stamp(6);
 }
 
 // ---------------------------------------------------------------------------------------------

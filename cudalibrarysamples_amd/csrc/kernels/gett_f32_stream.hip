@@ -660,6 +660,22 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         stamp(6);
         return;
     }
+    // Flat outputs (one M mode, one N mode, 16-byte lanes) leave as whole rows through a per-wave LDS image (gett_common.h, round 6).  The
+    // image lives in the ring slot BEHIND the last tile's: every multiplying wave passed the last tile's barrier, so every older slot has
+    // been read for the last time (S >= 3), while the last tile's own slot may still be feeding a slower wave's fragments.
+    {
+        constexpr int IMG = gett_f32_image_floats<TN>();
+        static_assert(4 * IMG <= STAGE, "four per-wave row images fit one ring slot");
+        const GettArgPtr q = gett_arg_ptr();
+        const float* Cl;
+        float* Dl;
+        if (gett_f32_rows_ok(q, l, Cl, Dl)) {
+            gett_store_tile_f32_rows<TM, TN>(q, Cl, Dl, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), laneE, lds + (size_t)(nTiles % S) * STAGE + wave * IMG);
+            stamp(4);
+            stamp(6);
+            return;
+        }
+    }
     const float* C = static_cast<const float*>(p.C);
     float*       D = static_cast<float*>(p.D);
     {

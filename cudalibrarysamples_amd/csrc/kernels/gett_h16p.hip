@@ -47,6 +47,13 @@ namespace ctamd {
 
 constexpr int kPRingBytes  = 8 * kHalfBytes;   // two K-tiles of 64 KiB
 constexpr int kPImageBytes = kPImgBytes;       // one pass of a wave: 128 columns x 16 rows x 2 B (gett_h16p_layout.h)
+// Height (in tiles along M) of the column-major tile groups the ids walk: with 32 consecutive ids per XCD and round, 8 gives every XCD an
+// 8 x 4 block of concurrent tiles = 12 operand panels per K-step.  -DCTAMD_P_XCD_GROUP=4 / 16 are the measurement builds of round 6
+// (4 x 8: the same 12 panels with the roles of A and B exchanged; 16 x 2: 18 panels; profiles/r06zt_*).
+#ifndef CTAMD_P_XCD_GROUP
+#define CTAMD_P_XCD_GROUP 8
+#endif
+constexpr uint32_t kPGroup = CTAMD_P_XCD_GROUP;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -174,10 +181,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
         id_ -= slice * tilesAll_;                                                                                  \
         l = VOdometer::sgpr(id_ / tilesMN_);                                                                       \
         id_ -= l * tilesMN_;                                                                                       \
-        const uint32_t perGroup_ = 8u * ps_.tilesN;                                                                \
+        const uint32_t perGroup_ = kPGroup * ps_.tilesN;                                                                \
         const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;                                    \
-        const uint32_t first_ = grp_ * 8u;                                                                         \
-        const uint32_t gsz_ = (ps_.tilesM - first_ < 8u) ? (ps_.tilesM - first_) : 8u;                             \
+        const uint32_t first_ = grp_ * kPGroup;                                                                         \
+        const uint32_t gsz_ = (ps_.tilesM - first_ < kPGroup) ? (ps_.tilesM - first_) : kPGroup;                             \
         m0 = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);                                                   \
         n0 = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                                            \
         const uint32_t tile0_ = slice * tilesPerSlice_;                                                            \
@@ -219,10 +226,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             id_ -= slice_ * tilesAll_;                                                                             \
             const uint32_t l_ = VOdometer::sgpr(id_ / tilesMN_);                                                   \
             id_ -= l_ * tilesMN_;                                                                                  \
-            const uint32_t perGroup_ = 8u * pn_.tilesN;                                                            \
+            const uint32_t perGroup_ = kPGroup * pn_.tilesN;                                                            \
             const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;                                \
-            const uint32_t first_ = grp_ * 8u;                                                                     \
-            const uint32_t gsz_ = (pn_.tilesM - first_ < 8u) ? (pn_.tilesM - first_) : 8u;                         \
+            const uint32_t first_ = grp_ * kPGroup;                                                                     \
+            const uint32_t gsz_ = (pn_.tilesM - first_ < kPGroup) ? (pn_.tilesM - first_) : kPGroup;                         \
             const uint32_t m0n_ = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);                              \
             const uint32_t n0n_ = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);                                       \
             const uint32_t tile0_ = slice_ * tilesPerSlice_;                                                       \
@@ -387,10 +394,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4p_kernel(const GettParams p)
             id_ -= curSlice * tilesAll_;
             curL = VOdometer::sgpr(id_ / tilesMN_);
             id_ -= curL * tilesMN_;
-            const uint32_t perGroup_ = 8u * pe.tilesN;
+            const uint32_t perGroup_ = kPGroup * pe.tilesN;
             const uint32_t grp_ = id_ / perGroup_, inGrp_ = id_ - grp_ * perGroup_;
-            const uint32_t first_ = grp_ * 8u;
-            const uint32_t gsz_ = (pe.tilesM - first_ < 8u) ? (pe.tilesM - first_) : 8u;
+            const uint32_t first_ = grp_ * kPGroup;
+            const uint32_t gsz_ = (pe.tilesM - first_ < kPGroup) ? (pe.tilesM - first_) : kPGroup;
             tM0 = VOdometer::sgpr((first_ + inGrp_ % gsz_) * kHTile);
             tN0 = VOdometer::sgpr((inGrp_ / gsz_) * kHTile);
         }

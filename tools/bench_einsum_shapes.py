@@ -47,7 +47,10 @@ def main():
     import torch
     from cudalibrarysamples_amd import torch_einsum
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
-    for eq, ext, note in CASES:
+    only = {int(x) for x in os.environ.get("EINSUM_SHAPES_ONLY", "").split(",") if x}   # indices into CASES (empty: all)
+    for idx, (eq, ext, note) in enumerate(CASES):
+        if only and idx not in only:
+            continue
         ins, out = eq.split("->")
         a_m, b_m = ins.split(",")
         if dt == torch.float32 and flop_of(ext, a_m, b_m) > 4e11:

@@ -17,7 +17,8 @@ h = ops.Handle()
 A = torch.rand(M * K, device="cuda")
 B = torch.rand(K * N, device="cuda")
 D = torch.zeros(M * N, device="cuda")
-p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", workspace_limit=1 << 30)
+algo = os.environ.get("F32_TIMELINE_ALGO")   # rank among the planner's candidates (tools/tune_gett.py lists them); unset: its choice
+p = ops.contraction_plan(h, [M, K], "mk", [K, N], "kn", [M, N], "mn", workspace_limit=1 << 30, **({"algo": int(algo)} if algo else {}))
 d = p.describe()
 ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
 fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, 0)   # noqa: E731
@@ -41,7 +42,7 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-print(json.dumps({"shape": [M, N, K], "kname": d["kname"], "tile": [d["bm"], d["bn"], d["bk"]], "blocks": d["blocks"], "splitK": d["splitK"],
+print(json.dumps({"shape": [M, N, K], "algo": algo, "pf": d["pf"], "kname": d["kname"], "tile": [d["bm"], d["bn"], d["bk"]], "blocks": d["blocks"], "splitK": d["splitK"],
                   "cycles_mean": dict(zip(["prologue", "steady", "drain", "epilogue"], [float(x) for x in ph.mean(axis=0)])),
                   "setup_cycles_mean": float((t[:, 7] - t[:, 0]).mean()) if (t[:, 7] > 0).all() else None,
                   "total_cycles_mean": float((t[:, 4] - t[:, 0]).mean()), "wg_dur_us_mean": float((end - start).mean()),
