@@ -204,8 +204,8 @@ __device__ __forceinline__ void reload_params(GettParams& q) {
 
 
 // ---------------------------------------------------------------------------------------------
-// The same tile on its way out as WHOLE ROWS, through a per-wave LDS image (round 6) — for outputs with ONE M mode and ONE N mode (batch
-// modes as they come) whose N mode is contiguous in D and a multiple of 4 long, 16-byte lanes everywhere (gett_f32_rows_ok).  That is the
+// The same tile on its way out as WHOLE ROWS, through a per-wave LDS image (round 6) — for outputs whose fastest N mode is contiguous in D
+// and a multiple of 4 long, with 16-byte lanes in every other stride of D (and of C when beta != 0) (gett_f32_rows_ok).  That is the
 // orientation the planner gives every GEMM-like output (plan_contraction.cpp: the free group that carries D's stride-1 mode becomes
 // kernel-N), and there the direct form above has no 16-byte path: a lane's four registers are four different ROWS, so a fragment
 // leaves as four instructions of 4 rows x 64 bytes, 4 bytes per lane — 64 store instructions per wave of a 128 x 128 tile.  Inside a
@@ -253,10 +253,32 @@ __device__ __forceinline__ bool gett_f32_rows_ok(GettArgPtr q, uint32_t l, const
     }
     Dl = static_cast<float*>(q->D) + oD;
     Cl = static_cast<const float*>(q->C) + oC;
-    bool ok = q->gM.n <= 1 && q->gN.n <= 1 && q->gN.stride[1][0] == 1 && (q->gN.div[0].d & 3u) == 0u && (q->gM.stride[1][0] & 3) == 0 &&
-              (reinterpret_cast<uintptr_t>(Dl) & 15u) == 0u;
-    if (q->beta != 0.f) ok = ok && q->cStrideN[0] == 1 && (q->cStrideM[0] & 3) == 0 && (reinterpret_cast<uintptr_t>(Cl) & 15u) == 0u;
+    const bool withC = q->beta != 0.f;
+    bool ok = q->gN.stride[1][0] == 1 && (q->gN.div[0].d & 3u) == 0u && (reinterpret_cast<uintptr_t>(Dl) & 15u) == 0u;
+    if (withC) ok = ok && q->cStrideN[0] == 1 && (reinterpret_cast<uintptr_t>(Cl) & 15u) == 0u;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {         // every other stride keeps the 16-byte lanes (padding entries: stride 0)
+        ok = ok && (q->gM.stride[1][i] & 3) == 0 && (i == 0 || (q->gN.stride[1][i] & 3) == 0);
+        if (withC) ok = ok && (q->cStrideM[i] & 3) == 0 && (i == 0 || (q->cStrideN[i] & 3) == 0);
+    }
     return ok;
+}
+
+// offsets of group index idx in D (slot 1 of the group) and C, the tables read through the laundered argument pointer
+typedef const __attribute__((address_space(4))) ModeGroup* GettArgGroup;
+typedef const __attribute__((address_space(4))) int64_t* GettArgStrides;
+__device__ __forceinline__ void gett_arg_offset2(GettArgGroup g, GettArgStrides cs, uint32_t idx, int64_t& offD, int64_t& offC) {
+    offD = 0;
+    offC = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxGroupModes; ++i) {
+        const uint32_t dd = g->div[i].d;
+        const uint32_t qq = __umulhi(idx, g->div[i].magic) >> g->div[i].shift;
+        const uint32_t digit = idx - qq * dd;
+        offD += (int64_t)digit * g->stride[1][i];
+        offC += (int64_t)digit * cs[i];
+        idx = qq;
+    }
 }
 
 template <int TM, int TN>
@@ -266,13 +288,17 @@ __device__ __forceinline__ void gett_store_tile_f32_rows(GettArgPtr q, const flo
     const uint32_t Mtot = q->gM.total, Ntot = q->gN.total;
     const float alpha = q->alpha, beta = q->beta;
     const int64_t sDm = q->gM.stride[1][0], sCm = q->cStrideM[0];
+    const bool flatM = q->gM.n <= 1, flatN = q->gN.n <= 1;   // wave-uniform: one mode per group -> offsets are products
     const int pol = q->partialPolicy;              // measurement switch (hooks flavour): 1 = plain stores, 3 = none
     const int g = lane >> 4, c16 = lane & 15;
-    // on the way out this lane holds n = nOut .. nOut + 3 of a row (lanes c16 < 4 TN); Ntot is a multiple of 4: all in or all out
+    // on the way out this lane holds n = nOut .. nOut + 3 of a row (lanes c16 < 4 TN); the fastest N mode is a multiple of 4 long: the four
+    // are contiguous, and all in or all out
     const uint32_t nOut = nBase + 4u * (uint32_t)c16;
     const bool okN = c16 < 4 * TN && nOut < Ntot;
-    float* dCol = D + nOut;
-    const float* cCol = C + nOut;
+    int64_t oDn = (int64_t)nOut, oCn = (int64_t)nOut;
+    if (!flatN && okN) gett_arg_offset2(&q->gN, q->cStrideN, nOut, oDn, oCn);
+    float* dCol = D + oDn;
+    const float* cCol = C + oCn;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         // in: register r of fragment (i, j) — image row 4 g + r (row 16 i + 4 g + r of the wave's tile), float 16 j + c16
@@ -288,13 +314,15 @@ __device__ __forceinline__ void gett_store_tile_f32_rows(GettArgPtr q, const flo
             const uint32_t m = mBase + 16u * (uint32_t)i + (uint32_t)row;
             if (okN && m < Mtot) {
                 f32x4 val = *reinterpret_cast<const f32x4*>(img + row * ROWF + 4 * c16);
+                int64_t oDm = (int64_t)m * sDm, oCm = (int64_t)m * sCm;
+                if (!flatM) gett_arg_offset2(&q->gM, q->cStrideM, m, oDm, oCm);
                 if (beta != 0.f) {
-                    const f32x4 cv = *reinterpret_cast<const f32x4*>(cCol + (int64_t)m * sCm);
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(cCol + oCm);
                     val[0] += beta * cv[0]; val[1] += beta * cv[1]; val[2] += beta * cv[2]; val[3] += beta * cv[3];
                 }
-                if (pol == 0) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm));
-                else if (pol == 1) *reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm) = val;
-                else if (val[0] == 12345.678f) *reinterpret_cast<f32x4*>(dCol + (int64_t)m * sDm) = val;   // measurement: no store
+                if (pol == 0) __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(dCol + oDm));
+                else if (pol == 1) *reinterpret_cast<f32x4*>(dCol + oDm) = val;
+                else if (val[0] == 12345.678f) *reinterpret_cast<f32x4*>(dCol + oDm) = val;   // measurement: no store
             }
         }
         asm volatile("" ::: "memory");             // ... and the next pass's writes stay behind these reads

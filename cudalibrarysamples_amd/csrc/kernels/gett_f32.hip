@@ -479,7 +479,8 @@ __global__ void __launch_bounds__(Cfg::THREADS, Cfg::MINW) gett_f32_kernel(const
         return;
     }
 
-    // flat outputs: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave (gett_common.h, round 6)
+    // outputs with 16-byte lanes along N: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave
+    // (gett_common.h, round 6)
     constexpr int IMG = gett_f32_image_floats<TN>();
     if constexpr (WM * WN * IMG <= LDS_FLOATS) {
         const GettArgPtr q = gett_arg_ptr();
@@ -695,7 +696,8 @@ __global__ void __launch_bounds__(2 * Cfg::THREADS, 2) gett_f32_pingpong_kernel(
         stamp(6);
         return;
     }
-    // flat outputs: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave (gett_common.h, round 6)
+    // outputs with 16-byte lanes along N: whole rows through a per-wave LDS image when the stage buffers hold one per storing wave
+    // (gett_common.h, round 6)
     constexpr int IMG = gett_f32_image_floats<TN>();
     if constexpr (WM * WN * IMG <= LDS_FLOATS) {
         const GettArgPtr q = gett_arg_ptr();

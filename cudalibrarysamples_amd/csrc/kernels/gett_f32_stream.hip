@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(512, 2) gett_f32_stream_kernel(const GettParam
         stamp(6);
         return;
     }
-    // Flat outputs (one M mode, one N mode, 16-byte lanes) leave as whole rows through a per-wave LDS image (gett_common.h, round 6).  The
+    // Outputs with 16-byte lanes along N leave as whole rows through a per-wave LDS image (gett_common.h, round 6).  The
     // image lives in the ring slot BEHIND the last tile's: every multiplying wave passed the last tile's barrier, so every older slot has
     // been read for the last time (S >= 3), while the last tile's own slot may still be feeding a slower wave's fragments.
     {

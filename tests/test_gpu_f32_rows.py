@@ -65,6 +65,38 @@ def run(mA, mB, m, n, k, alpha=1.0, beta=0.0, pad=(0, 0, 0), guard=4, seed=0, ws
     plan.destroy()
     return d, D.clone()
 
+def run_modes(mA, mB, mC, ext, alpha=1.0, beta=0.0, seed=0, algo=None, expect_untouched=False):
+    """packed tensors, any number of modes per group (modes listed fastest first, as the ABI takes them)"""
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    A = torch.rand([ext[c] for c in mA][::-1], generator=g, device="cuda")
+    B = torch.rand([ext[c] for c in mB][::-1], generator=g, device="cuda")
+    C = torch.rand([ext[c] for c in mC][::-1], generator=g, device="cuda")
+    D = torch.full_like(C, float("nan"))
+    kw = {} if algo is None else dict(algo=algo)
+    plan = ops.contraction_plan(h, [ext[c] for c in mA], mA, [ext[c] for c in mB], mB, [ext[c] for c in mC], mC, dtype=ct.R_32F, workspace_limit=1 << 28, **kw)
+    d = plan.describe()
+    if expect_untouched and d["splitK"] > 1:
+        plan.destroy()
+        return d
+    w = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), w.data_ptr(), plan.required_workspace)
+    torch.cuda.synchronize()
+    if expect_untouched:
+        assert torch.isnan(D).all(), (mA, mB, mC, d, "the row epilogue is not the path of this plan")
+    else:
+        ref = alpha * torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.double(), B.double()) + beta * C.double()
+        np.testing.assert_allclose(D.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, err_msg=str((mA, mB, mC, ext, d["kname"], d["bm"], d["splitK"])))
+    plan.destroy()
+    return d
+
+# several modes per output group (cuTENSOR/contraction.cu:46-59 is such a shape): D's fastest mode a multiple of 4 long -> the row epilogue
+# decodes a row's / a lane's offset digit by digit; fastest mode NOT a multiple of 4 -> the direct form
+MULTI = (("mhkn", "ukvh", "munv", dict(m=24, n=20, u=12, v=8, h=16, k=16)),        # contraction.cu's default equation, shrunk
+         ("kam", "nkb", "abnm", dict(a=8, b=12, m=36, n=28, k=64)),                # D's fastest mode from A's group
+         ("kma", "bnk", "nbma", dict(a=4, b=4, m=52, n=40, k=96)),
+         ("mkl", "nlk", "nml", dict(m=72, n=132, k=32, l=3)),
+         ("kam", "nkb", "abnm", dict(a=6, b=10, m=36, n=28, k=64)))               # extent 6: no 16-byte lanes in D
+
 LAYOUTS = (("mk", "kn"), ("km", "kn"), ("mk", "nk"), ("km", "nk"))
 MODE = os.environ.get("ROWS_TEST_MODE", "parity")
 if MODE == "parity":
@@ -88,6 +120,11 @@ if MODE == "parity":
             _, a = run(mA, mB, 260, 132, 96, algo=r, alpha=1.25, beta=0.5, guard=4, seed=90)
             _, b = run(mA, mB, 260, 132, 96, algo=r, alpha=1.25, beta=0.5, guard=3, seed=90)
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (mA, mB, r, "the two epilogue forms differ in bits")
+    for i, (mA, mB, mC, ext) in enumerate(MULTI):
+        for r in range(8):
+            d = run_modes(mA, mB, mC, ext, algo=r, seed=100 + i)
+            run_modes(mA, mB, mC, ext, algo=r, alpha=-0.5, beta=0.75, seed=200 + i)
+            kernels.add((d["kname"], d["bm"])); n_run += 2
     assert any(k[0] == "gett_f32_stream_kernel" for k in kernels) and any(k[0] == "gett_f32_kernel" for k in kernels), kernels
     print("OK", n_run, sorted(kernels))
 else:
@@ -97,6 +134,9 @@ else:
         for r in range(6):
             d, _ = run(mA, mB, 260, 132, 96, algo=r, seed=5, expect_untouched=True); n += 1
             d, _ = run(mA, mB, 132, 68, 64, algo=r, batch=3, beta=0.25, seed=6, expect_untouched=True); n += 1
+    for (mA, mB, mC, ext) in MULTI[:4]:
+        for r in range(6):
+            run_modes(mA, mB, mC, ext, algo=r, beta=0.5, seed=7, expect_untouched=True); n += 1
     print("OK", n)
 '''
 
