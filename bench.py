@@ -751,6 +751,30 @@ def secondary_round6(torch, ct, ops, h, stream, with_counters):
         del a, b, res
     except Exception as ex:   # noqa: BLE001
         out.append({"workload": "einsum bhqd,bhkd->bhqk bf16", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- the same shape in fp32, the headline's type: four K-tiles per tile, 1.07 GB of output — the launch the row epilogue of the fp32
+    #      kernels is for (round 6: D leaves as whole rows through a per-wave LDS image, gett_store_tile_f32_rows)
+    try:
+        from cudalibrarysamples_amd import torch_einsum
+        a = torch.rand((8, 8, 2048, 128), device="cuda") * 2 - 1
+        b = torch.rand((8, 8, 2048, 128), device="cuda") * 2 - 1
+        eq = "bhqd,bhkd->bhqk"
+        res = torch_einsum.einsum(eq, a, b)
+        pl = torch_einsum._plans[(eq, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
+        wsp = torch_einsum._get_workspace(a.device, pl.required_workspace)
+        fn = lambda: pl.execute(a, b, res, wsp)   # noqa: E731
+        for _ in range(10):
+            fn()
+        ms = min(timed_batch(torch, fn, reps=10), timed_batch(torch, fn, reps=10))
+        flop = 2.0 * 64 * 2048 * 2048 * 128
+        d = pl.describe()
+        out.append({"workload": "einsum 'bhqd,bhkd->bhqk' fp32 (8, 8, 2048, 2048, 128): attention scores, K = 128, 64 batches, 1.07 GB of output", "dtype": "f32",
+                    "value": flop / (ms * 1e-3) / 1e9, "unit": "GFLOP/s", "us_per_call": ms * 1e3, "kernel": d["kname"], "tile": [d["bm"], d["bn"], d["bk"]],
+                    "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_TFLOPS_F32_MFMA, "unit": "TFLOP/s",
+                                 "frac": flop / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_F32_MFMA, "algorithmic_flop": flop,
+                                 "algorithmic_bytes": 4.0 * (a.numel() + b.numel() + res.numel())}})
+        del a, b, res
+    except Exception as ex:   # noqa: BLE001
+        out.append({"workload": "einsum bhqd,bhkd->bhqk fp32", "error": "%s: %s" % (type(ex).__name__, ex)})
     # ---- complex64 1024^3: permutation abc->cab and reduction abc->ac on the tiled kernels of 8-byte elements ----------------
     try:
         n = 1024
