@@ -321,6 +321,115 @@ static bool split_lone_modes(const cutensorOperationDescriptor& desc, LoneSplit&
     return true;
 }
 
+// Repacked operands (round 6).  A 16-bit contraction whose operands the LDS-DMA kernels cannot stage in 16-byte units — an operand that is
+// contiguous in a mode the K order does not start with ('ijk,lkj->il': A contiguous in k, B in j; the reference's 'mlik,lkjm->lij'), or in
+// no staged mode at all — runs on the general family at 2-byte gathers: 70 TFLOP/s at 4096^2 x 1152 where the vendor BLAS reaches 630.
+// When the problem is large enough to pay for it, the operand is copied FIRST (cutensorPermute, ~5 TB/s) into a packed temporary in the
+// workspace — contracted modes fastest, in the order of the other operand's strides, then its free modes in D's order, then the batch
+// modes — and the contraction runs on the temporaries on the LDS-DMA kernels.  (The reference library's own heuristics are closed; its
+// samples only require that any stride pattern is accepted: cuTENSOR/contraction.cu:33-59.)  Decided by a time model: the copies at
+// 4 TB/s + 4 us each + the LDS-DMA plan's estimate against the general family at 100 TFLOP/s (an operand on 2-byte gathers) or 600.
+// several contracted modes and the fastest one fills less than 70 % of its K-tiles (the sweep mask of the LDS-DMA kernels keeps such a
+// problem, plan_contraction.cpp h16_sweep_ragged, at that efficiency)
+static bool h16_sweep_waste(const ContractionView& v) {
+    if (v.K.size() < 2) return false;
+    const int64_t e0 = v.K.front().extent;
+    return e0 % 64 != 0 && (double)e0 < 0.7 * 64.0 * (double)((e0 + 63) / 64);
+}
+struct RepackSplit {
+    cutensorOperationDescriptor inner, permA, permB;
+    bool hasA = false, hasB = false;
+    uint64_t bytesA = 0, bytesB = 0;       // packed sizes of the temporaries
+};
+// tDirectUs: the estimate of the plan that takes the operands as they lie, when the LDS-DMA family has one (sweeps of a short ragged contracted
+// mode waste most of every K-tile: 'abcd,dcbe->ae' with d = 16 keeps 16 of 64 k) — negative: the general family's model above.
+static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDescriptor& desc, const ContractionView& v, uint64_t wsLimit, double tDirectUs, RepackSplit& out) {
+    if (v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) || v.K.empty()) return false;
+    if (desc.A.op != CUTENSOR_OP_IDENTITY || desc.B.op != CUTENSOR_OP_IDENTITY) return false;
+    auto has = [](const std::vector<int32_t>& m, int32_t l) { return std::find(m.begin(), m.end(), l) != m.end(); };
+    auto stride_of = [](const TensorUse& T, int32_t l) -> int64_t {
+        for (size_t i = 0; i < T.modes.size(); ++i) if (T.modes[i] == l) return T.desc.stride[i];
+        return 0;
+    };
+    auto pack = [&](const TensorUse& X, const TensorUse& other, cutensorOperationDescriptor& perm, TensorUse& kept, uint64_t& bytes, double& copyUs) {
+        struct Km { int32_t label; int64_t extent, so; };
+        std::vector<Km> k;
+        for (size_t i = 0; i < X.modes.size(); ++i) {
+            const int32_t l = X.modes[i];
+            const bool inO = has(other.modes, l), inD = has(desc.D.modes, l);
+            if (!inO && !inD) return false;                                 // (an extent-1 mode nothing else carries: leave the descriptor alone)
+            if (inO && !inD) k.push_back(Km{l, X.desc.extent[i], std::llabs(stride_of(other, l))});
+        }
+        std::stable_sort(k.begin(), k.end(), [](const Km& a, const Km& b) { return a.so < b.so; });
+        kept = TensorUse{};
+        kept.present = true;
+        kept.op = X.op;
+        kept.desc.dtype = X.desc.dtype;
+        kept.desc.alignment = 256;
+        int64_t run = 1;
+        auto push = [&](int32_t l, int64_t e) { kept.modes.push_back(l); kept.desc.extent.push_back(e); kept.desc.stride.push_back(run); run *= e; };
+        for (const Km& m : k) push(m.label, m.extent);
+        for (int pass = 0; pass < 2; ++pass)                                // free modes in D's order, then the batch modes
+            for (int32_t l : desc.D.modes) {
+                if (!has(X.modes, l) || (has(other.modes, l) ? 1 : 0) != pass) continue;
+                for (size_t i = 0; i < X.modes.size(); ++i) if (X.modes[i] == l) push(l, X.desc.extent[i]);
+            }
+        if (kept.modes.size() != X.modes.size()) return false;
+        kept.desc.numModes = (uint32_t)kept.modes.size();
+        bytes = (uint64_t)run * dtype_size(X.desc.dtype);
+        perm = cutensorOperationDescriptor{};
+        perm.kind = OpKind::Permutation;
+        perm.A = X;
+        perm.D = kept; perm.D.op = CUTENSOR_OP_IDENTITY;
+        perm.compute = desc.compute;
+        perm.scalarType = desc.scalarType;
+        perm.movedBytes = 2.0 * (double)bytes;
+        // what the copy costs, by the kernel the element-wise planner gives it: the tiled kernels move whole tiles at ~4 TB/s (a tile mode
+        // much shorter than its tile pays for the padding), the element-gather kernel ~15 G elements per second (measured, round 6:
+        // 13 MB of bf16 from [d = 50, c, b, a] to [b, c, d, a] in 380 us)
+        EwPlan ep;
+        if (plan_elementwise(perm, ep, nullptr) != CUTENSOR_STATUS_SUCCESS) return false;
+        const double elems = (double)run;
+        if (ep.variant == EW_TRANSPOSE)
+            copyUs = 4.0 + 2.0 * 2.0 * (double)ep.p.tiles0 * ep.p.tile0 * (double)ep.p.tiles1 * ep.p.tile1 * (double)ep.p.rest.total / 4e6;
+        else if (ep.variant == EW_ROWCOPY) copyUs = 4.0 + 2.0 * 2.0 * elems / 4e6;
+        else copyUs = 4.0 + elems / 15e3;
+        return true;
+    };
+    const bool slowA = (v.swapped ? v.layB : v.layA) == LAY_S, slowB = (v.swapped ? v.layA : v.layB) == LAY_S;   // the user's A is kernel-B when swapped
+    const double flops = 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK;
+    const double tGeneral = tDirectUs >= 0.0 ? tDirectUs : flops / ((slowA || slowB) ? 100e12 : 600e12) * 1e6 + 8.0;
+    // candidates: A, B or both copied — with both, the temporaries share one order of the contracted modes, which then fuse into a single
+    // one (nothing ragged but the end of K).  The fastest one by the model, if it beats the direct plan by a fifth.
+    double best = 1e30;
+    for (int attempt = 1; attempt < 4; ++attempt) {                         // A alone, B alone, both
+        const bool doA = (attempt & 1) != 0, doB = (attempt & 2) != 0;
+        if ((slowA && !doA) || (slowB && !doB)) continue;                   // (an operand the kernels cannot stage is always copied)
+        RepackSplit r;
+        TensorUse keptA, keptB;
+        // the order of the contracted modes follows the OTHER operand as it will be contracted: with both repacked, B follows A's temporary
+        double usA = 0.0, usB = 0.0;
+        if (doA && !pack(desc.A, desc.B, r.permA, keptA, r.bytesA, usA)) return false;
+        if (doB && !pack(desc.B, doA ? keptA : desc.A, r.permB, keptB, r.bytesB, usB)) return false;
+        r.hasA = doA; r.hasB = doB;
+        r.inner = desc;
+        if (doA) r.inner.A = keptA;
+        if (doB) r.inner.B = keptB;
+        const uint64_t temps = ((r.bytesA + 255) & ~255ull) + ((r.bytesB + 255) & ~255ull);
+        if (temps > wsLimit) continue;
+        ContractionView vi;
+        ContractionChoice hc;
+        if (build_contraction_view(r.inner, vi, nullptr) != CUTENSOR_STATUS_SUCCESS || vi.wide) continue;
+        if (!pick_h16_choice(vi, wsLimit - temps, handle->numCUs, hc)) continue;
+        const double tCopies = usA + usB;
+        if (tCopies + hc.estimateUs < best) { best = tCopies + hc.estimateUs; out = r; }
+    }
+    if (best >= 1e30) return false;
+    // (CUTENSOR_AMD_REPACK=f, hooks flavour: whenever the temporaries fit — the fuzzers' way onto this path with small problems)
+    const bool forced = CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == 'f';
+    return forced || best < 0.8 * tGeneral;
+}
+
 // pointer alignment the offset operands of a peeled contraction still have
 static void peel_fix_alignment(cutensorOperationDescriptor& inner, const std::vector<PeelMode>& peel) {
     const int64_t es = (int64_t)dtype_size(inner.A.desc.dtype);
@@ -873,7 +982,18 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
         if (!v.wide && (v.dtype == HIP_R_16BF || v.dtype == HIP_R_16F)) {   // split-K partials of the 16-bit MFMA kernel
             ContractionChoice hc;
-            if (pick_h16_choice(v, cap, handle->numCUs, hc) || pick_gen_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
+            RepackSplit rs;
+            const bool direct = pick_h16_choice(v, cap, handle->numCUs, hc);
+            const bool h16ok = desc->scalarType == HIP_R_32F && !(desc->compute && desc->compute->id == 5);
+            if (direct && !(h16ok && h16_sweep_waste(v))) *workspaceSizeEstimate = hc.workspace;
+            else if (h16ok && plan_repack(handle, *desc, v, cap, direct ? hc.estimateUs : -1.0, rs)) {
+                // operands copied into packed temporaries first (plan_repack): the temporaries + what the copies and the inner contraction want
+                const uint64_t temps = ((rs.bytesA + 255) & ~255ull) + ((rs.bytesB + 255) & ~255ull);
+                uint64_t wI = 0;
+                cutensorStatus_t st2 = cutensorEstimateWorkspaceSize(handle, &rs.inner, planPref, workspacePref, &wI);
+                if (st2 != CUTENSOR_STATUS_SUCCESS) return st2;
+                *workspaceSizeEstimate = temps + wI;
+            } else if (direct || pick_gen_choice(v, cap, handle->numCUs, hc)) *workspaceSizeEstimate = hc.workspace;
             return CUTENSOR_STATUS_SUCCESS;
         }
         if (!v.wide && (v.dtype == HIP_R_64F || v.dtype == HIP_C_32F || v.dtype == HIP_C_64F)) {   // split-K partials of the general MFMA family
@@ -1319,6 +1439,32 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs, pr.operandsStreamed != 0);
         else if (h16Path && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
+        if (h16Path && (ch.empty() || h16_sweep_waste(pl->view)) && !CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && !CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") &&
+            !(CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == '0')) {
+            // the LDS-DMA kernels refuse the operands as they lie (or would spend most of every K-tile on the padding of a short ragged
+            // contracted mode): copy them into packed temporaries first when that pays (plan_repack)
+            RepackSplit rs;
+            if (plan_repack(handle, *desc, pl->view, workspaceSizeLimit, ch.empty() ? -1.0 : ch[0].estimateUs, rs)) {
+                const uint64_t offB = (rs.bytesA + 255) & ~255ull, offW = offB + ((rs.bytesB + 255) & ~255ull);
+                cutensorPlan_t pi = nullptr, pa = nullptr, pb = nullptr;
+                st = cutensorCreatePlan(handle, &pi, &rs.inner, pref, workspaceSizeLimit - offW);
+                if (st == CUTENSOR_STATUS_SUCCESS && rs.hasA) st = cutensorCreatePlan(handle, &pa, &rs.permA, pref, 0);
+                if (st == CUTENSOR_STATUS_SUCCESS && rs.hasB) st = cutensorCreatePlan(handle, &pb, &rs.permB, pref, 0);
+                if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == 1 && pi->sub1 == nullptr) {
+                    pl->sub1 = pi; pl->loneA = pa; pl->loneB = pb;
+                    pl->loneBytesA = rs.bytesA; pl->loneBytesB = rs.bytesB;
+                    pl->choice = ContractionChoice{};
+                    pl->choice.kernel = -4;
+                    pl->requiredWorkspace = offW + pi->requiredWorkspace;
+                    CT_LOG("plan: 16-bit contraction whose operands the LDS-DMA kernels cannot stage -> %s%scopied into packed temporaries first (%llu + %llu bytes), then the contraction",
+                           pa ? "A " : "", pb ? "B " : "", (unsigned long long)rs.bytesA, (unsigned long long)rs.bytesB);
+                    *plan = owner.release();
+                    return CUTENSOR_STATUS_SUCCESS;
+                }
+                delete pi; delete pa; delete pb;                            // (the copies or the inner plan refused: the general family takes the problem as it is)
+                st = CUTENSOR_STATUS_SUCCESS;
+            }
+        }
         if (ch.empty() && genPath && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == '0')) {
             ContractionChoice g;
             if (pick_gen_choice(pl->view, workspaceSizeLimit, handle->numCUs, g)) ch.push_back(g);
@@ -1558,12 +1704,15 @@ cutensorStatus_t cutensorContract(const cutensorHandle_t handle, const cutensorP
         const void* a = A;
         const void* bb = B;
         cutensorStatus_t st = CUTENSOR_STATUS_SUCCESS;
+        // (the first step of an operand is a reduction over its lone modes, or — plan_repack — a permuted copy into a packed temporary)
         if (plan->loneA) {
-            st = cutensorReduce(handle, plan->loneA, one, A, zero, ws, ws, ws + offW, workspaceSize - offW, stream);
+            st = plan->loneA->kind == OpKind::Permutation ? cutensorPermute(handle, plan->loneA, one, A, ws, stream)
+                                                         : cutensorReduce(handle, plan->loneA, one, A, zero, ws, ws, ws + offW, workspaceSize - offW, stream);
             a = ws;
         }
         if (st == CUTENSOR_STATUS_SUCCESS && plan->loneB) {
-            st = cutensorReduce(handle, plan->loneB, one, B, zero, ws + offB, ws + offB, ws + offW, workspaceSize - offW, stream);
+            st = plan->loneB->kind == OpKind::Permutation ? cutensorPermute(handle, plan->loneB, one, B, ws + offB, stream)
+                                                         : cutensorReduce(handle, plan->loneB, one, B, zero, ws + offB, ws + offB, ws + offW, workspaceSize - offW, stream);
             bb = ws + offB;
         }
         if (st != CUTENSOR_STATUS_SUCCESS) return st;
@@ -2005,7 +2154,9 @@ int ctamdDescribePlan(const cutensorPlan_t plan, char* buf, size_t len) try {
     }
     if (plan->kind == OpKind::Contraction && plan->choice.kernel == -4 && plan->sub1 != nullptr) {
         // a mode that one input alone carries: which operands are reduced first, then the inner contraction's description
-        n = std::snprintf(buf, len, "{\"lone_reduce_A\":%d,\"lone_reduce_B\":%d,\"lone_bytes\":%llu,", plan->loneA ? 1 : 0, plan->loneB ? 1 : 0,
+        const bool repA = plan->loneA && plan->loneA->kind == OpKind::Permutation, repB = plan->loneB && plan->loneB->kind == OpKind::Permutation;
+        n = std::snprintf(buf, len, "{\"lone_reduce_A\":%d,\"lone_reduce_B\":%d,\"repack_A\":%d,\"repack_B\":%d,\"lone_bytes\":%llu,",
+                          (plan->loneA && !repA) ? 1 : 0, (plan->loneB && !repB) ? 1 : 0, repA ? 1 : 0, repB ? 1 : 0,
                           (unsigned long long)(plan->loneBytesA + plan->loneBytesB));
         if (n < 0 || (size_t)n >= len) return -1;
         const int m = ctamdDescribePlan(plan->sub1, buf + n - 1, len - (size_t)n + 1);

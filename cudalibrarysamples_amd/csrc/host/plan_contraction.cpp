@@ -466,8 +466,26 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 // (ragged K: the masked last K-tile of the RAG instantiations).  Returns false -> the general MFMA family (pick_gen_choice).
 // The launch needs the kernels' RAG instantiation (masked last K-tile of the last slice): a ragged contracted range, or a free-contiguous
 // operand whose stride-1 mode is not a multiple of 8 long (its last row-unit can reach past the end of the tensor: x_rag_mask).
+// Sweep-ragged K (round 6): SEVERAL contracted modes and the fastest one does not hold whole 64-deep K-tiles ('abcd,dcbe->ae' at extents
+// of 96 or 40).  The RAG instantiations of the 256 x 256 and the 64 x 64 kernel count K-tiles in the padded space — ceil(E0 / 64) tiles per
+// sweep of the fastest mode — and stage the last tile of EVERY sweep with the lanes past the end of the mode out of range (x_rag_toggle:
+// the mask is switched on and off as the odometer goes).  Admitted when no 16-byte unit is partial or can reach past the tensor: a
+// K-contiguous operand has E0 % 8 == 0 by its layout class (pick16), a free-contiguous one needs a stride-1 extent that is a multiple of 8.
+static bool h16_sweep_ragged(const ContractionView& v) {
+    if (v.K.size() < 2 || v.K.front().extent % 64 == 0) return false;
+    if (v.layA == LAY_K || v.layB == LAY_K) { if (v.K.front().extent % 8 != 0) return false; }
+    if (v.layA == LAY_F && (v.M.empty() || v.M.front().extent % 8 != 0)) return false;
+    if (v.layB == LAY_F && (v.N.empty() || v.N.front().extent % 8 != 0)) return false;
+    return true;
+}
+// K-tiles of the 16-bit LDS-DMA family (padded per sweep of the fastest contracted mode when that one is ragged)
+static uint64_t h16_k_tiles(const ContractionView& v) {
+    if (h16_sweep_ragged(v)) return (uint64_t)((v.K.front().extent + 63) / 64) * (v.totK / (uint64_t)v.K.front().extent);
+    return (v.totK + 63) / 64;
+}
+
 static bool h16_needs_rag(const ContractionView& v) {
-    if (v.totK % 64 != 0) return true;
+    if (v.totK % 64 != 0 || h16_sweep_ragged(v)) return true;
     if (v.layA == LAY_F && !v.M.empty() && v.M.front().extent % 8 != 0) return true;
     if (v.layB == LAY_F && !v.N.empty() && v.N.front().extent % 8 != 0) return true;
     return false;
@@ -480,7 +498,10 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     // Whole 64-deep K-tiles in the fastest contracted mode — or (round 5) ONE contracted mode of any extent the 16-byte lanes admit
     // (a K-contiguous operand has extent % 8 == 0 by its layout class, a free-contiguous one takes any extent): the four-wave kernel
     // stages the last K-tile with the lanes past the end of the mode out of range (gett_h16w4x_kernel<..., RAG = true>).
-    if ((v.totK % 64 != 0) ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0)) return false;
+    // ... or (round 6) several contracted modes with a ragged fastest one: the masked last K-tile of every sweep (h16_sweep_ragged).
+    const bool sweep = h16_sweep_ragged(v);
+    if (!sweep && ((v.totK % 64 != 0) ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0))) return false;
+    if (sweep && h16_k_tiles(v) >= (1ull << 30)) return false;     // (GettParams::ragged carries the padded tile count in 30 bits)
     const bool ragged = h16_needs_rag(v);         // the candidates are the kernels that have a RAG instantiation
     // The 16-bit kernels address an operand with 32-bit byte offsets relative to a 64-bit base that moves with the workgroup
     // tile, the wave and the K-tile (gett_h16.hip, HOperand / HOdometer): what has to stay below 2^31 bytes is the span of
@@ -522,7 +543,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         return 48;
     }();
     const int layoutIdx = c.kernel;
-    const uint64_t kTiles = (v.totK + 63) / 64;
+    const uint64_t kTiles = h16_k_tiles(v);
     const uint64_t perSliceBytes = v.totL * v.totM * v.totN * 4ull;
     const bool forced = CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") != nullptr;
     auto tiles_of = [&](int var) {
@@ -593,6 +614,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     if (ragged && forced) {
         // CUTENSOR_AMD_H16_WAVES names the kernel: one of those that mask a partial K-tile (4x, 4m, 4m4, 4q), or the general family
         if (!usable || (var != 48 && var != 56 && var != 64 && var != 80)) return false;
+        if (sweep && var != 48 && var != 80) return false;          // the 128 x 128 pair has no sweep mask
         split = auto_split(var);
     } else if (ragged) {
         // the kernels of the family that mask a partial K-tile (the RAG instantiations): the 256 x 256 four-wave kernel, the 128 x 128
@@ -600,6 +622,7 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         double best = 1e30;
         for (int cand : {48, 64, 56, 80}) {
             if (layoutIdx + cand >= count) continue;
+            if (sweep && cand != 48 && cand != 80) continue;        // sweep-ragged K: the 256 x 256 and the 64 x 64 kernel (x_rag_toggle)
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {
                 const double t = model_us(cand, sp);
@@ -844,6 +867,7 @@ void fill_gett_params(const ContractionView& v, const ContractionChoice& c, Gett
         p.endA = spanA * es;
         p.endB = spanB * es;
         p.ragged = (c.family == 1 && h16_needs_rag(v)) ? 1u : 0u;
+        if (c.family == 1 && h16_sweep_ragged(v)) p.ragged |= 2u | ((uint32_t)h16_k_tiles(v) << 2);   // sweep-ragged K: the padded K-tile count
         if (c.family == 0 && v.dtype == HIP_R_32F && c.kernel >= 0) {
             int cnt = 0;
             const GettKernelInfo* t32 = gett_f32_kernels(&cnt);

@@ -283,7 +283,10 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = p.mOrg + mt * kHTile, n0 = p.nOrg + nt * kHTile;
-    const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    // sweep-ragged K (GettParams::ragged bit 1; the padded K-tile count in bits 2..31): several contracted modes, the fastest one without
+    // whole K-tiles — the last K-tile of EVERY sweep of that mode is staged masked (VOdometer::init_tiles, x_rag_toggle)
+    const bool sweep = RAG && (p.ragged & 2u) != 0u;
+    const uint32_t kTilesAll = sweep ? (p.ragged >> 2) : (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
@@ -294,18 +297,26 @@ __global__ void __launch_bounds__(256, 1) gett_h16w4x_kernel(const GettParams p)
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
-    odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    if (sweep) odo.init_tiles(p.gK, tile0, (uint32_t)nTiles, bA, bB);
+    else odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
     // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
     // of the last slice — and how many k of the contracted range it holds (x_rag_mask, x_rag_fix: gett_h16x_common.h)
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK);
+    const int maskAt = (RAG && !sweep && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(sweep ? p.gK.div[0].d - (odo.n0 - 1u) * (uint32_t)kHBK
+                                                  : ((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK));
     uint32_t stradA = 0u, stradB = 0u;            // units of the masked tile that x_rag_fix loads element by element
-    // called with the descriptor bases ON tile IDX
+    bool maskOn = false;                          // sweep-ragged K: the lanes past the end of the fastest contracted mode are out of range right now
+    // called with the descriptor bases ON tile IDX (sweep: tiles past the slice's last one are re-staged copies of it — the mask stays as it is)
 #define CTAMD_X_RAGMASK(IDX)                                                                                        \
     if constexpr (RAG) {                                                                                           \
         if ((IDX) == maskAt) {                                                                                     \
             stradA = x_rag_mask<LA, 2>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA));                      \
             stradB = x_rag_mask<LB, 2>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB));                      \
+        }                                                                                                          \
+        if (sweep && (IDX) < nTiles && odo.on_sweep_end() != maskOn) {                                             \
+            x_rag_toggle<LA, 2>(oa.src, wave, kValid);                                                             \
+            x_rag_toggle<LB, 2>(ob.src, wave, kValid);                                                             \
+            maskOn = !maskOn;                                                                                      \
         }                                                                                                          \
     }
     // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier: repair it when it holds a partial k-unit
@@ -1234,6 +1245,17 @@ __device__ __forceinline__ uint32_t q_rag_mask(uint32_t (&src)[2], int wave, uin
     }
     return strad;
 }
+// sweep-ragged K (x_rag_toggle) for QOperand's pieces: bit 31 of q_rag_mask's `out` lanes flipped
+template <int LAY>
+__device__ __forceinline__ void q_rag_toggle(uint32_t (&src)[2], int wave, uint32_t kValid) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ ((4u * (uint32_t)wave + (laneM >> 4)) & 7u)) >= kValid)
+                                        : (8u * (uint32_t)wave + 32u * (uint32_t)i + (laneM >> 3) >= kValid);
+        src[i] ^= out ? 0x80000000u : 0u;
+    }
+}
 // x_rag_fix for the 64 x 64 tile: ldsOp = LDS byte address of the operand's 8-KiB image in the buffer that holds the masked tile
 template <int LAY, int SLOTK>
 __device__ __forceinline__ void q_rag_fix(const ModeGroup& gFree, const ModeGroup& gK, uint64_t opBase, uint32_t row0, uint32_t kTile0, uint32_t kValid,
@@ -1328,7 +1350,8 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint32_t gsz = (rTilesM - first < 8u) ? (rTilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = (second ? ps.mOrg2 : ps.mOrg) + mt * kQTile, n0 = (second ? ps.nOrg2 : ps.nOrg) + nt * kQTile;
-    const uint32_t kTilesAll = (ps.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
+    const bool sweep = RAG && (ps.ragged & 2u) != 0u;         // sweep-ragged K: gett_h16w4x_kernel
+    const uint32_t kTilesAll = sweep ? (ps.ragged >> 2) : (ps.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = ps.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
     if constexpr (TIMED) { asm volatile("" :: "s"(nTiles), "s"(m0), "s"(n0)); qs[7] = __builtin_readcyclecounter(); }   // arguments fetched, tile located
@@ -1340,18 +1363,26 @@ __global__ void __launch_bounds__(256, 2) gett_h16w4q_kernel(const GettParams p)
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.A) + group_offset<0>(ps.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(ps.B) + group_offset<1>(ps.gL, l)) + ob.base);
     VOdometer odo;
-    odo.template init<RAG>(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    if (sweep) odo.init_tiles(ps.gK, tile0, (uint32_t)nTiles, bA, bB);
+    else odo.template init<RAG>(ps.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
     // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
     // of the last slice — and how many k of the contracted range it holds (q_rag_mask, q_rag_fix)
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr((ps.gK.total % kHBK) != 0u ? ps.gK.total % kHBK : (uint32_t)kHBK);
+    const int maskAt = (RAG && !sweep && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(sweep ? ps.gK.div[0].d - (odo.n0 - 1u) * (uint32_t)kHBK
+                                                  : ((ps.gK.total % kHBK) != 0u ? ps.gK.total % kHBK : (uint32_t)kHBK));
     uint32_t stradA = 0u, stradB = 0u;
-    // called with the descriptor bases ON tile IDX
+    bool maskOn = false;                          // sweep-ragged K: the masked lanes are out of range right now
+    // called with the descriptor bases ON tile IDX (sweep: tiles past the slice's last one are re-staged copies of it — the mask stays)
 #define CTAMD_Q_RAGMASK(IDX)                                                                                        \
     if constexpr (RAG) {                                                                                           \
         if ((IDX) == maskAt) {                                                                                     \
             stradA = q_rag_mask<LA>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA));                         \
             stradB = q_rag_mask<LB>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB));                         \
+        }                                                                                                          \
+        if (sweep && (IDX) < nTiles && odo.on_sweep_end() != maskOn) {                                             \
+            q_rag_toggle<LA>(oa.src, wave, kValid);                                                                \
+            q_rag_toggle<LB>(ob.src, wave, kValid);                                                                \
+            maskOn = !maskOn;                                                                                      \
         }                                                                                                          \
     }
     // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier (gett_h16w4x_kernel, CTAMD_X_RAGFIX)

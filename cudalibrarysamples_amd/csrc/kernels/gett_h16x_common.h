@@ -106,6 +106,39 @@ struct VOdometer {
         ended = 0;
         next_segment(untilCarry);
     }
+    // Sweep-ragged K (round 6, GettParams::ragged bit 1): SEVERAL contracted modes and the fastest one (extent E0) does not hold whole
+    // K-tiles — every sweep of that mode is ceil(E0 / 64) K-tiles and its last one is staged masked (x_rag_toggle).  The K-tiles are
+    // counted in that padded space: tile T = digit-0 tile T % n0 of the index q0 = T / n0 over the other contracted modes.
+    __device__ __forceinline__ void init_tiles(const ModeGroup& gK, uint32_t tile0, uint32_t nTiles, uint64_t bA, uint64_t bB) {
+        const uint32_t E0 = gK.div[0].d;
+        n0 = sgpr((E0 + (uint32_t)kHBK - 1u) / kHBK);
+        e1 = sgpr(gK.div[1].d);
+        const uint32_t q0 = (n0 == 1u) ? tile0 : tile0 / n0;
+        const uint32_t j0 = tile0 - q0 * n0;
+        const uint32_t k0 = q0 * E0 + j0 * (uint32_t)kHBK;
+        hi = sgpr((e1 < 2) ? q0 : fast_div(q0, gK.div[1]));
+        const uint32_t j1 = q0 - hi * e1;
+        baseA = bA;
+        baseB = bB;
+        addrA = h_uniform64(bA + (uint64_t)(group_offset<0>(gK, k0) * 2));
+        addrB = h_uniform64(bB + (uint64_t)(group_offset<1>(gK, k0) * 2));
+        stepA = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[0][0] * 2));
+        stepB = h_uniform64((uint64_t)((int64_t)kHBK * gK.stride[1][0] * 2));
+        wrapA = h_uniform64((uint64_t)(gK.stride[0][1] * 2) - (uint64_t)(n0 - 1) * stepA);
+        wrapB = h_uniform64((uint64_t)(gK.stride[1][1] * 2) - (uint64_t)(n0 - 1) * stepB);
+        untilWrap = sgpr(n0 - j0);
+        carryLen = sgpr(n0 * e1);
+        const uint32_t untilCarry = (e1 - j1) * n0 - j0;
+        left = sgpr(nTiles - 1u);
+        carryPending = 0;
+        untilEvent = 1;
+        recs = 0xffffffffu;
+        ended = 0;
+        next_segment(untilCarry);
+    }
+    // the tile the bases are on is the last one of a sweep of the fastest contracted mode (between advances; meaningless once the valid
+    // advances are used up — the callers stop looking then)
+    __device__ __forceinline__ bool on_sweep_end() const { return untilWrap == 1u; }
     // the valid advances that are left are cut into segments that end at a carry past digit 1 or at the end of the K range
     __device__ __forceinline__ void next_segment(uint32_t toCarry) {
         if (left == 0u) {
@@ -176,6 +209,20 @@ __device__ __forceinline__ uint32_t x_rag_mask(uint32_t (&src)[NH][4], int wave,
         }
     }
     return strad;
+}
+// Sweep-ragged K: the mask of the lanes past the end of the fastest contracted mode, switched ON for the last K-tile of every sweep and OFF
+// again for the next sweep's first tile (bit 31 of the lane offsets flipped: x_rag_mask's `out` lanes — the planner admits this form only
+// when no 16-byte unit is partial or can reach past the end of the tensor, so there is no `past` lane and nothing for x_rag_fix to do).
+template <int LAY, int NH>
+__device__ __forceinline__ void x_rag_toggle(uint32_t (&src)[NH][4], int wave, uint32_t kValid) {
+    const uint32_t laneM = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t kk0 = 4u * (uint32_t)wave + (laneM >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool out = (LAY == LAY_K) ? (8u * ((laneM & 7u) ^ (kk0 & 7u)) >= kValid) : (kk0 + 16u * (uint32_t)i >= kValid);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) src[h][i] ^= out ? 0x80000000u : 0u;
+    }
 }
 // bytes from `addr` (the descriptor base of the masked tile) to `end`, clamped to what a 31-bit lane offset can reach
 __device__ __forceinline__ uint32_t x_rag_limit(uint64_t end, uint64_t addr) {

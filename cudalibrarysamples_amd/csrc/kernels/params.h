@@ -63,6 +63,8 @@ struct GettParams {
     // kernel-A / kernel-B (set by cutensorContract from the plan's element spans): a 16-byte unit that would read past it is staged
     // masked and patched element by element (gett_h16x_common.h, x_rag_fix).  ragged: bit 0 — the launch needs the kernels' RAG
     // instantiation although K holds whole K-tiles (a free-contiguous operand whose row units can straddle the end of the tensor).
+    // bit 1 — sweep-ragged K (several contracted modes, the fastest one without whole K-tiles: the last K-tile of every sweep of that mode
+    // is staged masked, gett_h16x_common.h x_rag_toggle); bits 2..31 then hold the K-tile count of the padded index space.
     unsigned long long endA, endB;
     uint32_t    ragged;
     // Origin of this launch's tile grid inside the M x N index space (elements): a plan may cover the output with an interior launch

@@ -19,6 +19,22 @@ CASES = [
     ("bik,bjk->bij", dict(b=32, i=2048, j=2048, k=256), "both K-contiguous, 4 K-tiles, batched"),
 ]
 
+# EINSUM_SHAPES_SET=sweep: several contracted modes that do not fuse, the fastest one without whole 64-deep K-tiles (round 6: the masked
+# last K-tile of every sweep keeps them on the LDS-DMA kernels; CUTENSOR_AMD_GEN=f in the hooks flavour shows the general family beside it)
+SWEEP_CASES = [
+    ("abcd,dcbe->ae", dict(a=2048, b=8, c=8, d=96, e=2048), "the headline equation, contracted extents 8 x 8 x 96 (two K-tiles per sweep, 75 % live)"),
+    ("abcd,dcbe->ae", dict(a=2048, b=8, c=16, d=40, e=2048), "contracted extents 8 x 16 x 40 (one K-tile per sweep, 62 % live)"),
+    ("abcd,dcbe->ae", dict(a=4096, b=4, c=8, d=200, e=4096), "contracted extents 4 x 8 x 200 (four K-tiles per sweep, 78 % live)"),
+    ("ijk,lkj->il", dict(i=4096, l=4096, j=16, k=72), "A contiguous in k, B in j"),
+    ("abcd,dcbe->ae", dict(a=96, b=96, c=96, d=96, e=96), "the headline equation at extents of 96 (split-K)"),
+    # operands the LDS-DMA kernels cannot stage as they lie: copied into packed temporaries first (api.cpp plan_repack)
+    ("abcd,dcbe->ae", dict(a=2048, b=4, c=16, d=50, e=2048), "contracted extents 4 x 16 x 50: partial 16-byte units at the end of every sweep"),
+    ("abcd,dcbe->ae", dict(a=2048, b=8, c=16, d=16, e=2048), "contracted extents 8 x 16 x 16: a quarter of every K-tile live"),
+    ("mlik,lkjm->lij", dict(m=64, l=64, i=512, k=64, j=512), "the reference's test equation, larger: A contiguous in k, B in m"),
+]
+if os.environ.get("EINSUM_SHAPES_SET") == "sweep":
+    CASES = SWEEP_CASES
+
 
 def timed(torch, fn, reps):
     for _ in range(5):
@@ -65,6 +81,7 @@ def main():
         err = float((res.float() - ref.float()).abs().max() / ref.float().abs().max())
         p = torch_einsum._plans[(eq, tuple(a.shape), tuple(b.shape), a.dtype, False, False)]
         d = p.describe()
+        d["kname"] = ("copy " + "AB"[0:d["repack_A"]] + "AB"[1:1 + d["repack_B"]] + " + " if d.get("repack_A") or d.get("repack_B") else "") + str(d.get("kname"))
         ws = torch_einsum._get_workspace(a.device, p.required_workspace)
         o = torch.empty_like(res)
         ms = timed(torch, lambda: p.execute(a, b, o, ws), 20)
