@@ -336,6 +336,9 @@ static bool h16_sweep_waste(const ContractionView& v) {
     const int64_t e0 = v.K.front().extent;
     return e0 % 64 != 0 && (double)e0 < 0.7 * 64.0 * (double)((e0 + 63) / 64);
 }
+// set while the inner contraction of a repacked plan is estimated / planned: the temporaries are final, no second round of copies
+static thread_local bool t_inRepack = false;
+struct RepackScope { bool prev; RepackScope() : prev(t_inRepack) { t_inRepack = true; } ~RepackScope() { t_inRepack = prev; } };
 struct RepackSplit {
     cutensorOperationDescriptor inner, permA, permB;
     bool hasA = false, hasB = false;
@@ -344,7 +347,7 @@ struct RepackSplit {
 // tDirectUs: the estimate of the plan that takes the operands as they lie, when the LDS-DMA family has one (sweeps of a short ragged contracted
 // mode waste most of every K-tile: 'abcd,dcbe->ae' with d = 16 keeps 16 of 64 k) — negative: the general family's model above.
 static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDescriptor& desc, const ContractionView& v, uint64_t wsLimit, double tDirectUs, RepackSplit& out) {
-    if (v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) || v.K.empty()) return false;
+    if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) || v.K.empty()) return false;
     if (desc.A.op != CUTENSOR_OP_IDENTITY || desc.B.op != CUTENSOR_OP_IDENTITY) return false;
     auto has = [](const std::vector<int32_t>& m, int32_t l) { return std::find(m.begin(), m.end(), l) != m.end(); };
     auto stride_of = [](const TensorUse& T, int32_t l) -> int64_t {
@@ -990,6 +993,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
                 // operands copied into packed temporaries first (plan_repack): the temporaries + what the copies and the inner contraction want
                 const uint64_t temps = ((rs.bytesA + 255) & ~255ull) + ((rs.bytesB + 255) & ~255ull);
                 uint64_t wI = 0;
+                RepackScope scope;
                 cutensorStatus_t st2 = cutensorEstimateWorkspaceSize(handle, &rs.inner, planPref, workspacePref, &wI);
                 if (st2 != CUTENSOR_STATUS_SUCCESS) return st2;
                 *workspaceSizeEstimate = temps + wI;
@@ -1447,7 +1451,10 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             if (plan_repack(handle, *desc, pl->view, workspaceSizeLimit, ch.empty() ? -1.0 : ch[0].estimateUs, rs)) {
                 const uint64_t offB = (rs.bytesA + 255) & ~255ull, offW = offB + ((rs.bytesB + 255) & ~255ull);
                 cutensorPlan_t pi = nullptr, pa = nullptr, pb = nullptr;
-                st = cutensorCreatePlan(handle, &pi, &rs.inner, pref, workspaceSizeLimit - offW);
+                {
+                    RepackScope scope;
+                    st = cutensorCreatePlan(handle, &pi, &rs.inner, pref, workspaceSizeLimit - offW);
+                }
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasA) st = cutensorCreatePlan(handle, &pa, &rs.permA, pref, 0);
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasB) st = cutensorCreatePlan(handle, &pb, &rs.permB, pref, 0);
                 if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == 1 && pi->sub1 == nullptr) {

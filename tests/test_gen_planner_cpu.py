@@ -69,10 +69,16 @@ def test_vector_width_and_orientation_follow_the_layout(env):
         got = (d["orientA"], d["orientB"]) if not d["swapped"] else (d["orientB"], d["orientA"])
         assert d["family"] == 2 and d["vec"] == 8 and got == (oa, ob) and (d["bm"], d["bn"], d["bk"]) == (128, 128, 64), (mA, mB, d)
         p.destroy()
-    # ... and it is still where TWO contracted modes with a ragged fastest one go: C[m,n] = A[k,m,j] B[k,j,n], k = 40, j = 25
+    # ... TWO contracted modes with a ragged fastest one — C[m,n] = A[k,m,j] B[k,j,n], k = 40, j = 25 — went there until round 6; now the
+    # LDS-DMA kernels keep them (the masked last K-tile of every sweep of k: tests/test_h16_planner_cpu.py), unless a 16-byte unit would
+    # be partial (k = 36)
     p = ops.contraction_plan(h, [40, 512, 25], "kmj", [40, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
     d = p.describe()
-    assert d["family"] == 2 and d["vec"] == 8, d
+    assert d["family"] == 1 and d["rag"] == 1, d
+    p.destroy()
+    p = ops.contraction_plan(h, [36, 512, 25], "kmj", [36, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
+    d = p.describe()
+    assert d["family"] == 2, d
     p.destroy()
     # whole 64-deep K-tiles and 16-byte lanes: still the aligned LDS-DMA family
     p = plan(2048, 2048, 1024, "mk", "kn", ct.R_16BF)

@@ -22,6 +22,9 @@ def main():
                                                               "(peeled into a host loop up to 64 launches, mode-table kernel beyond)")
     ap.add_argument("--ragged-k", action="store_true", help="16-bit data, 16-byte lanes, ONE contracted mode whose extent is a multiple of 8 "
                                                             "but not of 64: the masked last K-tile of the LDS-DMA 16-bit kernels")
+    ap.add_argument("--sweep-k", action="store_true", help="16-bit data, two or three contracted modes with extents that are multiples of 8 but "
+                                                           "mostly not of 64, free extents multiples of 8: the sweep mask of the LDS-DMA kernels "
+                                                           "(and, with CUTENSOR_AMD_REPACK=f in the hooks flavour, operands copied into temporaries first)")
     args = ap.parse_args()
     import torch
     from cudalibrarysamples_amd import cutensor as ct, ops
@@ -34,6 +37,8 @@ def main():
         nM, nN, nK, nL = rnd.randint(1, 2), rnd.randint(1, 2), rnd.randint(1, 3), rnd.choice([0, 0, 0, 1])
         if args.ragged_k:
             dtype, nK = rnd.choice(["bfloat16", "bfloat16", "float16"]), 1
+        if args.sweep_k:
+            dtype, nK = rnd.choice(["bfloat16", "bfloat16", "float16"]), rnd.randint(2, 3)
         if args.many_modes:
             nM, nN, nK, nL = rnd.randint(2, 6), rnd.randint(1, 5), rnd.randint(1, 6), rnd.choice([0, 0, 1, 2])
         labels = list("abcdefghijklmnopqrstuvwxyz")
@@ -47,6 +52,8 @@ def main():
             table = ((M, [2, 3, 4, 5, 8]), (N, [2, 3, 4, 6, 8]), (K, [2, 3, 4, 8]), (L, [2, 3]))
         if args.ragged_k:
             table = ((M, [8, 16, 24, 40, 96, 104, 264, 520]), (N, [8, 16, 32, 48, 96, 120, 392]), (K, [8, 24, 72, 136, 200, 328, 520, 1000, 2056, 4104]), (L, [2, 3]))
+        if args.sweep_k:
+            table = ((M, [8, 16, 24, 40, 96, 104, 264, 520]), (N, [8, 16, 32, 48, 96, 120, 392]), (K, [2, 3, 8, 16, 24, 40, 64, 72, 96, 136, 200]), (L, [2, 3]))
         for g, choices in table:
             for c in g:
                 ext[c] = rnd.choice(choices)
@@ -92,7 +99,8 @@ def main():
             fails += 1
             continue
         d = plan.describe()
-        kname = d.get("kname") + ("+peel" if d.get("peeled_modes") else "")
+        kname = d.get("kname") + ("+peel" if d.get("peeled_modes") else "") + ("+copy" if d.get("repack_A") or d.get("repack_B") else "") + \
+            ("+sweep" if d.get("rag") and len(d.get("Kdigits", [])) > 1 else "")
         kinds[(kname, d["splitK"] > 1)] = kinds.get((kname, d["splitK"] > 1), 0) + 1
         ws = torch.empty(max(plan.required_workspace, 16), dtype=torch.uint8, device="cuda")
         plan.contract(alpha, A.data_ptr(), B.data_ptr(), beta, C.data_ptr(), D.data_ptr(), ws.data_ptr(), plan.required_workspace)
