@@ -401,7 +401,7 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
     };
     const bool slowA = (v.swapped ? v.layB : v.layA) == LAY_S, slowB = (v.swapped ? v.layA : v.layB) == LAY_S;   // the user's A is kernel-B when swapped
     const double flops = 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK;
-    const double tGeneral = tDirectUs >= 0.0 ? tDirectUs : flops / ((slowA || slowB) ? 100e12 : 600e12) * 1e6 + 8.0;
+    const double tGeneral = tDirectUs >= 0.0 ? tDirectUs : flops / ((slowA || slowB) ? 100e12 : 400e12) * 1e6 + 8.0;
     // candidates: A, B or both copied — with both, the temporaries share one order of the contracted modes, which then fuse into a single
     // one (nothing ragged but the end of K).  The fastest one by the model, if it beats the direct plan by a fifth.
     double best = 1e30;

@@ -471,12 +471,21 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 // sweep of the fastest mode — and stage the last tile of EVERY sweep with the lanes past the end of the mode out of range (x_rag_toggle:
 // the mask is switched on and off as the odometer goes).  Admitted when no 16-byte unit is partial or can reach past the tensor: a
 // K-contiguous operand has E0 % 8 == 0 by its layout class (pick16), a free-contiguous one needs a stride-1 extent that is a multiple of 8.
+// (Partial units — d = 50 — were built too: the tail of the unit zeroed in LDS behind an extra workgroup barrier in every sweep's last
+// tile, `past` units patched in the very last one.  Parity green, but the per-tile repair state in the main loop cost EVERY launch of the
+// RAG instantiations 10-20 % — 4096^2 x 4104 96-110 -> 111-133 us — and 'abcd,dcbe->ae' with d = 50 ran at 146 TFLOP/s against the
+// general family's 233: profiles/r06zz8_*; removed.)
 static bool h16_sweep_ragged(const ContractionView& v) {
     if (v.K.size() < 2 || v.K.front().extent % 64 == 0) return false;
     if (v.layA == LAY_K || v.layB == LAY_K) { if (v.K.front().extent % 8 != 0) return false; }
     if (v.layA == LAY_F && (v.M.empty() || v.M.front().extent % 8 != 0)) return false;
     if (v.layB == LAY_F && (v.N.empty() || v.N.front().extent % 8 != 0)) return false;
     return true;
+}
+// share of a sweep's K-tiles that holds data
+static double h16_sweep_fill(const ContractionView& v) {
+    const int64_t e0 = v.K.front().extent;
+    return (double)e0 / (64.0 * (double)((e0 + 63) / 64));
 }
 // K-tiles of the 16-bit LDS-DMA family (padded per sweep of the fastest contracted mode when that one is ragged)
 static uint64_t h16_k_tiles(const ContractionView& v) {
@@ -502,6 +511,10 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     const bool sweep = h16_sweep_ragged(v);
     if (!sweep && ((v.totK % 64 != 0) ? (v.K.size() != 1) : (v.K.front().extent % 64 != 0))) return false;
     if (sweep && h16_k_tiles(v) >= (1ull << 30)) return false;     // (GettParams::ragged carries the padded tile count in 30 bits)
+    // sweeps that fill less than 45 % of their K-tiles ('abcd,dcbe->ae' with d = 16: a quarter) are no faster than the general family on its
+    // 16-byte lanes (measured, profiles/r06zz6_*: d = 40, 62 %: 543 against 411 TFLOP/s; d = 16, 25 %: below its 360) — cutensorCreatePlan
+    // then looks at copying an operand so that the contracted modes fuse (api.cpp plan_repack), else the general family takes it
+    if (sweep && h16_sweep_fill(v) < 0.45 && !CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES")) return false;
     const bool ragged = h16_needs_rag(v);         // the candidates are the kernels that have a RAG instantiation
     // The 16-bit kernels address an operand with 32-bit byte offsets relative to a 64-bit base that moves with the workgroup
     // tile, the wave and the K-tile (gett_h16.hip, HOperand / HOdometer): what has to stay below 2^31 bytes is the span of

@@ -70,16 +70,13 @@ def test_vector_width_and_orientation_follow_the_layout(env):
         assert d["family"] == 2 and d["vec"] == 8 and got == (oa, ob) and (d["bm"], d["bn"], d["bk"]) == (128, 128, 64), (mA, mB, d)
         p.destroy()
     # ... TWO contracted modes with a ragged fastest one — C[m,n] = A[k,m,j] B[k,j,n], k = 40, j = 25 — went there until round 6; now the
-    # LDS-DMA kernels keep them (the masked last K-tile of every sweep of k: tests/test_h16_planner_cpu.py), unless a 16-byte unit would
-    # be partial (k = 36)
-    p = ops.contraction_plan(h, [40, 512, 25], "kmj", [40, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
-    d = p.describe()
-    assert d["family"] == 1 and d["rag"] == 1, d
-    p.destroy()
-    p = ops.contraction_plan(h, [36, 512, 25], "kmj", [36, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
-    d = p.describe()
-    assert d["family"] == 2, d
-    p.destroy()
+    # LDS-DMA kernels keep them (the masked last K-tile of every sweep of k: tests/test_h16_planner_cpu.py) unless a 16-byte unit would
+    # be partial (k = 36) or the sweeps fill less than 45 % of their K-tiles (k = 24)
+    for k, fam in ((40, 1), (36, 2), (24, 2)):
+        p = ops.contraction_plan(h, [k, 512, 25], "kmj", [k, 25, 512], "kjn", [512, 512], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28)
+        d = p.describe()
+        assert d["family"] == fam and (fam == 2 or d["rag"] == 1), d
+        p.destroy()
     # whole 64-deep K-tiles and 16-byte lanes: still the aligned LDS-DMA family
     p = plan(2048, 2048, 1024, "mk", "kn", ct.R_16BF)
     assert p.describe()["family"] == 1
@@ -124,15 +121,15 @@ def test_vector_width_and_orientation_follow_the_layout(env):
 def test_split_k_of_16_bit_data_and_workspace_invariant(env):
     ct, ops, h = env
     # one output tile, deep ragged K: split over the CUs, fp32 partials within the estimate (contraction.cu:239 asserts required <= estimate).
-    # (TWO contracted modes with a ragged fastest one — k = 44, j = 91: the LDS-DMA kernels mask ONE contracted mode,
-    # tests/test_h16_planner_cpu.py)
-    p = ops.contraction_plan(h, [44, 64, 91], "kmj", [44, 91, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF)
+    # (TWO contracted modes with a fastest one that fills a third of a K-tile — k = 20, j = 200: the LDS-DMA kernels' sweep mask is
+    # not offered below 45 %, tests/test_h16_planner_cpu.py)
+    p = ops.contraction_plan(h, [20, 64, 200], "kmj", [20, 200, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] > 1 and p.required_workspace == d["splitK"] * 64 * 48 * 4, d
     assert p.required_workspace <= p.workspace_estimate
     p.destroy()
     # no workspace allowed: no split
-    p = ops.contraction_plan(h, [44, 64, 91], "kmj", [44, 91, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
+    p = ops.contraction_plan(h, [20, 64, 200], "kmj", [20, 200, 48], "kjn", [64, 48], "mn", dtype=ct.R_16BF, workspace_limit=0)
     d = p.describe()
     assert d["family"] == 2 and d["splitK"] == 1 and p.required_workspace == 0, d
     p.destroy()

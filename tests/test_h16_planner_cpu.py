@@ -179,6 +179,7 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
     assert d["family"] == 1 and d["rag"] == 1 and d["splitK"] > 1 and d["splitK"] * d["kPerSlice"] >= 80 * 64, d
     assert plan2(dict(m=512, n=512, k=36, j=25), "kmj", "kjn")["family"] == 2     # partial 16-byte units at the end of every sweep
     assert plan2(dict(m=516, n=512, k=40, j=25), "mjk", "kjn")["family"] == 2     # a free-contiguous operand with a partial row unit
+    assert plan2(dict(m=512, n=512, k=24, j=25), "kmj", "kjn")["family"] == 2     # sweeps that fill 37 % of a K-tile: the general family
 
 
 def test_persistent_kernel_only_where_its_tiles_can_stream(env):

@@ -135,7 +135,12 @@ def test_argument_prefetch_keeps_one_register_per_touched_line(built, tmp_path, 
                          capture_output=True, text=True).stdout
     # the burst: s_load_dword sN, s[a:b], 0x40 * i — one per 64-byte line of the 848-byte argument block
     loads = re.findall(r"s_load_dword (s\d+), s\[\d+:\d+\], (0x[0-9a-f]+)", dis)
-    burst = {int(off, 16): reg for reg, off in loads if int(off, 16) % 64 == 0 and int(off, 16) < 896}
+    # (the FIRST load of each line: the fp32 kernels' epilogue re-reads single fields through a laundered argument pointer much later, and
+    # some of those fields sit at line starts)
+    burst = {}
+    for reg, off in loads:
+        if int(off, 16) % 64 == 0 and int(off, 16) < 896:
+            burst.setdefault(int(off, 16), reg)
     assert sorted(burst) == [64 * i for i in range(14)], loads[:20]
     assert len(set(burst.values())) == 14, burst          # fourteen lines, fourteen different destination registers
 

@@ -53,7 +53,7 @@ def main():
         if args.ragged_k:
             table = ((M, [8, 16, 24, 40, 96, 104, 264, 520]), (N, [8, 16, 32, 48, 96, 120, 392]), (K, [8, 24, 72, 136, 200, 328, 520, 1000, 2056, 4104]), (L, [2, 3]))
         if args.sweep_k:
-            table = ((M, [8, 16, 24, 40, 96, 104, 264, 520]), (N, [8, 16, 32, 48, 96, 120, 392]), (K, [2, 3, 8, 16, 24, 40, 64, 72, 96, 136, 200]), (L, [2, 3]))
+            table = ((M, [8, 16, 24, 40, 96, 104, 264, 520, 37, 100]), (N, [8, 16, 32, 48, 96, 120, 392, 29, 130]), (K, [2, 3, 8, 16, 24, 40, 50, 64, 72, 96, 136, 200]), (L, [2, 3]))
         for g, choices in table:
             for c in g:
                 ext[c] = rnd.choice(choices)
