@@ -354,14 +354,17 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         for (size_t i = 0; i < T.modes.size(); ++i) if (T.modes[i] == l) return T.desc.stride[i];
         return 0;
     };
-    auto pack = [&](const TensorUse& X, const TensorUse& other, cutensorOperationDescriptor& perm, TensorUse& kept, uint64_t& bytes, double& copyUs) {
+    // freeMajor: the FREE modes fastest (D's order), then the contracted modes in X's own order (a plain matrix transpose when they are
+    // adjacent in X): the temporary is free-contiguous, and a free-contiguous operand takes ANY fastest contracted extent under the sweep
+    // mask — the way out for sweeps that end in partial 16-byte units ('abcd,dcbe->ae' with d = 50)
+    auto pack = [&](const TensorUse& X, const TensorUse& other, bool freeMajor, cutensorOperationDescriptor& perm, TensorUse& kept, uint64_t& bytes, double& copyUs) {
         struct Km { int32_t label; int64_t extent, so; };
         std::vector<Km> k;
         for (size_t i = 0; i < X.modes.size(); ++i) {
             const int32_t l = X.modes[i];
             const bool inO = has(other.modes, l), inD = has(desc.D.modes, l);
             if (!inO && !inD) return false;                                 // (an extent-1 mode nothing else carries: leave the descriptor alone)
-            if (inO && !inD) k.push_back(Km{l, X.desc.extent[i], std::llabs(stride_of(other, l))});
+            if (inO && !inD) k.push_back(Km{l, X.desc.extent[i], std::llabs(freeMajor ? X.desc.stride[i] : stride_of(other, l))});
         }
         std::stable_sort(k.begin(), k.end(), [](const Km& a, const Km& b) { return a.so < b.so; });
         kept = TensorUse{};
@@ -371,12 +374,14 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         kept.desc.alignment = 256;
         int64_t run = 1;
         auto push = [&](int32_t l, int64_t e) { kept.modes.push_back(l); kept.desc.extent.push_back(e); kept.desc.stride.push_back(run); run *= e; };
-        for (const Km& m : k) push(m.label, m.extent);
-        for (int pass = 0; pass < 2; ++pass)                                // free modes in D's order, then the batch modes
+        if (!freeMajor) for (const Km& m : k) push(m.label, m.extent);
+        for (int pass = 0; pass < 2; ++pass) {                              // free modes in D's order, then the batch modes
+            if (freeMajor && pass == 1) for (const Km& m : k) push(m.label, m.extent);
             for (int32_t l : desc.D.modes) {
                 if (!has(X.modes, l) || (has(other.modes, l) ? 1 : 0) != pass) continue;
                 for (size_t i = 0; i < X.modes.size(); ++i) if (X.modes[i] == l) push(l, X.desc.extent[i]);
             }
+        }
         if (kept.modes.size() != X.modes.size()) return false;
         kept.desc.numModes = (uint32_t)kept.modes.size();
         bytes = (uint64_t)run * dtype_size(X.desc.dtype);
@@ -393,8 +398,12 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         EwPlan ep;
         if (plan_elementwise(perm, ep, nullptr) != CUTENSOR_STATUS_SUCCESS) return false;
         const double elems = (double)run;
-        if (ep.variant == EW_TRANSPOSE)
-            copyUs = 4.0 + 2.0 * 2.0 * (double)ep.p.tiles0 * ep.p.tile0 * (double)ep.p.tiles1 * ep.p.tile1 * (double)ep.p.rest.total / 4e6;
+        if (ep.variant == EW_TRANSPOSE) {
+            // (rows of a tile past the end of a mode are skipped, not moved: the padding costs about a third of live data — 'jkl -> kjl'
+            // with 16 x 72 of every 64 x 128 tile pair live, 9.4 MB, measured ~15 us)
+            const double padded = (double)ep.p.tiles0 * ep.p.tile0 * (double)ep.p.tiles1 * ep.p.tile1 * (double)ep.p.rest.total;
+            copyUs = 4.0 + 2.0 * 2.0 * (elems + 0.35 * (padded - elems)) / 4e6;
+        }
         else if (ep.variant == EW_ROWCOPY) copyUs = 4.0 + 2.0 * 2.0 * elems / 4e6;
         else copyUs = 4.0 + elems / 15e3;
         return true;
@@ -402,18 +411,20 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
     const bool slowA = (v.swapped ? v.layB : v.layA) == LAY_S, slowB = (v.swapped ? v.layA : v.layB) == LAY_S;   // the user's A is kernel-B when swapped
     const double flops = 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK;
     const double tGeneral = tDirectUs >= 0.0 ? tDirectUs : flops / ((slowA || slowB) ? 100e12 : 400e12) * 1e6 + 8.0;
-    // candidates: A, B or both copied — with both, the temporaries share one order of the contracted modes, which then fuse into a single
-    // one (nothing ragged but the end of K).  The fastest one by the model, if it beats the direct plan by a fifth.
+    // candidates: A, B or both copied, each with its contracted or its free modes fastest — with both K-major, the temporaries share one
+    // order of the contracted modes, which then fuse into a single one (nothing ragged but the end of K).  The fastest one by the model,
+    // if it beats the direct plan by a fifth.
     double best = 1e30;
-    for (int attempt = 1; attempt < 4; ++attempt) {                         // A alone, B alone, both
-        const bool doA = (attempt & 1) != 0, doB = (attempt & 2) != 0;
+    for (int attempt = 1; attempt < 9; ++attempt) {                         // per operand: 0 = as it lies, 1 = contracted modes fastest, 2 = free modes fastest
+        const int howA = attempt % 3, howB = attempt / 3;
+        const bool doA = howA != 0, doB = howB != 0;
         if ((slowA && !doA) || (slowB && !doB)) continue;                   // (an operand the kernels cannot stage is always copied)
         RepackSplit r;
         TensorUse keptA, keptB;
         // the order of the contracted modes follows the OTHER operand as it will be contracted: with both repacked, B follows A's temporary
         double usA = 0.0, usB = 0.0;
-        if (doA && !pack(desc.A, desc.B, r.permA, keptA, r.bytesA, usA)) return false;
-        if (doB && !pack(desc.B, doA ? keptA : desc.A, r.permB, keptB, r.bytesB, usB)) return false;
+        if (doA && !pack(desc.A, desc.B, howA == 2, r.permA, keptA, r.bytesA, usA)) continue;
+        if (doB && !pack(desc.B, doA ? keptA : desc.A, howB == 2, r.permB, keptB, r.bytesB, usB)) continue;
         r.hasA = doA; r.hasB = doB;
         r.inner = desc;
         if (doA) r.inner.A = keptA;

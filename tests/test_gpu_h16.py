@@ -281,6 +281,9 @@ REPACKED = [  # (extents, modes of A, B, D, operands copied first)
     (dict(m=1024, n=1024, j=16, k=64, l=3), "jmkl", "knjl", "mnl", (1, 0)),
     # the reference's test equation 'mlik,lkjm->lij' (einsum_test.py:84-107), larger: A contiguous in k, B in m
     (dict(m=64, l=16, i=256, k=64, j=256), "kilm", "mjkl", "jil", (0, 1)),
+    # the headline equation with d = 50: A's sweeps of d end in partial 16-byte units — A is copied with its FREE mode fastest (a plain
+    # transpose), and two free-contiguous operands take any fastest contracted extent under the sweep mask
+    (dict(a=2048, b=4, c=16, d=50, e=2048), "dcba", "ebcd", "ea", (1, 0)),
 ]
 
 
@@ -309,9 +312,8 @@ def test_small_problems_keep_their_operands_in_place(env):
     if not os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         assert d["family"] == 2 and "repack_A" not in d, d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=5e-2)
-    # (... and so does the headline equation with d = 50: sweeps that end in partial 16-byte units, and a copy of A that the element-wise
-    # planner could only run on its element-gather kernel)
-    got, ref, d = _run(env, dict(a=1024, b=4, c=16, d=50, e=1024), "dcba", "ebcd", "ea", seed=71, expect_mfma=False)
+    # (... and so does the headline equation with d = 50 when it is small: sweeps that end in partial 16-byte units)
+    got, ref, d = _run(env, dict(a=256, b=4, c=16, d=50, e=256), "dcba", "ebcd", "ea", seed=71, expect_mfma=False)
     if not os.environ.get("CUTENSOR_AMD_H16_WAVES"):
         assert d["family"] == 2 and "repack_A" not in d, d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=5e-2)
