@@ -336,6 +336,17 @@ static bool h16_sweep_waste(const ContractionView& v) {
     const int64_t e0 = v.K.front().extent;
     return e0 % 64 != 0 && (double)e0 < 0.7 * 64.0 * (double)((e0 + 63) / 64);
 }
+// fp32: what the plan that takes the operands as they lie will cost, when it is NOT on the LDS-DMA ring kernels (0: it is, or nothing to
+// compare) — the cost model's estimate of the register-staged kernels, corrected by what they measure on the shapes of
+// profiles/r06zzb_sweep_shapes_f32.jsonl: x 1.15 with 16-byte lanes (422 / 2103 / 170 us modelled, 498 / 2333 / 204 measured), x 2.5 when an
+// operand is gathered element by element (390 / 265 / 1346 modelled, 1064 / 552 / 5865 measured)
+static double f32_direct_estimate_us(const ContractionView& v, const std::vector<ContractionChoice>& ch) {
+    if (v.dtype != HIP_R_32F || v.wide || ch.empty() || ch[0].family != 0 || ch[0].kernel < 0) return 0.0;
+    int cnt = 0;
+    const GettKernelInfo* t32 = gett_f32_kernels(&cnt);
+    if (ch[0].kernel >= cnt || t32[ch[0].kernel].fragPartials) return 0.0;
+    return ch[0].estimateUs * ((v.layA == LAY_S || v.layB == LAY_S) ? 2.5 : 1.15);
+}
 // set while the inner contraction of a repacked plan is estimated / planned: the temporaries are final, no second round of copies
 static thread_local bool t_inRepack = false;
 struct RepackScope { bool prev; RepackScope() : prev(t_inRepack) { t_inRepack = true; } ~RepackScope() { t_inRepack = prev; } };
@@ -347,7 +358,9 @@ struct RepackSplit {
 // tDirectUs: the estimate of the plan that takes the operands as they lie, when the LDS-DMA family has one (sweeps of a short ragged contracted
 // mode waste most of every K-tile: 'abcd,dcbe->ae' with d = 16 keeps 16 of 64 k) — negative: the general family's model above.
 static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDescriptor& desc, const ContractionView& v, uint64_t wsLimit, double tDirectUs, RepackSplit& out) {
-    if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F) || v.K.empty()) return false;
+    const bool f32 = v.dtype == HIP_R_32F;
+    if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F && !f32) || v.K.empty()) return false;
+    const double es = (double)dtype_size(v.dtype);
     if (desc.A.op != CUTENSOR_OP_IDENTITY || desc.B.op != CUTENSOR_OP_IDENTITY) return false;
     auto has = [](const std::vector<int32_t>& m, int32_t l) { return std::find(m.begin(), m.end(), l) != m.end(); };
     auto stride_of = [](const TensorUse& T, int32_t l) -> int64_t {
@@ -402,9 +415,9 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
             // (rows of a tile past the end of a mode are skipped, not moved: the padding costs about a third of live data — 'jkl -> kjl'
             // with 16 x 72 of every 64 x 128 tile pair live, 9.4 MB, measured ~15 us)
             const double padded = (double)ep.p.tiles0 * ep.p.tile0 * (double)ep.p.tiles1 * ep.p.tile1 * (double)ep.p.rest.total;
-            copyUs = 4.0 + 2.0 * 2.0 * (elems + 0.35 * (padded - elems)) / 4e6;
+            copyUs = 4.0 + 2.0 * es * (elems + 0.35 * (padded - elems)) / 4e6;
         }
-        else if (ep.variant == EW_ROWCOPY) copyUs = 4.0 + 2.0 * 2.0 * elems / 4e6;
+        else if (ep.variant == EW_ROWCOPY) copyUs = 4.0 + 2.0 * es * elems / 4e6;
         else copyUs = 4.0 + elems / 15e3;
         return true;
     };
@@ -414,11 +427,14 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
     // candidates: A, B or both copied, each with its contracted or its free modes fastest — with both K-major, the temporaries share one
     // order of the contracted modes, which then fuse into a single one (nothing ragged but the end of K).  The fastest one by the model,
     // if it beats the direct plan by a fifth.
+    // (CUTENSOR_AMD_REPACK=f, hooks flavour: whenever the temporaries fit — the fuzzers' and the small parity cases' way onto this path)
+    const bool forced = CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == 'f';
     double best = 1e30;
     for (int attempt = 1; attempt < 9; ++attempt) {                         // per operand: 0 = as it lies, 1 = contracted modes fastest, 2 = free modes fastest
         const int howA = attempt % 3, howB = attempt / 3;
         const bool doA = howA != 0, doB = howB != 0;
-        if ((slowA && !doA) || (slowB && !doB)) continue;                   // (an operand the kernels cannot stage is always copied)
+        // (every combination is tried: an operand the kernels cannot stage as it lies may become stageable once the OTHER one is copied —
+        // A[d = 50, c, b, a] is K-contiguous in the fused mode (d, c, b) as soon as B holds the contracted modes in that order)
         RepackSplit r;
         TensorUse keptA, keptB;
         // the order of the contracted modes follows the OTHER operand as it will be contracted: with both repacked, B follows A's temporary
@@ -434,13 +450,19 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         ContractionView vi;
         ContractionChoice hc;
         if (build_contraction_view(r.inner, vi, nullptr) != CUTENSOR_STATUS_SUCCESS || vi.wide) continue;
-        if (!pick_h16_choice(vi, wsLimit - temps, handle->numCUs, hc)) continue;
+        if (f32) {
+            // fp32: the temporaries must put the problem on the LDS-DMA ring kernels (gett_f32_stream.hip: whole 32-deep K-tiles in the
+            // fastest contracted mode, or one ragged contracted mode)
+            const std::vector<ContractionChoice> ci = rank_contraction_choices(vi, wsLimit - temps, handle->numCUs, false);
+            int cnt = 0;
+            const GettKernelInfo* t32 = gett_f32_kernels(&cnt);
+            if (ci.empty() || ci[0].family != 0 || ci[0].kernel < 0 || ci[0].kernel >= cnt || (!forced && !t32[ci[0].kernel].fragPartials)) continue;
+            hc = ci[0];
+        } else if (!pick_h16_choice(vi, wsLimit - temps, handle->numCUs, hc)) continue;
         const double tCopies = usA + usB;
         if (tCopies + hc.estimateUs < best) { best = tCopies + hc.estimateUs; out = r; }
     }
     if (best >= 1e30) return false;
-    // (CUTENSOR_AMD_REPACK=f, hooks flavour: whenever the temporaries fit — the fuzzers' way onto this path with small problems)
-    const bool forced = CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == 'f';
     return forced || best < 0.8 * tGeneral;
 }
 
@@ -1028,6 +1050,19 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         if (v.dtype != HIP_R_32F) return CUTENSOR_STATUS_SUCCESS;
         // the largest workspace any of the best few candidates would like to have
         std::vector<ContractionChoice> ch = rank_contraction_choices(v, cap, handle->numCUs, planPref != nullptr && planPref->operandsStreamed != 0);
+        {
+            RepackSplit rs;     // fp32 off the ring kernels: operands copied into packed temporaries first when that pays (plan_repack)
+            const double tDirect = f32_direct_estimate_us(v, ch);
+            if (tDirect > 0.0 && !(desc->compute && desc->compute->id == 5) && desc->scalarType == HIP_R_32F && plan_repack(handle, *desc, v, cap, tDirect, rs)) {
+                const uint64_t temps = ((rs.bytesA + 255) & ~255ull) + ((rs.bytesB + 255) & ~255ull);
+                uint64_t wI = 0;
+                RepackScope scope;
+                cutensorStatus_t st2 = cutensorEstimateWorkspaceSize(handle, &rs.inner, planPref, workspacePref, &wI);
+                if (st2 != CUTENSOR_STATUS_SUCCESS) return st2;
+                *workspaceSizeEstimate = temps + wI;
+                return CUTENSOR_STATUS_SUCCESS;
+            }
+        }
         uint64_t want = 0;
         for (size_t i = 0; i < ch.size() && i < 4; ++i) want = std::max(want, ch[i].workspace);
         *workspaceSizeEstimate = want;
@@ -1454,12 +1489,15 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs, pr.operandsStreamed != 0);
         else if (h16Path && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
-        if (h16Path && (ch.empty() || h16_sweep_waste(pl->view)) && !CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && !CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") &&
+        const double tDirect32 = (mfmaPath && desc->scalarType == HIP_R_32F && (int)pr.algo < 0 && pr.kernelRank == 0 && !ctamd_research_env("CUTENSOR_AMD_KORDER"))
+                                     ? f32_direct_estimate_us(pl->view, ch) : 0.0;
+        if (((h16Path && (ch.empty() || h16_sweep_waste(pl->view)) && !CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && !CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES")) || tDirect32 > 0.0) &&
+            (int)pr.algo < 0 && pr.kernelRank == 0 &&                       // (a caller who names a candidate gets that candidate)
             !(CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == '0')) {
             // the LDS-DMA kernels refuse the operands as they lie (or would spend most of every K-tile on the padding of a short ragged
             // contracted mode): copy them into packed temporaries first when that pays (plan_repack)
             RepackSplit rs;
-            if (plan_repack(handle, *desc, pl->view, workspaceSizeLimit, ch.empty() ? -1.0 : ch[0].estimateUs, rs)) {
+            if (plan_repack(handle, *desc, pl->view, workspaceSizeLimit, tDirect32 > 0.0 ? tDirect32 : ch.empty() ? -1.0 : ch[0].estimateUs, rs)) {
                 const uint64_t offB = (rs.bytesA + 255) & ~255ull, offW = offB + ((rs.bytesB + 255) & ~255ull);
                 cutensorPlan_t pi = nullptr, pa = nullptr, pb = nullptr;
                 {
@@ -1468,7 +1506,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 }
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasA) st = cutensorCreatePlan(handle, &pa, &rs.permA, pref, 0);
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasB) st = cutensorCreatePlan(handle, &pb, &rs.permB, pref, 0);
-                if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == 1 && pi->sub1 == nullptr) {
+                if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == (mfmaPath ? 0 : 1) && pi->sub1 == nullptr) {
                     pl->sub1 = pi; pl->loneA = pa; pl->loneB = pb;
                     pl->loneBytesA = rs.bytesA; pl->loneBytesB = rs.bytesB;
                     pl->choice = ContractionChoice{};

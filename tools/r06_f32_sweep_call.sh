@@ -1,0 +1,12 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r06zzc; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_repack.py tests/test_gpu_h16.py -m gpu -x -q -k "repack or copied or in_place or sweep" > $O/pytest_repack.log 2>&1; echo "pytest rc $?"; tail -4 $O/pytest_repack.log
+EINSUM_SHAPES_SET=sweep timeout 900 python tools/bench_einsum_shapes.py f32 > $O/sweep_shapes_f32.jsonl 2> $O/sweep_shapes_f32.err
+EINSUM_SHAPES_SET=sweep timeout 900 python tools/bench_einsum_shapes.py bf16 > $O/sweep_shapes_bf16.jsonl 2> $O/sweep_shapes_bf16.err
+export CTAMD_LIB_FLAVOUR=hooks
+CUTENSOR_AMD_REPACK=f timeout 500 python tools/fuzz_contraction.py --cases 500 --seed 95 > $O/fuzz_default_copies_forced.log 2>&1; tail -1 $O/fuzz_default_copies_forced.log | cut -c1-700
+CUTENSOR_AMD_REPACK=f timeout 500 python tools/fuzz_contraction.py --cases 400 --seed 96 --strided > $O/fuzz_strided_copies_forced.log 2>&1; tail -1 $O/fuzz_strided_copies_forced.log | cut -c1-700
+CUTENSOR_AMD_REPACK=f timeout 500 python tools/fuzz_contraction.py --cases 400 --seed 97 --sweep-k > $O/fuzz_sweep_copies_forced.log 2>&1; tail -1 $O/fuzz_sweep_copies_forced.log | cut -c1-700
+timeout 500 python tools/fuzz_contraction.py --cases 400 --seed 98 > $O/fuzz_default.log 2>&1; tail -1 $O/fuzz_default.log | cut -c1-700
+CUTENSOR_AMD_REPACK=f timeout 400 python tools/fuzz_einsum.py > $O/fuzz_einsum_copies_forced.log 2>&1; tail -1 $O/fuzz_einsum_copies_forced.log | cut -c1-300
