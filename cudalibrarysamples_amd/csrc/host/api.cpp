@@ -417,7 +417,7 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
             const double padded = (double)ep.p.tiles0 * ep.p.tile0 * (double)ep.p.tiles1 * ep.p.tile1 * (double)ep.p.rest.total;
             copyUs = 4.0 + 2.0 * es * (elems + 0.35 * (padded - elems)) / 4e6;
         }
-        else if (ep.variant == EW_ROWCOPY) copyUs = 4.0 + 2.0 * es * elems / 4e6;
+        else if (ep.variant == EW_ROWCOPY || ep.variant == EW_BLOCK) copyUs = 4.0 + 2.0 * es * elems / 4e6;
         else copyUs = 4.0 + elems / 15e3;
         return true;
     };

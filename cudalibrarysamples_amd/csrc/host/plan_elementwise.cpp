@@ -233,6 +233,38 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
             plan.variant = EW_ROWCOPY; t0 = wide ? 64 * (int)vec : h16 ? 512 : 256; t1 = 8;
         }
     }
+    // EW_BLOCK (round 6): a pure permutation of 2- / 4-byte elements that the tiled kernels refuse, whose first n modes in D's order are
+    // packed in D AND the same set of modes is packed at the front of A — contiguous blocks, permuted inside (elementwise.hip
+    // ew_block_kernel).  The smallest such n; blocks of at most 32 KiB; a workgroup takes as many blocks as fill ~4 Ki elements.
+    if (plan.variant == EW_GENERIC && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
+        op.padLeft.empty() && op.padRight.empty() && modes.size() >= 2) {
+        const uint64_t cap = 32768 / (uint64_t)dtype_size(D.desc.dtype);
+        for (size_t n = 2; n <= modes.size() && n <= 4; ++n) {
+            uint64_t run = 1;
+            bool ok = true;
+            for (size_t i = 0; i < n && ok; ++i) { ok = modes[i].sD == (int64_t)run; run *= (uint64_t)modes[i].extent; }
+            if (!ok || run > cap) break;                                   // (D's leading modes are not packed, or the block outgrew LDS: no larger n helps)
+            std::vector<size_t> byA(n);
+            for (size_t i = 0; i < n; ++i) byA[i] = i;
+            std::sort(byA.begin(), byA.end(), [&](size_t x, size_t y) { return modes[x].sA < modes[y].sA; });
+            uint64_t runA = 1;
+            for (size_t i = 0; i < n && ok; ++i) { ok = modes[byA[i]].sA == (int64_t)runA; runA *= (uint64_t)modes[byA[i]].extent; }
+            if (!ok) continue;
+            std::vector<EwMode> others(modes.begin() + (long)n, modes.end());
+            if (!fill_rest(p.blkRest, others)) break;
+            p.blkN = (uint32_t)n;
+            p.blkTotal = (uint32_t)run;
+            for (size_t i = 0; i < n; ++i) { p.blkDiv[i] = make_fastdiv((uint32_t)modes[i].extent); p.blkSrc[i] = (uint32_t)modes[i].sA; }
+            for (size_t i = n; i < 4; ++i) { p.blkDiv[i] = make_fastdiv(1u); p.blkSrc[i] = 0u; }
+            uint64_t group = std::max<uint64_t>(1, 4096 / run);
+            group = std::min<uint64_t>(group, cap / run);
+            group = std::min<uint64_t>(group, std::max<uint64_t>(1, (uint64_t)p.blkRest.total / 512));   // (keep at least ~512 workgroups)
+            p.blkGroup = (uint32_t)std::max<uint64_t>(1, group);
+            p.blkBlocks = (p.blkRest.total + p.blkGroup - 1) / p.blkGroup;
+            plan.variant = EW_BLOCK;
+            break;
+        }
+    }
     plan.usesX = usesX;
     p.tile0 = (uint32_t)t0;
     p.tile1 = (uint32_t)t1;

@@ -606,6 +606,55 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// EW_BLOCK (round 6): D = alpha * perm(A) where the leading modes of D are the same packed set as the leading modes of A — every index
+// of the other modes owns a block of blkTotal elements that is contiguous in A and in D and only permuted inside.  A workgroup loads
+// blkGroup such blocks into LDS as they lie (coalesced), and writes them out in D's order (coalesced) through permuted LDS reads:
+// 2 |D| bytes, no strided global access.  What the element-gather kernel above does with such a tensor: 13 MB of bf16 from
+// [d = 50, c = 16, b = 4 | a] to [b, c, d | a] in 380 us (each lane of a store reads another 64-byte line); this kernel: one pass at the
+// rate of a copy.  alpha == 1 moves the bits untouched.  HBM-bound.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlkLdsBytes = 32768;
+
+template <typename T>
+__global__ void __launch_bounds__(256) ew_block_kernel(const Ew2DParams p) {
+    __shared__ __attribute__((aligned(16))) T lds[kBlkLdsBytes / sizeof(T)];
+    const T* A = static_cast<const T*>(p.A);
+    T*       D = static_cast<T*>(p.D);
+    const uint32_t P = p.blkTotal;
+    const uint32_t r0 = blockIdx.x * p.blkGroup;
+    const uint32_t nG = (p.blkRest.total - r0 < p.blkGroup) ? (p.blkRest.total - r0) : p.blkGroup;
+    const int tid = threadIdx.x;
+    for (uint32_t g = 0; g < nG; ++g) {
+        int64_t oA, oD, oC;
+        rest_offsets(p.blkRest, r0 + g, oA, oD, oC);
+        const T* src = A + oA;
+        T* dst = lds + g * P;
+        for (uint32_t e = tid; e < P; e += 256) dst[e] = src[e];
+    }
+    __syncthreads();
+    const bool raw = p.alpha == 1.0f;
+    for (uint32_t g = 0; g < nG; ++g) {
+        int64_t oA, oD, oC;
+        rest_offsets(p.blkRest, r0 + g, oA, oD, oC);
+        const T* src = lds + g * P;
+        T* dst = D + oD;
+        for (uint32_t f = tid; f < P; f += 256) {
+            uint32_t rem = f, idx = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < (int)p.blkN) {
+                    const uint32_t q = (i + 1 < (int)p.blkN) ? ew_fast_div(rem, p.blkDiv[i]) : 0u;
+                    idx += (rem - q * p.blkDiv[i].d) * p.blkSrc[i];
+                    rem = q;
+                }
+            }
+            if (raw) dst[f] = src[idx];
+            else ew_store<T>(dst + f, p.alpha * ew_load<T>(src + idx));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // EW_GENERIC for complex data (HIP_C_32F / HIP_C_64F): what the reference's binding runs for a unary einsum on complex tensors
 // (python/einsum.h:326-343,430-441: cutensorCreateReduction + cutensorReduce with no reduced mode = a permutation;
 // torch/einsum.cc:83 dispatches the complex types) and cutensorPermute / cutensorElementwiseBinaryExecute on complex tensors.
@@ -840,6 +889,18 @@ hipError_t launch_fill(void* D, uint64_t n, int dtype, double value, hipStream_t
 
 hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream) {
     if (p.nBlocks == 0) return hipSuccess;
+    if (variant == EW_BLOCK) {
+        // (the plan keeps the element-gather kernel's decomposition beside the block form: an attached C / E / X operand falls back to it)
+        if (p.blkN >= 2 && p.C == nullptr && p.E == nullptr && p.X == nullptr && p.blkBlocks > 0) {
+            switch (dtype) {
+                case HIP_R_32F:  hipLaunchKernelGGL(ew_block_kernel<float>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
+                case HIP_R_16F:  hipLaunchKernelGGL(ew_block_kernel<__half>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
+                case HIP_R_16BF: hipLaunchKernelGGL(ew_block_kernel<__hip_bfloat16>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
+                default: break;
+            }
+        }
+        variant = EW_GENERIC;
+    }
     // One workgroup per tile: a workgroup that loops over tiles serialises its own read -> barrier -> write phases, fresh
     // workgroups overlap them across the CU (2048^3 permutation, 64 x 64 tiles: 5.37 TB/s with the grid capped at 32 Ki
     // workgroups, 6.09-6.14 with one workgroup per tile; profiles/r03_transpose_sweep*.jsonl).  The grid-stride loop stays

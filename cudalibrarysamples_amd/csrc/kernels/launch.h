@@ -66,7 +66,9 @@ hipError_t launch_gett_wide(const WideParams& p, int dtype /*hipDataType*/, bool
 enum EwVariant : int {
     EW_TRANSPOSE = 0,  // sD0 == 1 and sA1 == 1: 64x64 LDS tile, 16-byte lanes on both sides
     EW_ROWCOPY   = 1,  // sD0 == 1 and sA0 == 1: 16-byte lanes along dim0, no LDS
-    EW_GENERIC   = 2   // any strides, any dtype: one element per lane
+    EW_GENERIC   = 2,  // any strides, any dtype: one element per lane
+    EW_BLOCK     = 3   // pure permutation of 2- / 4-byte elements whose leading modes are the same packed set in A and D: contiguous blocks
+                       // through LDS, permuted inside (Ew2DParams::blk*); falls back to EW_GENERIC when a C / E / X operand is attached
 };
 hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipStream_t stream);
 // D[0 .. n) = value (contiguous; the padded-permutation border fill)

@@ -167,6 +167,15 @@ struct Ew2DParams {
     // real parts) and conjugation of the permuted operand A / of C
     double      alphaIm, gammaIm;
     int32_t     conjA, conjC;
+    // EW_BLOCK (round 6, ew_block_kernel): the first blkN modes of D (packed: D-relative offset f = their mixed-radix index) are the SAME
+    // set of modes that is packed at the front of A — a block of blkTotal elements that is contiguous on both sides and only permuted
+    // inside ([d, c, b | a] -> [b, c, d | a]: the copy in front of a contraction, api.cpp plan_repack).  blkDiv: extents in D's order;
+    // blkSrc: each mode's stride in A = its position stride inside the block as it is loaded; blkRest: every other mode (slot 0 = A,
+    // slot 1 = D); a workgroup moves blkGroup consecutive rest indices; blkBlocks workgroups.  blkN == 0: no such form.
+    uint32_t    blkN, blkTotal, blkGroup, blkBlocks;
+    FastDiv     blkDiv[4];
+    uint32_t    blkSrc[4];
+    ModeGroup   blkRest;
 };
 
 // ---------------------------------------------------------------------------------------------

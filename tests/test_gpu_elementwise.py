@@ -23,7 +23,10 @@ def env(built):
     (dict(a=72, b=36, c=132), "abc", "cba", 0),            # full reversal, partial 64-tiles
     (dict(a=256, b=12, c=10), "abc", "acb", 1),            # shared fastest mode -> ROWCOPY
     (dict(a=4096), "a", "a", 1),                           # 1-D copy
-    (dict(a=33, b=17, c=5), "abc", "cab", 2),              # odd extents -> GENERIC
+    (dict(a=33, b=17, c=5), "abc", "cab", 3),              # odd extents, the whole tensor one contiguous block on both sides -> BLOCK (round 6)
+    (dict(a=33, b=170, c=7), "abc", "acb", 2),             # odd extents, shared fastest mode, more than a block's 32 KiB -> GENERIC
+    (dict(d=50, c=16, b=4, a=40), "dcba", "bcda", 3),      # the copy in front of 'abcd,dcbe->ae' with d = 50: blocks of 3200, permuted inside
+    (dict(a=6, b=5, c=4, d=300), "abcd", "cbad", 3),       # small blocks: several per workgroup
     (dict(a=7), "a", "a", 2),
     (dict(a=1, b=64, c=64), "abc", "cba", 0),              # extent-1 mode dropped
 ])
@@ -46,6 +49,38 @@ def test_permutation(env, case):
             assert np.array_equal(got, ref), (mA, mB)
         else:
             assert_close(got, ref, rtol=1e-6, what="permute")
+
+
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16", "float32"])
+def test_block_permutation_bit_exact_at_alpha_one(env, dtype_name):
+    """EW_BLOCK (elementwise.hip ew_block_kernel, round 6): the leading modes of D are the same packed set as the leading modes of A — blocks
+    that are contiguous on both sides, permuted inside through LDS.  Against torch's permute on the same bits (alpha = 1: pure data
+    movement), with a strided outer mode on both sides, and alpha = -0.5 (exact in every type)."""
+    ct, ops, h, torch = env
+    tdt = getattr(torch, dtype_name)
+    cdt = {"bfloat16": ct.R_16BF, "float16": ct.R_16F, "float32": ct.R_32F}[dtype_name]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    for (d, c, b, a, padA, padD) in ((50, 16, 4, 300, 0, 0), (7, 3, 5, 1000, 0, 0), (24, 10, 6, 77, 5, 9), (128, 8, 4, 64, 0, 0)):
+        # A[d, c, b, a] (d fastest) -> D[b, c, d, a]; with padA / padD the outer mode a has a longer pitch than the block
+        blk = d * c * b
+        bufA = (torch.rand((a, blk + padA), generator=g, device="cuda") * 2 - 1).to(tdt)
+        bufD = torch.full((a, blk + padD), 7.0, device="cuda", dtype=tdt)
+        sA = [1, d, d * c, blk + padA]
+        sD = [1, b, b * c, blk + padD]
+        p = ops.permutation_plan(h, [d, c, b, a], "dcba", [b, c, d, a], "bcda", dtype=cdt, strideA=sA, strideB=sD)
+        assert p.describe()["variant"] == 3, p.describe()
+        viewA = bufA[:, :blk].reshape(a, b, c, d)                      # row-major view: a slowest, d fastest
+        want = viewA.permute(0, 3, 2, 1).reshape(a, blk)               # [a][d][c][b]: b fastest
+        p.permute(1.0, bufA.data_ptr(), bufD.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(bufD[:, :blk], want), (dtype_name, d, c, b, a)
+        if padD:
+            assert bool((bufD[:, blk:] == 7.0).all())                  # the padding of D is not touched
+        p.permute(-0.5, bufA.data_ptr(), bufD.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(bufD[:, :blk], (want.float() * -0.5).to(tdt)), (dtype_name, d, c, b, a)
+        p.destroy()
 
 
 @pytest.mark.parametrize("case", [
