@@ -236,7 +236,10 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     // EW_BLOCK (round 6): a pure permutation of 2- / 4-byte elements that the tiled kernels refuse, whose first n modes in D's order are
     // packed in D AND the same set of modes is packed at the front of A — contiguous blocks, permuted inside (elementwise.hip
     // ew_block_kernel).  The smallest such n; blocks of at most 32 KiB; a workgroup takes as many blocks as fill ~4 Ki elements.
-    if (plan.variant == EW_GENERIC && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
+    // Also preferred to the transposing kernel when its tiles would be mostly padding (dim0 = b = 8, dim1 = d = 40 of a 64 x 64 tile:
+    // [d = 40, c, b | a] -> [b, c, d | a] at 0.7-0.9 TB/s, profiles/r06zze_block_permute.jsonl).
+    const double tileFill = (double)p.E0 * (double)p.E1 / ((double)((p.E0 + t0 - 1) / t0) * t0 * (double)((p.E1 + t1 - 1) / t1) * t1);
+    if ((plan.variant == EW_GENERIC || (plan.variant == EW_TRANSPOSE && tileFill < 0.5)) && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
         op.padLeft.empty() && op.padRight.empty() && modes.size() >= 2) {
         const uint64_t cap = 32768 / (uint64_t)dtype_size(D.desc.dtype);
         for (size_t n = 2; n <= modes.size() && n <= 4; ++n) {
@@ -261,6 +264,12 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
             group = std::min<uint64_t>(group, std::max<uint64_t>(1, (uint64_t)p.blkRest.total / 512));   // (keep at least ~512 workgroups)
             p.blkGroup = (uint32_t)std::max<uint64_t>(1, group);
             p.blkBlocks = (p.blkRest.total + p.blkGroup - 1) / p.blkGroup;
+            {   // 16-byte lanes: block size and the other modes' strides multiples of the lane's elements (the base pointers are checked at launch)
+                const uint64_t lane = 16 / (uint64_t)dtype_size(D.desc.dtype);
+                bool v16 = run % lane == 0;
+                for (const EwMode& m : others) v16 = v16 && m.sA % (int64_t)lane == 0 && m.sD % (int64_t)lane == 0;
+                p.blkVec = v16 ? 1u : 0u;
+            }
             plan.variant = EW_BLOCK;
             break;
         }

@@ -615,7 +615,10 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kBlkLdsBytes = 32768;
 
-template <typename T>
+// VEC: elements per 16-byte lane when the planner found 16-byte lanes on both sides (blkVec: block size, rest strides and base alignment
+// multiples of it) — blocks are loaded 16 bytes per lane, and a lane gathers VEC consecutive output elements from LDS for ONE 16-byte
+// store; VEC = 1: element by element (any extents / alignment).
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256) ew_block_kernel(const Ew2DParams p) {
     __shared__ __attribute__((aligned(16))) T lds[kBlkLdsBytes / sizeof(T)];
     const T* A = static_cast<const T*>(p.A);
@@ -624,32 +627,54 @@ __global__ void __launch_bounds__(256) ew_block_kernel(const Ew2DParams p) {
     const uint32_t r0 = blockIdx.x * p.blkGroup;
     const uint32_t nG = (p.blkRest.total - r0 < p.blkGroup) ? (p.blkRest.total - r0) : p.blkGroup;
     const int tid = threadIdx.x;
+    struct alignas(16) Lane { T v[VEC]; };
     for (uint32_t g = 0; g < nG; ++g) {
         int64_t oA, oD, oC;
         rest_offsets(p.blkRest, r0 + g, oA, oD, oC);
         const T* src = A + oA;
         T* dst = lds + g * P;
-        for (uint32_t e = tid; e < P; e += 256) dst[e] = src[e];
+        if constexpr (VEC > 1) {
+            for (uint32_t e = tid * VEC; e < P; e += 256 * VEC) *reinterpret_cast<Lane*>(dst + e) = *reinterpret_cast<const Lane*>(src + e);
+        } else {
+            for (uint32_t e = tid; e < P; e += 256) dst[e] = src[e];
+        }
     }
     __syncthreads();
     const bool raw = p.alpha == 1.0f;
+    auto src_index = [&](uint32_t f) {
+        uint32_t rem = f, idx = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < (int)p.blkN) {
+                const uint32_t q = (i + 1 < (int)p.blkN) ? ew_fast_div(rem, p.blkDiv[i]) : 0u;
+                idx += (rem - q * p.blkDiv[i].d) * p.blkSrc[i];
+                rem = q;
+            }
+        }
+        return idx;
+    };
     for (uint32_t g = 0; g < nG; ++g) {
         int64_t oA, oD, oC;
         rest_offsets(p.blkRest, r0 + g, oA, oD, oC);
         const T* src = lds + g * P;
         T* dst = D + oD;
-        for (uint32_t f = tid; f < P; f += 256) {
-            uint32_t rem = f, idx = 0;
+        if constexpr (VEC > 1) {
+            for (uint32_t f = tid * VEC; f < P; f += 256 * VEC) {
+                Lane out;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < (int)p.blkN) {
-                    const uint32_t q = (i + 1 < (int)p.blkN) ? ew_fast_div(rem, p.blkDiv[i]) : 0u;
-                    idx += (rem - q * p.blkDiv[i].d) * p.blkSrc[i];
-                    rem = q;
+                for (int j = 0; j < VEC; ++j) {
+                    const T v = src[src_index(f + (uint32_t)j)];
+                    if (raw) out.v[j] = v;
+                    else { T w; ew_store<T>(&w, p.alpha * ew_load<T>(&v)); out.v[j] = w; }
                 }
+                *reinterpret_cast<Lane*>(dst + f) = out;
             }
-            if (raw) dst[f] = src[idx];
-            else ew_store<T>(dst + f, p.alpha * ew_load<T>(src + idx));
+        } else {
+            for (uint32_t f = tid; f < P; f += 256) {
+                const uint32_t idx = src_index(f);
+                if (raw) dst[f] = src[idx];
+                else ew_store<T>(dst + f, p.alpha * ew_load<T>(src + idx));
+            }
         }
     }
 }
@@ -892,10 +917,20 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
     if (variant == EW_BLOCK) {
         // (the plan keeps the element-gather kernel's decomposition beside the block form: an attached C / E / X operand falls back to it)
         if (p.blkN >= 2 && p.C == nullptr && p.E == nullptr && p.X == nullptr && p.blkBlocks > 0) {
+            const bool vec = p.blkVec != 0u && (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0u && (reinterpret_cast<uintptr_t>(p.D) & 15u) == 0u;
             switch (dtype) {
-                case HIP_R_32F:  hipLaunchKernelGGL(ew_block_kernel<float>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
-                case HIP_R_16F:  hipLaunchKernelGGL(ew_block_kernel<__half>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
-                case HIP_R_16BF: hipLaunchKernelGGL(ew_block_kernel<__hip_bfloat16>, dim3(p.blkBlocks), dim3(256), 0, stream, p); return hipGetLastError();
+                case HIP_R_32F:
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<float, 4>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<float, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    return hipGetLastError();
+                case HIP_R_16F:
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__half, 8>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<__half, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    return hipGetLastError();
+                case HIP_R_16BF:
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 8>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    return hipGetLastError();
                 default: break;
             }
         }

@@ -173,6 +173,7 @@ struct Ew2DParams {
     // blkSrc: each mode's stride in A = its position stride inside the block as it is loaded; blkRest: every other mode (slot 0 = A,
     // slot 1 = D); a workgroup moves blkGroup consecutive rest indices; blkBlocks workgroups.  blkN == 0: no such form.
     uint32_t    blkN, blkTotal, blkGroup, blkBlocks;
+    uint32_t    blkVec;            // 16-byte lanes on both sides: block size and every rest stride a multiple of the lane's elements
     FastDiv     blkDiv[4];
     uint32_t    blkSrc[4];
     ModeGroup   blkRest;

@@ -1,7 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r06zzd; mkdir -p $O
+O=gpurun_out/r06zzf; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_elementwise.py tests/test_gpu_repack.py tests/test_gpu_h16.py -m gpu -x -q -k "permutation or repack or copied or in_place or sweep or fp32" > $O/pytest_block.log 2>&1; echo "pytest rc $?"; tail -4 $O/pytest_block.log
+python tools/bench_block_permute.py > $O/block_permute.jsonl 2>&1; cat $O/block_permute.jsonl
 EINSUM_SHAPES_SET=sweep timeout 900 python tools/bench_einsum_shapes.py f32 > $O/sweep_shapes_f32.jsonl 2> $O/sweep_shapes_f32.err
 EINSUM_SHAPES_SET=sweep timeout 900 python tools/bench_einsum_shapes.py bf16 > $O/sweep_shapes_bf16.jsonl 2> $O/sweep_shapes_bf16.err
 export CTAMD_LIB_FLAVOUR=hooks
