@@ -805,6 +805,39 @@ def secondary_round6(torch, ct, ops, h, stream, with_counters):
         del A, R, ws
     except Exception as ex:   # noqa: BLE001
         out.append({"workload": "permute / reduce complex64 1024^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- contractions off the aligned path (round 6, end): the sweep mask and an operand copied first --------------------------------
+    for (label, ext, mA, mB, mC) in (
+            ("contraction bf16 'abcd,dcbe->ae' a=e=2048 b=c=8 d=96 (three contracted modes, the fastest one without whole K-tiles: sweep mask), U(-1,1) data",
+             dict(a=2048, b=8, c=8, d=96, e=2048), "dcba", "ebcd", "ea"),
+            ("contraction bf16 'ijk,lkj->il' i=l=4096 j=16 k=72 (A contiguous in k, B in j: one operand copied into a packed temporary first), U(-1,1) data",
+             dict(i=4096, l=4096, j=16, k=72), "kji", "jkl", "li")):
+        try:
+            g = torch.Generator(device="cuda")
+            g.manual_seed(4)
+            eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+            A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+            B = (torch.rand(eB[::-1], generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
+            D = torch.empty(eC[::-1], device="cuda", dtype=torch.bfloat16)
+            p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=ct.R_16BF, workspace_limit=1 << 30)
+            ws = torch.empty(max(p.required_workspace, 256), dtype=torch.uint8, device="cuda")
+            fn = lambda: p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace, stream=stream)   # noqa: E731
+            for _ in range(40):
+                fn()
+            ms = min(timed_batch(torch, fn, reps=30), timed_batch(torch, fn, reps=30))
+            flop = 2.0
+            for c in set(mA + mB):
+                flop *= ext[c]
+            tf = flop / (ms * 1e-3) / 1e12
+            d = p.describe()
+            out.append({"workload": label, "dtype": "bf16", "value": tf * 1e3, "unit": "GFLOP/s", "us_per_call": ms * 1e3, "kernel": d["kname"],
+                        "sweep_mask": bool(d.get("rag") and len(d.get("Kdigits", [])) > 1), "copied_first": [bool(d.get("repack_A")), bool(d.get("repack_B"))],
+                        "workspace_bytes": p.required_workspace,
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS_BF16_MFMA,
+                                     "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * (A.numel() + B.numel() + D.numel())}})
+            p.destroy()
+            del A, B, D, ws
+        except Exception as ex:   # noqa: BLE001
+            out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
     torch.cuda.empty_cache()
     return out
 
