@@ -613,14 +613,15 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
 // [d = 50, c = 16, b = 4 | a] to [b, c, d | a] in 380 us (each lane of a store reads another 64-byte line); this kernel: one pass at the
 // rate of a copy.  alpha == 1 moves the bits untouched.  HBM-bound.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBlkLdsBytes = 32768;
 
 // VEC: elements per 16-byte lane when the planner found 16-byte lanes on both sides (blkVec: block size, rest strides and base alignment
 // multiples of it) — blocks are loaded 16 bytes per lane, and a lane gathers VEC consecutive output elements from LDS for ONE 16-byte
 // store; VEC = 1: element by element (any extents / alignment).
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) ew_block_kernel(const Ew2DParams p) {
-    __shared__ __attribute__((aligned(16))) T lds[kBlkLdsBytes / sizeof(T)];
+    // (dynamic LDS, sized to the group's blocks: a 6-KiB block leaves room for eight workgroups per CU where a static 32 KiB allowed five)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ew_block_lds[];
+    T* const lds = reinterpret_cast<T*>(ew_block_lds);
     const T* A = static_cast<const T*>(p.A);
     T*       D = static_cast<T*>(p.D);
     const uint32_t P = p.blkTotal;
@@ -660,12 +661,32 @@ __global__ void __launch_bounds__(256) ew_block_kernel(const Ew2DParams p) {
         T* dst = D + oD;
         if constexpr (VEC > 1) {
             for (uint32_t f = tid * VEC; f < P; f += 256 * VEC) {
+                // the digits of f once (three divisions), then VEC - 1 increments with carry: the lane's VEC consecutive output elements
+                uint32_t dig[4], rem = f, idx = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t q = (i + 1 < (int)p.blkN) ? ew_fast_div(rem, p.blkDiv[i]) : 0u;
+                    dig[i] = (i < (int)p.blkN) ? rem - q * p.blkDiv[i].d : 0u;
+                    idx += dig[i] * p.blkSrc[i];
+                    rem = q;
+                }
                 Lane out;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const T v = src[src_index(f + (uint32_t)j)];
+                    const T v = src[idx];
                     if (raw) out.v[j] = v;
                     else { T w; ew_store<T>(&w, p.alpha * ew_load<T>(&v)); out.v[j] = w; }
+                    if (j + 1 < VEC) {
+                        bool carry = true;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (carry && i < (int)p.blkN) {
+                                dig[i] += 1u; idx += p.blkSrc[i];
+                                carry = dig[i] == p.blkDiv[i].d;
+                                if (carry) { idx -= dig[i] * p.blkSrc[i]; dig[i] = 0u; }
+                            }
+                        }
+                    }
                 }
                 *reinterpret_cast<Lane*>(dst + f) = out;
             }
@@ -918,18 +939,20 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
         // (the plan keeps the element-gather kernel's decomposition beside the block form: an attached C / E / X operand falls back to it)
         if (p.blkN >= 2 && p.C == nullptr && p.E == nullptr && p.X == nullptr && p.blkBlocks > 0) {
             const bool vec = p.blkVec != 0u && (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0u && (reinterpret_cast<uintptr_t>(p.D) & 15u) == 0u;
+            const size_t esz = dtype == HIP_R_32F ? 4 : 2;
+            const unsigned ldsBytes = (unsigned)(((size_t)p.blkTotal * p.blkGroup * esz + 15) & ~(size_t)15);
             switch (dtype) {
                 case HIP_R_32F:
-                    if (vec) hipLaunchKernelGGL((ew_block_kernel<float, 4>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
-                    else     hipLaunchKernelGGL((ew_block_kernel<float, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<float, 4>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<float, 1>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
                     return hipGetLastError();
                 case HIP_R_16F:
-                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__half, 8>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
-                    else     hipLaunchKernelGGL((ew_block_kernel<__half, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__half, 8>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<__half, 1>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
                     return hipGetLastError();
                 case HIP_R_16BF:
-                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 8>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
-                    else     hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 1>), dim3(p.blkBlocks), dim3(256), 0, stream, p);
+                    if (vec) hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 8>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
+                    else     hipLaunchKernelGGL((ew_block_kernel<__hip_bfloat16, 1>), dim3(p.blkBlocks), dim3(256), ldsBytes, stream, p);
                     return hipGetLastError();
                 default: break;
             }
