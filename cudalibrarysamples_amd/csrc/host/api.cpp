@@ -347,6 +347,15 @@ static double f32_direct_estimate_us(const ContractionView& v, const std::vector
     if (ch[0].kernel >= cnt || t32[ch[0].kernel].fragPartials) return 0.0;
     return ch[0].estimateUs * ((v.layA == LAY_S || v.layB == LAY_S) ? 2.5 : 1.15);
 }
+// fp64: what the general family costs when the direct plan gathers single elements (V = 1: 'ijk,lkj->il' 30 TFLOP/s, the larger 'mlik' case
+// 15 — profiles/r06zzi_sweep_shapes_f64.jsonl); 0 when it stages 16-byte units (nothing to gain from a copy)
+static double f64_direct_estimate_us(const ContractionView& v, const ContractionChoice& gc) {
+    if (v.dtype != HIP_R_64F || v.wide || gc.family != 2 || gc.kernel < 0) return 0.0;
+    int cnt = 0;
+    const GettKernelInfo* tg = gett_gen_kernels(&cnt);
+    if (gc.kernel >= cnt || tg[gc.kernel].vec >= 2) return 0.0;
+    return 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK / 22e12 * 1e6 + 8.0;
+}
 // set while the inner contraction of a repacked plan is estimated / planned: the temporaries are final, no second round of copies
 static thread_local bool t_inRepack = false;
 struct RepackScope { bool prev; RepackScope() : prev(t_inRepack) { t_inRepack = true; } ~RepackScope() { t_inRepack = prev; } };
@@ -358,8 +367,8 @@ struct RepackSplit {
 // tDirectUs: the estimate of the plan that takes the operands as they lie, when the LDS-DMA family has one (sweeps of a short ragged contracted
 // mode waste most of every K-tile: 'abcd,dcbe->ae' with d = 16 keeps 16 of 64 k) — negative: the general family's model above.
 static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDescriptor& desc, const ContractionView& v, uint64_t wsLimit, double tDirectUs, RepackSplit& out) {
-    const bool f32 = v.dtype == HIP_R_32F;
-    if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F && !f32) || v.K.empty()) return false;
+    const bool f32 = v.dtype == HIP_R_32F, f64 = v.dtype == HIP_R_64F;
+    if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F && !f32 && !f64) || v.K.empty()) return false;
     const double es = (double)dtype_size(v.dtype);
     if (desc.A.op != CUTENSOR_OP_IDENTITY || desc.B.op != CUTENSOR_OP_IDENTITY) return false;
     auto has = [](const std::vector<int32_t>& m, int32_t l) { return std::find(m.begin(), m.end(), l) != m.end(); };
@@ -450,7 +459,14 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         ContractionView vi;
         ContractionChoice hc;
         if (build_contraction_view(r.inner, vi, nullptr) != CUTENSOR_STATUS_SUCCESS || vi.wide) continue;
-        if (f32) {
+        if (f64) {
+            // fp64 (general MFMA family, gett_gen.inc): the temporaries must give both operands 16-byte units (V = 2) where the direct plan
+            // gathers single elements; the family's rates on the shapes of profiles/r06zzi_sweep_shapes_f64.jsonl: 52-59 TFLOP/s at V = 2
+            int cnt = 0;
+            const GettKernelInfo* tg = gett_gen_kernels(&cnt);
+            if (!pick_gen_choice(vi, wsLimit - temps, handle->numCUs, hc) || hc.kernel < 0 || hc.kernel >= cnt || tg[hc.kernel].vec < 2) continue;
+            hc.estimateUs = flops / 55e12 * 1e6 + 8.0;
+        } else if (f32) {
             // fp32: the temporaries must put the problem on the LDS-DMA ring kernels (gett_f32_stream.hip: whole 32-deep K-tiles in the
             // fastest contracted mode, or one ragged contracted mode)
             const std::vector<ContractionChoice> ci = rank_contraction_choices(vi, wsLimit - temps, handle->numCUs, false);
@@ -1035,7 +1051,19 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
         }
         if (!v.wide && (v.dtype == HIP_R_64F || v.dtype == HIP_C_32F || v.dtype == HIP_C_64F)) {   // split-K partials of the general MFMA family
             ContractionChoice gc;
-            if (pick_gen_choice(v, cap, handle->numCUs, gc)) *workspaceSizeEstimate = gc.workspace;
+            if (pick_gen_choice(v, cap, handle->numCUs, gc)) {
+                *workspaceSizeEstimate = gc.workspace;
+                RepackSplit rs;     // fp64 on element gathers: an operand copied first when that pays (plan_repack)
+                const double tDirect = desc->scalarType == HIP_R_64F ? f64_direct_estimate_us(v, gc) : 0.0;
+                if (tDirect > 0.0 && plan_repack(handle, *desc, v, cap, tDirect, rs)) {
+                    const uint64_t temps = ((rs.bytesA + 255) & ~255ull) + ((rs.bytesB + 255) & ~255ull);
+                    uint64_t wI = 0;
+                    RepackScope scope;
+                    cutensorStatus_t st2 = cutensorEstimateWorkspaceSize(handle, &rs.inner, planPref, workspacePref, &wI);
+                    if (st2 != CUTENSOR_STATUS_SUCCESS) return st2;
+                    *workspaceSizeEstimate = temps + wI;
+                }
+            }
             return CUTENSOR_STATUS_SUCCESS;
         }
         if (v.wide) {    // a peeled contraction wants what its inner, tiled problem wants
@@ -1489,8 +1517,12 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
         if (mfmaPath) ch = rank_contraction_choices(pl->view, workspaceSizeLimit, handle->numCUs, pr.operandsStreamed != 0);
         else if (h16Path && !(CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN")[0] == 'f'))   // "force" (measurement): the general family also where the aligned 16-bit kernels apply
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
-        const double tDirect32 = (mfmaPath && desc->scalarType == HIP_R_32F && (int)pr.algo < 0 && pr.kernelRank == 0 && !ctamd_research_env("CUTENSOR_AMD_KORDER"))
-                                     ? f32_direct_estimate_us(pl->view, ch) : 0.0;
+        double tDirect32 = (mfmaPath && desc->scalarType == HIP_R_32F && (int)pr.algo < 0 && pr.kernelRank == 0 && !ctamd_research_env("CUTENSOR_AMD_KORDER"))
+                               ? f32_direct_estimate_us(pl->view, ch) : 0.0;
+        if (pl->view.dtype == HIP_R_64F && desc->scalarType == HIP_R_64F && genPath && ch.empty()) {   // fp64 on element gathers (plan_repack)
+            ContractionChoice g64;
+            if (pick_gen_choice(pl->view, workspaceSizeLimit, handle->numCUs, g64)) tDirect32 = f64_direct_estimate_us(pl->view, g64);
+        }
         if (((h16Path && (ch.empty() || h16_sweep_waste(pl->view)) && !CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") && !CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES")) || tDirect32 > 0.0) &&
             (int)pr.algo < 0 && pr.kernelRank == 0 &&                       // (a caller who names a candidate gets that candidate)
             !(CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") && CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK")[0] == '0')) {
@@ -1506,7 +1538,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                 }
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasA) st = cutensorCreatePlan(handle, &pa, &rs.permA, pref, 0);
                 if (st == CUTENSOR_STATUS_SUCCESS && rs.hasB) st = cutensorCreatePlan(handle, &pb, &rs.permB, pref, 0);
-                if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == (mfmaPath ? 0 : 1) && pi->sub1 == nullptr) {
+                if (st == CUTENSOR_STATUS_SUCCESS && pi->choice.family == (mfmaPath ? 0 : h16Path ? 1 : 2) && pi->sub1 == nullptr) {
                     pl->sub1 = pi; pl->loneA = pa; pl->loneB = pb;
                     pl->loneBytesA = rs.bytesA; pl->loneBytesB = rs.bytesB;
                     pl->choice = ContractionChoice{};

@@ -93,3 +93,51 @@ def test_fp32_planners_own_choice_at_size(env):
         err = float((D.double() - ref).abs().max() / ref.abs().max())
         assert err < 1e-4, (err, d0)
         p0.destroy()
+
+
+def test_fp64_operands_copied_first(env):
+    """fp64 (einsum.cu:36-41 runs the helper in double): where the general MFMA family would gather single elements — 'ijk,lkj->il', the
+    reference's 'mlik,lkjm->lij' — one operand is copied first so that both sides stage 16-byte units.  Small cases with the copies
+    forced against the oracle (fp64 accumulation both sides: rtol 1e-12 of the magnitude), and the planner's own choice at
+    2048^2 x 16 x 72 against torch.einsum in fp64 on the device."""
+    ct, ops, h, torch = env
+    for case, (ext, mA, mB, mC) in enumerate(CASES):
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        A, B, C = make_tensor(eA, 21 + case, dtype=np.float64), make_tensor(eB, 22 + case, dtype=np.float64), make_tensor(eC, 23 + case, dtype=np.float64)
+        os.environ["CUTENSOR_AMD_REPACK"] = "f"
+        try:
+            p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=ct.R_64F, workspace_limit=1 << 28)
+        finally:
+            del os.environ["CUTENSOR_AMD_REPACK"]
+        d = p.describe()
+        if d.get("repack_A") or d.get("repack_B"):                      # (forced copies still need a direct plan on element gathers)
+            assert d["family"] == 2 and d["vec"] >= 2, d
+        dA, dB, dC = to_device(A), to_device(B), to_device(C)
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        p.contract(1.1, dA.data_ptr(), dB.data_ptr(), 0.7, dC.data_ptr(), dC.data_ptr(), ws.data_ptr(), p.required_workspace,
+                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = from_device(dC, C)
+        ref = np.zeros_like(C)
+        oracle.contract(A, mA, B, mB, ref, mC, alpha=1.1, beta=0.7, C=C)
+        scale = float(np.max(np.abs(ref)))
+        assert_close(got, ref, rtol=1e-12, atol=1e-12 * scale, what=str(d))
+        p.destroy()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    ext, mA, mB, mC = dict(i=2048, l=2048, j=16, k=72), "kji", "jkl", "li"
+    eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+    A = torch.rand(eA[::-1], generator=g, device="cuda", dtype=torch.float64)
+    B = torch.rand(eB[::-1], generator=g, device="cuda", dtype=torch.float64)
+    D = torch.full(eC[::-1], float("nan"), device="cuda", dtype=torch.float64)
+    p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=ct.R_64F, workspace_limit=1 << 30)
+    d = p.describe()
+    assert (d.get("repack_A") or d.get("repack_B")) and d["family"] == 2 and d["vec"] == 2, d
+    assert p.required_workspace <= p.workspace_estimate
+    ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+    p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace)
+    torch.cuda.synchronize()
+    ref = torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A, B)
+    err = float((D - ref).abs().max() / ref.abs().max())
+    assert err < 1e-12, (err, d)
+    p.destroy()

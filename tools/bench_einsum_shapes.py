@@ -62,7 +62,7 @@ def flop_of(ext, a_m, b_m):
 def main():
     import torch
     from cudalibrarysamples_amd import torch_einsum
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f64": torch.float64, "c64": torch.complex64}[sys.argv[1] if len(sys.argv) > 1 else "bf16"]
     only = {int(x) for x in os.environ.get("EINSUM_SHAPES_ONLY", "").split(",") if x}   # indices into CASES (empty: all)
     for idx, (eq, ext, note) in enumerate(CASES):
         if only and idx not in only:
