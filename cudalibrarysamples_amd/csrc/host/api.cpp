@@ -152,7 +152,8 @@ namespace {
 bool plan_env_override() {
     return ctamd_research_env("CUTENSOR_AMD_FORCE") || ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE") || CTAMD_HOOK_ENV("CUTENSOR_AMD_FUSED_FOLD") ||
            ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1") || CTAMD_HOOK_ENV("CUTENSOR_AMD_NT") || CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") || ctamd_research_env("CUTENSOR_AMD_H16_SPLITK") ||
-           ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL") || CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN");
+           ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL") || CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") ||
+           CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
@@ -201,9 +202,34 @@ static void resolve_pending_measurements(cutensorHandle* handle) {
 
 // A finished plan that owns nothing becomes the prototype later plans of the same problem are cloned from; the least
 // recently used prototype makes room when the cache is full (capacity = cutensorHandleResizePlanCache's numEntries).
+// A plan holds device memory, a trial's timing state or a block-sparse task list of its own: nothing a copy may share
+static bool plan_is_plain(const cutensorPlan& pl) {
+    return pl.tuneKey.empty() && pl.wide.modes == nullptr && pl.wideTab.empty() && !pl.bsp;
+}
+// Copy of a plan; the plans of a two-step contraction (choice.kernel == -4: an operand reduced over its lone modes or copied into a packed
+// temporary first, then the inner contraction) are copied with it — every one of them plain (round 6: such plans are memoised too; the
+// planner prices up to eight copy combinations for them, 100-240 us per cutensorCreatePlan, and einsum.cu plans inside every call)
+static cutensorPlan* clone_plan(const cutensorPlan& src) {
+    cutensorPlan* c = new (std::nothrow) cutensorPlan(src);
+    if (c == nullptr) return nullptr;
+    c->sub1 = c->sub2 = c->loneA = c->loneB = nullptr;
+    const cutensorPlan* from[4] = {src.sub1, src.sub2, src.loneA, src.loneB};
+    cutensorPlan** to[4] = {&c->sub1, &c->sub2, &c->loneA, &c->loneB};
+    for (int i = 0; i < 4; ++i)
+        if (from[i] != nullptr && (*to[i] = clone_plan(*from[i])) == nullptr) { delete c; return nullptr; }
+    return c;
+}
+static bool plan_is_prototype(const cutensorPlan& pl) {
+    if (!plan_is_plain(pl)) return false;
+    if (pl.sub1 == nullptr && pl.sub2 == nullptr && pl.loneA == nullptr && pl.loneB == nullptr) return true;
+    if (pl.kind != OpKind::Contraction || pl.choice.kernel != -4 || pl.sub2 != nullptr || pl.sub1 == nullptr) return false;   // (peeled / trinary plans: not memoised)
+    for (const cutensorPlan* q : {static_cast<const cutensorPlan*>(pl.sub1), static_cast<const cutensorPlan*>(pl.loneA), static_cast<const cutensorPlan*>(pl.loneB)})
+        if (q != nullptr && (!plan_is_plain(*q) || q->sub1 || q->sub2 || q->loneA || q->loneB)) return false;
+    return true;
+}
 static void memo_insert(cutensorHandle* h, const PlanMemoKey& key, uint64_t hash, const cutensorPlan& pl) {
-    if (!pl.tuneKey.empty() || pl.sub1 != nullptr || pl.sub2 != nullptr || pl.wide.modes != nullptr || !pl.wideTab.empty() || pl.bsp) return;   // plans that own something are not prototypes
-    std::shared_ptr<const cutensorPlan> proto(new (std::nothrow) cutensorPlan(pl));
+    if (!plan_is_prototype(pl)) return;   // plans that own something are not prototypes
+    std::shared_ptr<const cutensorPlan> proto(clone_plan(pl));
     if (!proto) return;
     std::lock_guard<std::mutex> g(h->mtx);
     if (h->planCacheCapacity == 0) return;
@@ -1335,7 +1361,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             }
         }
         if (proto) {
-            cutensorPlan* clone = new (std::nothrow) cutensorPlan(*proto);
+            cutensorPlan* clone = clone_plan(*proto);
             if (clone == nullptr) return CUTENSOR_STATUS_ALLOC_FAILED;
             handle->memoHits.fetch_add(1, std::memory_order_relaxed);
             *plan = clone;
@@ -1402,6 +1428,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             pl->requiredWorkspace = offW + std::max<uint64_t>(pi->requiredWorkspace, std::max<uint64_t>(pa ? pa->requiredWorkspace : 0, pb ? pb->requiredWorkspace : 0));
             CT_LOG("plan: contraction with modes that one input alone carries -> %s%sreduced first (%llu + %llu bytes of temporaries), then the contraction",
                    pa ? "A " : "", pb ? "B " : "", (unsigned long long)ls.bytesA, (unsigned long long)ls.bytesB);
+            if (memoable) memo_insert(handle, mkey, mhash, *pl);
             *plan = owner.release();
             return CUTENSOR_STATUS_SUCCESS;
         }
@@ -1546,6 +1573,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
                     pl->requiredWorkspace = offW + pi->requiredWorkspace;
                     CT_LOG("plan: 16-bit contraction whose operands the LDS-DMA kernels cannot stage -> %s%scopied into packed temporaries first (%llu + %llu bytes), then the contraction",
                            pa ? "A " : "", pb ? "B " : "", (unsigned long long)rs.bytesA, (unsigned long long)rs.bytesB);
+                    if (memoable && !t_inRepack) memo_insert(handle, mkey, mhash, *pl);
                     *plan = owner.release();
                     return CUTENSOR_STATUS_SUCCESS;
                 }

@@ -87,3 +87,34 @@ def test_reduction_and_permutation_plans_are_memoised_too(env):
     assert ct.plan_memo_stats(h.h) == (2, 2, 2)
     for p in (r1, r2, q1, q2):
         p.destroy()
+
+
+def test_two_step_plans_are_memoised_with_their_sub_plans(env):
+    """Round 6: a contraction that reduces an operand over its lone modes first, or copies an operand into a packed temporary first
+    (api.cpp plan_repack: up to eight copy combinations priced per cutensorCreatePlan), is a plan that owns sub-plans — the memo
+    keeps a deep copy and hands out deep copies; destroying one clone leaves the others (and the prototype) intact."""
+    ct, ops = env
+    h = ops.Handle(plan_cache=16)
+    ext = dict(i=4096, l=4096, j=16, k=72)
+    mk = lambda: ops.contraction_plan(h, [ext[c] for c in "kji"], "kji", [ext[c] for c in "jkl"], "jkl", [ext[c] for c in "li"], "li",   # noqa: E731
+                                      dtype=ct.R_16BF, workspace_limit=1 << 30)
+    p1 = mk()
+    d1 = p1.describe()
+    assert d1.get("repack_A") or d1.get("repack_B"), d1
+    hits0, misses0, _ = ct.plan_memo_stats(h.h)
+    p2, p3 = mk(), mk()
+    hits1, misses1, _ = ct.plan_memo_stats(h.h)
+    assert hits1 == hits0 + 2 and misses1 == misses0, (hits0, misses0, hits1, misses1)
+    p1.destroy()
+    p2.destroy()
+    assert p3.describe() == d1 and p3.required_workspace == d1["lone_bytes"]
+    p3.destroy()
+    e = dict(i=64, j=8, k=32, l=48)
+    lone = lambda: ops.contraction_plan(h, [e[c] for c in "ijk"], "ijk", [e[c] for c in "kl"], "kl", [e[c] for c in "il"], "il")   # noqa: E731
+    q1 = lone()
+    hits2 = ct.plan_memo_stats(h.h)[0]
+    q2 = lone()
+    assert ct.plan_memo_stats(h.h)[0] == hits2 + 1
+    assert q2.describe() == q1.describe() and q1.describe()["lone_reduce_A"] == 1
+    q1.destroy()
+    q2.destroy()
