@@ -1147,14 +1147,25 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
     uint64_t wsMax = 0;
     const size_t nTry = std::min<size_t>(ch.size(), 12);
     for (size_t i = 0; i < nTry; ++i) wsMax = std::max(wsMax, ch[i].workspace);
-    void *A = nullptr, *B = nullptr, *D = nullptr, *W = nullptr;
+    // scratch tensors and the event pair, released on every way out — an exception included (since round 5 the ABI turns bad_alloc into a
+    // status code: what it unwinds through must not leak device memory in a process that keeps running)
+    struct Scratch {
+        void *A = nullptr, *B = nullptr, *D = nullptr, *W = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            for (void* p : {A, B, D, W}) if (p) (void)hipFree(p);
+        }
+    } sc;
+    void *&A = sc.A, *&B = sc.B, *&D = sc.D, *&W = sc.W;
+    hipEvent_t &e0 = sc.e0, &e1 = sc.e1;
     int best = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipMalloc(&A, span(op.A.desc)) != hipSuccess || hipMalloc(&B, span(op.B.desc)) != hipSuccess ||
         hipMalloc(&D, span(op.D.desc)) != hipSuccess || (wsMax && hipMalloc(&W, wsMax) != hipSuccess) ||
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         (void)hipGetLastError();
-        goto done;
+        return best;
     }
     (void)hipMemset(A, 0x3c, span(op.A.desc));   // 0x3c3c3c3c = 0.0115f (0x3c3c: 0.0115 in bf16, 1.06 in fp16): finite, non-trivial data
     (void)hipMemset(B, 0x3c, span(op.B.desc));
@@ -1217,13 +1228,6 @@ static int autotune_contraction(cutensorHandle_t handle, const cutensorOperation
             if (ms < bestMs) { bestMs = ms; best = (int)i; }
         }
     }
-done:
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (A) (void)hipFree(A);
-    if (B) (void)hipFree(B);
-    if (D) (void)hipFree(D);
-    if (W) (void)hipFree(W);
     (void)handle;
     return best;
 }
