@@ -467,7 +467,7 @@ std::vector<ContractionChoice> rank_contraction_choices(const ContractionView& v
 // The launch needs the kernels' RAG instantiation (masked last K-tile of the last slice): a ragged contracted range, or a free-contiguous
 // operand whose stride-1 mode is not a multiple of 8 long (its last row-unit can reach past the end of the tensor: x_rag_mask).
 // Sweep-ragged K (round 6): SEVERAL contracted modes and the fastest one does not hold whole 64-deep K-tiles ('abcd,dcbe->ae' at extents
-// of 96 or 40).  The RAG instantiations of the 256 x 256 and the 64 x 64 kernel count K-tiles in the padded space — ceil(E0 / 64) tiles per
+// of 96 or 40).  The RAG instantiations of the 256 x 256, 128 x 128 and 64 x 64 kernels count K-tiles in the padded space — ceil(E0 / 64) tiles per
 // sweep of the fastest mode — and stage the last tile of EVERY sweep with the lanes past the end of the mode out of range (x_rag_toggle:
 // the mask is switched on and off as the odometer goes).  Admitted when no 16-byte unit is partial or can reach past the tensor: a
 // K-contiguous operand has E0 % 8 == 0 by its layout class (pick16), a free-contiguous one needs a stride-1 extent that is a multiple of 8.
@@ -627,7 +627,6 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
     if (ragged && forced) {
         // CUTENSOR_AMD_H16_WAVES names the kernel: one of those that mask a partial K-tile (4x, 4m, 4m4, 4q), or the general family
         if (!usable || (var != 48 && var != 56 && var != 64 && var != 80)) return false;
-        if (sweep && var != 48 && var != 80) return false;          // the 128 x 128 pair has no sweep mask
         split = auto_split(var);
     } else if (ragged) {
         // the kernels of the family that mask a partial K-tile (the RAG instantiations): the 256 x 256 four-wave kernel, the 128 x 128
@@ -635,7 +634,6 @@ bool pick_h16_choice(const ContractionView& v, uint64_t wsLimit, int numCUs, Con
         double best = 1e30;
         for (int cand : {48, 64, 56, 80}) {
             if (layoutIdx + cand >= count) continue;
-            if (sweep && cand != 48 && cand != 80) continue;        // sweep-ragged K: the 256 x 256 and the 64 x 64 kernel (x_rag_toggle)
             const uint64_t as = auto_split(cand);
             for (uint64_t sp : {(uint64_t)1, as}) {
                 const double t = model_us(cand, sp);

@@ -690,7 +690,8 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint32_t gsz = (p.tilesM - first < 8u) ? (p.tilesM - first) : 8u;
     const uint32_t mt = first + inGrp % gsz, nt = inGrp / gsz;
     const uint32_t m0 = p.mOrg + mt * kMTile, n0 = p.nOrg + nt * kMTile;
-    const uint32_t kTilesAll = (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
+    const bool sweep = RAG && (p.ragged & 2u) != 0u;          // sweep-ragged K: gett_h16w4x_kernel
+    const uint32_t kTilesAll = sweep ? (p.ragged >> 2) : (p.gK.total + (RAG ? (uint32_t)kHBK - 1u : 0u)) / kHBK, tilesPerSlice = p.kPerSlice / kHBK;
     const uint32_t tile0 = slice * tilesPerSlice;
     const int nTiles = (int)((tile0 + tilesPerSlice <= kTilesAll) ? tilesPerSlice : (kTilesAll - tile0));
 
@@ -701,15 +702,22 @@ __global__ void __launch_bounds__(256, (R == 2 ? 2 : 1)) gett_h16w4m_kernel(cons
     const uint64_t bA = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.A) + group_offset<0>(p.gL, l)) + oa.base);
     const uint64_t bB = h_uniform64((uint64_t)(uintptr_t)(static_cast<const uint16_t*>(p.B) + group_offset<1>(p.gL, l)) + ob.base);
     VOdometer odo;
-    odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
+    if (sweep) odo.init_tiles(p.gK, tile0, (uint32_t)nTiles, bA, bB);
+    else odo.template init<RAG>(p.gK, tile0 * kHBK, (uint32_t)nTiles, bA, bB);
     // ragged K / operands without 16-byte lanes: index (among this workgroup's K-tiles) of the tile that is staged masked — the last K-tile
     // of the last slice — and how many k of the contracted range it holds (x_rag_mask, x_rag_fix: gett_h16x_common.h)
-    const int maskAt = (RAG && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
-    const uint32_t kValid = VOdometer::sgpr((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK);
+    const int maskAt = (RAG && !sweep && tile0 + (uint32_t)nTiles == kTilesAll) ? nTiles - 1 : 0x7fffffff;
+    const uint32_t kValid = VOdometer::sgpr(sweep ? p.gK.div[0].d - (odo.n0 - 1u) * (uint32_t)kHBK
+                                                  : ((p.gK.total % kHBK) != 0u ? p.gK.total % kHBK : (uint32_t)kHBK));
     uint32_t stradA = 0u, stradB = 0u;            // units of the masked tile that x_rag_fix loads element by element
-    // called with the operand's descriptor base ON tile IDX
-#define CTAMD_M_RAGMASK_A(IDX) if constexpr (RAG) { if ((IDX) == maskAt) stradA = x_rag_mask<LA, 1>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA)); }
-#define CTAMD_M_RAGMASK_B(IDX) if constexpr (RAG) { if ((IDX) == maskAt) stradB = x_rag_mask<LB, 1>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB)); }
+    bool maskOnA = false, maskOnB = false;        // sweep-ragged K: one switch per operand (the deep ring stages A and B of a tile at different times)
+    // called with the operand's descriptor base ON tile IDX (sweep: tiles past the slice's last one are re-staged copies — the mask stays)
+#define CTAMD_M_RAGMASK_A(IDX) if constexpr (RAG) {                                                                    \
+        if ((IDX) == maskAt) stradA = x_rag_mask<LA, 1>(oa.src, wave, kValid, x_rag_limit(p.endA, odo.addrA));        \
+        if (sweep && (IDX) < nTiles && odo.on_sweep_end() != maskOnA) { x_rag_toggle<LA, 1>(oa.src, wave, kValid); maskOnA = !maskOnA; } }
+#define CTAMD_M_RAGMASK_B(IDX) if constexpr (RAG) {                                                                    \
+        if ((IDX) == maskAt) stradB = x_rag_mask<LB, 1>(ob.src, wave, kValid, x_rag_limit(p.endB, odo.addrB));        \
+        if (sweep && (IDX) < nTiles && odo.on_sweep_end() != maskOnB) { x_rag_toggle<LB, 1>(ob.src, wave, kValid); maskOnB = !maskOnB; } }
     // tile IDX (the masked one) has landed in buffer PB, behind a workgroup barrier (gett_h16w4x_kernel, CTAMD_X_RAGFIX)
 #define CTAMD_M_RAGFIX(IDX, PB)                                                                                     \
     if constexpr (RAG) {                                                                                           \

@@ -219,7 +219,7 @@ def test_sweep_ragged_k_stays_on_the_lds_dma_kernels(env, layout, dims):
     m, n, k, j = dims
     mA, mB = SWEEP_LAYOUTS[layout]
     got, ref, d = _run(env, dict(m=m, n=n, k=k, j=j), mA, mB, "mn", seed=hash((layout, dims)) % 1000)
-    assert d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4q_kernel") and d["rag"] == 1, d
+    assert d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4q_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel") and d["rag"] == 1, d
     np.testing.assert_allclose(got, ref, rtol=8e-3, atol=3e-2)
 
 
@@ -239,7 +239,8 @@ def test_sweep_ragged_k_three_modes_and_batch(env):
 
 
 def test_sweep_ragged_k_forced_kernels(built):
-    """Both kernels that carry the sweep mask, forced in a child process, on 1 .. 4 K-tiles per sweep and sweeps that end in the
+    """Every kernel that carries the sweep mask (the 128 x 128 pair switches it per operand: its deep ring stages a tile's A and B pieces at
+    different times), forced in a child process, on 1 .. 4 K-tiles per sweep and sweeps that end in the
     prologue, in the unrolled loop and in its tail; large enough for several rounds of workgroups."""
     import os, subprocess, sys
     code = r'''
@@ -265,7 +266,7 @@ for (mA, mB) in (("kmj", "kjn"), ("mjk", "kjn"), ("kmj", "nkj"), ("mjk", "nkj"),
         np.testing.assert_allclose(D.double().cpu().numpy(), ref.cpu().numpy(), rtol=8e-3, atol=3e-2, err_msg=str((mA, mB, m, n, k, j)))
 print("ok")
 '''
-    for waves, want in (("4x", "gett_h16w4x_kernel"), ("4q", "gett_h16w4q_kernel")):
+    for waves, want in (("4x", "gett_h16w4x_kernel"), ("4q", "gett_h16w4q_kernel"), ("4m", "gett_h16w4m_kernel"), ("4m4", "gett_h16w4m4_kernel")):
         envv = dict(os.environ, CUTENSOR_AMD_H16_WAVES=waves)
         r = subprocess.run([sys.executable, "-c", code.replace("WANT", repr(want))], env=envv, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -165,7 +165,7 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
         p.destroy()
     assert plan(2048, 2048, 1024)["family"] == 1                    # whole K-tiles: unchanged
     # round 6: SEVERAL contracted modes with a ragged fastest one stay as well (the mask is toggled per sweep of that mode): K-tiles are
-    # counted per sweep, rounded up — 'kmj,kjn->mn' with k = 96, j = 5 is 2 x 5 tiles; on the 256 x 256 or the 64 x 64 kernel only
+    # counted per sweep, rounded up — 'kmj,kjn->mn' with k = 96, j = 5 is 2 x 5 tiles
     def plan2(e, mA, mB, **kw):
         p = ops.contraction_plan(h, [e[c] for c in mA], mA, [e[c] for c in mB], mB, [e["m"], e["n"]], "mn", dtype=ct.R_16BF, workspace_limit=1 << 28, **kw)
         d = p.describe()
@@ -174,7 +174,7 @@ def test_ragged_k_stays_in_the_lds_dma_family(env):
     d = plan2(dict(m=4096, n=4096, k=96, j=5), "kmj", "kjn")
     assert d["family"] == 1 and d["rag"] == 1 and d["kname"] == "gett_h16w4x_kernel" and d["kPerSlice"] == 10 * 64, d
     d = plan2(dict(m=2048, n=2048, k=200, j=3), "kmj", "kjn")          # (a shape the 128 x 128 pair would take with one contracted mode)
-    assert d["family"] == 1 and d["rag"] == 1 and d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4q_kernel") and d["kPerSlice"] % 64 == 0, d
+    assert d["family"] == 1 and d["rag"] == 1 and d["kname"] in ("gett_h16w4x_kernel", "gett_h16w4q_kernel", "gett_h16w4m_kernel", "gett_h16w4m4_kernel") and d["kPerSlice"] % 64 == 0, d
     d = plan2(dict(m=96, n=96, k=72, j=40), "kmj", "kjn")              # split-K over the padded tile space (80 tiles)
     assert d["family"] == 1 and d["rag"] == 1 and d["splitK"] > 1 and d["splitK"] * d["kPerSlice"] >= 80 * 64, d
     assert plan2(dict(m=512, n=512, k=36, j=25), "kmj", "kjn")["family"] == 2     # partial 16-byte units at the end of every sweep

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, sweep-ragged K: parity of the new path, then its rate beside the general family and the vendor BLAS
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r06zza; mkdir -p $O
+O=gpurun_out/r06zzk; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_h16.py -m gpu -x -q -k "sweep or ragged or unaligned or copied or in_place" > $O/pytest_sweep.log 2>&1; echo "pytest rc $?" | tee -a $O/pytest_sweep.log
 tail -5 $O/pytest_sweep.log
 EINSUM_SHAPES_SET=sweep timeout 600 python tools/bench_einsum_shapes.py bf16 > $O/sweep_shapes_bf16.jsonl 2> $O/sweep_shapes_bf16.err
