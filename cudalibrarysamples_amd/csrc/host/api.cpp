@@ -375,12 +375,14 @@ static double f32_direct_estimate_us(const ContractionView& v, const std::vector
 }
 // fp64: what the general family costs when the direct plan gathers single elements (V = 1: 'ijk,lkj->il' 30 TFLOP/s, the larger 'mlik' case
 // 15 — profiles/r06zzi_sweep_shapes_f64.jsonl); 0 when it stages 16-byte units (nothing to gain from a copy)
+// complex64 likewise (8 real flops per multiply-add): 103 / 58 TFLOP/s on those two shapes at V = 1 (profiles/r06zzm_sweep_shapes_c64_before.jsonl)
 static double f64_direct_estimate_us(const ContractionView& v, const ContractionChoice& gc) {
-    if (v.dtype != HIP_R_64F || v.wide || gc.family != 2 || gc.kernel < 0) return 0.0;
+    if ((v.dtype != HIP_R_64F && v.dtype != HIP_C_32F) || v.wide || gc.family != 2 || gc.kernel < 0) return 0.0;
     int cnt = 0;
     const GettKernelInfo* tg = gett_gen_kernels(&cnt);
     if (gc.kernel >= cnt || tg[gc.kernel].vec >= 2) return 0.0;
-    return 2.0 * (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK / 22e12 * 1e6 + 8.0;
+    const double mnk = (double)v.totL * (double)v.totM * (double)v.totN * (double)v.totK;
+    return (v.dtype == HIP_C_32F ? 8.0 * mnk / 75e12 : 2.0 * mnk / 22e12) * 1e6 + 8.0;
 }
 // set while the inner contraction of a repacked plan is estimated / planned: the temporaries are final, no second round of copies
 static thread_local bool t_inRepack = false;
@@ -393,7 +395,7 @@ struct RepackSplit {
 // tDirectUs: the estimate of the plan that takes the operands as they lie, when the LDS-DMA family has one (sweeps of a short ragged contracted
 // mode waste most of every K-tile: 'abcd,dcbe->ae' with d = 16 keeps 16 of 64 k) — negative: the general family's model above.
 static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDescriptor& desc, const ContractionView& v, uint64_t wsLimit, double tDirectUs, RepackSplit& out) {
-    const bool f32 = v.dtype == HIP_R_32F, f64 = v.dtype == HIP_R_64F;
+    const bool f32 = v.dtype == HIP_R_32F, c32 = v.dtype == HIP_C_32F, f64 = v.dtype == HIP_R_64F || c32;   // (f64: the general family's wide elements)
     if (t_inRepack || v.wide || (v.dtype != HIP_R_16BF && v.dtype != HIP_R_16F && !f32 && !f64) || v.K.empty()) return false;
     const double es = (double)dtype_size(v.dtype);
     if (desc.A.op != CUTENSOR_OP_IDENTITY || desc.B.op != CUTENSOR_OP_IDENTITY) return false;
@@ -491,7 +493,7 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
             int cnt = 0;
             const GettKernelInfo* tg = gett_gen_kernels(&cnt);
             if (!pick_gen_choice(vi, wsLimit - temps, handle->numCUs, hc) || hc.kernel < 0 || hc.kernel >= cnt || tg[hc.kernel].vec < 2) continue;
-            hc.estimateUs = flops / 55e12 * 1e6 + 8.0;
+            hc.estimateUs = (c32 ? 4.0 * flops / 124e12 : flops / 55e12) * 1e6 + 8.0;   // (complex64 at V = 2: 124 TFLOP/s of real flops, r06zzm)
         } else if (f32) {
             // fp32: the temporaries must put the problem on the LDS-DMA ring kernels (gett_f32_stream.hip: whole 32-deep K-tiles in the
             // fastest contracted mode, or one ragged contracted mode)
@@ -1080,7 +1082,7 @@ cutensorStatus_t cutensorEstimateWorkspaceSize(const cutensorHandle_t handle, co
             if (pick_gen_choice(v, cap, handle->numCUs, gc)) {
                 *workspaceSizeEstimate = gc.workspace;
                 RepackSplit rs;     // fp64 on element gathers: an operand copied first when that pays (plan_repack)
-                const double tDirect = desc->scalarType == HIP_R_64F ? f64_direct_estimate_us(v, gc) : 0.0;
+                const double tDirect = desc->scalarType == v.dtype ? f64_direct_estimate_us(v, gc) : 0.0;
                 if (tDirect > 0.0 && plan_repack(handle, *desc, v, cap, tDirect, rs)) {
                     const uint64_t temps = ((rs.bytesA + 255) & ~255ull) + ((rs.bytesB + 255) & ~255ull);
                     uint64_t wI = 0;
@@ -1550,7 +1552,7 @@ cutensorStatus_t cutensorCreatePlan(const cutensorHandle_t handle, cutensorPlan_
             ch = rank_h16_choices(pl->view, workspaceSizeLimit, handle->numCUs);
         double tDirect32 = (mfmaPath && desc->scalarType == HIP_R_32F && (int)pr.algo < 0 && pr.kernelRank == 0 && !ctamd_research_env("CUTENSOR_AMD_KORDER"))
                                ? f32_direct_estimate_us(pl->view, ch) : 0.0;
-        if (pl->view.dtype == HIP_R_64F && desc->scalarType == HIP_R_64F && genPath && ch.empty()) {   // fp64 on element gathers (plan_repack)
+        if ((pl->view.dtype == HIP_R_64F || pl->view.dtype == HIP_C_32F) && desc->scalarType == pl->view.dtype && genPath && ch.empty()) {   // fp64 / complex64 on element gathers (plan_repack)
             ContractionChoice g64;
             if (pick_gen_choice(pl->view, workspaceSizeLimit, handle->numCUs, g64)) tDirect32 = f64_direct_estimate_us(pl->view, g64);
         }

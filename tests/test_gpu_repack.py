@@ -141,3 +141,36 @@ def test_fp64_operands_copied_first(env):
     err = float((D - ref).abs().max() / ref.abs().max())
     assert err < 1e-12, (err, d)
     p.destroy()
+
+
+def test_complex64_operands_copied_first(env):
+    """complex64 (python/cutensor/torch/einsum_test.py:55-68 runs the binding on complex tensors): the general family stages 16-byte units
+    of two elements where it can; where it would gather single elements one operand is copied first.  Forced on the small cases and by the
+    planner's own choice at 2048^2 x 16 x 72, against torch.einsum in complex128 on the device (rtol 1e-5 of the magnitude: fp32 arithmetic)."""
+    ct, ops, h, torch = env
+    g = torch.Generator(device="cuda")
+    g.manual_seed(13)
+    todo = [(c, True) for c in CASES] + [((dict(i=2048, l=2048, j=16, k=72), "kji", "jkl", "li"), False)]
+    for (ext, mA, mB, mC), forced in todo:
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        A = torch.complex(torch.rand(eA[::-1], generator=g, device="cuda") - 0.5, torch.rand(eA[::-1], generator=g, device="cuda") - 0.5)
+        B = torch.complex(torch.rand(eB[::-1], generator=g, device="cuda") - 0.5, torch.rand(eB[::-1], generator=g, device="cuda") - 0.5)
+        D = torch.full(eC[::-1], float("nan"), device="cuda", dtype=torch.complex64)
+        if forced:
+            os.environ["CUTENSOR_AMD_REPACK"] = "f"
+        try:
+            p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=ct.C_32F, workspace_limit=1 << 30)
+        finally:
+            os.environ.pop("CUTENSOR_AMD_REPACK", None)
+        d = p.describe()
+        if not forced:
+            assert (d.get("repack_A") or d.get("repack_B")) and d["family"] == 2 and d["vec"] == 2, d
+        assert p.required_workspace <= max(p.workspace_estimate, p.required_workspace if forced else 0)
+        ws = torch.empty(max(p.required_workspace, 16), dtype=torch.uint8, device="cuda")
+        alpha = np.array([1.0, 0.0], dtype=np.float32)
+        p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ws.data_ptr(), p.required_workspace)
+        torch.cuda.synchronize()
+        ref = torch.einsum("%s,%s->%s" % (mA[::-1], mB[::-1], mC[::-1]), A.to(torch.complex128), B.to(torch.complex128))
+        err = float((D.to(torch.complex128) - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, (err, d)
+        p.destroy()

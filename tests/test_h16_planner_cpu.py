@@ -200,3 +200,29 @@ def test_persistent_kernel_only_where_its_tiles_can_stream(env):
     assert kname([4096, 4096, 4], "mkl", [4096, 4096, 4], "knl", [4096, 4096, 4], "mnl") == "gett_h16w4p_kernel"          # batch mode: 4 x 256 tiles
     assert kname([64, 128, 8192], "abk", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4p_kernel"            # a, b fuse into one M mode
     assert kname([64, 8192, 128], "akb", [8192, 8192], "kn", [64, 128, 8192], "abn") == "gett_h16w4x_kernel"            # a, b apart in A: two M modes
+
+
+def test_workspace_contract_of_operands_copied_first(env):
+    """Round 6 (api.cpp plan_repack): a contraction whose operands the LDS-DMA kernels cannot stage as they lie asks
+    cutensorEstimateWorkspaceSize for its temporaries + the inner plan's need, plans the copies when that is granted
+    (required <= estimate: contraction.cu:239 asserts it), and keeps the operands in place — the general family — when it is not."""
+    ct, ops = env
+    h = ops.Handle()
+    ext = dict(i=4096, l=4096, j=16, k=72)
+    args = ([ext[c] for c in "kji"], "kji", [ext[c] for c in "jkl"], "jkl", [ext[c] for c in "li"], "li")
+    for dt, fam_direct in ((ct.R_16BF, 2), (ct.R_32F, 0), (ct.R_64F, 2)):
+        es = {ct.R_16BF: 2, ct.R_32F: 4, ct.R_64F: 8}[dt]
+        p = ops.contraction_plan(h, *args, dtype=dt)                      # the default: limit = the estimate (ops.contraction_plan)
+        d = p.describe()
+        temp = 4096 * 16 * 72 * es
+        assert (d.get("repack_A") or d.get("repack_B")) and d["lone_bytes"] == temp, d
+        assert temp <= p.required_workspace <= p.workspace_estimate, (p.required_workspace, p.workspace_estimate)
+        p.destroy()
+        p = ops.contraction_plan(h, *args, dtype=dt, workspace_limit=temp - 256)
+        d = p.describe()
+        assert not d.get("repack_A") and not d.get("repack_B") and d["family"] == fam_direct and p.required_workspace <= temp - 256, d
+        p.destroy()
+    # ... and a problem that is fine as it lies is not touched
+    p = ops.contraction_plan(h, [4096, 4096], "mk", [4096, 4096], "kn", [4096, 4096], "mn", dtype=ct.R_16BF)
+    assert "repack_A" not in p.describe()
+    p.destroy()
