@@ -315,7 +315,7 @@ static bool split_lone_modes(const cutensorOperationDescriptor& desc, LoneSplit&
         kept.present = true;
         kept.op = X.op;                                         // conj(sum) = sum(conj): the inner contraction conjugates
         kept.desc.dtype = X.desc.dtype;
-        kept.desc.alignment = 256;                              // a 256-byte-aligned piece of the workspace
+        kept.desc.alignment = 128;                              // a piece of the workspace at a multiple of 256 bytes: as aligned as the workspace itself (contraction.cu:242 asserts 128)
         int64_t run = 1;
         for (size_t i = 0; i < X.modes.size(); ++i) {
             if (!has(other.modes, X.modes[i]) && !has(desc.C.modes, X.modes[i])) continue;   // summed away (extent-1 lone modes too)
@@ -421,7 +421,7 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
         kept.present = true;
         kept.op = X.op;
         kept.desc.dtype = X.desc.dtype;
-        kept.desc.alignment = 256;
+        kept.desc.alignment = 128;                                          // (the workspace's own alignment, contraction.cu:242; the pieces start at multiples of 256 bytes)
         int64_t run = 1;
         auto push = [&](int32_t l, int64_t e) { kept.modes.push_back(l); kept.desc.extent.push_back(e); kept.desc.stride.push_back(run); run *= e; };
         if (!freeMajor) for (const Km& m : k) push(m.label, m.extent);
@@ -758,7 +758,7 @@ cutensorStatus_t cutensorCreateContractionTrinary(const cutensorHandle_t handle,
         TensorUse T;
         T.present = true;
         T.desc.dtype = X.desc.dtype;
-        T.desc.alignment = 256;
+        T.desc.alignment = 128;
         double flops1 = 2.0, tElems = 1.0;
         std::vector<int32_t> seen;
         auto visit = [&](const TensorUse& U) {

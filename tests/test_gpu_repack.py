@@ -174,3 +174,30 @@ def test_complex64_operands_copied_first(env):
         err = float((D.to(torch.complex128) - ref).abs().max() / ref.abs().max())
         assert err < 1e-5, (err, d)
         p.destroy()
+
+
+def test_workspace_at_a_128_byte_boundary(env):
+    """contraction.cu:242 asserts a 128-byte-aligned workspace — not 256.  The temporaries of a two-step plan (operands copied first, an
+    operand reduced over its lone modes) live at the head of that workspace and must not ask for more alignment than it has."""
+    ct, ops, h, torch = env
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    for ext, mA, mB, mC, dt, tdt in ((dict(i=2048, l=2048, j=16, k=72), "kji", "jkl", "li", ct.R_16BF, torch.bfloat16),
+                                     (dict(i=2048, l=2048, j=16, k=72), "kji", "jkl", "li", ct.R_32F, torch.float32),
+                                     (dict(i=96, j=8, k=64, l=72), "ijk", "kl", "il", ct.R_32F, torch.float32)):       # (lone mode j)
+        eA, eB, eC = [ext[c] for c in mA], [ext[c] for c in mB], [ext[c] for c in mC]
+        A = (torch.rand(eA[::-1], generator=g, device="cuda") - 0.5).to(tdt)
+        B = (torch.rand(eB[::-1], generator=g, device="cuda") - 0.5).to(tdt)
+        D = torch.full(eC[::-1], float("nan"), device="cuda", dtype=tdt)
+        p = ops.contraction_plan(h, eA, mA, eB, mB, eC, mC, dtype=dt, workspace_limit=1 << 30)
+        d = p.describe()
+        assert d.get("repack_A") or d.get("repack_B") or d.get("lone_reduce_A"), d
+        buf = torch.empty(p.required_workspace + 512, dtype=torch.uint8, device="cuda")
+        ptr = (buf.data_ptr() + 255) // 256 * 256 + 128                      # 128 (mod 256)
+        p.contract(1.0, A.data_ptr(), B.data_ptr(), 0.0, D.data_ptr(), D.data_ptr(), ptr, p.required_workspace)
+        torch.cuda.synchronize()
+        rA, rB, rC = mA[::-1], mB[::-1], mC[::-1]
+        ref = torch.einsum("%s,%s->%s" % (rA, rB, rC), A.double(), B.double())
+        err = float((D.double() - ref).abs().max() / ref.abs().max())
+        assert err < (1e-2 if tdt == torch.bfloat16 else 1e-4), (err, d)
+        p.destroy()
