@@ -153,7 +153,7 @@ bool plan_env_override() {
     return ctamd_research_env("CUTENSOR_AMD_FORCE") || ctamd_research_env("CUTENSOR_AMD_XCD_BALANCE") || CTAMD_HOOK_ENV("CUTENSOR_AMD_FUSED_FOLD") ||
            ctamd_research_env("CUTENSOR_AMD_H16_TRANSPOSE_T1") || CTAMD_HOOK_ENV("CUTENSOR_AMD_NT") || CTAMD_HOOK_ENV("CUTENSOR_AMD_H16_WAVES") || ctamd_research_env("CUTENSOR_AMD_H16_SPLITK") ||
            ctamd_research_env("CUTENSOR_AMD_KORDER") || ctamd_research_env("CUTENSOR_AMD_ABLATION") || CTAMD_HOOK_ENV("CUTENSOR_AMD_PEEL") || CTAMD_HOOK_ENV("CUTENSOR_AMD_GEN") ||
-           CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK");
+           CTAMD_HOOK_ENV("CUTENSOR_AMD_REPACK") || CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY");
 }
 
 double scalar_as_double(const void* s, hipDataType t) {   // real part for complex scalar types
@@ -455,6 +455,7 @@ static bool plan_repack(const cutensorHandle* handle, const cutensorOperationDes
             copyUs = 4.0 + 2.0 * es * (elems + 0.35 * (padded - elems)) / 4e6;
         }
         else if (ep.variant == EW_ROWCOPY || ep.variant == EW_BLOCK) copyUs = 4.0 + 2.0 * es * elems / 4e6;
+        else if (ep.variant == EW_TRANSPOSE_ANY) copyUs = 4.0 + 2.0 * es * elems / 2e6;
         else copyUs = 4.0 + elems / 15e3;
         return true;
     };

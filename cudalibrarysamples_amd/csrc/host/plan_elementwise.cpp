@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "internal.hpp"
+#include "api_guard.hpp"
 
 namespace ctamd {
 
@@ -273,6 +274,21 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
             plan.variant = EW_BLOCK;
             break;
         }
+    }
+    // EW_TRANSPOSE_ANY (round 6): what is left for the element-gather kernel although it IS a transposition — D contiguous along dim0, A
+    // along dim1, but odd extents / strides / base alignment (4097 x 4099: 0.9-1.5 TB/s there, each lane of a load on another line)
+    const bool anyForced = CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY") && CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY")[0] == '1';   // measurement: also where the 16-byte-lane kernel applies
+    // ... and it is the faster kernel for MID-SIZE pure permutations the 16-byte-lane kernels do take: their wide tiles (fp32: 256 x 64)
+    // leave a 4096^2 transposition on 1024 workgroups — 4.6 TB/s against 5.9 on 4096 tiles of 64 x 64 — and rows whose pitch is no
+    // multiple of 128 bytes cost them more (4104^2: 3.4 / 5.2; bf16 on the narrow 64 x 64 kernel 2.6 / 3.4).  Large tensors stay
+    // (1024^3: 5.6 / 5.0 fp32, 5.9 / 4.3 bf16 on the wide kernel) — profiles/r06zzo_permute_any_ab.jsonl.
+    const uint64_t vecTiles = (uint64_t)((p.E0 + t0 - 1) / t0) * (uint64_t)((p.E1 + t1 - 1) / t1) * (uint64_t)p.rest.total;
+    const bool anyOff = CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY") && CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY")[0] == '0';      // tests: the 16-byte-lane kernels on small tensors
+    const bool midSize = !anyOff && plan.variant == EW_TRANSPOSE && ((D.desc.dtype == HIP_R_32F && vecTiles < 4096) || (h16 && t0 == 64 && vecTiles < 16384));
+    if ((plan.variant == EW_GENERIC || midSize || (anyForced && plan.variant == EW_TRANSPOSE)) && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
+        op.padLeft.empty() && op.padRight.empty() && i1 >= 0 && p.sD0 == 1 && p.sA1 == 1 && p.sA0 != 1 && p.E0 >= 16 && p.E1 >= 16) {
+        plan.variant = EW_TRANSPOSE_ANY;
+        t0 = 64; t1 = 64;
     }
     plan.usesX = usesX;
     p.tile0 = (uint32_t)t0;

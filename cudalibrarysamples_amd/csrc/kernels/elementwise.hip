@@ -614,6 +614,48 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
 // rate of a copy.  alpha == 1 moves the bits untouched.  HBM-bound.
 // ---------------------------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------------------------
+// EW_TRANSPOSE_ANY (round 6): D = alpha * perm(A) with D contiguous along dim0 and A along dim1 — the transposing kernels' case — at ANY
+// extents, strides and base alignment (odd extents, 2-byte-aligned pointers: what the 16-byte-lane kernels refuse and the element-gather
+// kernel above runs at 0.9-1.5 TB/s, each lane of a load on another 64-byte line).  A 64 x 64 tile through LDS, element by element:
+// loads walk dim1 (A's contiguous mode), stores walk dim0 (D's), both coalesced; the LDS row pitch of 65 (fp32) / 66 (16-bit) elements
+// keeps the column reads off a single bank.  HBM-bound: 2 |D| bytes.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ew_transpose_any_kernel(const Ew2DParams p) {
+    constexpr int PITCH = sizeof(T) == 4 ? 65 : 66;
+    __shared__ T lds[64 * PITCH];
+    const T* A = static_cast<const T*>(p.A);
+    T*       D = static_cast<T*>(p.D);
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const bool raw = p.alpha == 1.0f;
+    for (uint32_t b = blockIdx.x; b < p.nBlocks; b += gridDim.x) {
+        const TileId t = decode_tile(p, b);
+        int64_t oA, oD, oC;
+        rest_offsets(p.rest, t.rest, oA, oD, oC);
+        const uint32_t c0 = t.t0 * 64u, r0 = t.t1 * 64u;            // tile origin along dim0 / dim1
+        const uint32_t n0 = (p.E0 - c0 < 64u) ? (p.E0 - c0) : 64u, n1 = (p.E1 - r0 < 64u) ? (p.E1 - r0) : 64u;
+        // in: lane = position along dim1 (A's stride-1 mode), four dim0 positions per pass
+        if ((uint32_t)lane < n1) {
+            const T* src = A + oA + (int64_t)(r0 + (uint32_t)lane) + (int64_t)c0 * p.sA0;
+#pragma unroll 4
+            for (uint32_t i = (uint32_t)row; i < n0; i += 4u) lds[i * PITCH + lane] = src[(int64_t)i * p.sA0];
+        }
+        __syncthreads();
+        // out: lane = position along dim0 (D's stride-1 mode), four dim1 positions per pass
+        if ((uint32_t)lane < n0) {
+            T* dst = D + oD + (int64_t)(c0 + (uint32_t)lane) + (int64_t)r0 * p.sD1;
+#pragma unroll 4
+            for (uint32_t j = (uint32_t)row; j < n1; j += 4u) {
+                const T v = lds[lane * PITCH + j];
+                if (raw) dst[(int64_t)j * p.sD1] = v;
+                else ew_store<T>(dst + (int64_t)j * p.sD1, p.alpha * ew_load<T>(&v));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // VEC: elements per 16-byte lane when the planner found 16-byte lanes on both sides (blkVec: block size, rest strides and base alignment
 // multiples of it) — blocks are loaded 16 bytes per lane, and a lane gathers VEC consecutive output elements from LDS for ONE 16-byte
 // store; VEC = 1: element by element (any extents / alignment).
@@ -958,6 +1000,16 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
             }
         }
         variant = EW_GENERIC;
+    }
+    if (variant == EW_TRANSPOSE_ANY) {
+        if (p.C != nullptr || p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;   // (planned for pure permutations only)
+        unsigned g = p.nBlocks < (1u << 22) ? p.nBlocks : (1u << 22);
+        switch (dtype) {
+            case HIP_R_32F:  hipLaunchKernelGGL(ew_transpose_any_kernel<float>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            case HIP_R_16F:  hipLaunchKernelGGL(ew_transpose_any_kernel<__half>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            case HIP_R_16BF: hipLaunchKernelGGL(ew_transpose_any_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            default: return hipErrorInvalidValue;
+        }
     }
     // One workgroup per tile: a workgroup that loops over tiles serialises its own read -> barrier -> write phases, fresh
     // workgroups overlap them across the CU (2048^3 permutation, 64 x 64 tiles: 5.37 TB/s with the grid capped at 32 Ki

@@ -67,6 +67,7 @@ enum EwVariant : int {
     EW_TRANSPOSE = 0,  // sD0 == 1 and sA1 == 1: 64x64 LDS tile, 16-byte lanes on both sides
     EW_ROWCOPY   = 1,  // sD0 == 1 and sA0 == 1: 16-byte lanes along dim0, no LDS
     EW_GENERIC   = 2,  // any strides, any dtype: one element per lane
+    EW_TRANSPOSE_ANY = 4,  // pure permutation of 2- / 4-byte elements, D contiguous along dim0 and A along dim1, any extents / alignment: 64 x 64 LDS tile, element-wise
     EW_BLOCK     = 3   // pure permutation of 2- / 4-byte elements whose leading modes are the same packed set in A and D: contiguous blocks
                        // through LDS, permuted inside (Ew2DParams::blk*); falls back to EW_GENERIC when a C / E / X operand is attached
 };

@@ -30,13 +30,23 @@ def env(built):
     (dict(a=7), "a", "a", 2),
     (dict(a=1, b=64, c=64), "abc", "cba", 0),              # extent-1 mode dropped
 ])
-def test_permutation(env, case):
+@pytest.mark.parametrize("lanes_only", [True, False])
+def test_permutation(env, case, lanes_only):
+    """lanes_only: CUTENSOR_AMD_EW_ANY=0 (hooks flavour) keeps transpositions of small tensors on the 16-byte-lane kernels — since round 6
+    the planner hands pure permutations below ~4096 wide tiles to the element-wise 64 x 64 transposer (variant 4), which is faster there;
+    both must be exact."""
+    import os
     ct, ops, h, torch = env
     ext, mA, mB, variant = case
     eA, eB = [ext[c] for c in mA], [ext[c] for c in mB]
     A = make_tensor(eA, 11)
-    p = ops.permutation_plan(h, eA, mA, eB, mB)
-    assert p.describe()["variant"] == variant, p.describe()
+    if lanes_only:
+        os.environ["CUTENSOR_AMD_EW_ANY"] = "0"
+    try:
+        p = ops.permutation_plan(h, eA, mA, eB, mB)
+    finally:
+        os.environ.pop("CUTENSOR_AMD_EW_ANY", None)
+    assert p.describe()["variant"] == variant or (not lanes_only and variant == 0 and p.describe()["variant"] == 4), p.describe()
     dA = to_device(A)
     dB = torch.zeros(int(np.prod(eB)), dtype=torch.float32, device="cuda")
     for alpha in (1.0, 1.5):
@@ -198,12 +208,18 @@ def test_16bit_vector_permutes_are_exact(built, dtype):
         (dict(a=128, b=80, c=256), "abc", "cba", 0),    # rest >= 64: still order 0 (rows < 1 MiB apart), many tiles
     ]
     wide_seen = set()
-    for ext, mA, mD, want in cases:
+    import os
+    for ext, mA, mD, want in cases + [(e, a, d_, 4) for (e, a, d_, w) in cases if w == 0][:4]:   # (want 4: the planner's own choice for small transpositions since round 6)
         eA, eD = [ext[c] for c in mA], [ext[c] for c in mD]
         A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)      # column-major tensor == reversed row-major
         D = torch.zeros(eD[::-1], device="cuda", dtype=tdt)
-        plan = ops.permutation_plan(h, eA, mA, eD, mD, dtype=cdt)
-        assert plan.describe()["variant"] == want, (plan.describe(), ext, mA, mD)
+        if want != 4:
+            os.environ["CUTENSOR_AMD_EW_ANY"] = "0"                                 # hooks flavour: the 16-byte-lane kernels also on small tensors
+        try:
+            plan = ops.permutation_plan(h, eA, mA, eD, mD, dtype=cdt)
+        finally:
+            os.environ.pop("CUTENSOR_AMD_EW_ANY", None)
+        assert plan.describe()["variant"] == want or (want == 4 and plan.describe()["variant"] == 0), (plan.describe(), ext, mA, mD)
         if plan.describe().get("tile0", 64) > 64 and want == 0:
             wide_seen.add(plan.describe()["tile0"])
         plan.permute(1.0, A.data_ptr(), D.data_ptr())
