@@ -282,9 +282,14 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     // leave a 4096^2 transposition on 1024 workgroups — 4.6 TB/s against 5.9 on 4096 tiles of 64 x 64 — and rows whose pitch is no
     // multiple of 128 bytes cost them more (4104^2: 3.4 / 5.2; bf16 on the narrow 64 x 64 kernel 2.6 / 3.4).  Large tensors stay
     // (1024^3: 5.6 / 5.0 fp32, 5.9 / 4.3 bf16 on the wide kernel) — profiles/r06zzo_permute_any_ab.jsonl.
+    // Second A/B, 3-D reversals of 96 MB .. 1.2 GB (profiles/r06zzq_permute_mid_ab.jsonl): fp32 (400, 200, 300) 3.6 / 4.7, (512, 256, 256)
+    // 5.1 / 6.4, (800, 400, 300) 4.0 / 5.2, 640^3 6.2 / 5.9; bf16 on the narrow kernel (1000, 500, 600) 2.3 / 3.0.  So: by bytes —
+    // fp32 below 512 MB, the narrow 16-bit kernel below 1 GB.
     const uint64_t vecTiles = (uint64_t)((p.E0 + t0 - 1) / t0) * (uint64_t)((p.E1 + t1 - 1) / t1) * (uint64_t)p.rest.total;
+    const uint64_t tensorBytes = (uint64_t)p.E0 * (uint64_t)p.E1 * (uint64_t)p.rest.total * (uint64_t)dtype_size(D.desc.dtype);
     const bool anyOff = CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY") && CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY")[0] == '0';      // tests: the 16-byte-lane kernels on small tensors
-    const bool midSize = !anyOff && plan.variant == EW_TRANSPOSE && ((D.desc.dtype == HIP_R_32F && vecTiles < 4096) || (h16 && t0 == 64 && vecTiles < 16384));
+    const bool midSize = !anyOff && plan.variant == EW_TRANSPOSE && ((D.desc.dtype == HIP_R_32F && (vecTiles < 4096 || tensorBytes < (512ull << 20))) ||
+                                                                     (h16 && t0 == 64 && (vecTiles < 16384 || tensorBytes < (1ull << 30))));
     if ((plan.variant == EW_GENERIC || midSize || (anyForced && plan.variant == EW_TRANSPOSE)) && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
         op.padLeft.empty() && op.padRight.empty() && i1 >= 0 && p.sD0 == 1 && p.sA1 == 1 && p.sA0 != 1 && p.E0 >= 16 && p.E1 >= 16) {
         plan.variant = EW_TRANSPOSE_ANY;

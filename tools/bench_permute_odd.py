@@ -7,6 +7,9 @@ CASES = [("float32", dict(a=4100, b=4100), "ab", "ba"), ("float32", dict(a=4097,
          ("float32", dict(a=401, b=403, c=399), "abc", "cba"), ("bfloat16", dict(a=401, b=403, c=399), "abc", "cab"), ("float32", dict(a=4096, b=4096), "ab", "ba"),
          ("float32", dict(a=4104, b=4104), "ab", "ba"), ("float32", dict(a=4160, b=4160), "ab", "ba"), ("bfloat16", dict(a=4104, b=4104), "ab", "ba"), ("bfloat16", dict(a=4096, b=4096), "ab", "ba"),
          ("float32", dict(a=1024, b=1024, c=1024), "abc", "cba"), ("bfloat16", dict(a=1024, b=1024, c=1024), "abc", "cab"), ("float32", dict(a=1000, b=1000, c=1000), "abc", "cab")]
+if os.environ.get("PERMUTE_SET") == "mid":     # mid-size 3-D reversals: where does the element-wise transposer stop winning?
+    CASES = [(dn, dict(a=a, b=b, c=c), "cba", "abc") for dn in ("float32", "bfloat16")
+             for (a, b, c) in ((400, 200, 300), (512, 256, 256), (384, 192, 320), (800, 400, 300), (640, 640, 640), (1000, 500, 600))]
 for dn, ext, mA, mB in CASES:
     tdt = getattr(torch, dn); cdt = {"bfloat16": ct.R_16BF, "float32": ct.R_32F}[dn]
     eA, eB = [ext[c] for c in mA], [ext[c] for c in mB]
