@@ -805,6 +805,26 @@ def secondary_round6(torch, ct, ops, h, stream, with_counters):
         del A, R, ws
     except Exception as ex:   # noqa: BLE001
         out.append({"workload": "permute / reduce complex64 1024^3", "error": "%s: %s" % (type(ex).__name__, ex)})
+    # ---- cutensorPermute off the 16-byte lanes (round 6, end): a transposition with odd extents, and a block permutation ----------------
+    for (label, eA, mA, eB, mB, tdt, cdt, es) in (
+            ("cutensorPermute A[a,b]->C[b,a] fp32 4097 x 4099 (odd extents: element-wise 64 x 64 LDS transposer)", [4097, 4099], "ab", [4099, 4097], "ba", torch.float32, ct.R_32F, 4),
+            ("cutensorPermute A[d,c,b,a]->C[b,c,d,a] bf16 (40, 16, 8, 8192) (leading modes the same packed set: block permutation through LDS)",
+             [40, 16, 8, 8192], "dcba", [8, 16, 40, 8192], "bcda", torch.bfloat16, ct.R_16BF, 2)):
+        try:
+            numel = 1
+            for e_ in eA:
+                numel *= e_
+            A = (torch.rand(numel, device="cuda") * 2 - 1).to(tdt)
+            D = torch.empty(numel, device="cuda", dtype=tdt)
+            p = ops.permutation_plan(h, eA, mA, eB, mB, dtype=cdt)
+            ms = timed_batch(torch, lambda: p.permute(1.0, A.data_ptr(), D.data_ptr(), stream), reps=20, warm=5)
+            gbs = 2.0 * numel * es / (ms * 1e-3) / 1e9
+            out.append({"workload": label, "dtype": "f32" if es == 4 else "bf16", "value": gbs, "unit": "GB/s", "us_per_call": ms * 1e3, "variant": p.describe().get("variant"),
+                        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBPS, "algorithmic_bytes": 2.0 * numel * es}})
+            p.destroy()
+            del A, D
+        except Exception as ex:   # noqa: BLE001
+            out.append({"workload": label, "error": "%s: %s" % (type(ex).__name__, ex)})
     # ---- contractions off the aligned path (round 6, end): the sweep mask and an operand copied first --------------------------------
     for (label, ext, mA, mB, mC) in (
             ("contraction bf16 'abcd,dcbe->ae' a=e=2048 b=c=8 d=96 (three contracted modes, the fastest one without whole K-tiles: sweep mask), U(-1,1) data",
