@@ -484,6 +484,12 @@ cutensorStatus_t plan_reduction(const cutensorOperationDescriptor& op, uint64_t 
     uint64_t items, wantItems, minRedPerSplit, gran;
     if (plan.variant == RED_COL)      { items = keptTot / (uint64_t)nv; wantItems = (uint64_t)numCUs * 1024; minRedPerSplit = 32;   gran = 4; }
     else if (plan.variant == RED_ROW) { items = keptTot;     wantItems = (uint64_t)numCUs * 32;   minRedPerSplit = 8192; gran = 256 * (uint64_t)nv; }
+    else if (!cplx && !red.empty() && red[0].sA == 1 && redTot >= 64) {
+        // the element-gather kernel with A's stride-1 mode reduced ('abc->bc', 'ab->b' at odd extents): a wave per kept element, lanes
+        // along that mode (reduce.hip reduce_row_any_kernel; 0.4-0.6 -> 2-3 TB/s, profiles/r06zzs_reduce_odd.jsonl)
+        p.rowAny = 1u;
+        items = keptTot; wantItems = (uint64_t)numCUs * 32; minRedPerSplit = 4096; gran = 256;
+    }
     else                              { items = keptTot;     wantItems = (uint64_t)numCUs * 512;  minRedPerSplit = 64;   gran = 4; }
     uint64_t split = 1;
     if (items < wantItems) split = (wantItems + items - 1) / std::max<uint64_t>(items, 1);

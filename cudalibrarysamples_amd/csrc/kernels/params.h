@@ -197,6 +197,9 @@ struct ReduceParams {
     // complex data (reduce_generic_cplx_kernel): imaginary parts of the scalars, conjugation of A / C; partials are (re, im) pairs
     double      alphaIm, betaIm;
     int32_t     conjA, conjC;
+    // RED_GENERIC on real data with A's stride-1 mode among the REDUCED ones (round 6): one wave per kept element, lanes along that mode
+    // (reduce_row_any_kernel) instead of one lane per kept element
+    uint32_t    rowAny;
 };
 
 }  // namespace ctamd

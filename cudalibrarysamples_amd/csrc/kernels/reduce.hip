@@ -330,7 +330,67 @@ __global__ void __launch_bounds__(256) reduce_generic_kernel(const ReduceParams 
     const int op = p.op;
     const T* A = static_cast<const T*>(p.A) + rd_offset<0>(p.kept, k);
     S acc = red_identity<S>(op);
-    for (uint32_t r = rBegin; r < rEnd; ++r) acc = red_apply<S>(op, acc, (S)rg_load<T>(A + rd_offset<0>(p.red, r)));
+    // (round 6: eight / four loads in flight per lane — the loop used to issue one load and wait for it, 1.5 TB/s on 'abc->ac' at odd
+    // extents where neighbouring lanes DO read neighbouring elements; same order of the combines, same bits)
+    uint32_t r = rBegin;
+    if (p.red.n == 1) {
+        const int64_t step = p.red.stride[0][0];
+        const T* q = A + (int64_t)r * step;
+        for (; r + 8 <= rEnd; r += 8, q += 8 * step) {
+            S v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (S)rg_load<T>(q + (int64_t)u * step);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = red_apply<S>(op, acc, v[u]);
+        }
+    }
+    for (; r + 4 <= rEnd; r += 4) {
+        S v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (S)rg_load<T>(A + rd_offset<0>(p.red, r + u));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = red_apply<S>(op, acc, v[u]);
+    }
+    for (; r < rEnd; ++r) acc = red_apply<S>(op, acc, (S)rg_load<T>(A + rd_offset<0>(p.red, r)));
+    if (p.partial != nullptr) {
+        static_cast<S*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
+        return;
+    }
+    const S alpha = sizeof(S) == 8 ? (S)p.alpha64 : (S)p.alpha;
+    const S beta  = sizeof(S) == 8 ? (S)p.beta64 : (S)p.beta;
+    S val = alpha * acc;
+    if (beta != (S)0) val += beta * (S)rg_load<T>(static_cast<const T*>(p.C) + rd_offset<2>(p.kept, k));
+    rg_store<T>(static_cast<T*>(p.D) + rd_offset<1>(p.kept, k), (double)val);
+}
+
+// RED_GENERIC with A's stride-1 mode REDUCED (ReduceParams::rowAny, round 6): 'abc->bc', 'ab->b' at extents / alignments the 16-byte-lane
+// row kernel refuses.  One lane per kept element (above) puts neighbouring lanes a kept stride apart — 0.4-0.6 TB/s; here one WAVE owns a
+// kept element, its lanes stride over the reduced range element by element (coalesced), four loads in flight, and meet through lane
+// shuffles.  Partials as above ([splitR][kept] accumulators).
+template <typename T, typename S>
+__global__ void __launch_bounds__(256) reduce_row_any_kernel(const ReduceParams p) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= p.kept.total) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t split = blockIdx.y;
+    const uint32_t rBegin = split * p.redPerSplit;
+    uint32_t rEnd = rBegin + p.redPerSplit;
+    if (rEnd > p.red.total) rEnd = p.red.total;
+    const int op = p.op;
+    const T* A = static_cast<const T*>(p.A) + rd_offset<0>(p.kept, k);
+    S acc = red_identity<S>(op);
+    uint32_t r = rBegin + lane;
+    for (; r + 3u * 64u < rEnd; r += 4u * 64u) {
+        S v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (S)rg_load<T>(A + rd_offset<0>(p.red, r + 64u * (uint32_t)u));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = red_apply<S>(op, acc, v[u]);
+    }
+    for (; r < rEnd; r += 64u) acc = red_apply<S>(op, acc, (S)rg_load<T>(A + rd_offset<0>(p.red, r)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = red_apply<S>(op, acc, __shfl_down(acc, off, 64));
+    if (lane != 0u) return;
     if (p.partial != nullptr) {
         static_cast<S*>(p.partial)[(size_t)split * p.kept.total + k] = acc;
         return;
@@ -418,6 +478,11 @@ __global__ void __launch_bounds__(256) reduce_finalize_cplx_kernel(const ReduceP
 
 template <typename T, typename S>
 static void launch_generic_t(const ReduceParams& p, hipStream_t stream) {
+    if (p.rowAny != 0u) {                         // A's stride-1 mode is reduced: a wave per kept element (reduce_row_any_kernel)
+        const dim3 grid((p.kept.total + 3u) / 4u, p.splitR);
+        hipLaunchKernelGGL((reduce_row_any_kernel<T, S>), grid, dim3(256), 0, stream, p);
+        return;
+    }
     const dim3 grid((p.kept.total + 255u) / 256u, p.splitR);
     hipLaunchKernelGGL((reduce_generic_kernel<T, S>), grid, dim3(256), 0, stream, p);
 }
