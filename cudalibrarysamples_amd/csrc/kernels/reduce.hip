@@ -453,7 +453,15 @@ __global__ void __launch_bounds__(256) reduce_generic_cplx_kernel(const ReducePa
     const RdCx<R>* A = static_cast<const RdCx<R>*>(p.A) + rd_offset<0>(p.kept, k);
     RdCx<R> acc = {op == OP_MUL ? (R)1 : (R)0, (R)0};
     const R sgn = p.conjA ? (R)-1 : (R)1;
-    for (uint32_t r = rBegin; r < rEnd; ++r) {
+    uint32_t r = rBegin;
+    for (; r + 4 <= rEnd; r += 4) {               // four loads in flight (reduce_generic_kernel, round 6); same order of the combines
+        RdCx<R> x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = A[rd_offset<0>(p.red, r + (uint32_t)u)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x[u].im *= sgn; acc = rc_apply<R>(op, acc, x[u]); }
+    }
+    for (; r < rEnd; ++r) {
         RdCx<R> x = A[rd_offset<0>(p.red, r)];
         x.im *= sgn;
         acc = rc_apply<R>(op, acc, x);
