@@ -101,6 +101,11 @@ def test_block_permutation_bit_exact_at_alpha_one(env, dtype_name):
     (dict(a=33, b=7, c=5), "abc", "ac", 2),                 # odd -> GENERIC
     (dict(a=64, b=48), "ab", "", 1),                        # full reduction to a scalar
     (dict(n=5, i=4, j=6), "jin", "ij", 2),                  # einsum.cu:451 "nij->ji" reversed
+    # round 6: odd extents with A's stride-1 mode REDUCED -> the element-gather variant's wave-per-kept-element form (reduce_row_any_kernel)
+    (dict(a=77, b=5, c=3), "abc", "bc", 2),                 # 77 reduced elements per kept one: two passes of a wave, ragged
+    (dict(a=4099, b=3), "ab", "b", 2),                      # three kept elements: the reduced range is split, partials + finalize
+    (dict(a=131, b=9, c=7), "abc", "c", 2),                 # two reduced modes (a, b), the walk crosses the mode boundary
+    (dict(a=131, b=67, c=5), "abc", "ac", 2),               # stride-1 mode kept, 67 reduced rows: the unrolled loop and its tails
 ])
 def test_reduction(env, case):
     ct, ops, h, torch = env
