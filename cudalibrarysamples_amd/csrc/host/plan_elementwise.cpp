@@ -290,7 +290,13 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
     const bool anyOff = CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY") && CTAMD_HOOK_ENV("CUTENSOR_AMD_EW_ANY")[0] == '0';      // tests: the 16-byte-lane kernels on small tensors
     const bool midSize = !anyOff && plan.variant == EW_TRANSPOSE && ((D.desc.dtype == HIP_R_32F && (vecTiles < 4096 || tensorBytes < (512ull << 20))) ||
                                                                      (h16 && t0 == 64 && (vecTiles < 16384 || tensorBytes < (1ull << 30))));
-    if ((plan.variant == EW_GENERIC || midSize || (anyForced && plan.variant == EW_TRANSPOSE)) && op.kind == OpKind::Permutation && !usesC && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
+    // (the binary form of cutensorElementwiseBinaryExecute too — allowWide tells it from the trinary planner's passes, which attach E / X
+    // operands at run time: C joins in the store phase, an instantiation of its own)
+    const bool anyKind = (op.kind == OpKind::Permutation && !usesC) || (op.kind == OpKind::ElementwiseBinary && allowWide && usesC);
+    // (measured, profiles/r06zzu_binary_any_ab.jsonl: the binary form gains where it came from the element-gather kernel — odd extents — and
+    // LOSES to the lane kernels at mid size, 4.14 / 3.71 TB/s at the sample's (400, 200, 300): the mid-size rule is the permutation's alone)
+    const bool fromLanes = (midSize || (anyForced && plan.variant == EW_TRANSPOSE)) && op.kind == OpKind::Permutation;
+    if ((plan.variant == EW_GENERIC || fromLanes) && anyKind && !usesX && !cplx && (h16 || D.desc.dtype == HIP_R_32F) &&
         op.padLeft.empty() && op.padRight.empty() && i1 >= 0 && p.sD0 == 1 && p.sA1 == 1 && p.sA0 != 1 && p.E0 >= 16 && p.E1 >= 16) {
         plan.variant = EW_TRANSPOSE_ANY;
         t0 = 64; t1 = 64;

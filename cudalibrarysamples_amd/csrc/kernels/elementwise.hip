@@ -621,11 +621,14 @@ __global__ void __launch_bounds__(256) ew_generic_kernel(const Ew2DParams p) {
 // loads walk dim1 (A's contiguous mode), stores walk dim0 (D's), both coalesced; the LDS row pitch of 65 (fp32) / 66 (16-bit) elements
 // keeps the column reads off a single bank.  HBM-bound: 2 |D| bytes.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// HASC: the binary form D = opAC(alpha perm(A), gamma C) (elementwise_binary.cu:149-153) — C joins in the store phase, along D's contiguous
+// mode; an instantiation of its own, so that the plain permutation carries no operand test in its store loop.
+template <typename T, bool HASC>
 __global__ void __launch_bounds__(256) ew_transpose_any_kernel(const Ew2DParams p) {
     constexpr int PITCH = sizeof(T) == 4 ? 65 : 66;
     __shared__ T lds[64 * PITCH];
     const T* A = static_cast<const T*>(p.A);
+    const T* C = static_cast<const T*>(p.C);
     T*       D = static_cast<T*>(p.D);
     const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
     const bool raw = p.alpha == 1.0f;
@@ -645,11 +648,20 @@ __global__ void __launch_bounds__(256) ew_transpose_any_kernel(const Ew2DParams 
         // out: lane = position along dim0 (D's stride-1 mode), four dim1 positions per pass
         if ((uint32_t)lane < n0) {
             T* dst = D + oD + (int64_t)(c0 + (uint32_t)lane) + (int64_t)r0 * p.sD1;
+            if constexpr (HASC) {
+                const T* csrc = C + oC + (int64_t)(c0 + (uint32_t)lane) * p.sC0 + (int64_t)r0 * p.sC1;
 #pragma unroll 4
-            for (uint32_t j = (uint32_t)row; j < n1; j += 4u) {
-                const T v = lds[lane * PITCH + j];
-                if (raw) dst[(int64_t)j * p.sD1] = v;
-                else ew_store<T>(dst + (int64_t)j * p.sD1, p.alpha * ew_load<T>(&v));
+                for (uint32_t j = (uint32_t)row; j < n1; j += 4u) {
+                    const T v = lds[lane * PITCH + j];
+                    ew_store<T>(dst + (int64_t)j * p.sD1, ew_comb<float>(p.opAC, p.alpha * ew_load<T>(&v), p.gamma * ew_load<T>(csrc + (int64_t)j * p.sC1)));
+                }
+            } else {
+#pragma unroll 4
+                for (uint32_t j = (uint32_t)row; j < n1; j += 4u) {
+                    const T v = lds[lane * PITCH + j];
+                    if (raw) dst[(int64_t)j * p.sD1] = v;
+                    else ew_store<T>(dst + (int64_t)j * p.sD1, p.alpha * ew_load<T>(&v));
+                }
             }
         }
         __syncthreads();
@@ -1002,12 +1014,20 @@ hipError_t launch_elementwise(const Ew2DParams& p, int variant, int dtype, hipSt
         variant = EW_GENERIC;
     }
     if (variant == EW_TRANSPOSE_ANY) {
-        if (p.C != nullptr || p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;   // (planned for pure permutations only)
+        if (p.E != nullptr || p.X != nullptr) return hipErrorInvalidValue;   // (planned for permutations and the binary form only)
         unsigned g = p.nBlocks < (1u << 22) ? p.nBlocks : (1u << 22);
+        if (p.C != nullptr) {
+            switch (dtype) {
+                case HIP_R_32F:  hipLaunchKernelGGL((ew_transpose_any_kernel<float, true>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+                case HIP_R_16F:  hipLaunchKernelGGL((ew_transpose_any_kernel<__half, true>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+                case HIP_R_16BF: hipLaunchKernelGGL((ew_transpose_any_kernel<__hip_bfloat16, true>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+                default: return hipErrorInvalidValue;
+            }
+        }
         switch (dtype) {
-            case HIP_R_32F:  hipLaunchKernelGGL(ew_transpose_any_kernel<float>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
-            case HIP_R_16F:  hipLaunchKernelGGL(ew_transpose_any_kernel<__half>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
-            case HIP_R_16BF: hipLaunchKernelGGL(ew_transpose_any_kernel<__hip_bfloat16>, dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            case HIP_R_32F:  hipLaunchKernelGGL((ew_transpose_any_kernel<float, false>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            case HIP_R_16F:  hipLaunchKernelGGL((ew_transpose_any_kernel<__half, false>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
+            case HIP_R_16BF: hipLaunchKernelGGL((ew_transpose_any_kernel<__hip_bfloat16, false>), dim3(g), dim3(256), 0, stream, p); return hipGetLastError();
             default: return hipErrorInvalidValue;
         }
     }
