@@ -465,3 +465,32 @@ def test_complex_unary_einsum_through_the_torch_front_end(env):
         zr = z.detach().clone().requires_grad_(True)
         torch.einsum("ijk->kij", zr).backward(g)
         torch.testing.assert_close(z.grad, zr.grad, rtol=5e-3, atol=6e-3)
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16", "float16"])
+def test_binary_form_at_odd_extents_on_the_elementwise_transposer(env, dtype_name):
+    """cutensorElementwiseBinaryExecute D = op(alpha perm(A), gamma C) (elementwise_binary.cu:149-153) where perm is a transposition and the
+    extents / alignment admit no 16-byte lanes: ew_transpose_any_kernel<T, HASC> (round 6; the element-gather kernel before).  ADD / MUL /
+    MAX against torch in fp32 arithmetic with ONE rounding to the data type (exact for fp32 ADD; within 1 ulp otherwise)."""
+    ct, ops, h, torch = env
+    tdt = getattr(torch, dtype_name)
+    cdt = {"float32": ct.R_32F, "bfloat16": ct.R_16BF, "float16": ct.R_16F}[dtype_name]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for ext in (dict(a=77, b=5, c=131), dict(a=401, b=3, c=67), dict(a=64, b=2, c=65)):
+        eA, eC = [ext[c] for c in "cba"], [ext[c] for c in "abc"]
+        A = (torch.rand(eA[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        C = (torch.rand(eC[::-1], generator=g, device="cuda") * 2 - 1).to(tdt)
+        for op, fn in (("ADD", lambda x, y: x + y), ("MUL", lambda x, y: x * y), ("MAX", torch.maximum)):
+            D = torch.full_like(C, float("nan"))
+            p = ops.binary_plan(h, eA, "cba", eC, "abc", op=op, dtype=cdt)
+            assert p.describe()["variant"] == 4, p.describe()
+            p.binary(1.5, A.data_ptr(), -0.75, C.data_ptr(), D.data_ptr())
+            torch.cuda.synchronize()
+            ref = fn(1.5 * torch.einsum("abc->cba", A.float()), -0.75 * C.float()).to(tdt)
+            if dtype_name == "float32":
+                assert torch.equal(D, ref), (ext, op)
+            else:
+                ulp = 2.0 ** -7 if dtype_name == "bfloat16" else 2.0 ** -10
+                assert bool(((D.float() - ref.float()).abs() <= ulp * ref.float().abs() + 1e-30).all()), (ext, op)
+            p.destroy()
