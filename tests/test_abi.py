@@ -138,7 +138,9 @@ def test_permutation_and_reduction_plans(ct, ops):
     h = ops.Handle()
     p = ops.permutation_plan(h, [32, 128, 128, 128], "whcn", [128, 32, 128, 128], "cwhn")   # elementwise_permute.cu:51-63
     d = p.describe()
-    assert d["variant"] == 0 and d["E0"] == 128 and d["E1"] == 4096 and p.required_workspace == 0
+    # (variant 4 since round 6: pure fp32 permutations below 512 MB go to the element-wise 64 x 64 transposer — level with the 16-byte-lane
+    # kernel at this shape, 5.71 / 5.74 TB/s, ahead at 4096^2-class shapes: profiles/r06zzo_*, r06zzq_*)
+    assert d["variant"] in (0, 4) and d["E0"] == 128 and d["E1"] == 4096 and p.required_workspace == 0
     r = ops.reduction_plan(h, [196, 256, 64, 64], "mhkv", [196, 64], "mv")                   # reduction.cu:49-61
     d = r.describe()
     assert d["kept"] == 196 * 64 and d["red"] == 256 * 64 and r.required_workspace <= r.workspace_estimate
