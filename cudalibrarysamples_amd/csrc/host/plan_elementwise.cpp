@@ -300,6 +300,14 @@ cutensorStatus_t plan_elementwise(const cutensorOperationDescriptor& op, EwPlan&
         op.padLeft.empty() && op.padRight.empty() && i1 >= 0 && p.sD0 == 1 && p.sA1 == 1 && p.sA0 != 1 && p.E0 >= 16 && p.E1 >= 16) {
         plan.variant = EW_TRANSPOSE_ANY;
         t0 = 64; t1 = 64;
+        // 16-bit pure permutations with even extents, even strides and 4-byte-aligned bases: pairs per lane, 128 x 128 tiles
+        // (ew_transpose_any_pair_kernel)
+        if (h16 && op.kind == OpKind::Permutation && !usesC && p.E0 % 2 == 0 && p.E1 % 2 == 0 && p.sA0 % 2 == 0 && p.sD1 % 2 == 0 &&
+            A.desc.alignment % 4 == 0 && D.desc.alignment % 4 == 0 && p.E0 >= 128 && p.E1 >= 128) {
+            bool even = true;
+            for (const EwMode& m : rest) even = even && m.sA % 2 == 0 && m.sD % 2 == 0;
+            if (even) { t0 = 128; t1 = 128; }
+        }
     }
     plan.usesX = usesX;
     p.tile0 = (uint32_t)t0;

@@ -205,6 +205,9 @@ def test_16bit_vector_permutes_are_exact(built, dtype):
         (dict(a=136, b=24, c=72), "abc", "cab", 0),
         (dict(a=37, b=5, c=11), "abc", "cba", 3),       # odd extents, the whole tensor one block that is contiguous on both sides (round 6)
         (dict(a=37, b=50, c=11), "abc", "cba", 2),      # odd extents, more than a block's 32 KiB: generic
+        (dict(a=130, b=3, c=134), "abc", "cba", 4),     # even extents without 16-byte lanes: the element-wise transposer's PAIR form (128 x 128 tiles, ragged)
+        (dict(a=258, b=2, c=132), "abc", "cab", 4),     # ... with a fused outer mode
+        (dict(a=131, b=3, c=134), "abc", "cba", 4),     # an odd extent: element by element
         # full tiles of the wide transposing kernel (ew_transpose_h16_wide_kernel<T0, T1>): 256 x 128, 128 x 128, 256 x 64, 128 x 64
         (dict(a=256, b=3, c=512), "abc", "cba", 0),
         (dict(a=128, b=5, c=384), "abc", "cab", 0),
